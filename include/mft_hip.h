@@ -1,0 +1,132 @@
+/*
+ * mft_hip.h -- C-ABI of libmft_hip.so: hand-written HIP kernels for gfx950 (MI355X)
+ * that replace the ATen/cuDNN/cuBLAS dispatches on the hot path of
+ * johncai117/Meta-Fine-Tuning (the reference has no native code; every entry
+ * point below names the reference call site whose implicit dispatch it replaces).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (fp32 unless
+ *     stated); `stream` is a hipStream_t passed as void*.
+ *   - kernels never allocate and never synchronise; workspaces are passed in.
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch,
+ *     or MFT_EINVAL (-22) for an argument the kernel does not support.
+ *   - activations are NHWC ("pixel-major"): a tensor [n_img, H, W, C] is a matrix of
+ *     n_img*H*W rows with a row stride (`ld*`, in floats) >= C.
+ *   - "group": a set of consecutive images (or rows) that forms one BatchNorm
+ *     mini-batch / one episode; grouped launches run many independent episodes in
+ *     one kernel (per-group statistics, optionally per-group weights).
+ */
+#ifndef MFT_HIP_H
+#define MFT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFT_EINVAL (-22)
+
+enum { MFT_ACT_NONE = 0, MFT_ACT_RELU = 1, MFT_ACT_LRELU = 2 };
+
+/* library / device ------------------------------------------------------------------ */
+int mft_version(void);                        /* 100*major + minor                          */
+int mft_device_info(int* cu_count, int* gcn_arch_is_gfx950);
+
+/* layout ---------------------------------------------------------------------------- */
+/* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
+int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);
+/* nn.Conv2d weight OIHW -> packed [Cout][KH][KW][Cin] padded to k_pad floats per row (zeros) */
+int mft_pack_oihw(const float* w_oihw, float* w_pk, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);
+int mft_unpack_oihw(const float* w_pk, float* w_oihw, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);
+/* packed forward weights -> packed dgrad weights: wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci];
+ * `groups` independent weight sets, strides in floats */
+int mft_pack_dgrad(const float* w_pk, float* wt_pk, int Cout, int Cin, int KH, int KW,
+                   int groups, long long w_stride, long long wt_stride, void* stream);
+
+/* convolution / GEMM on fp32 MFMA ----------------------------------------------------- */
+/* nn.Conv2d(bias=False).forward (backbone.py:221,226,239,408) and, with KH=KW=1, nn.Linear /
+ * 1x1 nn.Conv2d (gnnnet.py:30; gnn.py:64-76,38).  out[m][co] = sum_k A[m][k] * w[g][co][k] (+ bias[co]),
+ * A = implicit im2col of the NHWC input, k = (kh*KW+kw)*Cin + ci.  Cin % 32 == 0 unless the
+ * stem path (Cin == 3) is taken; w rows are k_pad = roundup(KH*KW*Cin, 32) floats.
+ * imgs_per_group > 0 with w_group_stride != 0 selects per-group weights (M tiles never
+ * straddle a group); imgs_per_group == 0 means one group of n_img images.                     */
+int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                    int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                    int imgs_per_group, long long w_group_stride, void* stream);
+
+/* conv weight gradient (autograd of nn.Conv2d in loss.backward(): finetune.py:293, gnnnet.py:174,
+ * meta_template.py:86): dw[g][co][kh][kw][ci] = sum_{m in group g} dy[m][co] * im2col(in)[m][(kh,kw,ci)].
+ * One weight gradient per group of imgs_per_group images (0: a single group).               */
+int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
+                          int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          int imgs_per_group, long long dw_group_stride, void* stream);
+
+/* BatchNorm (train mode, batch statistics) --------------------------------------------- */
+/* F.batch_norm(training=True) statistics (backbone.py:224,227,240,409; gnn.py:65-74; gnnnet.py:30):
+ * per (group, channel) mean and 1/sqrt(biased var + eps) over rows_per_group rows.
+ * ws: >= mft_bn_stats_ws_floats(...) floats.  running_mean/var (nullable, [C], n_groups must be 1
+ * when given) get the momentum update with the unbiased variance.                          */
+long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups);
+int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
+                 float* mean, float* rstd, float* ws,
+                 float* running_mean, float* running_var, float momentum, void* stream);
+/* y = act( bn(x) [+ residual | + bn_r(residual)] ); gamma/beta [C] shared (gb_group_stride 0) or per group.
+ * SimpleBlock.forward tail (backbone.py:251-261); F.leaky_relu(bn(.)) in Wcompute (gnn.py:84-102). */
+int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups,
+                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 long long gb_group_stride,
+                 const float* res, int ldr, const float* res_mean, const float* res_rstd,
+                 const float* res_gamma, const float* res_beta,
+                 int act, float slope, void* stream);
+/* trunk[1..3]: BatchNorm2d -> ReLU -> MaxPool2d(3,2,1) fused (backbone.py:409-411) */
+int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
+                        const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        void* stream);
+/* trunk[8..9]: global average pool + flatten (backbone.py:427-430) */
+int mft_global_avgpool(const float* x, float* y, int n_img, int HW, int C, void* stream);
+
+/* BatchNorm backward (train mode).  dy_eff = dy * (y > 0) when relu_out != NULL (ReLU backward fused).
+ * dx = gamma*rstd*(dy_eff - mean_g(dy_eff) - xhat*mean_g(dy_eff*xhat)); dgamma = sum dy_eff*xhat; dbeta = sum dy_eff.
+  * One workgroup per (group, 64-channel tile): fixed-order reduction, then dx (rows re-read from L2). */
+int mft_bn_backward(const float* x, int ldx, const float* dy, int lddy, const float* relu_out, int ldro,
+                    float* dx, int lddx, int C, int rows_per_group, int n_groups,
+                    const float* mean, const float* rstd, const float* gamma, long long gb_group_stride,
+                    float* dgamma, float* dbeta, void* stream);
+/* d(out)[n,hw,c] = (out>0) * dfeat[n,c] / HW : AvgPool + relu2 backward (backbone.py:260,427) */
+int mft_avgpool_relu_backward(const float* dfeat, const float* out, float* dout, int n_img, int HW, int C, void* stream);
+
+/* loss --------------------------------------------------------------------------------- */
+/* nn.CrossEntropyLoss forward+backward (finetune.py:291-293; gnnnet.py:170-174,221-224): mean over the
+ * rows of each group; loss[n_groups]; dlogits = (softmax - onehot)/rows_per_group (nullable).     */
+int mft_cross_entropy(const float* logits, int ld, const int* labels, int C, int rows_per_group, int n_groups,
+                      float* loss, float* dlogits, void* stream);
+int mft_softmax_rows(const float* x, int ldx, float* y, int ldy, int C, int rows, void* stream);
+
+/* optimisers --------------------------------------------------------------------------- */
+/* torch.optim.Adam.step (finetune.py:255,299; gnnnet.py:128,177; train.py:28), one flat slab of n floats:
+ * g += wd*p; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t)+eps) */
+int mft_adam_step(float* p, const float* g, float* m, float* v, long long n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* torch.optim.SGD(momentum, dampening, weight_decay).step (meta_template.py:166; baselinefinetune.py:35) */
+int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_step,
+                 float lr, float momentum, float dampening, float weight_decay, void* stream);
+/* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
+int mft_maml_delta(float* p, const float* p2, const float* p3, long long n, void* stream);
+
+/* GNN head ------------------------------------------------------------------------------ */
+/* Wcompute: W_new = abs(x_i - x_j) (gnn.py:79-82): x [n_graphs*N, ldx] -> d [n_graphs*N*N, ldd]; columns
+ * F..ldd-1 of d are zero-filled.                                                              */
+int mft_pair_absdiff(const float* x, int ldx, float* d, int ldd, int n_graphs, int N, int F, void* stream);
+/* Wcompute tail (gnn.py:103-115): s[b,i,j] (ld = lds_, column 0 of the conv2d_last GEMM) -> A[b,i,:] =
+ * softmax_j(s - 1e8*[i==j])                                                                    */
+int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, void* stream);
+/* gmul (gnn.py:16-28) with J=2: y[b,i,:] = cat(x[b,i,:F], (A[b] @ x[b])[i,:F]) zero padded to ldy */
+int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy,
+                        int n_graphs, int N, int F, void* stream);
+/* y[r, col_off + c] = act(x[r,c]) : strided copy used for GNN_nl's cat (gnn.py:160-161) */
+int mft_copy_cols(const float* x, int ldx, float* y, int ldy, int col_off, int C, int rows,
+                  int act, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFT_HIP_H */

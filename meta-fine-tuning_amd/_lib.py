@@ -1,0 +1,68 @@
+"""ctypes binding of libmft_hip.so (C-ABI declared in include/mft_hip.h).
+
+The product path has no CPU fallback: ``lib()`` raises if the shared library is
+missing, and every wrapper raises ``RuntimeError`` on a non-zero return code.
+"""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmft_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_longlong
+_F = ctypes.c_float
+
+# name -> argtypes; every function returns int unless listed in _RESTYPE
+SIGNATURES = {
+    "mft_version": [],
+    "mft_device_info": [_P, _P],
+    "mft_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _P],
+    "mft_pack_oihw": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mft_unpack_oihw": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mft_pack_dgrad": [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P],
+    "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "mft_bn_stats_ws_floats": [_I, _I, _I],
+    "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P],
+    "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
+    "mft_bn_relu_maxpool": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mft_global_avgpool": [_P, _P, _I, _I, _I, _P],
+    "mft_bn_backward": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P],
+    "mft_avgpool_relu_backward": [_P, _P, _P, _I, _I, _I, _P],
+    "mft_cross_entropy": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
+    "mft_softmax_rows": [_P, _I, _P, _I, _I, _I, _P],
+    "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
+    "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
+    "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_pair_absdiff": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "mft_masked_softmax": [_P, _I, _P, _I, _I, _P],
+    "mft_graph_aggregate": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "mft_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+}
+_RESTYPE = {"mft_bn_stats_ws_floats": _L}
+
+_lib = None
+
+
+def lib():
+    """Load libmft_hip.so; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmft_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "this package has no CPU or PyTorch fallback" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, _I)
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d (hipError_t / MFT_EINVAL=-22)" % (what, rc))

@@ -1,0 +1,370 @@
+// Grouped train-mode BatchNorm (statistics / apply / backward), pooling, ReLU for NHWC fp32 tensors.
+//
+// Replaces F.batch_norm(training=True), F.relu / F.leaky_relu, max/avg pooling and their autograd
+// on the reference hot path (backbone.py:224-261,409-411,427-430; gnn.py:65-102; gnnnet.py:30).
+// A "group" is one BatchNorm mini-batch (e.g. the 5 images of one episode's inner step); grouped
+// launches process many independent episodes per kernel.  All of this is HBM-bound streaming work:
+// every thread reads/writes float4 along the contiguous channel axis, reductions are fixed-order
+// (no float atomics) so reruns are bit-identical.
+#include "mft_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- stats
+// Shifted one-pass moments: s = x[first row of group][c]; S1 = sum(x-s), S2 = sum((x-s)^2).
+// mean = s + S1/n, var = S2/n - (S1/n)^2  (cancellation-free as long as s is within a few sigma).
+// grid (chunks, C/64 tiles... ) : block = 256 threads = 16 channel-quads (64 channels) x 16 row lanes.
+constexpr int ST_ROWS = 16;
+
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int ldx, int C,
+                                                        int rows_per_group, int rows_per_chunk, int chunks,
+                                                        float* __restrict__ ws) {
+    const int cq = threadIdx.x & 15;          // channel quad within the 64-channel tile
+    const int rl = threadIdx.x >> 4;          // row lane 0..15
+    const int c = blockIdx.y * 64 + cq * 4;
+    const int g = blockIdx.z;
+    const int chunk = blockIdx.x;
+    const long long row0 = (long long)g * rows_per_group;
+    __shared__ f32x4 red1[ST_ROWS][16];
+    __shared__ f32x4 red2[ST_ROWS][16];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const f32x4 sh = *(const f32x4*)(x + row0 * ldx + c);
+        const int rbeg = chunk * rows_per_chunk;
+        const int rend = min(rbeg + rows_per_chunk, rows_per_group);
+        for (int rr = rbeg + rl; rr < rend; rr += ST_ROWS) {
+            f32x4 v = *(const f32x4*)(x + (row0 + rr) * ldx + c);
+            v -= sh;
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    red1[rl][cq] = s1;
+    red2[rl][cq] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < ST_ROWS; ++k) {
+            s1 += red1[k][cq];
+            s2 += red2[k][cq];
+        }
+        float* o = ws + (((long long)g * chunks + chunk) * C + c) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = s1[e];
+            o[2 * e + 1] = s2[e];
+        }
+    }
+}
+
+__global__ void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group, int chunks,
+                                  const float* __restrict__ ws, float eps, float* __restrict__ mean,
+                                  float* __restrict__ rstd, float* running_mean, float* running_var,
+                                  float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        const float* o = ws + (((long long)g * chunks + k) * C + c) * 2;
+        s1 += o[0];
+        s2 += o[1];
+    }
+    const float inv = 1.f / (float)rows_per_group;
+    const float sh = x[(long long)g * rows_per_group * ldx + c];
+    const float d = s1 * inv;
+    const float m = sh + d;
+    float var = s2 * inv - d * d;
+    var = fmaxf(var, 0.f);
+    mean[(long long)g * C + c] = m;
+    rstd[(long long)g * C + c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) {
+        const float unb = var * ((float)rows_per_group / (float)max(rows_per_group - 1, 1));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- apply
+struct ApplyArgs {
+    const float* x; float* y; int ldx, ldy, C, rows_per_group, n_groups;
+    const float* mean; const float* rstd; const float* gamma; const float* beta; long long gbs;
+    const float* res; int ldr; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta;
+    int act; float slope;
+};
+
+__device__ __forceinline__ float act_f(float v, int act, float slope) {
+    if (act == MFT_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MFT_ACT_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
+    const int cq = p.C >> 2;
+    const long long total = (long long)p.n_groups * p.rows_per_group * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cq;
+        const int c = (int)(i - row * cq) * 4;
+        const int g = (int)(row / p.rows_per_group);
+        const f32x4 v = *(const f32x4*)(p.x + row * p.ldx + c);
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        const f32x4 ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
+        const f32x4 be = *(const f32x4*)(p.beta + g * p.gbs + c);
+        f32x4 o = (v - mu) * rs * ga + be;
+        if (p.res) {
+            f32x4 rv = *(const f32x4*)(p.res + row * p.ldr + c);
+            if (p.rmean) {
+                const f32x4 rmu = *(const f32x4*)(p.rmean + (long long)g * p.C + c);
+                const f32x4 rrs = *(const f32x4*)(p.rrstd + (long long)g * p.C + c);
+                const f32x4 rga = *(const f32x4*)(p.rgamma + g * p.gbs + c);
+                const f32x4 rbe = *(const f32x4*)(p.rbeta + g * p.gbs + c);
+                rv = (rv - rmu) * rrs * rga + rbe;
+            }
+            o += rv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
+        *(f32x4*)(p.y + row * p.ldy + c) = o;
+    }
+}
+
+// BN -> ReLU -> MaxPool(3,2,1), NHWC.  relu(max(.)) == max(relu(.)); padding never wins (>= 1 valid tap).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int n_img, int H, int W, int C, int OH, int OW,
+                                                              int imgs_per_group, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta) {
+    const int cq = C >> 2;
+    const long long total = (long long)n_img * OH * OW * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const int g = n / imgs_per_group;
+        const f32x4 mu = *(const f32x4*)(mean + (long long)g * C + c);
+        const f32x4 rs = *(const f32x4*)(rstd + (long long)g * C + c);
+        const f32x4 ga = *(const f32x4*)(gamma + c);
+        const f32x4 be = *(const f32x4*)(beta + c);
+        f32x4 best = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int ih = oh * 2 - 1 + dh;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int iw = ow * 2 - 1 + dw;
+                if (iw < 0 || iw >= W) continue;
+                const f32x4 v = *(const f32x4*)(x + (((long long)n * H + ih) * W + iw) * C + c);
+                const f32x4 o = (v - mu) * rs * ga + be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], o[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], 0.f);
+        *(f32x4*)(y + i * 4) = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int n_img, int HW, int C) {
+    const int cq = C >> 2;
+    const long long total = (long long)n_img * cq;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i / cq);
+    const int c = (int)(i % cq) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < HW; ++k) s += *(const f32x4*)(x + ((long long)n * HW + k) * C + c);
+    const float inv = 1.f / (float)HW;
+    *(f32x4*)(y + (long long)n * C + c) = s * inv;
+}
+
+__global__ __launch_bounds__(256) void avgpool_relu_bwd_kernel(const float* __restrict__ dfeat,
+                                                               const float* __restrict__ out,
+                                                               float* __restrict__ dout, int n_img, int HW, int C) {
+    const int cq = C >> 2;
+    const long long total = (long long)n_img * HW * cq;
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        const long long pix = i / cq;
+        const int n = (int)(pix / HW);
+        const f32x4 o = *(const f32x4*)(out + pix * C + c);
+        const f32x4 d = *(const f32x4*)(dfeat + (long long)n * C + c);
+        f32x4 rv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = o[e] > 0.f ? d[e] * inv : 0.f;
+        *(f32x4*)(dout + pix * C + c) = rv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// One block per (group, 64-channel tile): pass 1 reduces sum(dy) and sum(dy*xhat) over the group's rows
+// (fixed order), pass 2 writes dx.  Rows per group on the hot path are 9..245 (L2-resident re-read).
+struct BwdArgs {
+    const float* x; const float* dy; const float* ro; float* dx;
+    int ldx, lddy, ldro, lddx, C, rows_per_group;
+    const float* mean; const float* rstd; const float* gamma; long long gbs;
+    float* dgamma; float* dbeta;
+};
+
+__global__ __launch_bounds__(256) void bn_backward_kernel(BwdArgs p) {
+    const int cq = threadIdx.x & 15;
+    const int rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int g = blockIdx.y;
+    const long long row0 = (long long)g * p.rows_per_group;
+    __shared__ f32x4 red1[ST_ROWS][16];
+    __shared__ f32x4 red2[ST_ROWS][16];
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu;
+    const bool ok = c < p.C;
+    if (ok) {
+        mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
+    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (ok) {
+        for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+            f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+            if (p.ro) {
+                const f32x4 o = *(const f32x4*)(p.ro + (row0 + rr) * p.ldro + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            }
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            s1 += d;
+            s2 += d * xh;
+        }
+    }
+    red1[rl][cq] = s1;
+    red2[rl][cq] = s2;
+    __syncthreads();
+    s1 = red1[0][cq];
+    s2 = red2[0][cq];
+#pragma unroll
+    for (int k = 1; k < ST_ROWS; ++k) {
+        s1 += red1[k][cq];
+        s2 += red2[k][cq];
+    }
+    if (!ok) return;
+    if (rl == 0) {
+        if (p.dgamma) *(f32x4*)(p.dgamma + (long long)g * p.C + c) = s2;
+        if (p.dbeta) *(f32x4*)(p.dbeta + (long long)g * p.C + c) = s1;
+    }
+    if (!p.dx) return;
+    const float inv = 1.f / (float)p.rows_per_group;
+    const f32x4 m1 = s1 * inv, m2 = s2 * inv;
+    const f32x4 k = ga * rs;
+    for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+        f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+        if (p.ro) {
+            const f32x4 o = *(const f32x4*)(p.ro + (row0 + rr) * p.ldro + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        }
+        const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+        *(f32x4*)(p.dx + (row0 + rr) * p.lddx + c) = k * (d - m1 - xh * m2);
+    }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 256 * 8) {
+    long long b = (total + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+inline int stats_chunks(int rows_per_group, int n_groups, int C) {
+    // enough blocks to fill 256 CUs, at least 64 rows per chunk
+    const int tiles = (C + 63) / 64;
+    long long want = (1024 + (long long)n_groups * tiles - 1) / ((long long)n_groups * tiles);
+    int maxc = (rows_per_group + 63) / 64;
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace
+
+extern "C" long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups) {
+    return 2LL * n_groups * stats_chunks(rows_per_group, n_groups, C) * C;
+}
+
+extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
+                            float* mean, float* rstd, float* ws, float* running_mean, float* running_var,
+                            float momentum, void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || rows_per_group <= 0 || n_groups <= 0) return MFT_EINVAL;
+    if (running_mean && n_groups != 1) return MFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = stats_chunks(rows_per_group, n_groups, C);
+    const int rpc = (rows_per_group + chunks - 1) / chunks;
+    dim3 grid(chunks, (C + 63) / 64, n_groups);
+    hipLaunchKernelGGL(bn_stats_partial, grid, dim3(256), 0, s, x, ldx, C, rows_per_group, rpc, chunks, ws);
+    dim3 g2((C + 127) / 128, n_groups, 1);
+    hipLaunchKernelGGL(bn_stats_finalize, g2, dim3(128), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps, mean, rstd,
+                       running_mean, running_var, momentum);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            long long gb_group_stride, const float* res, int ldr, const float* res_mean,
+                            const float* res_rstd, const float* res_gamma, const float* res_beta, int act, float slope,
+                            void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || (res && ldr % 4 != 0)) return MFT_EINVAL;
+    ApplyArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, mean, rstd, gamma, beta, gb_group_stride,
+                res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope};
+    const long long total = (long long)n_groups * rows_per_group * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
+                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   void* stream) {
+    if (C % 4 != 0) return MFT_EINVAL;
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)n_img * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n_img, H,
+                       W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
+    return mft_launch_status();
+}
+
+extern "C" int mft_global_avgpool(const float* x, float* y, int n_img, int HW, int C, void* stream) {
+    if (C % 4 != 0) return MFT_EINVAL;
+    const long long total = (long long)n_img * (C / 4);
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       n_img, HW, C);
+    return mft_launch_status();
+}
+
+extern "C" int mft_avgpool_relu_backward(const float* dfeat, const float* out, float* dout, int n_img, int HW, int C,
+                                         void* stream) {
+    if (C % 4 != 0) return MFT_EINVAL;
+    const long long total = (long long)n_img * HW * (C / 4);
+    hipLaunchKernelGGL(avgpool_relu_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dfeat, out,
+                       dout, n_img, HW, C);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_backward(const float* x, int ldx, const float* dy, int lddy, const float* relu_out, int ldro,
+                               float* dx, int lddx, int C, int rows_per_group, int n_groups, const float* mean,
+                               const float* rstd, const float* gamma, long long gb_group_stride, float* dgamma,
+                               float* dbeta, void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0) return MFT_EINVAL;
+    BwdArgs p{x, dy, relu_out, dx, ldx, lddy, ldro, lddx, C, rows_per_group, mean, rstd, gamma, gb_group_stride,
+              dgamma, dbeta};
+    dim3 grid((C + 63) / 64, n_groups, 1);
+    hipLaunchKernelGGL(bn_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}

@@ -1,0 +1,399 @@
+// NHWC implicit-GEMM convolution / dense GEMM and conv weight-gradient on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate) for gfx950.
+//
+// Replaces the cuDNN/cuBLAS dispatches behind nn.Conv2d / nn.Linear on the reference hot path
+// (backbone.py:221-240,408; gnnnet.py:30; gnn.py:38,64-76) and conv weight gradients of
+// loss.backward() (finetune.py:293; gnnnet.py:174).
+//
+// Forward tiling: a 256-thread workgroup (4 waves) owns a BM x BN output tile; K is walked in
+// 32-wide steps whose A rows are gathered straight from the NHWC input (im2col is never
+// materialised: for a fixed (kh,kw) 32 input channels are one 128-byte run) and whose B rows are
+// weight rows packed [Cout][KH][KW][Cin].  Global -> registers -> LDS staging with the next
+// K-step's loads in flight during the MFMAs of the current one, double-buffered LDS, one barrier
+// per K-step.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads are
+// conflict-free.  Each lane reads 16 contiguous k of its row; MFMA step t pairs k=t (lanes 0-31)
+// with k=16+t (lanes 32-63) -- a fixed permutation of the reduction order shared by A and B.
+#include "mft_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* in;
+    const float* w;
+    const float* bias;
+    float* out;
+    int ldi, ldo;
+    int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+    int Kpad;            // weight row length in floats (multiple of 32)
+    int Ktot;            // KH*KW*Cin
+    int rows_per_group;  // imgs_per_group * OH * OW
+    int imgs_per_group;
+    int tiles_n;
+    long long wgs;       // weight group stride (floats), 0 = shared
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int PA = BM / 32;   // A passes: 32 rows per pass (8 threads x float4 per row)
+    constexpr int PB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nt = blockIdx.x % p.tiles_n;
+    const int mt = blockIdx.x / p.tiles_n;
+    const int g = blockIdx.y;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int lrow = tid >> 3;        // 0..31
+    const int c4 = (tid & 7) * 4;     // 0..28
+    const int ohw = p.OH * p.OW;
+
+    // per-thread A row descriptors
+    long long a_base[PA];
+    int a_ih0[PA], a_iw0[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        int m = m0 + lrow + 32 * j;
+        a_ok[j] = m < p.rows_per_group;
+        int mm = a_ok[j] ? m : 0;
+        int img = mm / ohw;
+        int rem = mm - img * ohw;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        a_ih0[j] = oh * p.stride - p.pad;
+        a_iw0[j] = ow * p.stride - p.pad;
+        a_base[j] = (long long)(g * p.imgs_per_group + img) * p.H * p.W;
+    }
+    const float* wg = p.w + (long long)g * p.wgs;
+    bool b_ok[PB];
+    const float* b_ptr[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        int n = n0 + lrow + 32 * j;
+        b_ok[j] = n < p.Cout;
+        b_ptr[j] = wg + (long long)(b_ok[j] ? n : 0) * p.Kpad + c4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[PA], rb[PB];
+    const int nk = p.Kpad / BK;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (!STEM) {
+            const int khkw = k0 / p.Cin;
+            const int ci0 = k0 - khkw * p.Cin;
+            const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+                bool ok = a_ok[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *(const f32x4*)(p.in + (a_base[j] + (long long)ih * p.W + iw) * p.ldi + ci0 + c4);
+                ra[j] = v;
+            }
+        } else {
+            // stem: Cin == 3, k = (kh*KW + kw)*3 + ci, scalar gather (K = 147 -> 5 K-steps)
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = k0 + c4 + e;
+                    if (a_ok[j] && k < p.Ktot) {
+                        int khkw = k / 3, ci = k - khkw * 3;
+                        int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+                        int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                            v[e] = p.in[(a_base[j] + (long long)ih * p.W + iw) * p.ldi + ci];
+                    }
+                }
+                ra[j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[j]) v = *(const f32x4*)(b_ptr[j] + k0);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LDS_LD;
+        float* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) *(f32x4*)(As + (lrow + 32 * j) * LDS_LD + c4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4*)(Bs + (lrow + 32 * j) * LDS_LD + c4) = rb[j];
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* As = smem + buf * (BM + BN) * LDS_LD;
+        const float* Bs = As + BM * LDS_LD;
+        f32x4 av[TM][4], bv[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float* ptr = As + (wm * (BM / WM) + i * 32 + r) * LDS_LD + h * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[i][q] = *(const f32x4*)(ptr + 4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float* ptr = Bs + (wn * (BN / WN) + j * 32 + r) * LDS_LD + h * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[j][q] = *(const f32x4*)(ptr + 4 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t >> 2][t & 3], bv[j][t >> 2][t & 3],
+                                                                     acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const long long out_row0 = (long long)g * p.rows_per_group;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + r;
+            if (n >= p.Cout) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                if (m < p.rows_per_group) p.out[(out_row0 + m) * p.ldo + n] = acc[i][j][e] + bias;
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
+    const int tiles_m = cdiv(a.rows_per_group, BM);
+    ConvArgs p = a;
+    p.tiles_n = cdiv(a.Cout, BN);
+    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM>;
+    if (lds > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+    }
+    dim3 grid(tiles_m * p.tiles_n, groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return mft_launch_status();
+}
+
+// ----------------------------------------------------------------------------------------- wgrad
+struct WgradArgs {
+    const float* in;
+    const float* dy;
+    float* dw;
+    int ldi, ldy;
+    int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+    int Kpad;
+    int rows_per_group, imgs_per_group;
+    int tiles_ci;        // Cin / BN
+    int tiles_co;        // Cout / BM
+    long long dwgs;
+};
+
+// dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
+// index of both operands, so tiles are staged k-major ([m][co], [m][ci]) and the MFMA fragments are
+// fetched with conflict-free ds_read_b32 (lane -> consecutive co / ci); MFMA step t uses m = 2t + h.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
+    constexpr int QA = BM / 4;                  // float4 per A row
+    constexpr int QB = BN / 4;
+    constexpr int PA = (32 * QA) / 256;         // passes over the 32-row A tile
+    constexpr int PB = (32 * QB) / 256;
+    constexpr int RPA = 256 / QA;               // rows per pass
+    constexpr int RPB = 256 / QB;
+    __shared__ __attribute__((aligned(16))) float As[32 * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+
+    int bx = blockIdx.x;
+    const int tci = bx % p.tiles_ci;
+    bx /= p.tiles_ci;
+    const int tco = bx % p.tiles_co;
+    const int khkw = bx / p.tiles_co;
+    const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+    const int co0 = tco * BM, ci0 = tci * BN;
+    const int ohw = p.OH * p.OW;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int arow = tid / QA, acol = (tid % QA) * 4;
+    const int brow = tid / QB, bcol = (tid % QB) * 4;
+    const long long row0 = (long long)g * p.rows_per_group;
+    const long long img0 = (long long)g * p.imgs_per_group;
+
+    for (int mk = 0; mk < p.rows_per_group; mk += 32) {
+        f32x4 va[PA], vb[PB];
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            int m = mk + arow + j * RPA;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.rows_per_group) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
+            va[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            int m = mk + brow + j * RPB;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.rows_per_group) {
+                int img = m / ohw;
+                int rem = m - img * ohw;
+                int oh = rem / p.OW, ow = rem - oh * p.OW;
+                int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    v = *(const f32x4*)(p.in + ((img0 + img) * p.H * p.W + (long long)ih * p.W + iw) * p.ldi + ci0 + bcol);
+            }
+            vb[j] = v;
+        }
+        __syncthreads();   // previous iteration's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < PA; ++j) *(f32x4*)(As + (arow + j * RPA) * BM + acol) = va[j];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4*)(Bs + (brow + j * RPB) * BN + bcol) = vb[j];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * t + h) * BM + wm * (BM / 2) + i * 32 + r];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * t + h) * BN + wn * (BN / 2) + j * 32 + r];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* dwg = p.dw + (long long)g * p.dwgs;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + wn * (BN / 2) + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = co0 + wm * (BM / 2) + i * 32 + row;
+                dwg[(long long)co * p.Kpad + (long long)khkw * p.Cin + ci] = acc[i][j][e];
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                               int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int imgs_per_group, long long w_group_stride, void* stream) {
+    if (n_img <= 0 || Cout <= 0) return MFT_EINVAL;
+    const bool stem = (Cin == 3);
+    if (!stem && (Cin % 32 != 0 || ldi % 4 != 0)) return MFT_EINVAL;
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    if (n_img % imgs_per_group != 0) return MFT_EINVAL;
+    const int groups = n_img / imgs_per_group;
+    ConvArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.ldi = ldi; a.ldo = ldo;
+    a.H = H; a.W = W; a.Cin = Cin; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    a.Cout = Cout;
+    a.Ktot = KH * KW * Cin;
+    a.Kpad = (a.Ktot + 31) / 32 * 32;
+    a.imgs_per_group = imgs_per_group;
+    a.rows_per_group = imgs_per_group * a.OH * a.OW;
+    a.wgs = (groups > 1) ? w_group_stride : 0;
+    a.tiles_n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (stem) return launch_conv<128, 64, 2, 2, true>(a, groups, s);
+    const bool small_m = a.rows_per_group <= 64;
+    if (Cout % 128 == 0) {
+        if (small_m) return launch_conv<64, 128, 2, 2, false>(a, groups, s);
+        return launch_conv<128, 128, 2, 2, false>(a, groups, s);
+    }
+    if (Cout >= 64) {
+        if (small_m) return launch_conv<64, 64, 2, 2, false>(a, groups, s);
+        return launch_conv<128, 64, 2, 2, false>(a, groups, s);
+    }
+    return launch_conv<128, 32, 4, 1, false>(a, groups, s);
+}
+
+extern "C" int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
+                                     int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int imgs_per_group, long long dw_group_stride, void* stream) {
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    if (n_img % imgs_per_group != 0) return MFT_EINVAL;
+    if (Cin % 64 != 0 || Cout % 64 != 0 || ldi % 4 != 0 || ldy % 4 != 0) return MFT_EINVAL;
+    const int groups = n_img / imgs_per_group;
+    WgradArgs a;
+    a.in = in; a.dy = dy; a.dw = dw; a.ldi = ldi; a.ldy = ldy;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    a.Kpad = (KH * KW * Cin + 31) / 32 * 32;
+    a.imgs_per_group = imgs_per_group;
+    a.rows_per_group = imgs_per_group * a.OH * a.OW;
+    a.dwgs = dw_group_stride;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin % 128 == 0 && Cout % 128 == 0) {
+        a.tiles_ci = Cin / 128; a.tiles_co = Cout / 128;
+        dim3 grid(a.tiles_ci * a.tiles_co * KH * KW, groups, 1);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a);
+    } else {
+        a.tiles_ci = Cin / 64; a.tiles_co = Cout / 64;
+        dim3 grid(a.tiles_ci * a.tiles_co * KH * KW, groups, 1);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a);
+    }
+    return mft_launch_status();
+}

@@ -1,0 +1,130 @@
+// GNN few-shot head glue kernels: pairwise |x_i - x_j| features, diagonal-masked row softmax, graph
+// aggregation cat(x, A x) and strided column copies.  The per-pair MLP GEMMs run on mft_conv2d_nhwc
+// (1x1 conv == GEMM) and the BatchNorm/leaky-relu on the grouped BN kernels.
+//
+// Replaces the tensor ops of gnn.Wcompute.forward / gmul / GNN_nl.forward (gnn.py:16-28,78-132,154-166).
+#include "mft_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pair_absdiff_kernel(const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ d, int ldd, int n_graphs, int N,
+                                                           int F) {
+    const int q = ldd >> 2;
+    const long long total = (long long)n_graphs * N * N * q;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % q) * 4;
+        long long t = i / q;
+        const int j = (int)(t % N); t /= N;
+        const int ii = (int)(t % N);
+        const int b = (int)(t / N);
+        const float* xi = x + ((long long)b * N + ii) * ldx + c;
+        const float* xj = x + ((long long)b * N + j) * ldx + c;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c + e < F) ? fabsf(xi[e] - xj[e]) : 0.f;
+        *(f32x4*)(d + i * 4) = o;
+    }
+}
+
+// one wave per (b,i) row; N <= 256 handled by striding
+__global__ __launch_bounds__(256) void masked_softmax_kernel(const float* __restrict__ s, int lds_,
+                                                             float* __restrict__ A, int n_graphs, int N) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long rows = (long long)n_graphs * N;
+    if (row >= rows) return;
+    const int i = (int)(row % N);
+    const float* sr = s + row * N * lds_;
+    float mx = -3.4e38f;
+    for (int j = lane; j < N; j += 64) {
+        float v = sr[(long long)j * lds_] - (j == i ? 1e8f : 0.f);
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < N; j += 64) se += __expf(sr[(long long)j * lds_] - (j == i ? 1e8f : 0.f) - mx);
+    se = wave_sum(se);
+    const float inv = 1.f / se;
+    for (int j = lane; j < N; j += 64)
+        A[row * N + j] = __expf(sr[(long long)j * lds_] - (j == i ? 1e8f : 0.f) - mx) * inv;
+}
+
+// y[b,i,0:F] = x[b,i,0:F]; y[b,i,F:2F] = sum_j A[b,i,j] x[b,j,0:F]; y[b,i,2F:ldy] = 0
+__global__ __launch_bounds__(256) void graph_aggregate_kernel(const float* __restrict__ A,
+                                                              const float* __restrict__ x, int ldx,
+                                                              float* __restrict__ y, int ldy, int n_graphs, int N,
+                                                              int F) {
+    const long long row = blockIdx.x;      // (b,i)
+    const int b = (int)(row / N);
+    const float* Ar = A + row * N;
+    const float* xb = x + (long long)b * N * ldx;
+    const float* xi = x + row * ldx;
+    float* yr = y + row * ldy;
+    for (int c = threadIdx.x; c < ldy; c += blockDim.x) {
+        float o = 0.f;
+        if (c < F) o = xi[c];
+        else if (c < 2 * F) {
+            const int f = c - F;
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc += Ar[j] * xb[(long long)j * ldx + f];
+            o = acc;
+        }
+        yr[c] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                        int ldy, int col_off, int C, long long rows, int act,
+                                                        float slope) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        float v = x[r * ldx + c];
+        if (act == MFT_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == MFT_ACT_LRELU) v = v > 0.f ? v : v * slope;
+        y[r * ldy + col_off + c] = v;
+    }
+}
+
+inline int ggrid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mft_pair_absdiff(const float* x, int ldx, float* d, int ldd, int n_graphs, int N, int F, void* stream) {
+    if (ldd % 4 != 0 || ldx < ldd) return MFT_EINVAL;   // reads up to column ldd-1 of x (finite padding)
+    const long long total = (long long)n_graphs * N * N * (ldd / 4);
+    hipLaunchKernelGGL(pair_absdiff_kernel, dim3(ggrid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, d, ldd,
+                       n_graphs, N, F);
+    return mft_launch_status();
+}
+
+extern "C" int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, void* stream) {
+    const long long rows = (long long)n_graphs * N;
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lds_,
+                       A, n_graphs, N);
+    return mft_launch_status();
+}
+
+extern "C" int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy, int n_graphs, int N,
+                                   int F, void* stream) {
+    if (ldy < 2 * F) return MFT_EINVAL;
+    hipLaunchKernelGGL(graph_aggregate_kernel, dim3(n_graphs * N), dim3(256), 0, (hipStream_t)stream, A, x, ldx, y,
+                       ldy, n_graphs, N, F);
+    return mft_launch_status();
+}
+
+extern "C" int mft_copy_cols(const float* x, int ldx, float* y, int ldy, int col_off, int C, int rows, int act,
+                             float slope, void* stream) {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(ggrid((long long)rows * C)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       y, ldy, col_off, C, (long long)rows, act, slope);
+    return mft_launch_status();
+}

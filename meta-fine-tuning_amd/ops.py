@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C-ABI kernels (include/mft_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the
+current HIP stream; every arithmetic op is a launch into libmft_hip.so.  All
+activations are NHWC fp32 CUDA tensors.  Nothing in this module falls back to
+torch math: a CPU tensor or a missing library raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+BN_EPS = 1e-5
+LRELU_SLOPE = 0.01
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("meta_fine_tuning_amd ops need CUDA (HIP) tensors; got a CPU tensor (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("expected a contiguous float32 tensor, got %s contiguous=%s" % (t.dtype, t.is_contiguous()))
+    return t
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------ layout
+
+def nchw_to_nhwc(x):
+    """[n,C,H,W] -> [n,H,W,C] (boundary ingest)."""
+    _f32c(x)
+    n, C, H, W = x.shape
+    y = torch.empty((n, H, W, C), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_nchw_to_nhwc(_p(x), _p(y), n, C, H, W, _stream()), "mft_nchw_to_nhwc")
+    return y
+
+
+def pack_conv_weight(w):
+    """OIHW (or [out,in] Linear) -> packed [Cout, roundup(KH*KW*Cin,32)]."""
+    if w.dim() == 2:
+        w = w.view(w.shape[0], w.shape[1], 1, 1)
+    w = _f32c(w.detach())
+    Cout, Cin, KH, KW = w.shape
+    kpad = round_up(KH * KW * Cin, 32)
+    pk = torch.empty((Cout, kpad), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_pack_oihw(_p(w), _p(pk), Cout, Cin, KH, KW, kpad, _stream()), "mft_pack_oihw")
+    return pk
+
+
+def unpack_conv_weight(pk, shape):
+    Cout, Cin, KH, KW = shape
+    w = torch.empty(shape, device=pk.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_unpack_oihw(_p(pk), _p(w), Cout, Cin, KH, KW, pk.shape[-1], _stream()), "mft_unpack_oihw")
+    return w
+
+
+def pack_dgrad_weight(w_pk, Cout, Cin, KH, KW, groups=1):
+    """packed fwd weights [groups, Cout, KH*KW*Cin] -> dgrad weights [groups, Cin, KH*KW*Cout]."""
+    w_pk = _f32c(w_pk)
+    K = KH * KW * Cin
+    wt = torch.empty((groups, Cin, KH * KW * Cout), device=w_pk.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_pack_dgrad(_p(w_pk), _p(wt), Cout, Cin, KH, KW, groups, Cout * K, Cin * KH * KW * Cout,
+                                         _stream()), "mft_pack_dgrad")
+    return wt
+
+
+# ------------------------------------------------------------------------------------ conv / gemm
+
+def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=None):
+    """x [n,H,W,Cin] NHWC, w_pk [Cout,Kpad] or [groups,Cout,Kpad] -> [n,OH,OW,Cout]."""
+    _f32c(x)
+    n, H, W, Cin = x.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((n, OH, OW, Cout), device=x.device, dtype=torch.float32)
+    wgs = 0
+    if w_pk.dim() == 3:
+        wgs = w_pk.shape[1] * w_pk.shape[2]
+        if imgs_per_group <= 0 or n // imgs_per_group != w_pk.shape[0]:
+            raise RuntimeError("per-group weights need imgs_per_group with n/imgs_per_group == groups")
+    rc = _lib.lib().mft_conv2d_nhwc(_p(x), Cin, _p(w_pk), _p(bias), _p(out), Cout, n, H, W, Cin, Cout, KH, KW,
+                                    stride, pad, imgs_per_group, wgs, _stream())
+    _lib.check(rc, "mft_conv2d_nhwc")
+    return out
+
+
+def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
+    """out[m, :N] = a[m, :K] @ w_pk[:N, :K].T + bias.  `a` is [M, lda] with lda >= K, K % 32 == 0."""
+    _f32c(a)
+    M, lda = a.shape
+    if out is None:
+        ldo = N if ldo is None else ldo
+        out = torch.empty((M, ldo), device=a.device, dtype=torch.float32)
+    else:
+        ldo = out.shape[1]
+    wgs = 0
+    if w_pk.dim() == 3:
+        wgs = w_pk.shape[1] * w_pk.shape[2]
+    rc = _lib.lib().mft_conv2d_nhwc(_p(a), lda, _p(w_pk), _p(bias), _p(out), ldo, M, 1, 1, K, N, 1, 1, 1, 0,
+                                    rows_per_group, wgs, _stream())
+    _lib.check(rc, "mft_conv2d_nhwc(gemm)")
+    return out
+
+
+def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None):
+    """x [n,H,W,Cin], dy [n,OH,OW,Cout] -> dw [groups, Cout, KH*KW*Cin] (packed layout)."""
+    _f32c(x)
+    _f32c(dy)
+    n, H, W, Cin = x.shape
+    groups = 1 if imgs_per_group <= 0 else n // imgs_per_group
+    K = KH * KW * Cin
+    if out is None:
+        out = torch.empty((groups, Cout, K), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mft_conv2d_wgrad_nhwc(_p(x), Cin, _p(dy), Cout, _p(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
+                                          imgs_per_group, Cout * K, _stream())
+    _lib.check(rc, "mft_conv2d_wgrad_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------ batch norm
+
+def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=None, momentum=0.1, eps=BN_EPS):
+    """x2d [rows, ld] -> mean, rstd [n_groups, C]."""
+    _f32c(x2d)
+    ld = x2d.shape[-1]
+    mean = torch.empty((n_groups, C), device=x2d.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    nws = _lib.lib().mft_bn_stats_ws_floats(C, rows_per_group, n_groups)
+    ws = torch.empty((max(int(nws), 1),), device=x2d.device, dtype=torch.float32)
+    rc = _lib.lib().mft_bn_stats(_p(x2d), ld, C, rows_per_group, n_groups, eps, _p(mean), _p(rstd), _p(ws),
+                                 _p(running_mean), _p(running_var), momentum, _stream())
+    _lib.check(rc, "mft_bn_stats")
+    return mean, rstd
+
+
+def bn_apply(x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act=ACT_NONE, res=None, res_bn=None,
+             out=None, gb_group_stride=0, slope=LRELU_SLOPE):
+    """y = act(bn(x) [+ res | + bn(res)]).  res_bn = (mean, rstd, gamma, beta) of the residual branch."""
+    _f32c(x2d)
+    if out is None:
+        out = torch.empty_like(x2d)
+    rm = rr = rg = rb = None
+    if res_bn is not None:
+        rm, rr, rg, rb = res_bn
+    rc = _lib.lib().mft_bn_apply(_p(x2d), x2d.shape[-1], _p(out), out.shape[-1], C, rows_per_group, n_groups,
+                                 _p(mean), _p(rstd), _p(gamma), _p(beta), gb_group_stride,
+                                 _p(res), 0 if res is None else res.shape[-1], _p(rm), _p(rr), _p(rg), _p(rb),
+                                 act, slope, _stream())
+    _lib.check(rc, "mft_bn_apply")
+    return out
+
+
+def bn_relu_maxpool(x, mean, rstd, gamma, beta, imgs_per_group=0):
+    _f32c(x)
+    n, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((n, OH, OW, C), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mft_bn_relu_maxpool(_p(x), _p(y), n, H, W, C, imgs_per_group, _p(mean), _p(rstd), _p(gamma),
+                                        _p(beta), _stream())
+    _lib.check(rc, "mft_bn_relu_maxpool")
+    return y
+
+
+def global_avgpool(x):
+    _f32c(x)
+    n, H, W, C = x.shape
+    y = torch.empty((n, C), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_global_avgpool(_p(x), _p(y), n, H * W, C, _stream()), "mft_global_avgpool")
+    return y
+
+
+def avgpool_relu_backward(dfeat, out):
+    _f32c(dfeat)
+    _f32c(out)
+    n, H, W, C = out.shape
+    d = torch.empty_like(out)
+    _lib.check(_lib.lib().mft_avgpool_relu_backward(_p(dfeat), _p(out), _p(d), n, H * W, C, _stream()),
+               "mft_avgpool_relu_backward")
+    return d
+
+
+def bn_backward(x2d, dy2d, C, rows_per_group, n_groups, mean, rstd, gamma, relu_out=None, need_dx=True,
+                gb_group_stride=0):
+    """-> dx [rows,C] (or None), dgamma [n_groups,C], dbeta [n_groups,C]."""
+    _f32c(x2d)
+    _f32c(dy2d)
+    dx = torch.empty_like(x2d) if need_dx else None
+    dg = torch.empty((n_groups, C), device=x2d.device, dtype=torch.float32)
+    db = torch.empty_like(dg)
+    rc = _lib.lib().mft_bn_backward(_p(x2d), x2d.shape[-1], _p(dy2d), dy2d.shape[-1], _p(relu_out),
+                                    0 if relu_out is None else relu_out.shape[-1], _p(dx),
+                                    0 if dx is None else dx.shape[-1], C, rows_per_group, n_groups, _p(mean), _p(rstd),
+                                    _p(gamma), gb_group_stride, _p(dg), _p(db), _stream())
+    _lib.check(rc, "mft_bn_backward")
+    return dx, dg, db
+
+
+# ------------------------------------------------------------------------------------ loss / optim
+
+def cross_entropy(logits, labels_i32, rows_per_group, n_groups, need_grad=True):
+    """-> loss [n_groups], dlogits (or None)."""
+    _f32c(logits)
+    rows, C = logits.shape
+    buf = torch.empty((n_groups + rows,), device=logits.device, dtype=torch.float32)
+    d = torch.empty_like(logits) if need_grad else None
+    rc = _lib.lib().mft_cross_entropy(_p(logits), C, _p(labels_i32), C, rows_per_group, n_groups, _p(buf), _p(d),
+                                      _stream())
+    _lib.check(rc, "mft_cross_entropy")
+    return buf[:n_groups], d
+
+
+def softmax_rows(x):
+    _f32c(x)
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().mft_softmax_rows(_p(x), C, _p(y), C, C, rows, _stream()), "mft_softmax_rows")
+    return y
+
+
+def adam_step(p, g, m, v, step, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """In-place fused Adam on flat (contiguous) fp32 tensors of equal numel."""
+    for t in (p, g, m, v):
+        _f32c(t)
+    rc = _lib.lib().mft_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), step, lr, beta1, beta2, eps, weight_decay,
+                                  _stream())
+    _lib.check(rc, "mft_adam_step")
+
+
+def sgd_step(p, g, buf, first_step, lr=0.01, momentum=0.9, dampening=0.9, weight_decay=0.001):
+    rc = _lib.lib().mft_sgd_step(_p(p), _p(g), _p(buf), p.numel(), 1 if first_step else 0, lr, momentum, dampening,
+                                 weight_decay, _stream())
+    _lib.check(rc, "mft_sgd_step")
+
+
+def maml_delta(p, p2, p3):
+    _lib.check(_lib.lib().mft_maml_delta(_p(p), _p(p2), _p(p3), p.numel(), _stream()), "mft_maml_delta")
+
+
+# ------------------------------------------------------------------------------------ gnn glue
+
+def pair_absdiff(x, N, F, ldd):
+    """x [n_graphs*N, ldx] -> d [n_graphs*N*N, ldd] = |x_i - x_j| (zero padded beyond F)."""
+    _f32c(x)
+    n_graphs = x.shape[0] // N
+    d = torch.empty((n_graphs * N * N, ldd), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_pair_absdiff(_p(x), x.shape[1], _p(d), ldd, n_graphs, N, F, _stream()),
+               "mft_pair_absdiff")
+    return d
+
+
+def masked_softmax(s, N):
+    """s [n_graphs*N*N, lds] (column 0) -> A [n_graphs, N, N]."""
+    _f32c(s)
+    n_graphs = s.shape[0] // (N * N)
+    A = torch.empty((n_graphs, N, N), device=s.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_masked_softmax(_p(s), s.shape[1], _p(A), n_graphs, N, _stream()), "mft_masked_softmax")
+    return A
+
+
+def graph_aggregate(A, x, F, ldy):
+    """-> y [n_graphs*N, ldy] = cat(x[:, :F], A@x[:, :F]) zero padded."""
+    _f32c(A)
+    _f32c(x)
+    n_graphs, N, _ = A.shape
+    y = torch.empty((n_graphs * N, ldy), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_graph_aggregate(_p(A), _p(x), x.shape[1], _p(y), ldy, n_graphs, N, F, _stream()),
+               "mft_graph_aggregate")
+    return y
+
+
+def copy_cols(x, y, col_off, C, act=ACT_NONE, slope=LRELU_SLOPE):
+    _lib.check(_lib.lib().mft_copy_cols(_p(x), x.shape[1], _p(y), y.shape[1], col_off, C, x.shape[0], act, slope,
+                                        _stream()), "mft_copy_cols")
+    return y

@@ -1,0 +1,269 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point of libmft_hip.so against a float64
+PyTorch-CPU statement of the same op (tolerances written per test).  `-m gpu` only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_SHAPES = [
+    # name, Cin, Cout, k, stride, pad, H
+    ("trunk.0", 3, 64, 7, 2, 3, 84),
+    ("trunk.4.C1", 64, 64, 3, 1, 1, 21),
+    ("trunk.5.C1", 64, 128, 3, 2, 1, 21),
+    ("trunk.5.C2", 128, 128, 3, 1, 1, 11),
+    ("trunk.5.shortcut", 64, 128, 1, 2, 0, 21),
+    ("trunk.6.C1", 128, 256, 3, 2, 1, 11),
+    ("trunk.6.C2", 256, 256, 3, 1, 1, 6),
+    ("trunk.6.shortcut", 128, 256, 1, 2, 0, 11),
+    ("trunk.7.C1", 256, 512, 3, 2, 1, 6),
+    ("trunk.7.C2", 512, 512, 3, 1, 1, 3),
+    ("trunk.7.shortcut", 256, 512, 1, 2, 0, 6),
+    ("trunk.7.C2@224", 512, 512, 3, 1, 1, 7),
+    ("trunk.0@224", 3, 64, 7, 2, 3, 224),
+]
+
+
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H", CONV_SHAPES)
+def test_conv2d_forward(name, Cin, Cout, k, stride, pad, H):
+    n = 5 if H < 200 else 2
+    x = rnd((n, Cin, H, H), 1)
+    w = rnd((Cout, Cin, k, k), 2, scale=(2.0 / (k * k * Cout)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    xg = ops.nchw_to_nhwc(x.to(DEV)) if Cin == 3 else nhwc(x).to(DEV)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    y = ops.conv2d(xg, wpk, Cout, k, k, stride, pad)
+    got = nchw(y.cpu()).double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), name
+
+
+def test_conv2d_grouped_weights():
+    """Per-episode weights: 3 groups x 5 images of trunk.7.C2 / C1 shapes; M tiles never straddle groups."""
+    G, ipg = 3, 5
+    for (Cin, Cout, k, stride, pad, H) in ((512, 512, 3, 1, 1, 3), (256, 512, 3, 2, 1, 6), (256, 512, 1, 2, 0, 6)):
+        x = rnd((G * ipg, Cin, H, H), 3)
+        w = rnd((G, Cout, Cin, k, k), 4, scale=0.05)
+        ref = torch.cat([F.conv2d(x[g * ipg:(g + 1) * ipg].double(), w[g].double(), None, stride, pad) for g in range(G)])
+        wpk = torch.stack([ops.pack_conv_weight(w[g].to(DEV)) for g in range(G)])
+        y = ops.conv2d(nhwc(x).to(DEV), wpk, Cout, k, k, stride, pad, imgs_per_group=ipg)
+        got = nchw(y.cpu()).double()
+        assert float((got - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("M,K,N", [(13500, 133, 192), (13500, 192, 96), (450, 266, 48), (450, 458, 5), (13500, 96, 1),
+                                   (100, 512, 128), (7, 32, 33)])
+def test_gemm_padded(M, K, N):
+    Kp = ops.round_up(K, 32)
+    a = torch.zeros(M, Kp + 32)
+    a[:, :K] = rnd((M, K), 5)
+    a[:, K:] = 7.0                       # junk beyond K inside the padded row must be masked by zero weights
+    w = rnd((N, K), 6, scale=K ** -0.5)
+    b = rnd((N,), 7)
+    ref = a[:, :K].double() @ w.double().t() + b.double()
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    assert wpk.shape == (N, Kp)
+    y = ops.gemm(a.to(DEV), Kp, wpk, N, bias=b.to(DEV))
+    assert float((y.cpu().double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+def test_pack_roundtrip_and_dgrad():
+    Cout, Cin, k, H, n = 512, 512, 3, 3, 5
+    w = rnd((Cout, Cin, k, k), 8, scale=0.02)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    assert torch.equal(ops.unpack_conv_weight(wpk, (Cout, Cin, k, k)).cpu(), w)
+    dy = rnd((n, Cout, H, H), 9)
+    ref = torch.nn.grad.conv2d_input((n, Cin, H, H), w.double(), dy.double(), stride=1, padding=1)
+    wt = ops.pack_dgrad_weight(wpk.view(1, Cout, -1), Cout, Cin, k, k, 1)[0]
+    dx = ops.conv2d(nhwc(dy).to(DEV), wt, Cin, k, k, 1, 1)
+    got = nchw(dx.cpu()).double()
+    assert float((got - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,G,ipg", [
+    (512, 512, 3, 1, 1, 3, 3, 5), (256, 512, 3, 2, 1, 6, 3, 5), (256, 512, 1, 2, 0, 6, 2, 5),
+    (512, 512, 3, 1, 1, 7, 1, 5), (64, 64, 3, 1, 1, 21, 1, 4), (256, 512, 3, 2, 1, 6, 1, 1)])
+def test_conv2d_wgrad(Cin, Cout, k, stride, pad, H, G, ipg):
+    OH = (H + 2 * pad - k) // stride + 1
+    x = rnd((G * ipg, Cin, H, H), 10)
+    dy = rnd((G * ipg, Cout, OH, OH), 11)
+    ref = torch.stack([torch.nn.grad.conv2d_weight(x[g * ipg:(g + 1) * ipg].double(), (Cout, Cin, k, k),
+                                                   dy[g * ipg:(g + 1) * ipg].double(), stride=stride, padding=pad)
+                       for g in range(G)])
+    dw = ops.conv2d_wgrad(nhwc(x).to(DEV), nhwc(dy).to(DEV), Cout, k, k, stride, pad, imgs_per_group=ipg)
+    got = dw.cpu().view(G, Cout, k, k, Cin).permute(0, 1, 4, 2, 3).double()
+    assert float((got - ref).abs().max()) <= 3e-5 * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("rows,C,G", [(45, 512, 4), (2205, 64, 3), (8820, 64, 1), (13500, 192, 1), (450, 48, 2),
+                                      (100, 128, 1), (1, 512, 2)])
+def test_bn_stats_apply_backward(rows, C, G):
+    x = rnd((G * rows, C), 12) * 2.0 + 3.0            # non-zero mean: exercises the shifted-moment path
+    gamma, beta = rnd((C,), 13).abs() + 0.5, rnd((C,), 14)
+    res = rnd((G * rows, C), 15)
+    dy = rnd((G * rows, C), 16)
+    xg = x.to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, rstd = ops.bn_stats(xg, C, rows, G, rm if G == 1 else None, rv if G == 1 else None)
+    xd = x.double().view(G, rows, C)
+    mref = xd.mean(1)
+    vref = xd.var(1, unbiased=False)
+    assert float((mean.cpu().double() - mref).abs().max()) < 1e-5
+    np.testing.assert_allclose(rstd.cpu().double().numpy(), (1.0 / torch.sqrt(vref + 1e-5)).numpy(), rtol=2e-5)
+    if G == 1 and rows > 1:
+        np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mref[0]).float().numpy(), atol=1e-6)
+        np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * xd.var(1, unbiased=True)[0]).float().numpy(), rtol=2e-5)
+    # apply (+ residual, relu)
+    y = ops.bn_apply(xg, C, rows, G, mean, rstd, gamma.to(DEV), beta.to(DEV), act=ops.ACT_RELU, res=res.to(DEV))
+    xhat = (xd - mref[:, None]) / torch.sqrt(vref[:, None] + 1e-5)
+    yref = torch.relu(xhat * gamma.double() + beta.double() + res.double().view(G, rows, C))
+    assert float((y.cpu().double().view(G, rows, C) - yref).abs().max()) < 2e-5
+    y2 = ops.bn_apply(xg, C, rows, G, mean, rstd, gamma.to(DEV), beta.to(DEV), act=ops.ACT_LRELU)
+    y2ref = F.leaky_relu(xhat * gamma.double() + beta.double(), 0.01)
+    assert float((y2.cpu().double().view(G, rows, C) - y2ref).abs().max()) < 2e-5
+    # backward through relu(bn(x)+res)
+    if rows > 1:
+        xa = x.double().view(G, rows, C).clone().requires_grad_(True)
+        ga = gamma.double().clone().requires_grad_(True)
+        ba = beta.double().clone().requires_grad_(True)
+        mu = xa.mean(1, keepdim=True)
+        va = xa.var(1, unbiased=False, keepdim=True)
+        out = torch.relu((xa - mu) / torch.sqrt(va + 1e-5) * ga + ba + res.double().view(G, rows, C))
+        gx, = torch.autograd.grad(out, xa, dy.double().view(G, rows, C), retain_graph=True)
+        dx, dg, db = ops.bn_backward(xg, dy.to(DEV), C, rows, G, mean, rstd, gamma.to(DEV), relu_out=y)
+        assert float((dx.cpu().double().view(G, rows, C) - gx).abs().max()) < 5e-5 * max(1.0, float(gx.abs().max()))
+        for g in range(G):
+            gg, gb = torch.autograd.grad(out[g], [ga, ba], dy.double().view(G, rows, C)[g], retain_graph=True)
+            assert float((dg[g].cpu().double() - gg).abs().max()) < 1e-4 * max(1.0, float(gg.abs().max()))
+            assert float((db[g].cpu().double() - gb).abs().max()) < 1e-4 * max(1.0, float(gb.abs().max()))
+
+
+def test_bn_apply_residual_bn():
+    rows, C, G = 45, 512, 3
+    x, r = rnd((G * rows, C), 17), rnd((G * rows, C), 18)
+    g1, b1, g2, b2 = (rnd((G, C), s) for s in (19, 20, 21, 22))     # per-group affine (per-episode last block)
+    xg, rg = x.to(DEV), r.to(DEV)
+    m1, s1 = ops.bn_stats(xg, C, rows, G)
+    m2, s2 = ops.bn_stats(rg, C, rows, G)
+    y = ops.bn_apply(xg, C, rows, G, m1, s1, g1.to(DEV), b1.to(DEV), act=ops.ACT_RELU, res=rg,
+                     res_bn=(m2, s2, g2.to(DEV), b2.to(DEV)), gb_group_stride=C)
+    xd, rd = x.double().view(G, rows, C), r.double().view(G, rows, C)
+
+    def bn(t, g, b):
+        return (t - t.mean(1, keepdim=True)) / torch.sqrt(t.var(1, unbiased=False, keepdim=True) + 1e-5) * g[:, None].double() + b[:, None].double()
+    ref = torch.relu(bn(xd, g1, b1) + bn(rd, g2, b2))
+    assert float((y.cpu().double().view(G, rows, C) - ref).abs().max()) < 3e-5
+
+
+def test_stem_tail_and_pools():
+    n, H, C = 10, 42, 64
+    x = rnd((n, C, H, H), 23)
+    gamma, beta = rnd((C,), 24).abs() + 0.5, rnd((C,), 25)
+    xg = nhwc(x).to(DEV)
+    ipg = 5
+    mean, rstd = ops.bn_stats(xg.view(-1, C), C, ipg * H * H, n // ipg)
+    y = ops.bn_relu_maxpool(xg, mean, rstd, gamma.to(DEV), beta.to(DEV), imgs_per_group=ipg)
+    refs = []
+    for g in range(n // ipg):
+        xx = x[g * ipg:(g + 1) * ipg].double()
+        bn = F.batch_norm(xx, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5)
+        refs.append(F.max_pool2d(torch.relu(bn), 3, 2, 1))
+    ref = torch.cat(refs)
+    assert float((nchw(y.cpu()).double() - ref).abs().max()) < 2e-5
+    # global avgpool + its backward fused with relu backward
+    o = torch.relu(rnd((n, 512, 3, 3), 26))
+    og = nhwc(o).to(DEV)
+    f = ops.global_avgpool(og)
+    assert float((f.cpu().double() - o.double().mean((2, 3))).abs().max()) < 1e-6
+    df = rnd((n, 512), 27)
+    d = ops.avgpool_relu_backward(df.to(DEV), og)
+    ref = (o > 0).double() * df.double()[:, :, None, None] / 9.0
+    assert float((nchw(d.cpu()).double() - ref).abs().max()) < 1e-7
+
+
+def test_cross_entropy_softmax():
+    G, rpg, C = 4, 5, 512
+    x = rnd((G * rpg, C), 28) * 3
+    y = torch.from_numpy(np.random.RandomState(29).randint(0, 5, size=(G * rpg,)))
+    loss, d = ops.cross_entropy(x.to(DEV), y.to(torch.int32).to(DEV), rpg, G)
+    for g in range(G):
+        xa = x[g * rpg:(g + 1) * rpg].double().requires_grad_(True)
+        l = F.cross_entropy(xa, y[g * rpg:(g + 1) * rpg])
+        gx, = torch.autograd.grad(l, xa)
+        assert abs(float(loss[g].cpu()) - float(l)) < 1e-5
+        assert float((d[g * rpg:(g + 1) * rpg].cpu().double() - gx).abs().max()) < 1e-6
+    s = ops.softmax_rows(x[:75, :5].contiguous().to(DEV))
+    assert float((s.cpu().double() - F.softmax(x[:75, :5].double(), 1)).abs().max()) < 1e-6
+
+
+def test_adam_sgd_maml():
+    n = 3_673_088 + 3
+    p, g = rnd((n,), 30, 0.05), rnd((n,), 31, 1e-3)
+    pd, md, vd = p.double().clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    pg, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t in range(1, 4):
+        gt = g * t
+        ops.adam_step(pg, gt.to(DEV), m, v, t, lr=0.01)
+        gd = gt.double()
+        md = 0.9 * md + 0.1 * gd
+        vd = 0.999 * vd + 0.001 * gd * gd
+        pd = pd - (0.01 / (1 - 0.9 ** t)) * md / (vd.sqrt() / (1 - 0.999 ** t) ** 0.5 + 1e-8)
+    assert float((pg.cpu().double() - pd).abs().max()) < 1e-6
+    # SGD with momentum/dampening/wd
+    p2, buf = p[:2565].clone().to(DEV), torch.zeros(2565, device=DEV)
+    pr, br = p[:2565].double().clone(), None
+    for t in range(3):
+        gt = g[:2565] * (t + 1)
+        ops.sgd_step(p2, gt.to(DEV), buf, first_step=(t == 0))
+        ge = gt.double() + 0.001 * pr
+        br = ge.clone() if br is None else 0.9 * br + 0.1 * ge
+        pr = pr - 0.01 * br
+    assert float((p2.cpu().double() - pr).abs().max()) < 1e-7
+    a, b, c = rnd((1000,), 32), rnd((1000,), 33), rnd((1000,), 34)
+    ag = a.to(DEV)
+    ops.maml_delta(ag, b.to(DEV), c.to(DEV))
+    assert torch.equal(ag.cpu(), a - (c - b))
+
+
+@pytest.mark.parametrize("B,N,Fd", [(15, 30, 133), (2, 105, 181), (2, 130, 229)])
+def test_gnn_glue(B, N, Fd):
+    ld = 256
+    x = torch.zeros(B * N, ld)
+    x[:, :Fd] = rnd((B * N, Fd), 35)
+    Kp = ops.round_up(Fd, 32)
+    d = ops.pair_absdiff(x.to(DEV), N, Fd, Kp)
+    xv = x[:, :Fd].view(B, N, Fd)
+    ref = (xv.unsqueeze(2) - xv.unsqueeze(1)).abs().reshape(B * N * N, Fd)
+    assert torch.equal(d.cpu()[:, :Fd], ref) and float(d.cpu()[:, Fd:].abs().max()) == 0.0
+    s = torch.zeros(B * N * N, 4)
+    s[:, 0] = rnd((B * N * N,), 36) * 2
+    A = ops.masked_softmax(s.to(DEV), N)
+    sref = s[:, 0].double().view(B, N, N) - torch.eye(N, dtype=torch.float64) * 1e8
+    Aref = F.softmax(sref, 2)
+    assert float((A.cpu().double() - Aref).abs().max()) < 1e-6
+    y = ops.graph_aggregate(A, x.to(DEV), Fd, ops.round_up(2 * Fd, 32))
+    yref = torch.cat([xv.double(), torch.bmm(A.cpu().double(), xv.double())], 2).view(B * N, 2 * Fd)
+    assert float((y.cpu().double()[:, :2 * Fd] - yref).abs().max()) < 1e-5
+    assert float(y.cpu()[:, 2 * Fd:].abs().max()) == 0.0
+    z = torch.zeros(B * N, ld, device=DEV)
+    ops.copy_cols(y, z, 7, 48, act=ops.ACT_LRELU)
+    assert float((z.cpu()[:, 7:55].double() - F.leaky_relu(y.cpu()[:, :48].double(), 0.01)).abs().max()) < 1e-7
