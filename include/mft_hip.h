@@ -126,6 +126,17 @@ int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int l
 int mft_copy_cols(const float* x, int ldx, float* y, int ldy, int col_off, int C, int rows,
                   int act, float slope, void* stream);
 
+/* z_stack + cat(z, support_label) (gnnnet.py:34-38,82-83,212): z [n_episodes*n_way*(S+n_query), zf] with
+ * S = n_support (fold 0) or 2*n_support (fold 1: supports k and k+n_support averaged, gnnnet_copy.py:67-72)
+ * -> nodes [n_episodes*n_query*n_way*(n_support+1), ld] = [z | one-hot label (zero for the query slot) | 0..] */
+int mft_build_graph_nodes(const float* z, int zf, float* nodes, int ld, int n_episodes, int n_way,
+                          int n_support, int n_query, int fold, void* stream);
+/* forward_gnn tail (gnnnet.py:215-216): scores[e, c*n_query+q, :] = out[node(e,q,c,last), :n_way] */
+int mft_gather_query_scores(const float* out, int ldo, float* scores, int n_episodes, int n_way,
+                            int n_support, int n_query, void* stream);
+/* x_a_i[selected_id] (finetune.py:282; gnnnet.py:162): dst[r,:] = src[idx[r],:], rows of row_floats (%4==0) floats */
+int mft_gather_rows(const float* src, const int* idx, float* dst, int n_rows, long long row_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ SIGNATURES = {
     "mft_masked_softmax": [_P, _I, _P, _I, _I, _P],
     "mft_graph_aggregate": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mft_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "mft_build_graph_nodes": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mft_gather_query_scores": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "mft_gather_rows": [_P, _P, _P, _I, _L, _P],
 }
 _RESTYPE = {"mft_bn_stats_ws_floats": _L}
 

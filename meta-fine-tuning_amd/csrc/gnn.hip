@@ -90,6 +90,59 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict_
     }
 }
 
+
+// nodes[((e*nq+i)*n_way+c)*(ns+1)+s] = cat(z[e, c, s<ns ? s : ns+i, :], onehot(c) if s<ns else 0), zero padded to ld.
+// fold != 0: the 2*ns supports per class are averaged pairwise (k with k+ns) first (gnnnet_copy.py:67-72).
+__global__ __launch_bounds__(256) void build_nodes_kernel(const float* __restrict__ z, int zf, float* __restrict__ nodes,
+                                                          int ld, int n_ep, int n_way, int ns, int nq, int fold) {
+    const long long rows = (long long)n_ep * nq * n_way * (ns + 1);
+    const int per_class = (fold ? 2 * ns : ns) + nq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * ld;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % ld);
+        long long r = i / ld;
+        const int s = (int)(r % (ns + 1)); r /= (ns + 1);
+        const int c = (int)(r % n_way); r /= n_way;
+        const int q = (int)(r % nq);
+        const int e = (int)(r / nq);
+        float v = 0.f;
+        const float* zc = z + ((long long)e * n_way + c) * per_class * zf;
+        if (col < zf) {
+            if (s < ns) v = fold ? 0.5f * (zc[(long long)s * zf + col] + zc[(long long)(s + ns) * zf + col]) : zc[(long long)s * zf + col];
+            else v = zc[(long long)((fold ? 2 * ns : ns) + q) * zf + col];
+        } else if (col < zf + n_way) {
+            v = (s < ns && col - zf == c) ? 1.f : 0.f;
+        }
+        nodes[i] = v;
+    }
+}
+
+// scores[e, c*nq+q, :] = out[((e*nq+q)*n_way+c)*(ns+1)+ns, :n_way]   (gnnnet.py:215-216)
+__global__ void gather_scores_kernel(const float* __restrict__ out, int ldo, float* __restrict__ scores, int n_ep,
+                                     int n_way, int ns, int nq) {
+    const long long total = (long long)n_ep * n_way * nq * n_way;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % n_way);
+    long long r = i / n_way;
+    const int q = (int)(r % nq); r /= nq;
+    const int c = (int)(r % n_way);
+    const int e = (int)(r / n_way);
+    const long long node = (((long long)e * nq + q) * n_way + c) * (ns + 1) + ns;
+    scores[i] = out[node * ldo + k];
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ dst, int n_rows, long long row_f4) {
+    const long long total = (long long)n_rows * row_f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / row_f4;
+        const long long c = i - r * row_f4;
+        ((f32x4*)dst)[i] = ((const f32x4*)src)[(long long)idx[r] * row_f4 + c];
+    }
+}
+
 inline int ggrid(long long total) {
     long long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -126,5 +179,30 @@ extern "C" int mft_copy_cols(const float* x, int ldx, float* y, int ldy, int col
                              float slope, void* stream) {
     hipLaunchKernelGGL(copy_cols_kernel, dim3(ggrid((long long)rows * C)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        y, ldy, col_off, C, (long long)rows, act, slope);
+    return mft_launch_status();
+}
+
+extern "C" int mft_build_graph_nodes(const float* z, int zf, float* nodes, int ld, int n_episodes, int n_way,
+                                     int n_support, int n_query, int fold, void* stream) {
+    if (ld < zf + n_way) return MFT_EINVAL;
+    const long long total = (long long)n_episodes * n_query * n_way * (n_support + 1) * ld;
+    hipLaunchKernelGGL(build_nodes_kernel, dim3(ggrid(total)), dim3(256), 0, (hipStream_t)stream, z, zf, nodes, ld,
+                       n_episodes, n_way, n_support, n_query, fold);
+    return mft_launch_status();
+}
+
+extern "C" int mft_gather_query_scores(const float* out, int ldo, float* scores, int n_episodes, int n_way,
+                                       int n_support, int n_query, void* stream) {
+    const long long total = (long long)n_episodes * n_way * n_query * n_way;
+    hipLaunchKernelGGL(gather_scores_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       ldo, scores, n_episodes, n_way, n_support, n_query);
+    return mft_launch_status();
+}
+
+extern "C" int mft_gather_rows(const float* src, const int* idx, float* dst, int n_rows, long long row_floats,
+                               void* stream) {
+    if (row_floats % 4 != 0) return MFT_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ggrid((long long)n_rows * (row_floats / 4))), dim3(256), 0,
+                       (hipStream_t)stream, src, idx, dst, n_rows, row_floats / 4);
     return mft_launch_status();
 }

@@ -1,0 +1,147 @@
+"""Episode-batched test-time fine-tuning engine (the BASELINE.json hot path).
+
+``finetune.finetune`` (finetune.py:182-328) fine-tunes ONE episode at a time: 500-5000 sequential
+Adam steps on a 5-image mini-batch, i.e. ~2 GFLOP per step -- far too little to fill 256 CUs.
+Episodes are independent (each reloads the checkpoint, finetune.py:185-198), so this engine runs
+``E`` episodes in lockstep: step ``t`` of all episodes is one set of grouped launches over E*5
+images with per-episode BatchNorm statistics (the frozen trunk.0-6 weights are shared) and
+per-episode last-block weights / Adam state held in HBM (44 MB per episode).  Host work per batch
+is index tables only; the numpy permutations are drawn in the reference's order.
+"""
+import numpy as np
+import torch
+
+from . import functional as Fn
+from . import ops
+
+
+class AdaptState:
+    """Per-episode adaptable parameters + gradient + Adam moments (four tensor-major slabs)."""
+
+    def __init__(self, E, device):
+        self.E = E
+        self.w = Fn.LastBlockSlab(E, device)
+        self.g = Fn.LastBlockSlab(E, device)
+        self.m = Fn.LastBlockSlab(E, device)
+        self.v = Fn.LastBlockSlab(E, device)
+        self.step = 0
+
+    def reset(self, W):
+        self.w.load_shared(W)
+        self.m.flat.zero_()
+        self.v.flat.zero_()
+        self.step = 0
+
+
+def draw_perms(n_total, total_epoch, rng=np.random):
+    """finetune.py:270-272: one np.random.permutation(n_total) per epoch, from the global numpy RNG."""
+    return [rng.permutation(n_total) for _ in range(total_epoch)]
+
+
+class FinetuneEngine:
+    def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
+                 episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False):
+        """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
+        ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
+        self.dev = torch.device(device)
+        self.n_way, self.n_support, self.n_query = n_way, n_support, n_query
+        self.size, self.n_views, self.epochs = image_size, n_views, fine_tune_epoch
+        self.E, self.bs, self.lr = episodes_per_batch, batch_size, lr
+        self.fold50 = fold50
+        self.n_per_view = n_way * n_support
+        self.n_total = self.n_per_view * (n_views + 1)            # finetune.py:214-233,269
+        self.n_all = n_way * (n_support + n_query)
+        fsd = {k[len("feature."):]: v for k, v in state.items()
+               if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))}
+        self.W = Fn.ResNet10Weights(fsd, self.dev)
+        self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way)
+        self.arena = Fn.Arena(self.dev)
+        self.adapt = AdaptState(self.E, self.dev)
+        px = image_size * image_size * 3
+        self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
+        self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
+        ya = np.repeat(np.arange(n_way), n_support)
+        self.y_support = np.tile(ya, n_views + 1).astype(np.int32)
+
+    # ------------------------------------------------------------------ ingest
+    def load_episode(self, slot, liz_x):
+        """finetune.py:208-233: support images of view 0 twice, then of views 1.. (device NCHW -> NHWC store)."""
+        ns, npv, H = self.n_support, self.n_per_view, self.size
+        assert len(liz_x) == self.n_views
+        x0 = liz_x[0].to(self.dev, non_blocking=True)
+        assert x0.shape[1] == ns + self.n_query
+        base = slot * self.n_total
+        store = self.Xs.view(self.E * self.n_total, H, H, 3)
+        lib = ops._lib.lib()
+
+        def put(dst_row, src_nchw, n):
+            rc = lib.mft_nchw_to_nhwc(ops._p(src_nchw), ops._p(store[dst_row]), n, 3, H, H, ops._stream())
+            ops._lib.check(rc, "mft_nchw_to_nhwc")
+
+        xa0 = x0[:, :ns].contiguous().view(npv, 3, H, H)
+        put(base, xa0, npv)
+        put(base + npv, xa0, npv)
+        for vi, xv in enumerate(liz_x[1:]):
+            xa = xv.to(self.dev, non_blocking=True)[:, :ns].contiguous().view(npv, 3, H, H)
+            put(base + (vi + 2) * npv, xa, npv)
+        xin = x0.contiguous().view(self.n_all, 3, H, H)
+        rc = lib.mft_nchw_to_nhwc(ops._p(xin), ops._p(self.Xall[slot * self.n_all]), self.n_all, 3, H, H, ops._stream())
+        ops._lib.check(rc, "mft_nchw_to_nhwc")
+
+    def step_tables(self, perms, n_active):
+        """Index/label tables for all inner steps.  perms[e][epoch] is a permutation of n_total."""
+        E, bs, nt = self.E, self.bs, self.n_total
+        tables = []
+        for ep in range(self.epochs):
+            for j in range(0, nt, bs):
+                k = min(bs, nt - j)
+                idx = np.empty((E, k), dtype=np.int32)
+                lab = np.empty((E, k), dtype=np.int32)
+                for e in range(E):
+                    sel = perms[min(e, n_active - 1)][ep][j:j + k]
+                    idx[e] = e * nt + sel
+                    lab[e] = self.y_support[sel]
+                tables.append((k, idx.reshape(-1), lab.reshape(-1)))
+        return tables
+
+    # ------------------------------------------------------------------ inner loop
+    def inner_step(self, idx_dev, lab_dev, k):
+        E, H = self.E, self.size
+        xb = ops.gather_rows(self.Xs, idx_dev, out=self.arena.get("xb%d" % k, (E * k, H * H * 3)))
+        tape = {}
+        feat = Fn.resnet10_forward(self.W, xb.view(E * k, H, H, 3), self.arena, ipg=k, slab=self.adapt.w, tape=tape,
+                                   tag="s%d" % k)
+        loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
+        Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k)
+        self.adapt.step += 1
+        ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
+                      lr=self.lr)
+        return loss
+
+    def final_scores(self):
+        """finetune.py:306-317: transductive feature pass over all n_way*(n_support+n_query) images, then
+        GnnNet.set_forward(is_feature=True) and softmax.  (finetune.py:307's second pass is dead compute.)"""
+        feats = Fn.resnet10_forward(self.W, self.Xall, self.arena, ipg=self.n_all, slab=self.adapt.w, tag="fin")
+        ns = self.n_support // 2 if self.fold50 else self.n_support
+        scores = Fn.gnnnet_scores(self.G, feats, self.E, self.n_way, ns, self.n_query, self.arena, fold=self.fold50)
+        return ops.softmax_rows(scores).view(self.E, self.n_way * self.n_query, self.n_way), feats
+
+    def run_batch(self, episodes, perms=None, return_feats=False):
+        """episodes: list (<= E) of liz_x; perms: per-episode list of per-epoch permutations (default: drawn from
+        the global numpy RNG episode by episode, exactly the reference's draw order).  Returns softmax scores
+        [len(episodes), n_way*n_query, n_way]."""
+        n = len(episodes)
+        assert 0 < n <= self.E
+        if perms is None:
+            perms = [draw_perms(self.n_total, self.epochs) for _ in range(n)]
+        for slot in range(self.E):
+            self.load_episode(slot, episodes[min(slot, n - 1)])      # pad a short batch by repeating the last episode
+        self.adapt.reset(self.W)
+        for k, idx, lab in self.step_tables(perms, n):
+            self.inner_step(torch.from_numpy(idx).to(self.dev), torch.from_numpy(lab).to(self.dev), k)
+        scores, feats = self.final_scores()
+        if return_feats:
+            return scores[:n], feats.view(self.E, self.n_all, 512)[:n]
+        return scores[:n]

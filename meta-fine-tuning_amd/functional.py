@@ -1,0 +1,357 @@
+"""Device-side functional layer: ResNet10 forward, last-block backward and the GNN head expressed
+as sequences of launches into libmft_hip.so (via ``ops``).  Everything is *grouped*: a call
+processes ``n_groups`` independent BatchNorm mini-batches / episodes at once, optionally with
+per-group last-block weights (the episode-batched inner loop).
+
+Reference call sites restated: backbone.ResNet.forward / SimpleBlock.forward
+(backbone.py:251-261,401-439), the autograd of the inner-loop loss (finetune.py:286-299;
+gnnnet.py:168-177), gnn.GNN_nl / Wcompute / Gconv (gnn.py:16-166), GnnNet.fc and forward_gnn
+(gnnnet.py:30,82-87,210-217).
+"""
+import torch
+
+from . import ops
+
+STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
+
+# adaptable tensors of trunk.7 in reference named_parameters() order (finetune.py:236-252)
+ADAPT_KEYS = [
+    "trunk.7.C1.weight", "trunk.7.BN1.weight", "trunk.7.BN1.bias",
+    "trunk.7.C2.weight", "trunk.7.BN2.weight", "trunk.7.BN2.bias",
+    "trunk.7.shortcut.weight", "trunk.7.BNshortcut.weight", "trunk.7.BNshortcut.bias",
+]
+ADAPT_SHAPES = {
+    "trunk.7.C1.weight": (512, 256, 3, 3), "trunk.7.C2.weight": (512, 512, 3, 3),
+    "trunk.7.shortcut.weight": (512, 256, 1, 1),
+    "trunk.7.BN1.weight": (512,), "trunk.7.BN1.bias": (512,), "trunk.7.BN2.weight": (512,),
+    "trunk.7.BN2.bias": (512,), "trunk.7.BNshortcut.weight": (512,), "trunk.7.BNshortcut.bias": (512,),
+}
+ADAPT_NUMEL = sum(int(torch.Size(s).numel()) for s in ADAPT_SHAPES.values())      # 3,673,088
+
+
+class Arena:
+    """Named, shape-keyed persistent device buffers: static addresses (hipGraph-friendly), no per-step malloc."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), device=self.device, dtype=dtype)
+            self.bufs[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class ResNet10Weights:
+    """Packed device copy of a backbone.ResNet10 state dict (keys 'trunk.*' under ``prefix``)."""
+
+    def __init__(self, sd, device, prefix=""):
+        self.device = device
+        self.conv = {}
+        self.bn = {}
+
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        def conv(name):
+            self.conv[name] = ops.pack_conv_weight(dev(sd[prefix + name + ".weight"]))
+
+        def bn(name):
+            self.bn[name] = (dev(sd[prefix + name + ".weight"]), dev(sd[prefix + name + ".bias"]))
+
+        conv("trunk.0")
+        bn("trunk.1")
+        for idx, (cin, cout, s) in STAGES.items():
+            p = "trunk.%d" % idx
+            conv(p + ".C1"); bn(p + ".BN1"); conv(p + ".C2"); bn(p + ".BN2")
+            if cin != cout:
+                conv(p + ".shortcut"); bn(p + ".BNshortcut")
+
+
+class LastBlockSlab:
+    """``E`` copies of trunk.7's nine adaptable tensors, tensor-major inside ONE flat fp32 buffer
+    (so Adam over all episodes is a single launch and every kernel sees a constant group stride).
+    Conv weights are kept in the packed [Cout][KH][KW][Cin] layout."""
+
+    ORDER = [("c1w", 512 * 2304), ("c2w", 512 * 4608), ("scw", 512 * 256),
+             ("bn1g", 512), ("bn1b", 512), ("bn2g", 512), ("bn2b", 512), ("bnsg", 512), ("bnsb", 512)]
+    KEY = {"c1w": "trunk.7.C1.weight", "c2w": "trunk.7.C2.weight", "scw": "trunk.7.shortcut.weight",
+           "bn1g": "trunk.7.BN1.weight", "bn1b": "trunk.7.BN1.bias", "bn2g": "trunk.7.BN2.weight",
+           "bn2b": "trunk.7.BN2.bias", "bnsg": "trunk.7.BNshortcut.weight", "bnsb": "trunk.7.BNshortcut.bias"}
+
+    def __init__(self, E, device, zero=True):
+        self.E = E
+        total = E * ADAPT_NUMEL
+        self.flat = torch.zeros(total, device=device) if zero else torch.empty(total, device=device)
+        off = 0
+        for name, n in self.ORDER:
+            v = self.flat[off:off + E * n]
+            if name.endswith("w"):
+                cout = 512
+                v = v.view(E, cout, n // cout)
+            else:
+                v = v.view(E, n)
+            setattr(self, name, v)
+            off += E * n
+        assert off == total
+
+    def load_shared(self, W):
+        """Every episode starts from the same checkpoint weights (finetune.py:185-198)."""
+        self.c1w.copy_(W.conv["trunk.7.C1"].unsqueeze(0).expand_as(self.c1w))
+        self.c2w.copy_(W.conv["trunk.7.C2"].unsqueeze(0).expand_as(self.c2w))
+        self.scw.copy_(W.conv["trunk.7.shortcut"].unsqueeze(0).expand_as(self.scw))
+        for nm, bnname in (("bn1", "trunk.7.BN1"), ("bn2", "trunk.7.BN2"), ("bns", "trunk.7.BNshortcut")):
+            g, b = W.bn[bnname]
+            getattr(self, nm + "g").copy_(g.unsqueeze(0).expand(self.E, -1))
+            getattr(self, nm + "b").copy_(b.unsqueeze(0).expand(self.E, -1))
+
+    def export(self, e):
+        """Episode ``e``'s tensors as a reference-keyed dict (OIHW conv weights)."""
+        out = {}
+        for name, _ in self.ORDER:
+            key = self.KEY[name]
+            t = getattr(self, name)[e]
+            if name.endswith("w"):
+                out[key] = ops.unpack_conv_weight(t.contiguous(), ADAPT_SHAPES[key])
+            else:
+                out[key] = t.clone()
+        return out
+
+
+def _bn_stats4(arena, tag, x, ipg, groups, running=None):
+    n, H, W, C = x.shape
+    mean = arena.get(tag + ".mean", (groups, C))
+    rstd = arena.get(tag + ".rstd", (groups, C))
+    rows = ipg * H * W
+    nws = max(int(ops._lib.lib().mft_bn_stats_ws_floats(C, rows, groups)), 1)
+    ws = arena.get("bn.ws", (max(nws, 1 << 16),)) if nws <= (1 << 16) else arena.get(tag + ".ws", (nws,))
+    rm = rv = None
+    if running is not None:
+        rm, rv = running
+    rc = ops._lib.lib().mft_bn_stats(ops._p(x), C, C, rows, groups, ops.BN_EPS, ops._p(mean), ops._p(rstd), ops._p(ws),
+                                     ops._p(rm), ops._p(rv), 0.1, ops._stream())
+    ops._lib.check(rc, "mft_bn_stats")
+    return mean, rstd
+
+
+def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t"):
+    """trunk[0..upto-1] with shared (frozen) weights.  x [n,H,W,3] NHWC -> activation entering trunk[upto].
+    ``running``: optional dict bn-name -> (running_mean, running_var) updated when a single group is run."""
+    n = x.shape[0]
+    groups = n // ipg
+
+    def run(name):
+        return None if running is None else running.get(name)
+
+    c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3, out=arena.get(tag + ".c0", (n, (x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1, 64)))
+    m, s = _bn_stats4(arena, tag + ".bn0", c0, ipg, groups, run("trunk.1"))
+    g, b = W.bn["trunk.1"]
+    a = ops.bn_relu_maxpool(c0, m, s, g, b, imgs_per_group=ipg)
+    for idx in (4, 5, 6, 7):
+        if idx >= upto:
+            break
+        cin, cout, stride = STAGES[idx]
+        p = "trunk.%d" % idx
+        a = simple_block(W, p, a, arena, ipg, cin, cout, stride, running, tag + "." + p)
+    return a
+
+
+def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None):
+    """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's."""
+    n, H, Wd, _ = x.shape
+    groups = n // ipg
+    OH = (H + 2 - 3) // stride + 1
+
+    def run(name):
+        return None if running is None else running.get(name)
+
+    if slab is None:
+        c1w, c2w = W.conv[p + ".C1"], W.conv[p + ".C2"]
+        (g1, b1), (g2, b2) = W.bn[p + ".BN1"], W.bn[p + ".BN2"]
+        scw = W.conv.get(p + ".shortcut")
+        gs, bs = W.bn.get(p + ".BNshortcut", (None, None))
+        gbs = 0
+    else:
+        c1w, c2w, scw = slab.c1w, slab.c2w, slab.scw
+        g1, b1, g2, b2, gs, bs = slab.bn1g, slab.bn1b, slab.bn2g, slab.bn2b, slab.bnsg, slab.bnsb
+        gbs = cout
+    wipg = ipg if slab is not None else 0
+    c1 = ops.conv2d(x, c1w, cout, 3, 3, stride, 1, imgs_per_group=wipg, out=arena.get(tag + ".c1", (n, OH, OH, cout)))
+    m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"))
+    rows = ipg * OH * OH
+    r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
+                      out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
+    c2 = ops.conv2d(r1, c2w, cout, 3, 3, 1, 1, imgs_per_group=wipg, out=arena.get(tag + ".c2", (n, OH, OH, cout)))
+    m2, s2 = _bn_stats4(arena, tag + ".bn2", c2, ipg, groups, run(p + ".BN2"))
+    out = arena.get(tag + ".out", (n * OH * OH, cout))
+    sc = ms = ss = None
+    if cin != cout:
+        sc = ops.conv2d(x, scw, cout, 1, 1, stride, 0, imgs_per_group=wipg, out=arena.get(tag + ".sc", (n, OH, OH, cout)))
+        ms, ss = _bn_stats4(arena, tag + ".bns", sc, ipg, groups, run(p + ".BNshortcut"))
+        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc.view(-1, cout),
+                     res_bn=(ms, ss, gs, bs), out=out, gb_group_stride=gbs)
+    else:
+        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=x.view(-1, cin),
+                     out=out, gb_group_stride=gbs)
+    out = out.view(n, OH, OH, cout)
+    if tape is not None:
+        tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out)
+    return out
+
+
+def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag="f"):
+    """Full ResNet10(flatten=True) forward in train mode: x [n,H,W,3] NHWC -> features [n,512].
+    ``slab`` selects per-group last-block parameters (episode-batched inner loop)."""
+    n = x.shape[0]
+    if ipg <= 0:
+        ipg = n
+    a = resnet10_trunk(W, x, arena, ipg, upto=7, running=running, tag=tag)
+    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=tape)
+    feat = arena.get(tag + ".feat", (n, 512))
+    ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
+                                                     ops._stream()), "mft_global_avgpool")
+    return feat
+
+
+def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw"):
+    """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
+    ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``."""
+    x, c1, r1, c2, sc, out = tape["x"], tape["c1"], tape["r1"], tape["c2"], tape["sc"], tape["out"]
+    n, oh, ow, C = out.shape
+    groups = n // ipg
+    rows = ipg * oh * ow
+    E = params.E
+    d_out = arena.get(tag + ".dout", (n, oh, ow, C))
+    ops._lib.check(ops._lib.lib().mft_avgpool_relu_backward(ops._p(dfeat), ops._p(out), ops._p(d_out), n, oh * ow, C,
+                                                            ops._stream()), "mft_avgpool_relu_backward")
+    lib = ops._lib.lib()
+
+    def bn_bwd(xraw, dy, mean, rstd, gamma, dgamma, dbeta, relu_out, name, need_dx=True):
+        dx = arena.get(tag + "." + name, tuple(xraw.shape)) if need_dx else None
+        rc = lib.mft_bn_backward(ops._p(xraw), C, ops._p(dy), C, ops._p(relu_out), C, ops._p(dx), C, C, rows, groups,
+                                 ops._p(mean), ops._p(rstd), ops._p(gamma), C, ops._p(dgamma), ops._p(dbeta),
+                                 ops._stream())
+        ops._lib.check(rc, "mft_bn_backward")
+        return dx
+
+    dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
+    dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
+    ops.conv2d_wgrad(r1, dc2, 512, 3, 3, 1, 1, imgs_per_group=ipg, out=grads.c2w)
+    wt = arena.get(tag + ".c2wt", (E, 512, 9 * 512))
+    ops._lib.check(lib.mft_pack_dgrad(ops._p(params.c2w), ops._p(wt), 512, 512, 3, 3, E, 512 * 4608, 512 * 4608,
+                                      ops._stream()), "mft_pack_dgrad")
+    dr1 = ops.conv2d(dc2, wt, 512, 3, 3, 1, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
+    dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
+    ops.conv2d_wgrad(x, dc1, 512, 3, 3, 2, 1, imgs_per_group=ipg, out=grads.c1w)
+    ops.conv2d_wgrad(x, dsc, 512, 1, 1, 2, 0, imgs_per_group=ipg, out=grads.scw)
+
+
+# ------------------------------------------------------------------------------------------ GNN head
+
+class GnnHeadWeights:
+    """Packed device copy of GnnNet.fc and GnnNet.gnn (state dict keys 'fc.*', 'gnn.*')."""
+
+    def __init__(self, sd, device, n_way):
+        self.n_way = n_way
+
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        self.fc_w = ops.pack_conv_weight(dev(sd["fc.0.weight"]))
+        self.fc_b = dev(sd["fc.0.bias"])
+        self.fc_g, self.fc_beta = dev(sd["fc.1.weight"]), dev(sd["fc.1.bias"])
+        self.wc = {}
+        self.gc = {}
+        for name in ("layer_w0", "layer_w1", "w_comp_last"):
+            layers = []
+            for li in range(1, 5):
+                w = dev(sd["gnn.%s.conv2d_%d.weight" % (name, li)])
+                layers.append((ops.pack_conv_weight(w), dev(sd["gnn.%s.conv2d_%d.bias" % (name, li)]),
+                               dev(sd["gnn.%s.bn_%d.weight" % (name, li)]), dev(sd["gnn.%s.bn_%d.bias" % (name, li)]),
+                               w.shape[0]))
+            last = (ops.pack_conv_weight(dev(sd["gnn.%s.conv2d_last.weight" % name])),
+                    dev(sd["gnn.%s.conv2d_last.bias" % name]))
+            self.wc[name] = (layers, last)
+        for name, bn in (("layer_l0", True), ("layer_l1", True), ("layer_last", False)):
+            w = dev(sd["gnn.%s.fc.weight" % name])
+            g = b = None
+            if bn:
+                g, b = dev(sd["gnn.%s.bn.weight" % name]), dev(sd["gnn.%s.bn.bias" % name])
+            self.gc[name] = (ops.pack_conv_weight(w), dev(sd["gnn.%s.fc.bias" % name]), g, b, w.shape[0])
+
+
+def wcompute(G, name, x, F, n_graphs, N, n_groups, arena, tag="wc"):
+    """gnn.Wcompute.forward (gnn.py:78-132): x [n_graphs*N, ld] -> A [n_graphs, N, N].  BatchNorm statistics are
+    per group of n_graphs/n_groups graphs (one episode), over all graphs*N*N pair positions."""
+    layers, (w5, b5) = G.wc[name]
+    Kp = ops.round_up(F, 32)
+    rows = n_graphs * N * N
+    rpg = rows // n_groups
+    lib = ops._lib.lib()
+    d = arena.get(tag + ".d", (rows, Kp))
+    ops._lib.check(lib.mft_pair_absdiff(ops._p(x), x.shape[1], ops._p(d), Kp, n_graphs, N, F, ops._stream()),
+                   "mft_pair_absdiff")
+    h, K = d, Kp
+    for li, (w, b, g, beta, cout) in enumerate(layers):
+        o = ops.gemm(h, K, w, cout, bias=b, out=arena.get(tag + ".h%d" % li, (rows, cout)))
+        m, s = _bn_stats4(arena, tag + ".bn%d" % li, o.view(rows, 1, 1, cout), rpg, n_groups)
+        ops.bn_apply(o, cout, rpg, n_groups, m, s, g, beta, act=ops.ACT_LRELU, out=o)
+        h, K = o, cout
+    sc = ops.gemm(h, K, w5, 1, bias=b5, out=arena.get(tag + ".s", (rows, 1)))
+    A = arena.get(tag + ".A", (n_graphs, N, N))
+    ops._lib.check(lib.mft_masked_softmax(ops._p(sc), 1, ops._p(A), n_graphs, N, ops._stream()), "mft_masked_softmax")
+    return A
+
+
+def gconv(G, name, A, x, F, n_graphs, N, n_groups, arena, tag="gc"):
+    """gnn.Gconv.forward with gmul (gnn.py:16-56): fc(cat(x, A@x)) [+ BatchNorm1d over the group's graphs*N rows]."""
+    w, b, g, beta, cout = G.gc[name]
+    rows = n_graphs * N
+    ldy = ops.round_up(2 * F, 32)
+    y = arena.get(tag + ".y", (rows, ldy))
+    ops._lib.check(ops._lib.lib().mft_graph_aggregate(ops._p(A), ops._p(x), x.shape[1], ops._p(y), ldy, n_graphs, N, F,
+                                                      ops._stream()), "mft_graph_aggregate")
+    o = ops.gemm(y, ldy, w, cout, bias=b, out=arena.get(tag + ".o", (rows, cout)))
+    if g is not None:
+        rpg = rows // n_groups
+        m, s = _bn_stats4(arena, tag + ".bn", o.view(rows, 1, 1, cout), rpg, n_groups)
+        ops.bn_apply(o, cout, rpg, n_groups, m, s, g, beta, act=ops.ACT_NONE, out=o)
+    return o
+
+
+def gnn_forward(G, nodes, n_graphs, N, n_groups, arena, tag="gnn"):
+    """gnn.GNN_nl.forward (gnn.py:154-166).  nodes [n_graphs*N, ld>=256] with features in columns 0..132+.
+    Returns [n_graphs*N, n_way].  ``nodes`` is extended in place (x = cat(x, x_new))."""
+    F = 128 + G.n_way
+    x = nodes
+    for i in range(2):
+        A = wcompute(G, "layer_w%d" % i, x, F, n_graphs, N, n_groups, arena, tag + ".w%d" % i)
+        o = gconv(G, "layer_l%d" % i, A, x, F, n_graphs, N, n_groups, arena, tag + ".l%d" % i)
+        ops.copy_cols(o, x, F, o.shape[1], act=ops.ACT_LRELU)
+        F += o.shape[1]
+    A = wcompute(G, "w_comp_last", x, F, n_graphs, N, n_groups, arena, tag + ".wl")
+    return gconv(G, "layer_last", A, x, F, n_graphs, N, n_groups, arena, tag + ".ll")
+
+
+def gnnnet_scores(G, feats, n_episodes, n_way, n_support, n_query, arena, fold=False, tag="head"):
+    """GnnNet.set_forward(is_feature=True) tail (gnnnet.py:71-87,210-217) for ``n_episodes`` episodes at once:
+    feats [n_episodes*n_way*(S+n_query), 512] -> scores [n_episodes*n_way*n_query, n_way]."""
+    rows = feats.shape[0]
+    rpg = rows // n_episodes
+    z = ops.gemm(feats, 512, G.fc_w, 128, bias=G.fc_b, out=arena.get(tag + ".z", (rows, 128)))
+    m, s = _bn_stats4(arena, tag + ".fcbn", z.view(rows, 1, 1, 128), rpg, n_episodes)
+    ops.bn_apply(z, 128, rpg, n_episodes, m, s, G.fc_g, G.fc_beta, act=ops.ACT_NONE, out=z)
+    N = n_way * (n_support + 1)
+    n_graphs = n_episodes * n_query
+    nodes = arena.get(tag + ".nodes", (n_graphs * N, 256))
+    ops._lib.check(ops._lib.lib().mft_build_graph_nodes(ops._p(z), 128, ops._p(nodes), 256, n_episodes, n_way,
+                                                        n_support, n_query, 1 if fold else 0, ops._stream()),
+                   "mft_build_graph_nodes")
+    out = gnn_forward(G, nodes, n_graphs, N, n_episodes, arena, tag + ".gnn")
+    return ops.gather_query_scores(out, n_episodes, n_way, n_support, n_query)

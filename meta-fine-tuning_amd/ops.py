@@ -287,3 +287,32 @@ def copy_cols(x, y, col_off, C, act=ACT_NONE, slope=LRELU_SLOPE):
     _lib.check(_lib.lib().mft_copy_cols(_p(x), x.shape[1], _p(y), y.shape[1], col_off, C, x.shape[0], act, slope,
                                         _stream()), "mft_copy_cols")
     return y
+
+
+def build_graph_nodes(z, n_episodes, n_way, n_support, n_query, ld=256, fold=False):
+    """z [n_episodes*n_way*(S+n_query), 128] -> nodes [n_episodes*n_query*n_way*(n_support+1), ld]."""
+    _f32c(z)
+    rows = n_episodes * n_query * n_way * (n_support + 1)
+    nodes = torch.empty((rows, ld), device=z.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_build_graph_nodes(_p(z), z.shape[1], _p(nodes), ld, n_episodes, n_way, n_support,
+                                                n_query, 1 if fold else 0, _stream()), "mft_build_graph_nodes")
+    return nodes
+
+
+def gather_query_scores(out, n_episodes, n_way, n_support, n_query):
+    _f32c(out)
+    scores = torch.empty((n_episodes * n_way * n_query, n_way), device=out.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_gather_query_scores(_p(out), out.shape[1], _p(scores), n_episodes, n_way, n_support,
+                                                  n_query, _stream()), "mft_gather_query_scores")
+    return scores
+
+
+def gather_rows(src2d, idx_i32, out=None):
+    """dst[r] = src2d[idx[r]] for rows of src2d.shape[1] floats."""
+    _f32c(src2d)
+    n = idx_i32.numel()
+    if out is None:
+        out = torch.empty((n, src2d.shape[1]), device=src2d.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mft_gather_rows(_p(src2d), _p(idx_i32), _p(out), n, src2d.shape[1], _stream()),
+               "mft_gather_rows")
+    return out

@@ -1,0 +1,163 @@
+"""Hot-path parity on a real MI355X: the HIP ResNet10 forward, the teacher-forced inner step
+(last-block backward + fused Adam), the GNN head and the episode-batched FinetuneEngine against
+the CPU oracle (run in float64 where the comparison is per-step) and the golden vectors produced
+by the reference itself.  Tolerances follow BASELINE.json: 1e-3 on logits for forward-only and
+teacher-forced single steps; full inner loops are held to the fp32 Adam envelope."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import engine as eng
+from meta_fine_tuning_amd import functional as Fn
+from meta_fine_tuning_amd import ops, synthetic
+from oracle import mft_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_num_threads(8)
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("size", [84, 224])
+def test_resnet10_forward_vs_reference_golden(golden_dir, size):
+    g = _g(golden_dir, "g1_resnet10_fwd.npz")
+    sd = synthetic.resnet10_state_dict(seed=3)
+    x = synthetic.train_episode(11, 5, 1, 0, size).view(5, 3, size, size)
+    W = Fn.ResNet10Weights(sd, DEV)
+    arena = Fn.Arena(DEV)
+    feat = Fn.resnet10_forward(W, ops.nchw_to_nhwc(x.to(DEV)), arena)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat_%d" % size], atol=1e-4)     # bar: 1e-3 on logits
+
+
+def test_resnet10_forward_grouped_equals_per_group():
+    """3 groups of 5 images in one grouped launch == 3 separate 5-image forwards (per-group BN statistics)."""
+    sd = synthetic.resnet10_state_dict(seed=4)
+    W = Fn.ResNet10Weights(sd, DEV)
+    x = synthetic.train_episode(12, 5, 3, 0, 84).view(15, 3, 84, 84)
+    xg = ops.nchw_to_nhwc(x.to(DEV))
+    f_all = Fn.resnet10_forward(W, xg, Fn.Arena(DEV), ipg=5).clone()
+    for gi in range(3):
+        f = Fn.resnet10_forward(W, xg[gi * 5:(gi + 1) * 5].contiguous(), Fn.Arena(DEV), ipg=5)
+        assert float((f - f_all[gi * 5:(gi + 1) * 5]).abs().max()) < 1e-5
+    sd64 = O.clone_state(sd, torch.float64)
+    with torch.no_grad():
+        ref = O.resnet10_forward(sd64, x[:5].double(), "", train=True)
+    assert float((f_all[:5].cpu().double() - ref).abs().max()) < 1e-4
+
+
+def test_inner_step_teacher_forced(golden_dir):
+    """One inner step (forward, CE, last-block backward, Adam) for E=2 episodes with different batches:
+    gradients and Adam moments against the float64 oracle and the reference's fp32 golden gradients."""
+    g = _g(golden_dir, "g4_inner_loop.npz")
+    size = 84
+    sd = synthetic.resnet10_state_dict(seed=9)
+    views = synthetic.test_episode(31, 5, 5, 15, size, gen_examples=1)
+    xa = torch.cat([v[:, :5].contiguous().view(25, 3, size, size) for v in [views[0]] + views], 0)
+    ya = torch.from_numpy(np.tile(np.repeat(np.arange(5), 5), len(views) + 1))
+    perm = g["perm"]
+    sels = [perm[0:5], perm[5:10]]
+    E = 2
+    W = Fn.ResNet10Weights(sd, DEV)
+    arena = Fn.Arena(DEV)
+    ad = eng.AdaptState(E, DEV)
+    ad.reset(W)
+    xb = torch.cat([xa[torch.from_numpy(s)] for s in sels], 0)
+    yb = torch.cat([ya[torch.from_numpy(s)] for s in sels], 0)
+    tape = {}
+    feat = Fn.resnet10_forward(W, ops.nchw_to_nhwc(xb.to(DEV)), arena, ipg=5, slab=ad.w, tape=tape)
+    loss, dlog = ops.cross_entropy(feat, yb.to(torch.int32).to(DEV), 5, E)
+    Fn.last_block_backward(tape, dlog, ad.w, ad.g, arena, ipg=5)
+    np.testing.assert_allclose(feat[:5].cpu().numpy(), g["feat0_f32"], atol=1e-4)
+    assert abs(float(loss[0].cpu()) - float(g["loss0_f32"])) < 1e-4
+    grads0 = ad.g.export(0)
+    np.testing.assert_allclose(grads0["trunk.7.C1.weight"][:2, :4].cpu().numpy(), g["g_c1_slice_f64"], atol=2e-5)
+    np.testing.assert_allclose(grads0["trunk.7.C2.weight"][:2, :4].cpu().numpy(), g["g_c2_slice_f64"], atol=2e-5)
+    np.testing.assert_allclose(grads0["trunk.7.shortcut.weight"][:4, :8, 0, 0].cpu().numpy(), g["g_sc_slice_f64"], atol=2e-5)
+    for nm, key in (("bn1", "BN1"), ("bn2", "BN2"), ("bnsc", "BNshortcut")):
+        np.testing.assert_allclose(grads0["trunk.7.%s.weight" % key].cpu().numpy(), g["g_%s_w_f64" % nm], atol=5e-5)
+        np.testing.assert_allclose(grads0["trunk.7.%s.bias" % key].cpu().numpy(), g["g_%s_b_f64" % nm], atol=5e-5)
+    # full-tensor check of both episodes against the float64 oracle
+    for e in range(E):
+        sd64 = O.clone_state(sd, torch.float64)
+        adam = O.adam_init([sd64[k] for k in O.ADAPT_KEYS])
+        sel = torch.from_numpy(sels[e])
+        _, f64, gr, _ = O.inner_step(sd64, xa[sel].double(), ya[sel], adam, return_aux=True)
+        ge = ad.g.export(e)
+        for k, gref in zip(O.ADAPT_KEYS, gr):
+            err = float((ge[k].cpu().double() - gref).abs().max())
+            assert err < 3e-5 * max(1.0, float(gref.abs().max())), (k, err)
+    # Adam: moments are linear in g; the weight step is checked on the well-conditioned entries
+    w_before = ad.w.flat.clone()
+    ops.adam_step(ad.w.flat, ad.g.flat, ad.m.flat, ad.v.flat, 1, lr=0.01)
+    assert float((ad.m.flat - 0.1 * ad.g.flat).abs().max()) < 1e-7
+    big = ad.g.flat.abs() > 1e-6
+    dw = (ad.w.flat - w_before)[big]
+    assert float((dw + 0.01 * torch.sign(ad.g.flat[big])).abs().max()) < 1e-4      # first Adam step = -lr*sign(g)
+
+
+@pytest.mark.parametrize("B,N", [(15, 30), (2, 105), (2, 130)])
+def test_gnn_forward_vs_reference_golden(golden_dir, B, N):
+    g = _g(golden_dir, "g2_gnn.npz")
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    G = Fn.GnnHeadWeights(sd, DEV, 5)
+    rs = np.random.RandomState(100 + N + B)
+    nodes = torch.from_numpy(rs.standard_normal((B, N, 133)).astype(np.float32))
+    x = torch.zeros(B * N, 256)
+    x[:, :133] = nodes.view(B * N, 133)
+    arena = Fn.Arena(DEV)
+    xd = x.to(DEV)
+    A0 = Fn.wcompute(G, "layer_w0", xd, 133, B, N, 1, arena).clone()
+    np.testing.assert_allclose(A0.cpu().numpy(), g["A0_%d_%d" % (B, N)], atol=1e-5)
+    out = Fn.gnn_forward(G, xd, B, N, 1, arena)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, N, 5), g["out_%d_%d" % (B, N)], atol=2e-4)
+
+
+def test_gnnnet_scores_50shot_fold(golden_dir):
+    g = _g(golden_dir, "g7_gnnnet50.npz")
+    sd = synthetic.gnn_head_state_dict(seed=19)
+    G = Fn.GnnHeadWeights(sd, DEV, 5)
+    feats = torch.from_numpy(np.random.RandomState(61).standard_normal((5, 65, 512)).astype(np.float32))
+    sc = Fn.gnnnet_scores(G, feats.view(-1, 512).to(DEV), 1, 5, 25, 15, Fn.Arena(DEV), fold=True)
+    np.testing.assert_allclose(sc.cpu().numpy(), g["scores"], atol=1e-3)
+
+
+@pytest.mark.parametrize("E_epochs,G_aug", [(0, 0), (1, 0), (1, 2)])
+def test_engine_vs_reference_finetune_golden(golden_dir, E_epochs, G_aug):
+    """FinetuneEngine (one episode in a batch of 2 slots) against the scores the reference's own
+    finetune() produced on the same episode, weights and numpy seed."""
+    g = _g(golden_dir, "g5_finetune.npz")
+    sd = synthetic.gnnnet_state_dict(seed=13)
+    liz = synthetic.test_episode(41 + G_aug, 5, 5, 15, 84, gen_examples=G_aug)
+    e = eng.FinetuneEngine(sd, n_views=2 + G_aug, fine_tune_epoch=E_epochs, episodes_per_batch=2, device=DEV)
+    np.random.seed(10)
+    sc = e.run_batch([liz])[0].cpu().numpy()
+    ref = g["scores_E%d_G%d" % (E_epochs, G_aug)]
+    if E_epochs == 0:
+        np.testing.assert_allclose(sc, ref, atol=1e-4)          # forward-only: bar is 1e-3 on logits
+    else:
+        err = np.abs(sc - ref)
+        assert err.max() < 2e-2 and (sc.argmax(1) == ref.argmax(1)).mean() >= 0.96, err.max()
+
+
+def test_engine_batched_matches_oracle_envelope():
+    """Two different episodes run in lockstep; each must stay within k x the reference's own fp32-vs-fp64
+    distance of the float64 oracle (SURVEY.md §0 D7 gate (ii)), with the same permutations."""
+    sd = synthetic.gnnnet_state_dict(seed=21)
+    eps = [synthetic.test_episode(300 + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)]
+    rs = np.random.RandomState(5)
+    perms = [[rs.permutation(100) for _ in range(1)] for _ in range(2)]
+    e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    sc = e.run_batch(eps, perms=perms).cpu().numpy()
+    for i in range(2):
+        o64 = O.finetune_episode(sd, eps[i], 5, 5, total_epoch=1, perms=perms[i], dtype=torch.float64).numpy()
+        o32 = O.finetune_episode(sd, eps[i], 5, 5, total_epoch=1, perms=perms[i], dtype=torch.float32).numpy()
+        d_ref = np.abs(o32 - o64).max()
+        d_hip = np.abs(sc[i] - o64).max()
+        assert d_hip <= max(4.0 * d_ref, 2e-3), (d_hip, d_ref)
+        assert (sc[i].argmax(1) == o64.argmax(1)).mean() >= 0.96
