@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- episodes/sec of the test-time meta-fine-tuning hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 5-way 5-shot ResNet10+GNN, fine_tune_epoch=5, gen_examples=17
+(=> 500 Adam inner steps of 5 images per episode, finetune.py:270-299), 15 queries, 84x84 synthetic
+episodes, followed by the 100-image transductive feature pass and the GNN head (finetune.py:306-317).
+A "step" = one lockstep batch of E episodes through FinetuneEngine.run_batch.  Inputs (the E resident
+synthetic episodes, NCHW fp32, all 19 views) are in HBM before the timed region; every step draws
+fresh numpy permutations.  One process per GPU; episodes shard across ranks with no data-path
+collective (only a final all-gather of per-episode accuracies), so scaling is "weak".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--episodes-per-batch E]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic FLOPs (2*MAC; conv + linear + per-pair MLP only) -- SURVEY.md §8(d)
+F_IMG_84 = 0.28585e9          # ResNet10 forward per 84x84 image
+F_LB_84 = 0.1086e9            # last-block backward per image (wgrad C1,C2,shortcut + dgrad C2)
+F_GNN_15_30 = 8.08e9          # GNN forward, 15 graphs of 30 nodes
+PEAK_F32_MFMA = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def episode_flops(n_way, n_shot, n_query, views, epochs):
+    passes = epochs * n_way * n_shot * (views + 1)
+    return passes * (F_IMG_84 + F_LB_84) + n_way * (n_shot + n_query) * F_IMG_84 + F_GNN_15_30
+
+
+def conv_flops(n_img, OH, Cout, K):
+    return 2.0 * n_img * OH * OH * Cout * K
+
+
+def cpu_baseline(state, episode, n_steps_sample=40):
+    """Oracle (CPU restatement validated against the reference) timed on this box's host cores on a bounded
+    sample: `n_steps_sample` inner steps + the final 100-image pass + GNN, extrapolated to 500 steps."""
+    from oracle import mft_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_all = O.clone_state(state)
+    fsd = O.feature_state(sd_all)
+    xa, ya = O.finetune_support_set(episode, 5, 5)
+    adam = O.adam_init([fsd[k] for k in O.ADAPT_KEYS])
+    perm = np.random.RandomState(0).permutation(xa.shape[0])
+    # warm
+    O.inner_step(fsd, xa[torch.from_numpy(perm[:5])], ya[torch.from_numpy(perm[:5])], adam)
+    t0 = time.perf_counter()
+    for s in range(n_steps_sample):
+        sel = torch.from_numpy(perm[(s * 5) % 495:(s * 5) % 495 + 5])
+        O.inner_step(fsd, xa[sel], ya[sel], adam)
+    t_step = (time.perf_counter() - t0) / n_steps_sample
+    x0 = episode[0]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feats = O.resnet10_forward(fsd, x0.reshape(100, *x0.shape[2:]), "", train=True).view(5, 20, -1)
+        O.gnnnet_set_forward(sd_all, feats, 5, 5, 15, is_feature=True)
+    t_final = time.perf_counter() - t0
+    t_episode = 500 * t_step + t_final
+    return {"value": 1.0 / t_episode, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": "%d inner steps (%.1f ms each) + final 100-image pass + GNN (%.2f s), extrapolated to 500 steps; "
+                      "torch-CPU oracle, %d threads" % (n_steps_sample, t_step * 1e3, t_final, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "32")))
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--gen-examples", type=int, default=17)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import meta_fine_tuning_amd  # noqa: F401
+    from meta_fine_tuning_amd import engine as eng
+    from meta_fine_tuning_amd import ops, synthetic
+
+    E = args.episodes_per_batch
+    n_way, n_shot, n_query, size = 5, 5, 15, 84
+    views = 2 + args.gen_examples
+    state = synthetic.gnnnet_state_dict(seed=0)
+    e = eng.FinetuneEngine(state, n_way, n_shot, n_query, size, n_views=views, fine_tune_epoch=args.epochs,
+                           episodes_per_batch=E, device=dev)
+    # resident synthetic episodes (class-structured so accuracy is meaningful); distinct per rank
+    pool = [[v.to(dev) for v in synthetic.test_episode(1000 * 2 + rank * 100000 + i, n_way, n_shot, n_query, size,
+                                                       gen_examples=args.gen_examples)] for i in range(E)]
+    y_query = np.repeat(np.arange(n_way), n_query)
+    np.random.seed(10 + rank)
+
+    # ---- dominant-kernel timer: HIP events on the launch stream around the conv implicit-GEMM launches
+    conv_events = []
+    orig_conv2d = ops.conv2d
+    timing = {"on": False}
+
+    def timed_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=None):
+        if not timing["on"]:
+            return orig_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group, bias, out)
+        s = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        r = orig_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group, bias, out)
+        b.record(s)
+        OH = r.shape[1]
+        conv_events.append((a, b, conv_flops(x.shape[0], OH, Cout, KH * KW * x.shape[3])))
+        return r
+
+    ops.conv2d = timed_conv2d
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    accs = []
+    for _ in range(args.warmup):
+        e.run_batch(pool)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc = e.run_batch(pool)
+        accs.append(sc)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    acc = torch.cat(accs).argmax(2).cpu().numpy() == y_query[None]
+    acc_ep = acc.mean(1) * 100.0
+    if dist is not None:
+        gathered = [torch.zeros(len(acc_ep), device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(acc_ep, device=dev, dtype=torch.float64))
+        acc_ep = torch.cat(gathered).cpu().numpy()
+
+    # ---- roofline of the dominant kernel (conv implicit GEMM): one extra, separately timed batch with events
+    roof = None
+    if rank == 0:
+        timing["on"] = True
+        e.run_batch(pool)
+        torch.cuda.synchronize()
+        timing["on"] = False
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
+        tot_fl = sum(f for _, _, f in conv_events)
+        n_launch = len(conv_events)
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit GEMM, all shapes)",
+                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": None,
+                "launches": n_launch, "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
+                "algorithmic_gflop_per_launch": round(tot_fl / n_launch / 1e9, 3)}
+
+    if rank == 0:
+        total_eps = E * args.steps * world
+        value = total_eps / dt
+        fl = episode_flops(n_way, n_shot, n_query, views, args.epochs)
+        out = {
+            "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node",
+            "value": round(value, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "5-way 5-shot ResNet10+GNN test-time finetune, 84x84, fine_tune_epoch=%d, "
+                                   "gen_examples=%d (%d inner Adam steps/episode), 15 queries" %
+                                   (args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
+                       "episodes_per_step": E, "episodes_total": total_eps, "image_size": size,
+                       "parallelism": "episode-parallel x%d" % world},
+            "episode_tflop": round(fl / 1e12, 4),
+            "whole_path_tflops": round(value * fl / 1e12, 2),
+            "whole_path_frac_of_f32_mfma_peak": round(value * fl / world / PEAK_F32_MFMA, 4),
+            "mean_acc": round(float(acc_ep.mean()), 2),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cpu_ep = [v.cpu() for v in pool[0]]
+            out["cpu_baseline"] = cpu_baseline(state, cpu_ep)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
