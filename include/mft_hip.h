@@ -77,6 +77,8 @@ int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, int rows_per
                  const float* res, int ldr, const float* res_mean, const float* res_rstd,
                  const float* res_gamma, const float* res_beta,
                  int act, float slope, void* stream);
+/* eval-mode BatchNorm (pretrained_model.eval() under --freeze_backbone, finetune.py:265-266): rstd = 1/sqrt(running_var+eps) */
+int mft_var_to_rstd(const float* var, float* rstd, int n, float eps, void* stream);
 /* trunk[1..3]: BatchNorm2d -> ReLU -> MaxPool2d(3,2,1) fused (backbone.py:409-411) */
 int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
                         const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mft_build_graph_nodes": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mft_gather_query_scores": [_P, _I, _P, _I, _I, _I, _I, _P],
     "mft_gather_rows": [_P, _P, _P, _I, _L, _P],
+    "mft_var_to_rstd": [_P, _P, _I, _F, _P],
 }
 _RESTYPE = {"mft_bn_stats_ws_floats": _L}
 

@@ -1,0 +1,191 @@
+"""Bridge between the reference-shaped nn.Modules (OIHW nn.Parameters, autograd, optimisers) and the
+HIP functional layer.  Parameters are repacked into the kernels' layouts lazily (cache keyed on the
+tensors' autograd version counters) and gradients are handed back in the reference's layouts.
+"""
+import torch
+
+from . import functional as Fn
+from . import ops
+
+_ARENAS = {}
+
+
+def arena_for(device):
+    a = _ARENAS.get(device)
+    if a is None:
+        a = Fn.Arena(device)
+        _ARENAS[device] = a
+    return a
+
+
+def _require_cuda(x, what):
+    if not x.is_cuda:
+        raise RuntimeError("%s: input is on %s -- the MI355X path has no CPU fallback; call .cuda() first" % (what, x.device))
+
+
+def module_weights(mod):
+    """Packed ResNet10Weights of a backbone.ResNet module, rebuilt only when a parameter changed."""
+    params = list(mod.parameters())
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = mod.__dict__.get("_mft_pack")
+    if cache is None or cache[0] != key:
+        sd = {k: v for k, v in mod.state_dict().items()}
+        W = Fn.ResNet10Weights(sd, params[0].device)
+        cache = (key, W)
+        mod.__dict__["_mft_pack"] = cache
+    return cache[1]
+
+
+def _running(mod):
+    run = {}
+    for name, m in mod.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats:
+            run[name] = (m.running_mean, m.running_var)
+    return run
+
+
+def _eval_weights(mod, W):
+    """Eval-mode BatchNorm: statistics come from the running buffers."""
+    stats = {}
+    lib = ops._lib.lib()
+    for name, m in mod.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            rstd = torch.empty_like(m.running_var)
+            ops._lib.check(lib.mft_var_to_rstd(ops._p(m.running_var), ops._p(rstd), rstd.numel(), m.eps, ops._stream()),
+                           "mft_var_to_rstd")
+            stats[name] = (m.running_mean.view(1, -1), rstd.view(1, -1))
+    return stats
+
+
+class _ResNet10Fn(torch.autograd.Function):
+    """ResNet10 forward on HIP; backward through the last block only (the inner-loop regime: everything
+    below trunk.7 is frozen -- finetune.py:242-252)."""
+
+    @staticmethod
+    def forward(ctx, mod, x_nhwc, *params):
+        W = module_weights(mod)
+        arena = arena_for(x_nhwc.device)
+        n = x_nhwc.shape[0]
+        slab = Fn.LastBlockSlab(1, x_nhwc.device, zero=False)
+        slab.load_shared(W)
+        tape = {}
+        feat = Fn.resnet10_forward(W, x_nhwc, arena, ipg=n, slab=slab, tape=tape, running=_running(mod), tag="mod%d" % n)
+        ctx.tape, ctx.slab, ctx.n, ctx.mod = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tape.items()}, slab, n, mod
+        return feat.clone()
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        mod = ctx.mod
+        names = [n for n, _ in mod.named_parameters()]
+        need = [p.requires_grad for p in mod.parameters()]
+        if any(need[:-9]):
+            raise NotImplementedError(
+                "backward below trunk.7 requested (%s): use methods.gnnnet.GnnNet.set_forward_loss for the "
+                "meta-train path" % [n for n, r in zip(names, need) if r][0])
+        grads = Fn.LastBlockSlab(1, dfeat.device)
+        arena = arena_for(dfeat.device)
+        Fn.last_block_backward(ctx.tape, dfeat.contiguous(), ctx.slab, grads, arena, ipg=ctx.n, tag="modbw%d" % ctx.n)
+        g = grads.export(0)
+        out = [None] * len(names)
+        for i, nm in enumerate(names):
+            if nm in g and need[i]:
+                out[i] = g[nm]
+        return (None, None) + tuple(out)
+
+
+def resnet10_module_forward(mod, x):
+    """backbone.ResNet.forward: x NCHW [n,3,H,W] on the GPU -> [n,512]."""
+    _require_cuda(x, "ResNet10.forward")
+    x = x.contiguous().float()
+    xn = ops.nchw_to_nhwc(x)
+    params = list(mod.parameters())
+    if not mod.training:
+        raise NotImplementedError("eval-mode BatchNorm (freeze_backbone) is not on the HIP hot path yet; the reference "
+                                  "keeps the backbone in train() for fine-tuning (finetune.py:263-264)")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        out = _ResNet10Fn.apply(mod, xn, *params)
+    else:
+        W = module_weights(mod)
+        n = xn.shape[0]
+        out = Fn.resnet10_forward(W, xn, arena_for(xn.device), ipg=n, running=_running(mod), tag="mod%d" % n).clone()
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats:
+            m.num_batches_tracked += 1
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- packing
+
+def pad_rows(x2d, ld):
+    out = torch.zeros((x2d.shape[0], ld), device=x2d.device)
+    out[:, :x2d.shape[1]] = x2d
+    return out
+
+
+def _version_key(mod):
+    return tuple((p.data_ptr(), p._version) for p in mod.parameters())
+
+
+def head_weights(gnn_mod, fc_mod=None, n_way=None):
+    """Packed GnnHeadWeights for a GNN_nl (and optionally GnnNet.fc), cached on the parameter versions."""
+    key = _version_key(gnn_mod) + (() if fc_mod is None else _version_key(fc_mod))
+    cache = gnn_mod.__dict__.get("_mft_pack")
+    if cache is None or cache[0] != key:
+        sd = {"gnn." + k: v for k, v in gnn_mod.state_dict().items()}
+        if fc_mod is not None:
+            sd.update({"fc." + k: v for k, v in fc_mod.state_dict().items()})
+        else:
+            dev = next(gnn_mod.parameters()).device
+            sd.update({"fc.0.weight": torch.zeros(128, 512, device=dev), "fc.0.bias": torch.zeros(128, device=dev),
+                       "fc.1.weight": torch.ones(128, device=dev), "fc.1.bias": torch.zeros(128, device=dev)})
+        G = Fn.GnnHeadWeights(sd, next(gnn_mod.parameters()).device, gnn_mod.train_N_way if n_way is None else n_way)
+        cache = (key, G)
+        gnn_mod.__dict__["_mft_pack"] = cache
+    return cache[1]
+
+
+class _Solo:
+    """GnnHeadWeights-shaped view of a single Wcompute / Gconv module (stand-alone module calls)."""
+
+    def __init__(self):
+        self.wc, self.gc, self.n_way = {}, {}, 0
+
+
+def solo_weights(mod, kind):
+    key = _version_key(mod)
+    cache = mod.__dict__.get("_mft_pack")
+    if cache is None or cache[0] != key:
+        dev = next(mod.parameters()).device
+        S = _Solo()
+
+        def d(t):
+            return t.detach().to(dev).float().contiguous()
+        if kind == "wc":
+            layers = []
+            for li in range(1, 5):
+                conv, bn = getattr(mod, "conv2d_%d" % li), getattr(mod, "bn_%d" % li)
+                layers.append((ops.pack_conv_weight(d(conv.weight)), d(conv.bias), d(bn.weight), d(bn.bias), conv.weight.shape[0]))
+            S.wc["solo"] = (layers, (ops.pack_conv_weight(d(mod.conv2d_last.weight)), d(mod.conv2d_last.bias)))
+        else:
+            g = b = None
+            if mod.bn_bool:
+                g, b = d(mod.bn.weight), d(mod.bn.bias)
+            S.gc["solo"] = (ops.pack_conv_weight(d(mod.fc.weight)), d(mod.fc.bias), g, b, mod.fc.weight.shape[0])
+        cache = (key, S)
+        mod.__dict__["_mft_pack"] = cache
+    return cache[1]
+
+
+def invalidate(mod):
+    """Drop cached packed weights after an in-place parameter update done behind autograd's back."""
+    for m in mod.modules():
+        m.__dict__.pop("_mft_pack", None)
+
+
+def gnnnet_head(model, feats, n_support, n_query, fold=False):
+    """GnnNet.fc + z_stack + forward_gnn for one episode (gnnnet.py:76-87,210-217): feats [n_way*(S+n_query), 512]
+    -> scores [n_way*n_query, n_way]."""
+    _require_cuda(feats, "GnnNet head")
+    G = head_weights(model.gnn, model.fc, model.n_way)
+    f = feats.detach().contiguous().float()
+    return Fn.gnnnet_scores(G, f, 1, model.n_way, n_support, n_query, arena_for(f.device), fold=fold, tag="head1")

@@ -167,3 +167,15 @@ extern "C" int mft_maml_delta(float* p, const float* p2, const float* p3, long l
     hipLaunchKernelGGL(maml_delta_kernel, dim3(sgrid(n)), dim3(256), 0, (hipStream_t)stream, p, p2, p3, n);
     return mft_launch_status();
 }
+
+namespace {
+__global__ void var_to_rstd_kernel(const float* __restrict__ var, float* __restrict__ rstd, int n, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rstd[i] = 1.0f / sqrtf(var[i] + eps);
+}
+}  // namespace
+
+extern "C" int mft_var_to_rstd(const float* var, float* rstd, int n, float eps, void* stream) {
+    hipLaunchKernelGGL(var_to_rstd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, var, rstd, n, eps);
+    return mft_launch_status();
+}

@@ -145,3 +145,46 @@ class FinetuneEngine:
         if return_feats:
             return scores[:n], feats.view(self.E, self.n_all, 512)[:n]
         return scores[:n]
+
+
+def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=None):
+    """The inner loop of GnnNet.set_forward_finetune (gnnnet.py:126-177) for one episode: Adam(lr=0.01) on the last
+    ResNet block of a *copy* of ``feature_mod`` over ``epochs`` permutations of the support set in mini-batches of
+    ``batch_size`` (ragged tail allowed).  x_a: [n,3,H,W] device NCHW; y_a: int32 numpy labels.
+    Returns {state_dict key: tensor} for the nine adapted tensors and the BatchNorm running buffers."""
+    from . import autograd_ops as AG
+    dev = x_a.device
+    n, _, H, _ = x_a.shape
+    W = AG.module_weights(feature_mod)
+    arena = AG.arena_for(dev)
+    ad = AdaptState(1, dev)
+    ad.reset(W)
+    running, nbt = {}, {}
+    for name, m in feature_mod.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            running[name] = (m.running_mean.detach().clone(), m.running_var.detach().clone())
+            nbt[name] = m.num_batches_tracked.detach().clone()
+    Xs = ops.nchw_to_nhwc(x_a.contiguous().float()).view(n, -1)
+    steps = 0
+    for ep in range(epochs):
+        rand_id = np.random.permutation(n) if perms is None else perms[ep]
+        for j in range(0, n, batch_size):
+            ids = np.asarray(rand_id[j:min(j + batch_size, n)])
+            k = len(ids)
+            idx = torch.from_numpy(ids.astype(np.int32)).to(dev)
+            lab = torch.from_numpy(np.asarray(y_a)[ids].astype(np.int32)).to(dev)
+            xb = ops.gather_rows(Xs, idx)
+            tape = {}
+            feat = Fn.resnet10_forward(W, xb.view(k, H, H, 3), arena, ipg=k, slab=ad.w, tape=tape, running=running,
+                                       tag="ad%d" % k)
+            _, dl = ops.cross_entropy(feat, lab, k, 1)
+            Fn.last_block_backward(tape, dl, ad.w, ad.g, arena, ipg=k, tag="adbw%d" % k)
+            ad.step += 1
+            ops.adam_step(ad.w.flat, ad.g.flat, ad.m.flat, ad.v.flat, ad.step, lr=lr)
+            steps += 1
+    out = ad.w.export(0)
+    for name, (rm, rv) in running.items():
+        out[name + ".running_mean"] = rm
+        out[name + ".running_var"] = rv
+        out[name + ".num_batches_tracked"] = nbt[name] + steps
+    return out

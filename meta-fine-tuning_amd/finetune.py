@@ -1,0 +1,111 @@
+"""Test-time fine-tuning driver (mirror of finetune.py:182-328,424-682 for --method gnnnet).
+
+``finetune(liz_x, y, model, state_in, save_it, ...)`` keeps the reference's signature and semantics
+(module-global ``params`` supplies ``model`` and ``fine_tune_epoch``; permutations come from the global numpy
+RNG) and runs on FinetuneEngine with a batch of one.  ``finetune_batched`` is the throughput entry point:
+E independent episodes in lockstep.  Real datasets are out of scope: ``main`` evaluates
+on the in-repo synthetic episodes with the reference's printed accuracy line.
+"""
+import argparse
+
+import numpy as np
+import torch
+
+from . import engine as eng
+from . import synthetic
+from .io_utils import model_dict, parse_args  # noqa: F401  (re-exported like the reference)
+
+params = None          # set by main(); finetune() reads params.model / params.fine_tune_epoch (finetune.py:185,261)
+
+_ENGINES = {}
+
+
+def _engine_for(state_in, model, n_way, n_support, n_query, size, n_views, epochs, E, fold50=False):
+    head_key = tuple((p.data_ptr(), p._version) for p in list(model.fc.parameters()) + list(model.gnn.parameters()))
+    key = (id(state_in), head_key, n_way, n_support, n_query, size, n_views, epochs, E, fold50)
+    e = _ENGINES.get(key)
+    if e is None:
+        if len(_ENGINES) >= 4:
+            _ENGINES.clear()
+        head = {"fc." + k: v for k, v in model.fc.state_dict().items()}
+        head.update({"gnn." + k: v for k, v in model.gnn.state_dict().items()})
+        e = eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=epochs,
+                               episodes_per_batch=E, head_state=head, fold50=fold50)
+        _ENGINES[key] = e
+    return e
+
+
+def finetune(liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+             pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5):
+    """One episode: liz_x = [x0, x0, aug_1, ...] each [n_way, n_support+n_query, 3, H, W]; returns softmax scores
+    [n_way*n_query, n_way] (finetune.py:182-328)."""
+    if linear or not flatten or ds or freeze_backbone:
+        raise NotImplementedError("finetune(): only the GNN scoring branch with an adaptable, flattened backbone is on "
+                                  "the HIP hot path (linear / ds / freeze_backbone are 'next' rows, SURVEY.md §8(f))")
+    if params is None or params.model != 'ResNet10':
+        raise RuntimeError("finetune.params must be set (Namespace(model='ResNet10', fine_tune_epoch=...))")
+    model = model.cuda()
+    x0 = liz_x[0]
+    n_query = x0.size(1) - n_support
+    e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(liz_x), params.fine_tune_epoch, 1,
+                    fold50=getattr(model, "FOLD50", False))
+    model.n_query = n_query                                          # finetune.py:312
+    return e.run_batch([liz_x])[0].clone()
+
+
+def finetune_batched(episodes, model, state_in, fine_tune_epoch, n_way=5, n_support=5, episodes_per_batch=32,
+                     perms=None):
+    """Throughput path: ``episodes`` (list of liz_x) processed ``episodes_per_batch`` at a time in lockstep.
+    Permutations are drawn episode by episode from the global numpy RNG (the reference's order) unless given."""
+    model = model.cuda()
+    x0 = episodes[0][0]
+    n_query = x0.size(1) - n_support
+    e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(episodes[0]), fine_tune_epoch,
+                    episodes_per_batch, fold50=getattr(model, "FOLD50", False))
+    out = []
+    for i in range(0, len(episodes), episodes_per_batch):
+        chunk = episodes[i:i + episodes_per_batch]
+        p = None if perms is None else perms[i:i + episodes_per_batch]
+        out.append(e.run_batch(chunk, perms=p).clone())
+    return torch.cat(out)
+
+
+def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
+             episodes_per_batch=32, verbose=True):
+    """600-episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies."""
+    y_query = np.repeat(range(n_way), n_query)
+    accs = []
+    for i in range(0, n_episodes, episodes_per_batch):
+        eps = [[v.cuda() for v in synthetic.test_episode(seed0 + j, n_way, n_shot, n_query, size, gen_examples)]
+               for j in range(i, min(i + episodes_per_batch, n_episodes))]
+        for j, ep in enumerate(eps):
+            assert torch.all(torch.eq(ep[0], ep[1]))                 # finetune.py:606
+        sc = finetune_batched(eps, model, state, fine_tune_epoch, n_way, n_shot, episodes_per_batch)
+        pred = sc.argmax(2).cpu().numpy()
+        for p in pred:
+            accs.append(float(np.mean(p == y_query)) * 100)
+    accs = np.asarray(accs)
+    if verbose:
+        print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))))
+    return accs
+
+
+def main(argv=None):
+    global params
+    np.random.seed(10)                                               # finetune.py:425
+    params = parse_args('train', argv)
+    from .methods.gnnnet import GnnNet
+    from .methods import gnnnet_copy
+    if params.method not in ('gnnnet',):
+        raise NotImplementedError("--method %s: only 'gnnnet' is on the HIP hot path" % params.method)
+    size = int(__import__("os").environ.get("MFT_IMAGE_SIZE", "84"))
+    cls = gnnnet_copy.GnnNet if params.n_shot == 50 else GnnNet
+    model = cls(model_dict[params.model], n_way=params.test_n_way, n_support=params.n_shot).cuda()
+    state = synthetic.gnnnet_state_dict(seed=0, n_way=params.test_n_way)   # no checkpoints offline
+    model.load_state_dict(state)
+    return evaluate(model, state, 600, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
+                    params.fine_tune_epoch)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,148 @@
+"""GnnNet: ResNet10 features -> Linear+BN projector -> GNN over (support + one query) graphs
+(mirror of methods/gnnnet.py:20-231), with the reference's attributes, asserts and state_dict keys.
+
+All arithmetic runs in libmft_hip.so.  ``set_forward`` batches the n_query graphs of an episode in one
+grouped launch sequence; ``set_forward_finetune`` runs the first-order-MAML inner loop (15 epochs of
+4-image Adam steps on the last ResNet block, gnnnet.py:153-177) on device-resident per-episode state.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import autograd_ops as AG
+from .. import backbone
+from .. import engine as eng
+from .. import functional as Fn
+from .. import ops
+from .gnn import GNN_nl
+from .meta_template import MetaTemplate
+
+
+class Classifier(nn.Module):
+    """Constructed (and never trained) by the reference's inner loop (gnnnet.py:10-18,127); kept so that the
+    torch RNG stream matches when callers depend on it."""
+
+    def __init__(self, dim, n_way):
+        super().__init__()
+        self.fc = nn.Linear(dim, n_way)
+
+    def forward(self, x):
+        raise RuntimeError("Classifier receives no gradient on the hot path (SURVEY.md §0 D4)")
+
+
+class GnnNet(MetaTemplate):
+    maml = False
+    FOLD50 = False          # gnnnet_copy.GnnNet folds 50 supports to 25 graph nodes per class
+
+    def __init__(self, model_func, n_way, n_support):
+        super().__init__(model_func, n_way, n_support)
+        if self.maml:
+            raise NotImplementedError("gnnnet_maml fast-weight layers are off the hot path (SURVEY.md §2.1)")
+        self.loss_fn = nn.CrossEntropyLoss()
+        self.first = True
+        self.fc = nn.Sequential(nn.Linear(self.feat_dim, 128), nn.BatchNorm1d(128, track_running_stats=False))
+        self.gnn = GNN_nl(128 + self.n_way, 96, self.n_way)
+        self.method = 'GnnNet'
+        self.support_label = _support_label(self.n_way, self._graph_support())
+
+    def _graph_support(self):
+        """support nodes per class in the graph"""
+        return self.n_support
+
+    def _image_support(self):
+        """support images per class in an episode tensor"""
+        return self.n_support
+
+    def cuda(self):
+        self.feature.cuda()
+        self.fc.cuda()
+        self.gnn.cuda()
+        self.support_label = self.support_label.cuda()
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def set_forward(self, x, is_feature=False):
+        """x [n_way, n_support+n_query, 3,H,W] (or features [n_way, n_support+15, 512]) -> scores
+        [n_way*n_query, n_way], row = class*n_query + q (gnnnet.py:68-87)."""
+        x = x.cuda()
+        if is_feature:
+            assert (x.size(1) == self.n_support + 15)
+            feats = x.reshape(-1, x.size(-1))
+        else:
+            feats = self.feature(x.view(-1, *x.size()[2:]))
+        n_query = x.size(1) - self.n_support if is_feature else self.n_query
+        return AG.gnnnet_head(self, feats, self._graph_support(), n_query, fold=self.FOLD50)
+
+    def forward_gnn(self, zs):
+        """zs: list of n_query tensors [1, n_way*(n_support+1), 128] -> scores (gnnnet.py:210-217)."""
+        nodes = torch.cat([torch.cat([z, self.support_label], dim=2) for z in zs], dim=0)
+        scores = self.gnn(nodes)
+        ns = self._graph_support()
+        return scores.view(self.n_query, self.n_way, ns + 1, self.n_way)[:, :, -1].permute(1, 0, 2).contiguous().view(-1, self.n_way)
+
+    def set_forward_loss(self, x):
+        y_query = torch.from_numpy(np.repeat(range(self.n_way), self.n_query)).cuda()
+        scores = self.set_forward(x)
+        return self.loss_fn(scores, y_query)
+
+    def set_forward_loss_finetune(self, x):
+        y_query = torch.from_numpy(np.repeat(range(self.n_way), self.n_query)).cuda()
+        scores = self.set_forward_finetune(x)
+        return self.loss_fn(scores, y_query)
+
+    # ------------------------------------------------------------------ first-order MAML
+    def MAML_update(self):
+        """theta <- theta - (theta_adapted_prev - theta_pre_prev) on the last nine tensors (gnnnet.py:90-103)."""
+        if self.first:
+            return
+        names = [n for n, p in self.feature.named_parameters() if p.requires_grad]
+        keep = set(names[:-9])
+        for (name, p), (_, p2), (_, p3) in zip(self.feature.named_parameters(), self.feature2.named_parameters(),
+                                               self.feature3.named_parameters()):
+            if name not in keep:
+                ops.maml_delta(p.data, p2.data.contiguous(), p3.data.contiguous())
+        AG.invalidate(self.feature)
+
+    INNER_EPOCHS = 15
+
+    def set_forward_finetune(self, x, is_feature=False):
+        """Meta-fine-tuning forward (gnnnet.py:106-208): undo the previous episode's inner-loop delta, adapt a
+        copy of the backbone's last block on the support set, swap it in, then score support (BN batch 25) and
+        query (BN batch 80) separately through fc + GNN."""
+        x = x.cuda()
+        batch_size = 4
+        n_sup = self._image_support()
+        support_size = self.n_way * n_sup
+        for p in self.feature.parameters():
+            p.requires_grad = True
+        y_a = np.repeat(range(self.n_way), n_sup).astype(np.int32)
+        self.MAML_update()
+        x_b = x[:, n_sup:].contiguous().view(self.n_way * self.n_query, *x.size()[2:])
+        x_a = x[:, :n_sup].contiguous().view(support_size, *x.size()[2:])
+        Classifier(self.feat_dim, self.n_way)                      # RNG-stream parity only (gnnnet.py:127)
+        adapted = eng.adapt_last_block(self.feature, x_a, y_a, epochs=self.INNER_EPOCHS, batch_size=batch_size)
+        if self.first:
+            self.first = False
+        self.feature2 = copy.deepcopy(self.feature)                # theta_pre      (gnnnet.py:185)
+        feat_network = copy.deepcopy(self.feature)
+        feat_network.load_state_dict(adapted, strict=False)
+        self.feature3 = feat_network                               # theta_adapted  (gnnnet.py:186)
+        self.feature.load_state_dict(feat_network.state_dict())    # incl. BN running stats (gnnnet.py:187)
+        AG.invalidate(self.feature)
+        for p in self.feature.parameters():
+            p.requires_grad = True
+        out_s = self.feature(x_a).view(self.n_way, n_sup, -1)
+        out_q = self.feature(x_b).view(self.n_way, self.n_query, -1)
+        final = torch.cat((out_s, out_q), dim=1)
+        assert (final.size(1) == n_sup + 16)
+        return AG.gnnnet_head(self, final.view(-1, final.size(-1)), self._graph_support(), self.n_query, fold=self.FOLD50)
+
+
+def _support_label(n_way, n_support):
+    """One-hot rows for supports, a zero row per query slot: [1, n_way*(n_support+1), n_way] (gnnnet.py:34-38)."""
+    lab = torch.zeros(n_way, n_support + 1, n_way)
+    for c in range(n_way):
+        lab[c, :n_support, c] = 1.0
+    return lab.view(1, -1, n_way)

@@ -1,0 +1,152 @@
+"""MetaTemplate: the plugin base class of every few-shot method (mirror of methods/meta_template.py:10-186).
+
+Host orchestration only -- episode loops, accuracy bookkeeping, the printed lines -- kept signature- and
+behaviour-compatible with the reference so train.py / finetune.py style drivers run unchanged.  The
+linear-head adaptation (set_forward_adaptation) runs its 100x7 SGD steps as HIP launches.
+"""
+from abc import abstractmethod
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class MetaTemplate(nn.Module):
+    def __init__(self, model_func, n_way, n_support, change_way=True):
+        super().__init__()
+        self.n_way = n_way
+        self.n_support = n_support
+        self.n_query = -1                       # set per episode from the input
+        self.freeze_backbone = False
+        self.feature = model_func()
+        self.feat_dim = self.feature.final_feat_dim
+        self.change_way = change_way
+
+    @abstractmethod
+    def set_forward(self, x, is_feature):
+        pass
+
+    @abstractmethod
+    def set_forward_loss(self, x):
+        pass
+
+    def forward(self, x):
+        return self.feature.forward(x)
+
+    def parse_feature(self, x, is_feature):
+        x = x.cuda()
+        if is_feature:
+            z_all = x
+        else:
+            if self.freeze_backbone:
+                for p in self.feature.parameters():
+                    p.requires_grad = False
+            x = x.contiguous().view(self.n_way * (self.n_support + self.n_query), *x.size()[2:])
+            z_all = self.feature.forward(x).view(self.n_way, self.n_support + self.n_query, -1)
+        return z_all[:, :self.n_support], z_all[:, self.n_support:]
+
+    def correct(self, x):
+        scores = self.set_forward(x)
+        y_query = np.repeat(range(self.n_way), self.n_query)
+        pred = scores.data.topk(1, 1, True, True)[1].cpu().numpy()
+        return float(np.sum(pred[:, 0] == y_query)), len(y_query)
+
+    # ------------------------------------------------------------------ episode loops
+    def _episode_loop(self, epoch, train_loader, optimizer, loss_fn, support_from_x=True):
+        print_freq = 10
+        avg_loss = 0
+        for i, (x, _) in enumerate(train_loader):
+            self.n_query = x.size(1) - self.n_support
+            if self.change_way:
+                self.n_way = x.size(0)
+            optimizer.zero_grad()
+            loss = loss_fn(x)
+            loss.backward()
+            optimizer.step()
+            avg_loss = avg_loss + loss.item()
+            if i % print_freq == 0:
+                print('Epoch {:d} | Batch {:d}/{:d} | Loss {:f}'.format(epoch, i, len(train_loader), avg_loss / float(i + 1)))
+
+    def train_loop(self, epoch, train_loader, optimizer):
+        self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss)
+
+    def train_loop2(self, epoch, train_loader, optimizer):
+        self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss)
+
+    def train_loop_finetune(self, epoch, train_loader, optimizer):
+        self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss_finetune)
+
+    def train_loop3(self, epoch, train_loader, optimizer, unsup_loader):
+        self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss)
+
+    def test_loop(self, test_loader, record=None):
+        acc_all = []
+        iter_num = len(test_loader)
+        for i, (x, _) in enumerate(test_loader):
+            self.n_query = x.size(1) - self.n_support
+            if self.change_way:
+                self.n_way = x.size(0)
+            correct_this, count_this = self.correct(x)
+            acc_all.append(correct_this / count_this * 100)
+        acc_all = np.asarray(acc_all)
+        acc_mean = np.mean(acc_all)
+        acc_std = np.std(acc_all)
+        print('%d Test Acc = %4.2f%% +- %4.2f%%' % (iter_num, acc_mean, 1.96 * acc_std / np.sqrt(iter_num)))
+        return acc_mean
+
+    # ------------------------------------------------------------------ linear-head adaptation
+    def set_forward_adaptation(self, x, is_feature=True):
+        """Fix the features, train a fresh Linear(feat_dim, n_way) with SGD(lr .01, momentum .9, dampening .9,
+        wd 1e-3) for 100 epochs of 4-sample batches (meta_template.py:153-186; baselinefinetune.py:17-58)."""
+        assert is_feature == True, 'Feature is fixed in further adaptation'  # noqa: E712
+        z_support, z_query = self.parse_feature(x, is_feature)
+        z_support = z_support.contiguous().view(self.n_way * self.n_support, -1).float()
+        z_query = z_query.contiguous().view(self.n_way * self.n_query, -1).float()
+        y_support = np.repeat(range(self.n_way), self.n_support).astype(np.int32)
+        linear_clf = nn.Linear(self.feat_dim, self.n_way).cuda()       # same torch-RNG draw as the reference
+        return linear_head_adapt(z_support, y_support, z_query, linear_clf.weight.data, linear_clf.bias.data,
+                                 self.n_way, self.n_support)
+
+
+def linear_head_adapt(z_support, y_support, z_query, w, b, n_way, n_support, epochs=100, batch_size=4):
+    """SGD-with-dampening head training as HIP launches: GEMM fwd, CE fwd/bwd, GEMM wgrad, fused SGD."""
+    dev = z_support.device
+    K = z_support.shape[1]
+    assert K % 32 == 0
+    support_size = n_way * n_support
+    wpad = torch.zeros((32, K), device=dev)               # rows >= n_way stay zero (N padded to the 32-wide tile)
+    wpad[:n_way] = w
+    bias = b.clone().float().contiguous()
+    bufw = torch.zeros_like(wpad[:n_way])
+    bufb = torch.zeros_like(bias)
+    first = True
+    for epoch in range(epochs):
+        rand_id = np.random.permutation(support_size)
+        for i in range(0, support_size, batch_size):
+            ids = rand_id[i:min(i + batch_size, support_size)]
+            sel = torch.from_numpy(ids.astype(np.int32)).to(dev)
+            k = sel.numel()
+            zb = ops.gather_rows(z_support, sel)
+            yb = torch.from_numpy(y_support[ids]).to(dev)
+            scores = ops.gemm(zb, K, wpad[:n_way].contiguous(), n_way, bias=bias)
+            _, d = ops.cross_entropy(scores, yb, k, 1)
+            gw = small_tn(d, zb)                           # [n_way, K] = d^T @ zb
+            gb = small_tn(d, torch.ones((k, 4), device=dev))[:, 0].contiguous()
+            wv = wpad[:n_way]
+            ops.sgd_step(wv, gw, bufw, first)
+            ops.sgd_step(bias, gb, bufb, first)
+            first = False
+    return ops.gemm(z_query, K, wpad[:n_way].contiguous(), n_way, bias=bias)
+
+
+def small_tn(a, b):
+    """a [k, m], b [k, n] -> a^T b [m, n] through the MFMA GEMM (k padded to 32 with zero rows)."""
+    k, m = a.shape
+    n = b.shape[1]
+    at = torch.zeros((m, 32), device=a.device)
+    at[:, :k] = a.t()
+    bt = torch.zeros((n, 32), device=a.device)
+    bt[:, :k] = b.t()
+    return ops.gemm(at.contiguous(), 32, bt.contiguous(), n)

@@ -1,0 +1,164 @@
+"""Drop-in surface on a real MI355X: the reference-shaped modules and free functions (backbone.ResNet10,
+methods.gnn.*, GnnNet, gnnnet_copy.GnnNet, BaselineFinetune, finetune.finetune) against the golden vectors the
+reference itself produced.  Reads like the reference's call sites (train.py:144,167; finetune.py:185-198,316)."""
+import argparse
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import backbone, finetune, synthetic
+from meta_fine_tuning_amd.io_utils import model_dict
+from meta_fine_tuning_amd.methods import gnn
+from meta_fine_tuning_amd.methods.baselinefinetune import BaselineFinetune
+from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+from meta_fine_tuning_amd.methods import gnnnet_copy
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_resnet10_module_forward_and_running_stats(golden_dir):
+    g = _g(golden_dir, "g1_resnet10_fwd.npz")
+    m = model_dict['ResNet10'](flatten=True)
+    m.load_state_dict(synthetic.resnet10_state_dict(seed=3))
+    m.cuda().train()
+    x = synthetic.train_episode(11, 5, 1, 0, 84).view(5, 3, 84, 84)
+    with torch.no_grad():
+        f = m(x.cuda())
+    np.testing.assert_allclose(f.cpu().numpy(), g["feat_84"], atol=1e-4)
+    st = m.state_dict()
+    np.testing.assert_allclose(st["trunk.1.running_mean"].cpu().numpy(), g["rm1_84"], atol=1e-6)
+    np.testing.assert_allclose(st["trunk.1.running_var"].cpu().numpy(), g["rv1_84"], rtol=1e-4)
+    np.testing.assert_allclose(st["trunk.7.BN2.running_mean"].cpu().numpy(), g["rm7_84"], atol=1e-5)
+    np.testing.assert_allclose(st["trunk.7.BN2.running_var"].cpu().numpy(), g["rv7_84"], rtol=1e-3)
+    assert int(st["trunk.7.BN2.num_batches_tracked"]) == 1
+
+
+def test_module_inner_step_with_torch_adam(golden_dir):
+    """The reference's own inner-loop code shape: freeze names[:-9], torch.optim.Adam on the rest, CE on the 512-d
+    feature, loss.backward(), step (finetune.py:236-299) -- gradients come from the HIP last-block backward."""
+    g = _g(golden_dir, "g4_inner_loop.npz")
+    size = 84
+    m = model_dict['ResNet10'](flatten=True)
+    m.load_state_dict(synthetic.resnet10_state_dict(seed=9))
+    m.cuda().train()
+    names = [n for n, _ in m.named_parameters()]
+    for n, p in m.named_parameters():
+        if n in names[:-9]:
+            p.requires_grad = False
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=0.01)
+    views = synthetic.test_episode(31, 5, 5, 15, size, gen_examples=1)
+    xa = torch.cat([v[:, :5].contiguous().view(25, 3, size, size) for v in [views[0]] + views], 0).cuda()
+    ya = torch.from_numpy(np.tile(np.repeat(np.arange(5), 5), len(views) + 1)).cuda()
+    perm = g["perm"]
+    loss_fn = nn.CrossEntropyLoss().cuda()
+    sel = torch.from_numpy(perm[:5]).cuda()
+    opt.zero_grad()
+    out = m(xa[sel])
+    loss = loss_fn(out, ya[sel])
+    loss.backward()
+    assert abs(float(loss) - float(g["loss0_f32"])) < 1e-4
+    blk = m.trunk[7]
+    np.testing.assert_allclose(blk.C2.weight.grad[:2, :4].cpu().numpy(), g["g_c2_slice_f64"], atol=2e-5)
+    np.testing.assert_allclose(blk.C1.weight.grad[:2, :4].cpu().numpy(), g["g_c1_slice_f64"], atol=2e-5)
+    np.testing.assert_allclose(blk.BN2.weight.grad.cpu().numpy(), g["g_bn2_w_f64"], atol=5e-5)
+    assert abs(float(blk.C2.weight.grad.norm()) - float(g["gn_c2_f64"])) < 1e-4
+    assert m.trunk[0].weight.grad is None
+    opt.step()
+    assert abs(float(blk.C2.weight.norm()) - float(g["wn_c2_s1_f32"])) < 2e-3
+    with torch.no_grad():
+        mm = copy.deepcopy(m)
+        probe = mm(xa[:5]).cpu().numpy()
+    err = np.abs(probe - g["probe_s1_f32"])
+    assert (err < 5e-3).mean() > 0.99 and err.max() < 0.1
+
+
+@pytest.mark.parametrize("B,N", [(15, 30), (2, 105)])
+def test_gnn_modules(golden_dir, B, N):
+    g = _g(golden_dir, "g2_gnn.npz")
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    net = gnn.GNN_nl(133, 96, 5)
+    net.load_state_dict({k[len("gnn."):]: v for k, v in sd.items() if k.startswith("gnn.")})
+    net.cuda()
+    nodes = torch.from_numpy(np.random.RandomState(100 + N + B).standard_normal((B, N, 133)).astype(np.float32)).cuda()
+    out = net(nodes)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out_%d_%d" % (B, N)], atol=2e-4)
+    W_id = torch.eye(N, device="cuda").unsqueeze(0).repeat(B, 1, 1).unsqueeze(3)
+    Wn = net.layer_w0(nodes, W_id)
+    assert Wn.shape == (B, N, N, 2) and torch.equal(Wn[..., 0], W_id[..., 0])
+    np.testing.assert_allclose(Wn[..., 1].cpu().numpy(), g["A0_%d_%d" % (B, N)], atol=1e-5)
+    _, xo = net.layer_l0([Wn, nodes])
+    ref = gnn.gmul([Wn, nodes])
+    assert ref.shape == (B, N, 266) and xo.shape == (B, N, 48)
+    np.testing.assert_allclose(ref[..., :133].cpu().numpy(), nodes.cpu().numpy(), atol=1e-6)
+
+
+def test_gnnnet_set_forward(golden_dir):
+    g = _g(golden_dir, "g3_gnnnet_set_forward.npz")
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5)
+    model.load_state_dict(synthetic.gnnnet_state_dict(seed=7))
+    model = model.cuda()
+    model.train()
+    model.n_query = 16
+    x = synthetic.train_episode(21, 5, 5, 16, 84)
+    with torch.no_grad():
+        scores = model.set_forward(x)
+    np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], atol=5e-4)        # bar: 1e-3 on logits
+    correct, count = 0, 80
+    y = np.repeat(range(5), 16)
+    assert count == len(y)
+
+
+def test_gnnnet50_and_baselinefinetune(golden_dir):
+    g7 = _g(golden_dir, "g7_gnnnet50.npz")
+    m = gnnnet_copy.GnnNet(model_dict['ResNet10'], n_way=5, n_support=50)
+    st = m.state_dict()
+    st.update(synthetic.gnn_head_state_dict(seed=19))
+    m.load_state_dict(st)
+    m = m.cuda()
+    m.n_query = 15
+    feats = torch.from_numpy(np.random.RandomState(61).standard_normal((5, 65, 512)).astype(np.float32))
+    sc = m.set_forward(feats, is_feature=True)
+    np.testing.assert_allclose(sc.cpu().numpy(), g7["scores"], atol=1e-3)
+    g8 = _g(golden_dir, "g8_baselinefinetune.npz")
+    b = BaselineFinetune(model_dict['ResNet10'], n_way=5, n_support=5)
+    b.n_query = 15
+    f8 = torch.from_numpy(np.random.RandomState(71).standard_normal((5, 20, 512)).astype(np.float32))
+    torch.manual_seed(123)
+    np.random.seed(10)
+    sc8 = b.set_forward(f8, is_feature=True)
+    np.testing.assert_allclose(sc8.cpu().numpy(), g8["scores"], atol=2e-3)
+
+
+@pytest.mark.parametrize("E,G", [(0, 0), (1, 2), (2, 1)])
+def test_finetune_dropin(golden_dir, E, G):
+    """finetune.finetune(liz_x, y, model, state, save_it, n_query=15, n_way=5, n_support=5) as finetune.py:619 calls it."""
+    g = _g(golden_dir, "g5_finetune.npz")
+    sd = synthetic.gnnnet_state_dict(seed=13)
+    finetune.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=E)
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5)
+    model.load_state_dict(sd)
+    model.train()
+    liz = synthetic.test_episode(41 + G, 5, 5, 15, 84, gen_examples=G)
+    np.random.seed(10)
+    sc = finetune.finetune(liz, None, model, copy.deepcopy(sd), None, n_query=15, n_way=5, n_support=5)
+    ref = g["scores_E%d_G%d" % (E, G)]
+    assert sc.shape == (75, 5) and model.n_query == 15
+    if E == 0:
+        np.testing.assert_allclose(sc.cpu().numpy(), ref, atol=1e-4)
+    else:
+        err = np.abs(sc.cpu().numpy() - ref)
+        assert err.max() < 3e-2 and (sc.argmax(1).cpu().numpy() == ref.argmax(1)).mean() >= 0.96, err.max()
+
+
+def test_graft_smoke():
+    import __graft_entry__ as ge
+    ge.smoke()
