@@ -53,12 +53,28 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
                     int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int imgs_per_group, long long w_group_stride, void* stream);
 
+/* conv data gradient for stride-1 "same" convolutions (autograd of trunk.*.C2 in loss.backward(), finetune.py:293):
+ * dx[m][ci] = sum_{kh,kw,co} dy[pix(m)+pad-(kh,kw)][co] * w[g][co][kh][kw][ci], reading the FORWARD weight pack directly
+ * (flipped taps / transposed channels are resolved in the B-tile loader: no per-step weight transpose).
+ * H, W: spatial size of dx (and of dy).  Cin/Cout are the forward convolution's.                               */
+int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx,
+                          int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          int imgs_per_group, long long w_group_stride, void* stream);
+
 /* conv weight gradient (autograd of nn.Conv2d in loss.backward(): finetune.py:293, gnnnet.py:174,
  * meta_template.py:86): dw[g][co][kh][kw][ci] = sum_{m in group g} dy[m][co] * im2col(in)[m][(kh,kw,ci)].
  * One weight gradient per group of imgs_per_group images (0: a single group).               */
 int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
                           int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int imgs_per_group, long long dw_group_stride, void* stream);
+
+/* conv weight gradient with torch.optim.Adam.step fused into the epilogue (finetune.py:293-299): the gradient tile stays
+ * in MFMA accumulators; w, m, v (same packed layout / group stride as dw) are updated in place.  dw_or_null, when given,
+ * also receives the gradient.  Same Adam form as mft_adam_step (no weight decay).                                    */
+int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ldy, float* w, float* m, float* v,
+                               float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                               int stride, int pad, int imgs_per_group, long long group_stride,
+                               int step, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */
 /* F.batch_norm(training=True) statistics (backbone.py:224,227,240,409; gnn.py:65-74; gnnnet.py:30):

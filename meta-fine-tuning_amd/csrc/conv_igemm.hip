@@ -35,7 +35,12 @@ struct ConvArgs {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 
-template <int BM, int BN, int WM, int WN, bool STEM>
+// BT == true is the data-gradient form: the B operand is read straight from the *forward* weight pack
+// w[co][kh][kw][ci] as B[n=ci][k=(kh',kw',co)] = w[co][KH-1-kh'][KW-1-kw'][ci] (flipped taps, transposed
+// channels), so dX = conv(dY, flip/transposed W) needs no per-step weight transpose.  Its B tile is staged
+// k-major ([32 co][BN ci], coalesced 16-byte loads along ci) and the fragments are fetched with
+// conflict-free ds_read_b32 using the same k = 16*h + t mapping as the A operand.
+template <int BM, int BN, int WM, int WN, bool STEM, bool BT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -77,11 +82,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const float* wg = p.w + (long long)g * p.wgs;
     bool b_ok[PB];
     const float* b_ptr[PB];
+    constexpr int QB = BN / 4;            // BT: float4 per k-row of the B tile
+    constexpr int RB = 256 / QB;          // BT: k-rows per pass
+    const int bt_q = tid % QB, bt_k = tid / QB;
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        int n = n0 + lrow + 32 * j;
-        b_ok[j] = n < p.Cout;
-        b_ptr[j] = wg + (long long)(b_ok[j] ? n : 0) * p.Kpad + c4;
+        if (!BT) {
+            int n = n0 + lrow + 32 * j;
+            b_ok[j] = n < p.Cout;
+            b_ptr[j] = wg + (long long)(b_ok[j] ? n : 0) * p.Kpad + c4;
+        } else {
+            // row (co) stride of the forward pack = KH*KW*Cout_here (Cout_here = forward Cin)
+            b_ok[j] = (n0 + 4 * bt_q) < p.Cout;
+            b_ptr[j] = wg + (long long)(bt_k + j * RB) * ((long long)p.KH * p.KW * p.Cout) + n0 + 4 * bt_q;
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -128,11 +142,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 ra[j] = v;
             }
         }
+        if (!BT) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[j]) v = *(const f32x4*)(b_ptr[j] + k0);
-            rb[j] = v;
+            for (int j = 0; j < PB; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok[j]) v = *(const f32x4*)(b_ptr[j] + k0);
+                rb[j] = v;
+            }
+        } else {
+            const int khkw = k0 / p.Cin;                 // p.Cin = forward Cout (reduction channels)
+            const int co0 = k0 - khkw * p.Cin;
+            const int tapf = p.KH * p.KW - 1 - khkw;     // flipped tap
+            const long long off = (long long)co0 * ((long long)p.KH * p.KW * p.Cout) + (long long)tapf * p.Cout;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok[j]) v = *(const f32x4*)(b_ptr[j] + off);
+                rb[j] = v;
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -140,8 +167,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         float* Bs = As + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < PA; ++j) *(f32x4*)(As + (lrow + 32 * j) * LDS_LD + c4) = ra[j];
+        if (!BT) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) *(f32x4*)(Bs + (lrow + 32 * j) * LDS_LD + c4) = rb[j];
+            for (int j = 0; j < PB; ++j) *(f32x4*)(Bs + (lrow + 32 * j) * LDS_LD + c4) = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PB; ++j) *(f32x4*)(Bs + (bt_k + j * RB) * BN + 4 * bt_q) = rb[j];
+        }
     };
 
     load_tile(0);
@@ -162,9 +194,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float* ptr = Bs + (wn * (BN / WN) + j * 32 + r) * LDS_LD + h * 16;
+            if (!BT) {
+                const float* ptr = Bs + (wn * (BN / WN) + j * 32 + r) * LDS_LD + h * 16;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[j][q] = *(const f32x4*)(ptr + 4 * q);
+                for (int q = 0; q < 4; ++q) bv[j][q] = *(const f32x4*)(ptr + 4 * q);
+            } else {
+                const float* ptr = Bs + (h * 16) * BN + wn * (BN / WN) + j * 32 + r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][q][e] = ptr[(4 * q + e) * BN];
+            }
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t)
@@ -196,13 +236,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
 }
 
-template <int BM, int BN, int WM, int WN, bool STEM>
+template <int BM, int BN, int WM, int WN, bool STEM, bool BT = false>
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     const int tiles_m = cdiv(a.rows_per_group, BM);
     ConvArgs p = a;
     p.tiles_n = cdiv(a.Cout, BN);
     const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, BT>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -220,7 +260,7 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
 struct WgradArgs {
     const float* in;
     const float* dy;
-    float* dw;
+    float* dw;           // gradient output (may be null when the Adam epilogue is used)
     int ldi, ldy;
     int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
     int Kpad;
@@ -228,12 +268,18 @@ struct WgradArgs {
     int tiles_ci;        // Cin / BN
     int tiles_co;        // Cout / BM
     long long dwgs;
+    // fused Adam epilogue (ADAM == true): the gradient tile never reaches HBM
+    float* w; float* m; float* v;
+    float step_size, inv_sqrt_bc2, b1, b2, eps;
 };
 
 // dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
 // index of both operands, so tiles are staged k-major ([m][co], [m][ci]) and the MFMA fragments are
 // fetched with conflict-free ds_read_b32 (lane -> consecutive co / ci); MFMA step t uses m = 2t + h.
-template <int BM, int BN>
+// ADAM == true applies torch.optim.Adam (finetune.py:255,299) in the epilogue: the gradient tile is parked
+// in LDS ([BM][BN+4]) and the w/m/v update streams with 16 B per lane and 4*BN contiguous bytes per row:
+// 3 reads + 3 writes per parameter instead of a gradient write plus Adam's 4 reads + 3 writes.
+template <int BM, int BN, bool ADAM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
     constexpr int QA = BM / 4;                  // float4 per A row
@@ -242,8 +288,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int PB = (32 * QB) / 256;
     constexpr int RPA = 256 / QA;               // rows per pass
     constexpr int RPB = 256 / QB;
-    __shared__ __attribute__((aligned(16))) float As[32 * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * BN];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [32][BM]
+    float* Bs = smem + 32 * BM;       // [32][BN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -316,19 +363,95 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    float* dwg = p.dw + (long long)g * p.dwgs;
+    if (!ADAM) {
+        float* dwg = p.dw + (long long)g * p.dwgs;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + wn * (BN / 2) + j * 32 + r;
+            for (int j = 0; j < TN; ++j) {
+                const int ci = ci0 + wn * (BN / 2) + j * 32 + r;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int co = co0 + wm * (BM / 2) + i * 32 + row;
-                dwg[(long long)co * p.Kpad + (long long)khkw * p.Cin + ci] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int co = co0 + wm * (BM / 2) + i * 32 + row;
+                    dwg[(long long)co * p.Kpad + (long long)khkw * p.Cin + ci] = acc[i][j][e];
+                }
             }
+    } else {
+        constexpr int GLD = BN + 4;
+        float* Gs = smem;             // aliases As/Bs
+        __syncthreads();              // all fragment reads of As/Bs are done
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    Gs[(wm * (BM / 2) + i * 32 + row) * GLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+                }
+        __syncthreads();
+        constexpr int Q = BN / 4;             // float4 per row
+        constexpr int RP = 256 / Q;           // rows per pass
+        const int q = tid % Q, rr = tid / Q;
+        const long long gbase = (long long)g * p.dwgs + (long long)khkw * p.Cin + ci0 + 4 * q;
+#pragma unroll 4
+        for (int row = rr; row < BM; row += RP) {
+            const long long gi = gbase + (long long)(co0 + row) * p.Kpad;
+            const f32x4 ge = *(const f32x4*)(Gs + row * GLD + 4 * q);
+            f32x4 mm = *(const f32x4*)(p.m + gi);
+            f32x4 vv = *(const f32x4*)(p.v + gi);
+            f32x4 ww = *(const f32x4*)(p.w + gi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mm[e] = p.b1 * mm[e] + (1.f - p.b1) * ge[e];
+                vv[e] = p.b2 * vv[e] + (1.f - p.b2) * ge[e] * ge[e];
+                ww[e] -= p.step_size * (mm[e] / (sqrtf(vv[e]) * p.inv_sqrt_bc2 + p.eps));
+            }
+            *(f32x4*)(p.m + gi) = mm;
+            *(f32x4*)(p.v + gi) = vv;
+            *(f32x4*)(p.w + gi) = ww;
+            if (p.dw) *(f32x4*)(p.dw + gi) = ge;
         }
+    }
+}
+
+template <int BM, int BN, bool ADAM>
+int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
+    constexpr int lds_mm = 32 * (BM + BN) * 4;
+    constexpr int lds_ad = BM * (BN + 4) * 4;
+    constexpr int lds = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
+    auto kern = conv_wgrad_kernel<BM, BN, ADAM>;
+    if (lds > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+    }
+    WgradArgs p = a;
+    p.tiles_ci = a.Cin / BN;
+    p.tiles_co = a.Cout / BM;
+    dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return mft_launch_status();
+}
+
+int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, hipStream_t s) {
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    if (n_img % imgs_per_group != 0) return MFT_EINVAL;
+    if (a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.ldi % 4 != 0 || a.ldy % 4 != 0) return MFT_EINVAL;
+    const int groups = n_img / imgs_per_group;
+    a.OH = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
+    a.OW = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
+    a.Kpad = (a.KH * a.KW * a.Cin + 31) / 32 * 32;
+    a.imgs_per_group = imgs_per_group;
+    a.rows_per_group = imgs_per_group * a.OH * a.OW;
+    const int taps = a.KH * a.KW;
+    if (a.Cin % 128 == 0 && a.Cout % 128 == 0)
+        return adam ? launch_wgrad<128, 128, true>(a, taps, groups, s) : launch_wgrad<128, 128, false>(a, taps, groups, s);
+    return adam ? launch_wgrad<64, 64, true>(a, taps, groups, s) : launch_wgrad<64, 64, false>(a, taps, groups, s);
 }
 
 }  // namespace
@@ -369,31 +492,62 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     return launch_conv<128, 32, 4, 1, false>(a, groups, s);
 }
 
+extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
+                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int imgs_per_group, long long w_group_stride, void* stream) {
+    // H, W: spatial size of dx (= forward input); stride-1 "same" convolutions only (trunk.*.C2)
+    if (stride != 1 || 2 * pad != KH - 1 || KH != KW) return MFT_EINVAL;
+    if (Cout % 32 != 0 || Cin % 64 != 0 || ldy % 4 != 0) return MFT_EINVAL;
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    if (n_img % imgs_per_group != 0) return MFT_EINVAL;
+    const int groups = n_img / imgs_per_group;
+    ConvArgs a;
+    a.in = dy; a.w = w; a.bias = nullptr; a.out = dx;
+    a.ldi = ldy; a.ldo = ldx;
+    a.H = H; a.W = W; a.Cin = Cout; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = KH - 1 - pad;
+    a.OH = H; a.OW = W;
+    a.Cout = Cin;
+    a.Ktot = KH * KW * Cout;
+    a.Kpad = a.Ktot;
+    a.imgs_per_group = imgs_per_group;
+    a.rows_per_group = imgs_per_group * H * W;
+    a.wgs = (groups > 1) ? w_group_stride : 0;
+    a.tiles_n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool small_m = a.rows_per_group <= 64;
+    if (Cin % 128 == 0) {
+        if (small_m) return launch_conv<64, 128, 2, 2, false, true>(a, groups, s);
+        return launch_conv<128, 128, 2, 2, false, true>(a, groups, s);
+    }
+    if (small_m) return launch_conv<64, 64, 2, 2, false, true>(a, groups, s);
+    return launch_conv<128, 64, 2, 2, false, true>(a, groups, s);
+}
+
 extern "C" int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
                                      int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                      int imgs_per_group, long long dw_group_stride, void* stream) {
-    if (imgs_per_group <= 0) imgs_per_group = n_img;
-    if (n_img % imgs_per_group != 0) return MFT_EINVAL;
-    if (Cin % 64 != 0 || Cout % 64 != 0 || ldi % 4 != 0 || ldy % 4 != 0) return MFT_EINVAL;
-    const int groups = n_img / imgs_per_group;
-    WgradArgs a;
+    WgradArgs a = {};
     a.in = in; a.dy = dy; a.dw = dw; a.ldi = ldi; a.ldy = ldy;
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-    a.OH = (H + 2 * pad - KH) / stride + 1;
-    a.OW = (W + 2 * pad - KW) / stride + 1;
-    a.Kpad = (KH * KW * Cin + 31) / 32 * 32;
-    a.imgs_per_group = imgs_per_group;
-    a.rows_per_group = imgs_per_group * a.OH * a.OW;
     a.dwgs = dw_group_stride;
-    hipStream_t s = (hipStream_t)stream;
-    if (Cin % 128 == 0 && Cout % 128 == 0) {
-        a.tiles_ci = Cin / 128; a.tiles_co = Cout / 128;
-        dim3 grid(a.tiles_ci * a.tiles_co * KH * KW, groups, 1);
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, s, a);
-    } else {
-        a.tiles_ci = Cin / 64; a.tiles_co = Cout / 64;
-        dim3 grid(a.tiles_ci * a.tiles_co * KH * KW, groups, 1);
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, a);
-    }
-    return mft_launch_status();
+    return wgrad_dispatch(a, n_img, imgs_per_group, false, (hipStream_t)stream);
+}
+
+extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ldy, float* w, float* m,
+                                          float* v, float* dw_or_null, int n_img, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad, int imgs_per_group,
+                                          long long group_stride, int step, float lr, float beta1, float beta2,
+                                          float eps, void* stream) {
+    if (step < 1 || (KH * KW * Cin) % 32 != 0) return MFT_EINVAL;
+    WgradArgs a = {};
+    a.in = in; a.dy = dy; a.dw = dw_or_null; a.ldi = ldi; a.ldy = ldy;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.dwgs = group_stride;
+    a.w = w; a.m = m; a.v = v;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    return wgrad_dispatch(a, n_img, imgs_per_group, true, (hipStream_t)stream);
 }

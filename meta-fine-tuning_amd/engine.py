@@ -40,7 +40,8 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
-                 episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False):
+                 episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
+                 fused_adam=True):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316)."""
         if not torch.cuda.is_available():
@@ -50,6 +51,7 @@ class FinetuneEngine:
         self.size, self.n_views, self.epochs = image_size, n_views, fine_tune_epoch
         self.E, self.bs, self.lr = episodes_per_batch, batch_size, lr
         self.fold50 = fold50
+        self.fused_adam = fused_adam
         self.n_per_view = n_way * n_support
         self.n_total = self.n_per_view * (n_views + 1)            # finetune.py:214-233,269
         self.n_all = n_way * (n_support + n_query)
@@ -114,10 +116,14 @@ class FinetuneEngine:
         feat = Fn.resnet10_forward(self.W, xb.view(E * k, H, H, 3), self.arena, ipg=k, slab=self.adapt.w, tape=tape,
                                    tag="s%d" % k)
         loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
-        Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k)
         self.adapt.step += 1
-        ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
-                      lr=self.lr)
+        if self.fused_adam:
+            Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
+                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr))
+        else:
+            Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k)
+            ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
+                          lr=self.lr)
         return loss
 
     def final_scores(self):

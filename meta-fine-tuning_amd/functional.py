@@ -219,14 +219,15 @@ def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag
     return feat
 
 
-def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw"):
+def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None):
     """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
-    ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``."""
+    ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
+    ``adam`` = (m_slab, v_slab, step, lr): fuse the Adam update of the three conv weights into the wgrad
+    epilogues (their gradients are then not materialised) and update the BatchNorm affine tail separately."""
     x, c1, r1, c2, sc, out = tape["x"], tape["c1"], tape["r1"], tape["c2"], tape["sc"], tape["out"]
     n, oh, ow, C = out.shape
     groups = n // ipg
     rows = ipg * oh * ow
-    E = params.E
     d_out = arena.get(tag + ".dout", (n, oh, ow, C))
     ops._lib.check(ops._lib.lib().mft_avgpool_relu_backward(ops._p(dfeat), ops._p(out), ops._p(d_out), n, oh * ow, C,
                                                             ops._stream()), "mft_avgpool_relu_backward")
@@ -240,16 +241,26 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw"):
         ops._lib.check(rc, "mft_bn_backward")
         return dx
 
+    def wgrad(xin, dy, name, k, stride, pad):
+        if adam is None:
+            ops.conv2d_wgrad(xin, dy, 512, k, k, stride, pad, imgs_per_group=ipg, out=getattr(grads, name))
+        else:
+            m, v, step, lr = adam
+            ops.conv2d_wgrad_adam(xin, dy, getattr(params, name), getattr(m, name), getattr(v, name), 512, k, k,
+                                  stride, pad, step, imgs_per_group=ipg, lr=lr)
+
     dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
     dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
-    ops.conv2d_wgrad(r1, dc2, 512, 3, 3, 1, 1, imgs_per_group=ipg, out=grads.c2w)
-    wt = arena.get(tag + ".c2wt", (E, 512, 9 * 512))
-    ops._lib.check(lib.mft_pack_dgrad(ops._p(params.c2w), ops._p(wt), 512, 512, 3, 3, E, 512 * 4608, 512 * 4608,
-                                      ops._stream()), "mft_pack_dgrad")
-    dr1 = ops.conv2d(dc2, wt, 512, 3, 3, 1, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
+    # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
+    dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
     dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
-    ops.conv2d_wgrad(x, dc1, 512, 3, 3, 2, 1, imgs_per_group=ipg, out=grads.c1w)
-    ops.conv2d_wgrad(x, dsc, 512, 1, 1, 2, 0, imgs_per_group=ipg, out=grads.scw)
+    wgrad(r1, dc2, "c2w", 3, 1, 1)
+    wgrad(x, dc1, "c1w", 3, 2, 1)
+    wgrad(x, dsc, "scw", 1, 2, 0)
+    if adam is not None:
+        m, v, step, lr = adam
+        nb = params.E * 6 * 512                       # BatchNorm affine tail of the tensor-major slab
+        ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], step, lr=lr)
 
 
 # ------------------------------------------------------------------------------------------ GNN head

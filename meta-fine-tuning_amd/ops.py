@@ -117,6 +117,19 @@ def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     return out
 
 
+def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None):
+    """dy [n,H,W,Cout], forward weight pack [Cout,KH*KW*Cin] or [groups,Cout,KH*KW*Cin] -> dx [n,H,W,Cin] (stride 1)."""
+    _f32c(dy)
+    n, H, W, Cout = dy.shape
+    if out is None:
+        out = torch.empty((n, H, W, Cin), device=dy.device, dtype=torch.float32)
+    wgs = w_pk.shape[1] * w_pk.shape[2] if w_pk.dim() == 3 else 0
+    rc = _lib.lib().mft_conv2d_dgrad_nhwc(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, 1, pad,
+                                          imgs_per_group, wgs, _stream())
+    _lib.check(rc, "mft_conv2d_dgrad_nhwc")
+    return out
+
+
 def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None):
     """x [n,H,W,Cin], dy [n,OH,OW,Cout] -> dw [groups, Cout, KH*KW*Cin] (packed layout)."""
     _f32c(x)
@@ -130,6 +143,19 @@ def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None):
                                           imgs_per_group, Cout * K, _stream())
     _lib.check(rc, "mft_conv2d_wgrad_nhwc")
     return out
+
+
+def conv2d_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group=0, lr=0.01, beta1=0.9,
+                      beta2=0.999, eps=1e-8, dw=None):
+    """Weight gradient of a conv with the Adam update of (w, m, v) [groups, Cout, KH*KW*Cin] fused in the epilogue."""
+    _f32c(x)
+    _f32c(dy)
+    n, H, W, Cin = x.shape
+    K = KH * KW * Cin
+    rc = _lib.lib().mft_conv2d_wgrad_adam_nhwc(_p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dw), n, H, W, Cin,
+                                               Cout, KH, KW, stride, pad, imgs_per_group, Cout * K, step, lr, beta1,
+                                               beta2, eps, _stream())
+    _lib.check(rc, "mft_conv2d_wgrad_adam_nhwc")
 
 
 # ------------------------------------------------------------------------------------ batch norm

@@ -161,3 +161,20 @@ def test_engine_batched_matches_oracle_envelope():
         d_hip = np.abs(sc[i] - o64).max()
         assert d_hip <= max(4.0 * d_ref, 2e-3), (d_hip, d_ref)
         assert (sc[i].argmax(1) == o64.argmax(1)).mean() >= 0.96
+
+
+def test_fused_wgrad_adam_equals_unfused():
+    """The wgrad kernels with Adam in the epilogue must produce the same (w, m, v) as wgrad -> mft_adam_step."""
+    sd = synthetic.gnnnet_state_dict(seed=23)
+    eps = [synthetic.test_episode(400 + i, 5, 5, 15, 84, gen_examples=0) for i in range(2)]
+    rs = np.random.RandomState(6)
+    perms = [[rs.permutation(75)] for _ in range(2)]
+    outs = []
+    for fused in (False, True):
+        e = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=1, episodes_per_batch=2, device=DEV, fused_adam=fused)
+        sc = e.run_batch(eps, perms=perms)
+        outs.append((sc.clone(), e.adapt.w.flat.clone(), e.adapt.m.flat.clone(), e.adapt.v.flat.clone()))
+    (s0, w0, m0, v0), (s1, w1, m1, v1) = outs
+    assert float((m0 - m1).abs().max()) < 1e-6 and float((v0 - v1).abs().max()) < 1e-8
+    frac_far = float(((w0 - w1).abs() > 1e-4).float().mean())
+    assert frac_far < 1e-3 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))

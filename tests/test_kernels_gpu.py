@@ -97,6 +97,21 @@ def test_pack_roundtrip_and_dgrad():
     dx = ops.conv2d(nhwc(dy).to(DEV), wt, Cin, k, k, 1, 1)
     got = nchw(dx.cpu()).double()
     assert float((got - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+    # direct dgrad from the forward pack (no transpose pass), shared and per-group weights
+    dx2 = ops.conv2d_dgrad(nhwc(dy).to(DEV), wpk, Cin, k, k, 1)
+    assert float((nchw(dx2.cpu()).double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,G,ipg", [(512, 512, 3, 3, 5), (512, 512, 7, 2, 5), (64, 64, 21, 1, 4), (128, 256, 6, 1, 5)])
+def test_conv2d_dgrad_direct(Cin, Cout, H, G, ipg):
+    k = 3
+    w = rnd((G, Cout, Cin, k, k), 40, scale=0.05)
+    dy = rnd((G * ipg, Cout, H, H), 41)
+    ref = torch.cat([torch.nn.grad.conv2d_input((ipg, Cin, H, H), w[g].double(), dy[g * ipg:(g + 1) * ipg].double(),
+                                                stride=1, padding=1) for g in range(G)])
+    wpk = torch.stack([ops.pack_conv_weight(w[g].to(DEV)) for g in range(G)])
+    dx = ops.conv2d_dgrad(nhwc(dy).to(DEV), wpk if G > 1 else wpk[0], Cin, k, k, 1, imgs_per_group=ipg if G > 1 else 0)
+    assert float((nchw(dx.cpu()).double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,G,ipg", [
