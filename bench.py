@@ -75,10 +75,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "32")))
+    ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "128")))
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--gen-examples", type=int, default=17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="single-stream inner loop (A/B against the 2-stream pipeline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,10 +106,10 @@ def main():
     views = 2 + args.gen_examples
     state = synthetic.gnnnet_state_dict(seed=0)
     e = eng.FinetuneEngine(state, n_way, n_shot, n_query, size, n_views=views, fine_tune_epoch=args.epochs,
-                           episodes_per_batch=E, device=dev)
+                           episodes_per_batch=E, device=dev, pipeline=not args.no_pipeline)
     # resident synthetic episodes (class-structured so accuracy is meaningful); distinct per rank
-    pool = [[v.to(dev) for v in synthetic.test_episode(1000 * 2 + rank * 100000 + i, n_way, n_shot, n_query, size,
-                                                       gen_examples=args.gen_examples)] for i in range(E)]
+    pool = [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
+                                          gen_examples=args.gen_examples) for i in range(E)]
     y_query = np.repeat(np.arange(n_way), n_query)
     np.random.seed(10 + rank)
 

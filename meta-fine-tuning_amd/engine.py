@@ -41,7 +41,7 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True):
+                 fused_adam=True, pipeline=True):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316)."""
         if not torch.cuda.is_available():
@@ -60,7 +60,11 @@ class FinetuneEngine:
         self.W = Fn.ResNet10Weights(fsd, self.dev)
         self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way)
         self.arena = Fn.Arena(self.dev)
+        self.arena_trunk = Fn.Arena(self.dev)      # the frozen-trunk stream owns its own buffers / BN workspace
         self.adapt = AdaptState(self.E, self.dev)
+        self.pipeline = pipeline
+        self.s_trunk = torch.cuda.Stream(device=self.dev) if pipeline else None
+        self.s_last = torch.cuda.Stream(device=self.dev) if pipeline else None
         px = image_size * image_size * 3
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
@@ -109,12 +113,20 @@ class FinetuneEngine:
         return tables
 
     # ------------------------------------------------------------------ inner loop
-    def inner_step(self, idx_dev, lab_dev, k):
+    def trunk_step(self, idx_dev, k, parity):
+        """Frozen part of one inner step: gather the mini-batches, run trunk.0-6 (shared weights, per-episode BN
+        statistics).  Independent of the adapted weights, hence of the previous step."""
         E, H = self.E, self.size
-        xb = ops.gather_rows(self.Xs, idx_dev, out=self.arena.get("xb%d" % k, (E * k, H * H * 3)))
+        a = self.arena_trunk
+        xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (E * k, H * H * 3)))
+        return Fn.resnet10_trunk(self.W, xb.view(E * k, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
+
+    def last_step(self, x6, lab_dev, k):
+        """Adapted part: trunk.7 forward with per-episode weights, CE on the 512-d feature, last-block backward,
+        Adam (finetune.py:286-299)."""
+        E = self.E
         tape = {}
-        feat = Fn.resnet10_forward(self.W, xb.view(E * k, H, H, 3), self.arena, ipg=k, slab=self.adapt.w, tape=tape,
-                                   tag="s%d" % k)
+        feat = Fn.last_block_forward(self.W, x6, self.arena, k, slab=self.adapt.w, tape=tape, tag="s%d" % k)
         loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
         self.adapt.step += 1
         if self.fused_adam:
@@ -125,6 +137,43 @@ class FinetuneEngine:
             ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
                           lr=self.lr)
         return loss
+
+    def inner_step(self, idx_dev, lab_dev, k):
+        return self.last_step(self.trunk_step(idx_dev, k, 0), lab_dev, k)
+
+    def inner_loop(self, tables):
+        """All inner steps.  With ``pipeline`` the frozen trunk of step t+1 runs on its own HIP stream while the
+        HBM-bound last-block backward + Adam of step t runs on another (x6 is double-buffered); the two halves of a
+        step stress different resources (MFMA vs HBM)."""
+        if not tables:
+            return
+        dev = self.dev
+        idx_all = [torch.from_numpy(t[1]).to(dev, non_blocking=True) for t in tables]
+        lab_all = [torch.from_numpy(t[2]).to(dev, non_blocking=True) for t in tables]
+        if not self.pipeline:
+            for (k, _, _), idx, lab in zip(tables, idx_all, lab_all):
+                self.inner_step(idx, lab, k)
+            return
+        cur = torch.cuda.current_stream(dev)
+        self.s_trunk.wait_stream(cur)
+        self.s_last.wait_stream(cur)
+        done = [None, None]                          # last-block completion events per x6 buffer
+        for t, ((k, _, _), idx, lab) in enumerate(zip(tables, idx_all, lab_all)):
+            par = t & 1
+            with torch.cuda.stream(self.s_trunk):
+                if done[par] is not None:
+                    self.s_trunk.wait_event(done[par])
+                x6 = self.trunk_step(idx, k, par)
+                ready = torch.cuda.Event()
+                ready.record(self.s_trunk)
+            with torch.cuda.stream(self.s_last):
+                self.s_last.wait_event(ready)
+                self.last_step(x6, lab, k)
+                ev = torch.cuda.Event()
+                ev.record(self.s_last)
+                done[par] = ev
+        cur.wait_stream(self.s_trunk)
+        cur.wait_stream(self.s_last)
 
     def final_scores(self):
         """finetune.py:306-317: transductive feature pass over all n_way*(n_support+n_query) images, then
@@ -145,8 +194,7 @@ class FinetuneEngine:
         for slot in range(self.E):
             self.load_episode(slot, episodes[min(slot, n - 1)])      # pad a short batch by repeating the last episode
         self.adapt.reset(self.W)
-        for k, idx, lab in self.step_tables(perms, n):
-            self.inner_step(torch.from_numpy(idx).to(self.dev), torch.from_numpy(lab).to(self.dev), k)
+        self.inner_loop(self.step_tables(perms, n))
         scores, feats = self.final_scores()
         if return_feats:
             return scores[:n], feats.view(self.E, self.n_all, 512)[:n]

@@ -205,6 +205,16 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
     return out
 
 
+def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f"):
+    """trunk.7 + global average pool on the activation ``a`` [n,h,w,256] entering the last block -> features [n,512]."""
+    n = a.shape[0]
+    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=tape)
+    feat = arena.get(tag + ".feat", (n, 512))
+    ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
+                                                     ops._stream()), "mft_global_avgpool")
+    return feat
+
+
 def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag="f"):
     """Full ResNet10(flatten=True) forward in train mode: x [n,H,W,3] NHWC -> features [n,512].
     ``slab`` selects per-group last-block parameters (episode-batched inner loop)."""
@@ -212,11 +222,7 @@ def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag
     if ipg <= 0:
         ipg = n
     a = resnet10_trunk(W, x, arena, ipg, upto=7, running=running, tag=tag)
-    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=tape)
-    feat = arena.get(tag + ".feat", (n, 512))
-    ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
-                                                     ops._stream()), "mft_global_avgpool")
-    return feat
+    return last_block_forward(W, a, arena, ipg, slab=slab, tape=tape, running=running, tag=tag)
 
 
 def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None):

@@ -150,3 +150,23 @@ def test_episode(seed, n_way=5, n_support=5, n_query=15, size=84, gen_examples=1
 def episode_labels(n_way, n):
     """Implicit labels ``np.repeat(range(n_way), n)`` (gnnnet.py:119,220; finetune.py:217)."""
     return np.repeat(np.arange(n_way), n)
+
+
+def test_episode_device(seed, device, n_way=5, n_support=5, n_query=15, size=84, gen_examples=17, noise=1.0,
+                        aug_noise=0.1):
+    """Same contract as ``test_episode`` but drawn with torch's device generator straight into HBM (used by bench.py
+    to keep start-up short: 19 views x 100 images x 84 KB = 160 MB per episode).  Deterministic per (seed, device type);
+    NOT bit-identical to the numpy version."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    low = torch.randn((n_way, 3, 7, 7), generator=g, device=device)
+    t = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)
+    n = n_support + n_query
+    base = (t[:, None] + noise * torch.randn((n_way, n, 3, size, size), generator=g, device=device)).contiguous()
+    views = [base, base.clone()]
+    for k in range(gen_examples):
+        v = base + aug_noise * torch.randn(base.shape, generator=g, device=device)
+        if k % 2 == 1:
+            v = torch.flip(v, dims=[-1])
+        views.append(v.contiguous())
+    return views

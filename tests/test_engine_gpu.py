@@ -178,3 +178,17 @@ def test_fused_wgrad_adam_equals_unfused():
     assert float((m0 - m1).abs().max()) < 1e-6 and float((v0 - v1).abs().max()) < 1e-8
     frac_far = float(((w0 - w1).abs() > 1e-4).float().mean())
     assert frac_far < 1e-3 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))
+
+
+def test_two_stream_pipeline_is_bit_identical():
+    """Running the frozen trunk of step t+1 on a second stream must not change a single bit."""
+    sd = synthetic.gnnnet_state_dict(seed=25)
+    eps = [synthetic.test_episode(500 + i, 5, 5, 15, 84, gen_examples=1) for i in range(3)]
+    rs = np.random.RandomState(7)
+    perms = [[rs.permutation(100), rs.permutation(100)] for _ in range(3)]
+    res = []
+    for pipe in (False, True):
+        e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=3, device=DEV, pipeline=pipe)
+        sc = e.run_batch(eps, perms=perms)
+        res.append((sc.clone(), e.adapt.w.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
