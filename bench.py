@@ -101,6 +101,9 @@ def main():
     from meta_fine_tuning_amd import engine as eng
     from meta_fine_tuning_amd import ops, synthetic
 
+    if os.environ.get("MFT_WGRAD_TILE"):
+        from meta_fine_tuning_amd import _lib
+        _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
     E = args.episodes_per_batch
     n_way, n_shot, n_query, size = 5, 5, 15, 84
     views = 2 + args.gen_examples

@@ -53,6 +53,9 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
                     int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int imgs_per_group, long long w_group_stride, void* stream);
 
+/* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
+int mft_debug_set_conv_tile(int tile);
+
 /* conv data gradient for stride-1 "same" convolutions (autograd of trunk.*.C2 in loss.backward(), finetune.py:293):
  * dx[m][ci] = sum_{kh,kw,co} dy[pix(m)+pad-(kh,kw)][co] * w[g][co][kh][kw][ci], reading the FORWARD weight pack directly
  * (flipped taps / transposed channels are resolved in the B-tile loader: no per-step weight transpose).

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mft_unpack_oihw": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mft_pack_dgrad": [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P],
     "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "mft_debug_set_conv_tile": [_I],
     "mft_conv2d_dgrad_nhwc": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,

@@ -34,6 +34,8 @@ struct ConvArgs {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
+int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
+int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
 
 // BT == true is the data-gradient form: the B operand is read straight from the *forward* weight pack
 // w[co][kh][kw][ci] as B[n=ci][k=(kh',kw',co)] = w[co][KH-1-kh'][KW-1-kw'][ci] (flipped taps, transposed
@@ -449,7 +451,7 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, hipStr
     a.imgs_per_group = imgs_per_group;
     a.rows_per_group = imgs_per_group * a.OH * a.OW;
     const int taps = a.KH * a.KW;
-    if (a.Cin % 128 == 0 && a.Cout % 128 == 0)
+    if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64)
         return adam ? launch_wgrad<128, 128, true>(a, taps, groups, s) : launch_wgrad<128, 128, false>(a, taps, groups, s);
     return adam ? launch_wgrad<64, 64, true>(a, taps, groups, s) : launch_wgrad<64, 64, false>(a, taps, groups, s);
 }
@@ -480,16 +482,24 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
     if (stem) return launch_conv<128, 64, 2, 2, true>(a, groups, s);
-    const bool small_m = a.rows_per_group <= 64;
-    if (Cout % 128 == 0) {
-        if (small_m) return launch_conv<64, 128, 2, 2, false>(a, groups, s);
-        return launch_conv<128, 128, 2, 2, false>(a, groups, s);
+    // tile choice (tools/conv_tune.py, MI355X): with fp32 MFMA the 64x64 tile (58 VGPRs, 36.9 KB LDS, 4 workgroups
+    // per CU) beats every larger tile on all ResNet10 shapes (84-97 vs 61-88 TFLOP/s): latency hiding through
+    // occupancy matters more than operand reuse, LDS bandwidth is not a constraint at 2 floats per 64-cycle MFMA.
+    int tile = g_conv_tile;
+    if (tile == 0) tile = (Cout >= 64) ? 4 : 5;
+    switch (tile) {
+        case 1: return launch_conv<128, 128, 2, 2, false>(a, groups, s);
+        case 2: return launch_conv<128, 64, 2, 2, false>(a, groups, s);
+        case 3: return launch_conv<64, 128, 2, 2, false>(a, groups, s);
+        case 4: return launch_conv<64, 64, 2, 2, false>(a, groups, s);
+        default: return launch_conv<128, 32, 4, 1, false>(a, groups, s);
     }
-    if (Cout >= 64) {
-        if (small_m) return launch_conv<64, 64, 2, 2, false>(a, groups, s);
-        return launch_conv<128, 64, 2, 2, false>(a, groups, s);
-    }
-    return launch_conv<128, 32, 4, 1, false>(a, groups, s);
+}
+
+extern "C" int mft_debug_set_conv_tile(int tile) {
+    if (tile >= 1000) g_wgrad_tile = tile - 1000;      // 1064 / 1128: choose the wgrad tile
+    else g_conv_tile = tile;
+    return 0;
 }
 
 extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
