@@ -56,20 +56,25 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
 int mft_debug_set_conv_tile(int tile);
 
-/* conv data gradient for stride-1 "same" convolutions (autograd of trunk.*.C2 in loss.backward(), finetune.py:293):
- * dx[m][ci] = sum_{kh,kw,co} dy[pix(m)+pad-(kh,kw)][co] * w[g][co][kh][kw][ci], reading the FORWARD weight pack directly
- * (flipped taps / transposed channels are resolved in the B-tile loader: no per-step weight transpose).
- * H, W: spatial size of dx (and of dy).  Cin/Cout are the forward convolution's.                               */
+/* conv data gradient (autograd of nn.Conv2d / nn.Linear inputs in loss.backward(), finetune.py:293; meta_template.py:86):
+ * dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] * w[g][co][kh][kw][ci] (divisible offsets only), reading
+ * the FORWARD weight pack directly (the transposition is resolved in the B-tile loader: no per-step weight transpose).
+ * H, W: spatial size of dx (the forward input).  Cin/Cout/stride/pad are the forward convolution's; Cout % 32 == 0.   */
 int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx,
                           int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int imgs_per_group, long long w_group_stride, void* stream);
 
 /* conv weight gradient (autograd of nn.Conv2d in loss.backward(): finetune.py:293, gnnnet.py:174,
  * meta_template.py:86): dw[g][co][kh][kw][ci] = sum_{m in group g} dy[m][co] * im2col(in)[m][(kh,kw,ci)].
- * One weight gradient per group of imgs_per_group images (0: a single group).               */
+ * One weight gradient per group of imgs_per_group images (0: a single group).  Groups with more than 2048 rows are
+ * reduced in 1024-row chunks (one workgroup column per chunk) through `ws` (mft_conv2d_wgrad_ws_floats floats; may be
+ * NULL = no split) followed by a fixed-order sum.  Cin == 3 selects the 7x7 stem form.  Also nn.Linear / 1x1-conv
+ * weight gradients (H=W=1, rows = n_img).                                                                          */
+long long mft_conv2d_wgrad_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int imgs_per_group);
 int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
                           int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                          int imgs_per_group, long long dw_group_stride, void* stream);
+                          int imgs_per_group, long long dw_group_stride, float* ws, void* stream);
 
 /* conv weight gradient with torch.optim.Adam.step fused into the epilogue (finetune.py:293-299): the gradient tile stays
  * in MFMA accumulators; w, m, v (same packed layout / group stride as dw) are updated in place.  dw_or_null, when given,

@@ -25,7 +25,8 @@ SIGNATURES = {
     "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_debug_set_conv_tile": [_I],
     "mft_conv2d_dgrad_nhwc": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "mft_conv2d_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,
                                    _F, _P],
     "mft_bn_stats_ws_floats": [_I, _I, _I],
@@ -49,7 +50,7 @@ SIGNATURES = {
     "mft_gather_rows": [_P, _P, _P, _I, _L, _P],
     "mft_var_to_rstd": [_P, _P, _I, _F, _P],
 }
-_RESTYPE = {"mft_bn_stats_ws_floats": _L}
+_RESTYPE = {"mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L}
 
 _lib = None
 

@@ -30,6 +30,7 @@ struct ConvArgs {
     int imgs_per_group;
     int tiles_n;
     long long wgs;       // weight group stride (floats), 0 = shared
+    int bt_stride;       // BT (data-gradient) mode: stride of the forward convolution
 };
 
 constexpr int BK = 32;
@@ -37,9 +38,9 @@ constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
 
-// BT == true is the data-gradient form: the B operand is read straight from the *forward* weight pack
-// w[co][kh][kw][ci] as B[n=ci][k=(kh',kw',co)] = w[co][KH-1-kh'][KW-1-kw'][ci] (flipped taps, transposed
-// channels), so dX = conv(dY, flip/transposed W) needs no per-step weight transpose.  Its B tile is staged
+// BT == true is the data-gradient form: dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] *
+// w[co][kh][kw][ci] (taps whose offset is not divisible by the stride contribute nothing).  The B operand is
+// read straight from the *forward* weight pack as B[n=ci][k=(kh,kw,co)], so no per-step weight transpose.  Its B tile is staged
 // k-major ([32 co][BN ci], coalesced 16-byte loads along ci) and the fragments are fetched with
 // conflict-free ds_read_b32 using the same k = 16*h + t mapping as the A operand.
 template <int BM, int BN, int WM, int WN, bool STEM, bool BT>
@@ -119,8 +120,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
 #pragma unroll
             for (int j = 0; j < PA; ++j) {
-                int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-                bool ok = a_ok[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                int ih, iw;
+                bool ok;
+                if (!BT) {
+                    ih = a_ih0[j] + kh; iw = a_iw0[j] + kw;
+                    ok = a_ok[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                } else {
+                    // dx pixel (h,w) receives dy[(h+pad-kh)/s][(w+pad-kw)/s] * w[co][kh][kw][ci] when divisible
+                    const int th = a_ih0[j] - kh, tw = a_iw0[j] - kw;        // a_ih0 = h + pad_fwd
+                    ih = th / p.bt_stride; iw = tw / p.bt_stride;
+                    ok = a_ok[j] && th >= 0 && tw >= 0 && ih * p.bt_stride == th && iw * p.bt_stride == tw &&
+                         ih < p.H && iw < p.W;
+                }
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (ok) v = *(const f32x4*)(p.in + (a_base[j] + (long long)ih * p.W + iw) * p.ldi + ci0 + c4);
                 ra[j] = v;
@@ -154,8 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         } else {
             const int khkw = k0 / p.Cin;                 // p.Cin = forward Cout (reduction channels)
             const int co0 = k0 - khkw * p.Cin;
-            const int tapf = p.KH * p.KW - 1 - khkw;     // flipped tap
-            const long long off = (long long)co0 * ((long long)p.KH * p.KW * p.Cout) + (long long)tapf * p.Cout;
+            const long long off = (long long)co0 * ((long long)p.KH * p.KW * p.Cout) + (long long)khkw * p.Cout;
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -273,6 +283,9 @@ struct WgradArgs {
     // fused Adam epilogue (ADAM == true): the gradient tile never reaches HBM
     float* w; float* m; float* v;
     float step_size, inv_sqrt_bc2, b1, b2, eps;
+    // split-M: grid.z chunks of chunk_rows rows each write partial gradients to ws (reduced afterwards)
+    int chunk_rows, chunks;
+    float* ws;
 };
 
 // dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
@@ -281,7 +294,8 @@ struct WgradArgs {
 // ADAM == true applies torch.optim.Adam (finetune.py:255,299) in the epilogue: the gradient tile is parked
 // in LDS ([BM][BN+4]) and the w/m/v update streams with 16 B per lane and 4*BN contiguous bytes per row:
 // 3 reads + 3 writes per parameter instead of a gradient write plus Adam's 4 reads + 3 writes.
-template <int BM, int BN, bool ADAM>
+// STEMW: the 7x7x3 stem (Cin == 3): the "ci" axis of the tile is the flattened k = (kh*KW+kw)*3+ci (147 -> 160).
+template <int BM, int BN, bool ADAM, bool STEMW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
     constexpr int QA = BM / 4;                  // float4 per A row
@@ -322,26 +336,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const long long row0 = (long long)g * p.rows_per_group;
     const long long img0 = (long long)g * p.imgs_per_group;
 
-    for (int mk = 0; mk < p.rows_per_group; mk += 32) {
+    const int m_begin = blockIdx.z * p.chunk_rows;
+    const int m_end = min(m_begin + p.chunk_rows, p.rows_per_group);
+    const bool a_col_ok = (co0 + acol) < p.Cout;
+    const bool b_col_ok = STEMW ? true : (ci0 + bcol) < p.Cin;
+    for (int mk = m_begin; mk < m_end; mk += 32) {
         f32x4 va[PA], vb[PB];
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             int m = mk + arow + j * RPA;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.rows_per_group) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
+            if (m < m_end && a_col_ok) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
             va[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
             int m = mk + brow + j * RPB;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.rows_per_group) {
+            if (m < m_end && b_col_ok) {
                 int img = m / ohw;
                 int rem = m - img * ohw;
                 int oh = rem / p.OW, ow = rem - oh * p.OW;
-                int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                    v = *(const f32x4*)(p.in + ((img0 + img) * p.H * p.W + (long long)ih * p.W + iw) * p.ldi + ci0 + bcol);
+                if (!STEMW) {
+                    int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        v = *(const f32x4*)(p.in + ((img0 + img) * p.H * p.W + (long long)ih * p.W + iw) * p.ldi + ci0 + bcol);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = ci0 + bcol + e;
+                        if (k < p.KH * p.KW * 3) {
+                            const int tap = k / 3, ci = k - tap * 3;
+                            const int skh = tap / p.KW, skw = tap - skh * p.KW;
+                            const int ih = oh * p.stride - p.pad + skh, iw = ow * p.stride - p.pad + skw;
+                            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                                v[e] = p.in[((img0 + img) * p.H * p.W + (long long)ih * p.W + iw) * p.ldi + ci];
+                        }
+                    }
+                }
             }
             vb[j] = v;
         }
@@ -366,17 +398,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
     if (!ADAM) {
-        float* dwg = p.dw + (long long)g * p.dwgs;
+        float* dwg = (p.chunks > 1) ? p.ws + ((long long)g * p.chunks + blockIdx.z) * p.dwgs
+                                    : p.dw + (long long)g * p.dwgs;
+        const int ci_lim = STEMW ? p.Kpad : p.Cin;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ci = ci0 + wn * (BN / 2) + j * 32 + r;
+                if (ci >= ci_lim) continue;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                     const int co = co0 + wm * (BM / 2) + i * 32 + row;
-                    dwg[(long long)co * p.Kpad + (long long)khkw * p.Cin + ci] = acc[i][j][e];
+                    if (co < p.Cout) dwg[(long long)co * p.Kpad + (long long)khkw * p.Cin + ci] = acc[i][j][e];
                 }
             }
     } else {
@@ -418,12 +453,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
-template <int BM, int BN, bool ADAM>
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                            long long n, int chunks, long long dwgs) {
+    const int g = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += ws[((long long)g * chunks + c) * dwgs + i];
+        dw[(long long)g * dwgs + i] = s;
+    }
+}
+
+template <int BM, int BN, bool ADAM, bool STEMW = false>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
     constexpr int lds_ad = BM * (BN + 4) * 4;
     constexpr int lds = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
-    auto kern = conv_wgrad_kernel<BM, BN, ADAM>;
+    auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -433,27 +478,48 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
         }
     }
     WgradArgs p = a;
-    p.tiles_ci = a.Cin / BN;
-    p.tiles_co = a.Cout / BM;
-    dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
+    p.tiles_ci = ((STEMW ? a.Kpad : a.Cin) + BN - 1) / BN;
+    p.tiles_co = (a.Cout + BM - 1) / BM;
+    dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, p.chunks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    if (p.chunks > 1) {
+        const long long n = (long long)a.Cout * a.Kpad;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks, groups), dim3(256), 0, s, (const float*)p.ws, p.dw, n,
+                           p.chunks, p.dwgs);
+    }
     return mft_launch_status();
 }
 
-int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, hipStream_t s) {
+constexpr int WGRAD_CHUNK_ROWS = 1024;
+
+int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float* ws, hipStream_t s) {
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     if (n_img % imgs_per_group != 0) return MFT_EINVAL;
-    if (a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.ldi % 4 != 0 || a.ldy % 4 != 0) return MFT_EINVAL;
+    const bool stem = (a.Cin == 3);
+    if ((!stem && a.Cin % 4 != 0) || a.Cout % 4 != 0 || (!stem && a.ldi % 4 != 0) || a.ldy % 4 != 0) return MFT_EINVAL;
     const int groups = n_img / imgs_per_group;
     a.OH = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
     a.OW = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
     a.Kpad = (a.KH * a.KW * a.Cin + 31) / 32 * 32;
     a.imgs_per_group = imgs_per_group;
     a.rows_per_group = imgs_per_group * a.OH * a.OW;
+    a.chunk_rows = a.rows_per_group;
+    a.chunks = 1;
+    a.ws = ws;
+    if (!adam && ws != nullptr && a.rows_per_group > 2 * WGRAD_CHUNK_ROWS) {
+        a.chunk_rows = WGRAD_CHUNK_ROWS;
+        a.chunks = (a.rows_per_group + WGRAD_CHUNK_ROWS - 1) / WGRAD_CHUNK_ROWS;
+    }
     const int taps = a.KH * a.KW;
-    if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64)
-        return adam ? launch_wgrad<128, 128, true>(a, taps, groups, s) : launch_wgrad<128, 128, false>(a, taps, groups, s);
-    return adam ? launch_wgrad<64, 64, true>(a, taps, groups, s) : launch_wgrad<64, 64, false>(a, taps, groups, s);
+    if (stem) return adam ? MFT_EINVAL : launch_wgrad<64, 64, false, true>(a, 1, groups, s);
+    if (adam) {
+        if (a.Cin % 64 != 0 || a.Cout % 64 != 0) return MFT_EINVAL;
+        if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64) return launch_wgrad<128, 128, true>(a, taps, groups, s);
+        return launch_wgrad<64, 64, true>(a, taps, groups, s);
+    }
+    return launch_wgrad<64, 64, false>(a, taps, groups, s);
 }
 
 }  // namespace
@@ -480,6 +546,7 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     a.rows_per_group = imgs_per_group * a.OH * a.OW;
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
+    a.bt_stride = 1;
     hipStream_t s = (hipStream_t)stream;
     if (stem) return launch_conv<128, 64, 2, 2, true>(a, groups, s);
     // tile choice (tools/conv_tune.py, MI355X): with fp32 MFMA the 64x64 tile (58 VGPRs, 36.9 KB LDS, 4 workgroups
@@ -505,16 +572,19 @@ extern "C" int mft_debug_set_conv_tile(int tile) {
 extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
                                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                      int imgs_per_group, long long w_group_stride, void* stream) {
-    // H, W: spatial size of dx (= forward input); stride-1 "same" convolutions only (trunk.*.C2)
-    if (stride != 1 || 2 * pad != KH - 1 || KH != KW) return MFT_EINVAL;
-    if (Cout % 32 != 0 || Cin % 64 != 0 || ldy % 4 != 0) return MFT_EINVAL;
+    // H, W: spatial size of dx (= forward input); dy is [(H+2p-KH)/s+1, (W+2p-KW)/s+1]
+    if (Cout % 32 != 0 || Cin % 4 != 0 || ldy % 4 != 0 || stride < 1) return MFT_EINVAL;
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     if (n_img % imgs_per_group != 0) return MFT_EINVAL;
     const int groups = n_img / imgs_per_group;
     ConvArgs a;
     a.in = dy; a.w = w; a.bias = nullptr; a.out = dx;
     a.ldi = ldy; a.ldo = ldx;
-    a.H = H; a.W = W; a.Cin = Cout; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = KH - 1 - pad;
+    a.H = (H + 2 * pad - KH) / stride + 1;       // dy spatial size (the "input" of this gather)
+    a.W = (W + 2 * pad - KW) / stride + 1;
+    a.Cin = Cout; a.KH = KH; a.KW = KW;
+    a.stride = 1; a.pad = -pad;                  // row setup yields a_ih0 = h + pad
+    a.bt_stride = stride;
     a.OH = H; a.OW = W;
     a.Cout = Cin;
     a.Ktot = KH * KW * Cout;
@@ -524,23 +594,29 @@ extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, f
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool small_m = a.rows_per_group <= 64;
-    if (Cin % 128 == 0) {
-        if (small_m) return launch_conv<64, 128, 2, 2, false, true>(a, groups, s);
-        return launch_conv<128, 128, 2, 2, false, true>(a, groups, s);
-    }
-    if (small_m) return launch_conv<64, 64, 2, 2, false, true>(a, groups, s);
-    return launch_conv<128, 64, 2, 2, false, true>(a, groups, s);
+    if (Cin % 64 == 0) return launch_conv<64, 64, 2, 2, false, true>(a, groups, s);
+    return launch_conv<128, 32, 4, 1, false, true>(a, groups, s);
+}
+
+extern "C" long long mft_conv2d_wgrad_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                                 int pad, int imgs_per_group) {
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const long long rows = (long long)imgs_per_group * OH * OW;
+    if (rows <= 2 * WGRAD_CHUNK_ROWS) return 0;
+    const long long chunks = (rows + WGRAD_CHUNK_ROWS - 1) / WGRAD_CHUNK_ROWS;
+    const long long kpad = (KH * KW * Cin + 31) / 32 * 32;
+    return (long long)(n_img / imgs_per_group) * chunks * Cout * kpad;
 }
 
 extern "C" int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,
                                      int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                     int imgs_per_group, long long dw_group_stride, void* stream) {
+                                     int imgs_per_group, long long dw_group_stride, float* ws, void* stream) {
     WgradArgs a = {};
     a.in = in; a.dy = dy; a.dw = dw; a.ldi = ldi; a.ldy = ldy;
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.dwgs = dw_group_stride;
-    return wgrad_dispatch(a, n_img, imgs_per_group, false, (hipStream_t)stream);
+    return wgrad_dispatch(a, n_img, imgs_per_group, false, ws, (hipStream_t)stream);
 }
 
 extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ldy, float* w, float* m,
@@ -559,5 +635,5 @@ extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float*
     a.step_size = (float)((double)lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.b1 = beta1; a.b2 = beta2; a.eps = eps;
-    return wgrad_dispatch(a, n_img, imgs_per_group, true, (hipStream_t)stream);
+    return wgrad_dispatch(a, n_img, imgs_per_group, true, nullptr, (hipStream_t)stream);
 }

@@ -117,30 +117,34 @@ def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     return out
 
 
-def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None):
-    """dy [n,H,W,Cout], forward weight pack [Cout,KH*KW*Cin] or [groups,Cout,KH*KW*Cin] -> dx [n,H,W,Cin] (stride 1)."""
+def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None, stride=1, in_hw=None):
+    """dy [n,OH,OW,Cout], forward weight pack [Cout,KH*KW*Cin] or [groups,...] -> dx [n,H,W,Cin].
+    ``in_hw`` = (H, W) of the forward input (needed when stride > 1; defaults to dy's size for stride 1)."""
     _f32c(dy)
-    n, H, W, Cout = dy.shape
+    n, OH, OW, Cout = dy.shape
+    H, W = (OH, OW) if in_hw is None else in_hw
     if out is None:
         out = torch.empty((n, H, W, Cin), device=dy.device, dtype=torch.float32)
     wgs = w_pk.shape[1] * w_pk.shape[2] if w_pk.dim() == 3 else 0
-    rc = _lib.lib().mft_conv2d_dgrad_nhwc(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, 1, pad,
+    rc = _lib.lib().mft_conv2d_dgrad_nhwc(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride, pad,
                                           imgs_per_group, wgs, _stream())
     _lib.check(rc, "mft_conv2d_dgrad_nhwc")
     return out
 
 
-def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None):
-    """x [n,H,W,Cin], dy [n,OH,OW,Cout] -> dw [groups, Cout, KH*KW*Cin] (packed layout)."""
+def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None, ldy=None):
+    """x [n,H,W,Cin], dy [n,OH,OW,Cout] (row stride ldy) -> dw [groups, Cout, roundup(KH*KW*Cin,32)] (packed layout)."""
     _f32c(x)
     _f32c(dy)
     n, H, W, Cin = x.shape
     groups = 1 if imgs_per_group <= 0 else n // imgs_per_group
-    K = KH * KW * Cin
+    K = round_up(KH * KW * Cin, 32)
     if out is None:
         out = torch.empty((groups, Cout, K), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().mft_conv2d_wgrad_nhwc(_p(x), Cin, _p(dy), Cout, _p(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-                                          imgs_per_group, Cout * K, _stream())
+    nws = int(_lib.lib().mft_conv2d_wgrad_ws_floats(n, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group))
+    ws = torch.empty((nws,), device=x.device, dtype=torch.float32) if nws > 0 else None
+    rc = _lib.lib().mft_conv2d_wgrad_nhwc(_p(x), Cin, _p(dy), dy.shape[-1] if ldy is None else ldy, _p(out), n, H, W,
+                                          Cin, Cout, KH, KW, stride, pad, imgs_per_group, Cout * K, _p(ws), _stream())
     _lib.check(rc, "mft_conv2d_wgrad_nhwc")
     return out
 

@@ -114,6 +114,50 @@ def test_conv2d_dgrad_direct(Cin, Cout, H, G, ipg):
     assert float((nchw(dx.cpu()).double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", [(64, 128, 3, 2, 1, 21), (64, 128, 1, 2, 0, 21), (256, 512, 3, 2, 1, 6),
+                                                     (128, 256, 1, 2, 0, 11), (256, 512, 3, 2, 1, 14)])
+def test_conv2d_dgrad_strided(Cin, Cout, k, stride, pad, H):
+    n = 4
+    OH = (H + 2 * pad - k) // stride + 1
+    w = rnd((Cout, Cin, k, k), 42, scale=0.05)
+    dy = rnd((n, Cout, OH, OH), 43)
+    ref = torch.nn.grad.conv2d_input((n, Cin, H, H), w.double(), dy.double(), stride=stride, padding=pad)
+    dx = ops.conv2d_dgrad(nhwc(dy).to(DEV), ops.pack_conv_weight(w.to(DEV)), Cin, k, k, pad, stride=stride, in_hw=(H, H))
+    assert float((nchw(dx.cpu()).double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
+def test_linear_dgrad_wgrad_odd_dims():
+    """nn.Linear / 1x1-conv gradients of the GNN head: K padded to 32, N not a multiple of 64."""
+    for (M, K, N) in ((14400, 133, 192), (14400, 192, 96), (480, 266, 48), (3000, 96, 4)):
+        Kp = ops.round_up(K, 32)
+        Np = ops.round_up(N, 32)
+        x = torch.zeros(M, Kp); x[:, :K] = rnd((M, K), 44)
+        dy = torch.zeros(M, Np); dy[:, :N] = rnd((M, N), 45)
+        w = rnd((N, K), 46, scale=0.1)
+        wp = torch.zeros(Np, Kp); wp[:N, :K] = w
+        dx = ops.conv2d_dgrad(dy.to(DEV).view(M, 1, 1, Np), wp.to(DEV), Kp, 1, 1, 0)
+        ref = dy[:, :N].double() @ w.double()
+        assert float((dx.view(M, Kp)[:, :K].cpu().double() - ref).abs().max()) <= 3e-5 * max(float(ref.abs().max()), 1.0)
+        dw = ops.conv2d_wgrad(x.to(DEV).view(M, 1, 1, Kp), dy.to(DEV).view(M, 1, 1, Np), Np, 1, 1, 1, 0)
+        refw = dy[:, :N].double().t() @ x[:, :K].double()
+        assert float((dw[0, :N, :K].cpu().double() - refw).abs().max()) <= 1e-4 * max(float(refw.abs().max()), 1.0)
+
+
+def test_stem_and_large_m_wgrad():
+    n, H = 21, 84
+    x = rnd((n, 3, H, H), 47)
+    dy = rnd((n, 64, 42, 42), 48)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy.double(), stride=2, padding=3)
+    dw = ops.conv2d_wgrad(ops.nchw_to_nhwc(x.to(DEV)), nhwc(dy).to(DEV), 64, 7, 7, 2, 3)
+    got = dw[0, :, :147].cpu().view(64, 7, 7, 3).permute(0, 3, 1, 2).double()
+    assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 1.0)
+    x2, dy2 = rnd((n, 64, 21, 21), 49), rnd((n, 64, 21, 21), 50)          # 9261 rows -> 10 chunks
+    ref2 = torch.nn.grad.conv2d_weight(x2.double(), (64, 64, 3, 3), dy2.double(), stride=1, padding=1)
+    dw2 = ops.conv2d_wgrad(nhwc(x2).to(DEV), nhwc(dy2).to(DEV), 64, 3, 3, 1, 1)
+    got2 = dw2[0].cpu().view(64, 3, 3, 64).permute(0, 3, 1, 2).double()
+    assert float((got2 - ref2).abs().max()) <= 2e-4 * max(float(ref2.abs().max()), 1.0)
+
+
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,G,ipg", [
     (512, 512, 3, 1, 1, 3, 3, 5), (256, 512, 3, 2, 1, 6, 3, 5), (256, 512, 1, 2, 0, 6, 2, 5),
     (512, 512, 3, 1, 1, 7, 1, 5), (64, 64, 3, 1, 1, 21, 1, 4), (256, 512, 3, 2, 1, 6, 1, 1)])
