@@ -163,6 +163,41 @@ int mft_gather_query_scores(const float* out, int ldo, float* scores, int n_epis
 /* x_a_i[selected_id] (finetune.py:282; gnnnet.py:162): dst[r,:] = src[idx[r],:], rows of row_floats (%4==0) floats */
 int mft_gather_rows(const float* src, const int* idx, float* dst, int n_rows, long long row_floats, void* stream);
 
+/* backward-only entry points of the meta-training path (loss.backward() in MetaTemplate.train_loop*,
+ * meta_template.py:76-109) --------------------------------------------------------------------------------------- */
+/* BatchNorm backward for any group size (three launches: chunked partial sums, fixed-order finalize, elementwise dx) with
+ * the derivative of the activation that followed the BN fused in: dy_eff = dy * act'(y_act) (y_act = post-activation
+ * output, NULL for none).  ws: mft_bn_backward_ws_floats floats.  dx may be NULL (parameter gradients only).          */
+long long mft_bn_backward_ws_floats(int C, int rows_per_group, int n_groups);
+int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, const float* y_act, int ldya,
+                        float* dx, int lddx, int C, int rows_per_group, int n_groups,
+                        const float* mean, const float* rstd, const float* gamma, long long gb_group_stride,
+                        float* dgamma, float* dbeta, int act, float slope, float* ws, void* stream);
+/* dx (+)= dy * act'(y)  (ReLU / leaky-ReLU backward; GNN_nl's F.leaky_relu before the concat, gnn.py:160) */
+int mft_act_backward(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long long rows,
+                     int act, float slope, int accumulate, void* stream);
+/* out[c] = sum_r x[r][c] (bias gradients of nn.Linear / 1x1 nn.Conv2d); ws >= ceil(rows/1024)*C floats */
+int mft_colsum(const float* x, int ldx, int C, long long rows, float* out, float* ws, void* stream);
+/* trunk[1..3] forward that also records each window's argmax (uint8, first maximum wins) for the backward pass */
+int mft_bn_relu_maxpool_arg(const float* x, float* y, unsigned char* argmax, int n_img, int H, int W, int C,
+                            int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, void* stream);
+/* MaxPool2d(3,2,1) + ReLU backward: dx [n,H,W,C] w.r.t. the BatchNorm output, from dy / argmax / y of the pooled map */
+int mft_maxpool_relu_backward(const float* dy, const unsigned char* argmax, const float* y, float* dx,
+                              int n_img, int H, int W, int C, void* stream);
+/* Wcompute softmax backward: ds[(b,i,j)*ldds] = A*(dA - sum_j dA*A) */
+int mft_masked_softmax_backward(const float* A, const float* dA, float* ds, int ldds, int n_graphs, int N, void* stream);
+/* |x_i - x_j| backward, accumulated into dx */
+int mft_pair_absdiff_backward(const float* x, int ldx, const float* dd, int ldd, float* dx, int lddx,
+                              int n_graphs, int N, int F, void* stream);
+/* gmul backward: dx += dy[:, :F] + A^T dy[:, F:2F];  dA = dy[:, F:2F] x^T */
+int mft_graph_aggregate_backward(const float* A, const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
+                                 float* dA, int n_graphs, int N, int F, void* stream);
+int mft_build_graph_nodes_backward(const float* dnodes, int ld, float* dz, int zf, int n_episodes, int n_way,
+                                   int n_support, int n_query, int fold, void* stream);
+int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,
+                                     int n_support, int n_query, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,8 +49,19 @@ SIGNATURES = {
     "mft_gather_query_scores": [_P, _I, _P, _I, _I, _I, _I, _P],
     "mft_gather_rows": [_P, _P, _P, _I, _L, _P],
     "mft_var_to_rstd": [_P, _P, _I, _F, _P],
+    "mft_bn_backward_ws_floats": [_I, _I, _I],
+    "mft_bn_backward_act": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P],
+    "mft_act_backward": [_P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _I, _P],
+    "mft_colsum": [_P, _I, _I, _L, _P, _P, _P],
+    "mft_bn_relu_maxpool_arg": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mft_maxpool_relu_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mft_masked_softmax_backward": [_P, _P, _P, _I, _I, _I, _P],
+    "mft_pair_absdiff_backward": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "mft_graph_aggregate_backward": [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P],
+    "mft_build_graph_nodes_backward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L}
+_RESTYPE = {"mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L}
 
 _lib = None
 

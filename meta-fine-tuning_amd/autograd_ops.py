@@ -5,6 +5,7 @@ tensors' autograd version counters) and gradients are handed back in the referen
 import torch
 
 from . import functional as Fn
+from . import functional_bwd as FB
 from . import ops
 
 _ARENAS = {}
@@ -93,6 +94,48 @@ class _ResNet10Fn(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
+class _ResNet10FullFn(torch.autograd.Function):
+    """ResNet10 forward + full backward on HIP (meta-training: every parameter receives a gradient,
+    train.py:28; meta_template.py:76-92)."""
+
+    @staticmethod
+    def forward(ctx, mod, x_nhwc, *params):
+        W = module_weights(mod)
+        feat, tape = FB.resnet10_forward_taped(W, x_nhwc, running=_running(mod))
+        ctx.tape, ctx.W, ctx.mod = tape, W, mod
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        mod = ctx.mod
+        names = [n for n, _ in mod.named_parameters()]
+        need = [p.requires_grad for p in mod.parameters()]
+        g = FB.resnet10_backward(ctx.W, ctx.tape, dfeat.contiguous().float(), set(names))
+        out = [g[nm] if r else None for nm, r in zip(names, need)]
+        return (None, None) + tuple(out)
+
+
+class _HeadFn(torch.autograd.Function):
+    """GnnNet.fc + graph assembly + GNN_nl + score gather with a hand-written backward (gnnnet.py:76-87,210-217)."""
+
+    @staticmethod
+    def forward(ctx, model, feats, n_support, n_query, fold, *params):
+        G = head_weights(model.gnn, model.fc, model.n_way)
+        scores, tape = FB.head_forward_taped(G, feats.contiguous().float(), model.n_way, n_support, n_query, fold)
+        ctx.tape, ctx.G, ctx.model = tape, G, model
+        ctx.feats_need = feats.requires_grad
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        model = ctx.model
+        dfeats, g = FB.head_backward(ctx.G, ctx.tape, dscores.contiguous().float())
+        names = ["fc." + n for n, _ in model.fc.named_parameters()] + ["gnn." + n for n, _ in model.gnn.named_parameters()]
+        plist = list(model.fc.parameters()) + list(model.gnn.parameters())
+        out = [g[nm].view_as(p) if p.requires_grad else None for nm, p in zip(names, plist)]
+        return (None, dfeats if ctx.feats_need else None, None, None, None) + tuple(out)
+
+
 def resnet10_module_forward(mod, x):
     """backbone.ResNet.forward: x NCHW [n,3,H,W] on the GPU -> [n,512]."""
     _require_cuda(x, "ResNet10.forward")
@@ -103,7 +146,10 @@ def resnet10_module_forward(mod, x):
         raise NotImplementedError("eval-mode BatchNorm (freeze_backbone) is not on the HIP hot path yet; the reference "
                                   "keeps the backbone in train() for fine-tuning (finetune.py:263-264)")
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        out = _ResNet10Fn.apply(mod, xn, *params)
+        if any(p.requires_grad for p in params[:-9]):
+            out = _ResNet10FullFn.apply(mod, xn, *params)       # meta-training: gradients for the whole backbone
+        else:
+            out = _ResNet10Fn.apply(mod, xn, *params)           # inner loop: last block only
     else:
         W = module_weights(mod)
         n = xn.shape[0]
@@ -184,8 +230,11 @@ def invalidate(mod):
 
 def gnnnet_head(model, feats, n_support, n_query, fold=False):
     """GnnNet.fc + z_stack + forward_gnn for one episode (gnnnet.py:76-87,210-217): feats [n_way*(S+n_query), 512]
-    -> scores [n_way*n_query, n_way]."""
+    -> scores [n_way*n_query, n_way].  Differentiable (hand-written backward) when autograd is recording."""
     _require_cuda(feats, "GnnNet head")
+    plist = list(model.fc.parameters()) + list(model.gnn.parameters())
+    if torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in plist)):
+        return _HeadFn.apply(model, feats, n_support, n_query, fold, *plist)
     G = head_weights(model.gnn, model.fc, model.n_way)
     f = feats.detach().contiguous().float()
-    return Fn.gnnnet_scores(G, f, 1, model.n_way, n_support, n_query, arena_for(f.device), fold=fold, tag="head1")
+    return Fn.gnnnet_scores(G, f, 1, model.n_way, n_support, n_query, arena_for(f.device), fold=fold, tag="head1").clone()

@@ -1,0 +1,437 @@
+// Backward-only kernels of the meta-training path (loss.backward() in MetaTemplate.train_loop*, meta_template.py:76-109):
+// multi-workgroup BatchNorm backward with fused activation derivative, max-pool with saved argmax and its backward,
+// column sums (bias gradients), and the GNN head's backward glue (masked-softmax, |x_i-x_j|, graph aggregation, node
+// assembly, score gather).  All HBM-bound; reductions are fixed-order (bit-reproducible).
+#include "mft_common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_grad(float y, int act, float slope) {
+    if (act == MFT_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == MFT_ACT_LRELU) return y > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// ---------------------------------------------------------------------------------- BN backward, two phase
+struct BnBwdArgs {
+    const float* x; const float* dy; const float* y_act; float* dx;
+    int ldx, lddy, ldya, lddx, C, rows_per_group, rows_per_chunk, chunks;
+    const float* mean; const float* rstd; const float* gamma; long long gbs;
+    float* dgamma; float* dbeta; float* ws; int act; float slope;
+};
+
+// phase 1: per (chunk, 64-channel tile, group) partial sums of dy_eff and dy_eff * xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) {
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    const int g = blockIdx.z, chunk = blockIdx.x;
+    const long long row0 = (long long)g * p.rows_per_group;
+    __shared__ f32x4 red1[16][16];
+    __shared__ f32x4 red2[16][16];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (c < p.C) {
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        const int rbeg = chunk * p.rows_per_chunk, rend = min(rbeg + p.rows_per_chunk, p.rows_per_group);
+        for (int rr = rbeg + rl; rr < rend; rr += 16) {
+            f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+            if (p.y_act) {
+                const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + rr) * p.ldya + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+            }
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            s1 += d;
+            s2 += d * xh;
+        }
+    }
+    red1[rl][cq] = s1;
+    red2[rl][cq] = s2;
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { s1 += red1[k][cq]; s2 += red2[k][cq]; }
+        float* o = p.ws + (((long long)g * p.chunks + chunk) * p.C + c) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
+    }
+}
+
+// phase 2: fixed-order sum of the partials -> dgamma, dbeta and the two group means used by phase 3
+__global__ void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= p.C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < p.chunks; ++k) {
+        const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
+        s1 += o[0];
+        s2 += o[1];
+    }
+    if (p.dbeta) p.dbeta[(long long)g * p.C + c] = s1;
+    if (p.dgamma) p.dgamma[(long long)g * p.C + c] = s2;
+    sums[((long long)g * p.C + c) * 2] = s1 / (float)p.rows_per_group;
+    sums[((long long)g * p.C + c) * 2 + 1] = s2 / (float)p.rows_per_group;
+}
+
+// phase 3: dx = gamma * rstd * (dy_eff - mean(dy_eff) - xhat * mean(dy_eff * xhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p, const float* sums, int n_groups) {
+    const int cq = p.C >> 2;
+    const long long total = (long long)n_groups * p.rows_per_group * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cq;
+        const int c = (int)(i - row * cq) * 4;
+        const int g = (int)(row / p.rows_per_group);
+        f32x4 d = *(const f32x4*)(p.dy + row * p.lddy + c);
+        if (p.y_act) {
+            const f32x4 ya = *(const f32x4*)(p.y_act + row * p.ldya + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+        }
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        const f32x4 ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
+        const f32x4 xh = (*(const f32x4*)(p.x + row * p.ldx + c) - mu) * rs;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m1 = sums[((long long)g * p.C + c + e) * 2], m2 = sums[((long long)g * p.C + c + e) * 2 + 1];
+            o[e] = ga[e] * rs[e] * (d[e] - m1 - xh[e] * m2);
+        }
+        *(f32x4*)(p.dx + row * p.lddx + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------- elementwise helpers
+// dx = dy * act'(y) (+ optionally accumulate into dx)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
+                                                      int ldy, float* __restrict__ dx, int lddx, int C, long long rows,
+                                                      int act, float slope, int accumulate) {
+    const long long total = rows * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        const float v = dy[r * lddy + c] * act_grad(y[r * ldy + c], act, slope);
+        if (accumulate) dx[r * lddx + c] += v;
+        else dx[r * lddx + c] = v;
+    }
+}
+
+// out[c] = sum_r x[r][c], two phase (partials [chunks][C] then fixed-order sum)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, int C, long long rows,
+                                                             int rows_per_chunk, float* __restrict__ ws) {
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (c < C) {
+        const long long rbeg = (long long)blockIdx.x * rows_per_chunk;
+        const long long rend = min(rbeg + rows_per_chunk, rows);
+        for (long long r = rbeg + rl; r < rend; r += 4) s += x[r * ldx + c];
+    }
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) ws[(long long)blockIdx.x * C + c] = red[0][c & 63] + red[1][c & 63] + red[2][c & 63] + red[3][c & 63];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int C, int chunks, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += ws[(long long)k * C + c];
+    out[c] = s;
+}
+
+// ---------------------------------------------------------------------------------- max pool with argmax
+__global__ __launch_bounds__(256) void bn_relu_maxpool_arg_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  unsigned char* __restrict__ arg, int n_img, int H, int W,
+                                                                  int C, int OH, int OW, int imgs_per_group,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta) {
+    const long long total = (long long)n_img * OH * OW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const int g = n / imgs_per_group;
+        const float mu = mean[(long long)g * C + c], rs = rstd[(long long)g * C + c], ga = gamma[c], be = beta[c];
+        float best = -3.4e38f;
+        int barg = 0;
+        for (int dh = 0; dh < 3; ++dh) {
+            const int ih = oh * 2 - 1 + dh;
+            if (ih < 0 || ih >= H) continue;
+            for (int dw = 0; dw < 3; ++dw) {
+                const int iw = ow * 2 - 1 + dw;
+                if (iw < 0 || iw >= W) continue;
+                const float v = fmaxf((x[(((long long)n * H + ih) * W + iw) * C + c] - mu) * rs * ga + be, 0.f);
+                if (v > best) { best = v; barg = dh * 3 + dw; }     // first maximum wins, like ATen's max_pool2d
+            }
+        }
+        y[i] = best;
+        arg[i] = (unsigned char)barg;
+    }
+}
+
+// gradient w.r.t. the BN output (pre-ReLU): each input pixel gathers from the <= 4 windows that contain it
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __restrict__ dy,
+                                                               const unsigned char* __restrict__ arg,
+                                                               const float* __restrict__ y, float* __restrict__ dx,
+                                                               int n_img, int H, int W, int C, int OH, int OW) {
+    const long long total = (long long)n_img * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        float s = 0.f;
+        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {           // windows with oh*2-1 <= ih <= oh*2+1
+            if (oh < 0 || oh >= OH) continue;
+            const int dh = ih - (oh * 2 - 1);
+            if (dh < 0 || dh > 2) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= OW) continue;
+                const int dw = iw - (ow * 2 - 1);
+                if (dw < 0 || dw > 2) continue;
+                const long long o = (((long long)n * OH + oh) * OW + ow) * C + c;
+                if (arg[o] == dh * 3 + dw && y[o] > 0.f) s += dy[o];          // y > 0: ReLU derivative
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------- GNN head backward glue
+// A = softmax_j(s - 1e8*[i==j]);  ds[b,i,j] = A * (dA - sum_k dA*A)
+__global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                                 float* __restrict__ ds, int ldds, int n_graphs, int N) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)n_graphs * N) return;
+    const float* a = A + row * N;
+    const float* d = dA + row * N;
+    float dot = 0.f;
+    for (int j = lane; j < N; j += 64) dot += a[j] * d[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < N; j += 64) ds[(row * N + j) * ldds] = a[j] * (d[j] - dot);
+}
+
+// d[b,i,j,f] = |x_i - x_j| : dx[b,i,f] = sum_j sign(x_i-x_j) * (dd[b,i,j,f] + dd[b,j,i,f])  (accumulated into dx)
+__global__ __launch_bounds__(256) void pair_absdiff_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ dd, int ldd,
+                                                               float* __restrict__ dx, int lddx, int n_graphs, int N,
+                                                               int F) {
+    const long long total = (long long)n_graphs * N * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const long long bi = i / F;
+        const int ii = (int)(bi % N);
+        const long long b = bi / N;
+        const float xi = x[bi * ldx + f];
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float df = xi - x[(b * N + j) * ldx + f];
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            s += sg * (dd[((b * N + ii) * N + j) * ldd + f] + dd[((b * N + j) * N + ii) * ldd + f]);
+        }
+        dx[bi * lddx + f] += s;
+    }
+}
+
+// y = [x | A x]:  dx[b,i,f] += dy[b,i,f] + sum_j A[b,j,i] * dy[b,j,F+f];   dA[b,i,j] = sum_f dy[b,i,F+f] * x[b,j,f]
+__global__ __launch_bounds__(256) void graph_aggregate_bwd_kernel(const float* __restrict__ A,
+                                                                  const float* __restrict__ x, int ldx,
+                                                                  const float* __restrict__ dy, int lddy,
+                                                                  float* __restrict__ dx, int lddx,
+                                                                  float* __restrict__ dA, int n_graphs, int N, int F) {
+    const long long row = blockIdx.x;     // (b, i)
+    const long long b = row / N;
+    const int i = (int)(row % N);
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        float s = dy[row * lddy + f];
+        for (int j = 0; j < N; ++j) s += A[(b * N + j) * N + i] * dy[(b * N + j) * lddy + F + f];
+        dx[row * lddx + f] += s;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = wv; j < N; j += 4) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) s += dy[row * lddy + F + f] * x[(b * N + j) * ldx + f];
+        s = wave_sum(s);
+        if (lane == 0) dA[row * N + j] = s;
+    }
+}
+
+// dz[e, c, slot, :] = sum over the node rows that read it (supports: all n_query graphs; query q: graph q)
+__global__ __launch_bounds__(256) void build_nodes_bwd_kernel(const float* __restrict__ dnodes, int ld,
+                                                              float* __restrict__ dz, int zf, int n_ep, int n_way, int ns,
+                                                              int nq, int fold) {
+    const int per_class = (fold ? 2 * ns : ns) + nq;
+    const long long total = (long long)n_ep * n_way * per_class * zf;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % zf);
+        long long t = i / zf;
+        const int slot = (int)(t % per_class); t /= per_class;
+        const int c = (int)(t % n_way);
+        const long long e = t / n_way;
+        const int nsup = fold ? 2 * ns : ns;
+        float s = 0.f;
+        if (slot < nsup) {
+            const int sn = fold ? (slot % ns) : slot;
+            for (int q = 0; q < nq; ++q)
+                s += dnodes[((((e * nq + q) * n_way + c) * (ns + 1)) + sn) * ld + col];
+            if (fold) s *= 0.5f;
+        } else {
+            const int q = slot - nsup;
+            s = dnodes[((((e * nq + q) * n_way + c) * (ns + 1)) + ns) * ld + col];
+        }
+        dz[i] = s;
+    }
+}
+
+// dout[node(e,q,c,last), k] = dscores[e, c*nq+q, k]; zero elsewhere
+__global__ __launch_bounds__(256) void gather_scores_bwd_kernel(const float* __restrict__ dscores, float* __restrict__ dout,
+                                                                int ldo, int n_ep, int n_way, int ns, int nq) {
+    const long long rows = (long long)n_ep * nq * n_way * (ns + 1);
+    const long long total = rows * ldo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ldo);
+        long long r = i / ldo;
+        const int s = (int)(r % (ns + 1)); r /= (ns + 1);
+        const int c = (int)(r % n_way); r /= n_way;
+        const int q = (int)(r % nq);
+        const long long e = r / nq;
+        float v = 0.f;
+        if (s == ns && k < n_way) v = dscores[((e * n_way + c) * nq + q) * n_way + k];
+        dout[i] = v;
+    }
+}
+
+inline int bgrid(long long total, int cap = 4096) {
+    long long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+inline int bwd_chunks(int rows_per_group, int n_groups, int C) {
+    const int tiles = (C + 63) / 64;
+    long long want = (1024 + (long long)n_groups * tiles - 1) / ((long long)n_groups * tiles);
+    int maxc = (rows_per_group + 63) / 64;
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace
+
+extern "C" long long mft_bn_backward_ws_floats(int C, int rows_per_group, int n_groups) {
+    return 2LL * n_groups * bwd_chunks(rows_per_group, n_groups, C) * C + 2LL * n_groups * C;
+}
+
+extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, const float* y_act, int ldya,
+                                   float* dx, int lddx, int C, int rows_per_group, int n_groups, const float* mean,
+                                   const float* rstd, const float* gamma, long long gb_group_stride, float* dgamma,
+                                   float* dbeta, int act, float slope, float* ws, void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0 || (dx && lddx % 4 != 0) || (y_act && ldya % 4 != 0)) return MFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    BnBwdArgs p;
+    p.x = x; p.dy = dy; p.y_act = y_act; p.dx = dx;
+    p.ldx = ldx; p.lddy = lddy; p.ldya = ldya; p.lddx = lddx; p.C = C; p.rows_per_group = rows_per_group;
+    p.chunks = bwd_chunks(rows_per_group, n_groups, C);
+    p.rows_per_chunk = (rows_per_group + p.chunks - 1) / p.chunks;
+    p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.gbs = gb_group_stride;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws; p.act = act; p.slope = slope;
+    float* sums = ws + 2LL * n_groups * p.chunks * C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.chunks, (C + 63) / 64, n_groups), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128, n_groups), dim3(128), 0, s, p, sums);
+    if (dx) {
+        const long long total = (long long)n_groups * rows_per_group * (C / 4);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bgrid(total, 2048)), dim3(256), 0, s, p, (const float*)sums, n_groups);
+    }
+    return mft_launch_status();
+}
+
+extern "C" int mft_act_backward(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C,
+                                long long rows, int act, float slope, int accumulate, void* stream) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(bgrid(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, dx,
+                       lddx, C, rows, act, slope, accumulate);
+    return mft_launch_status();
+}
+
+extern "C" int mft_colsum(const float* x, int ldx, int C, long long rows, float* out, float* ws, void* stream) {
+    // ws: >= ceil(rows/1024) * C floats
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (int)((rows + 1023) / 1024);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 1024, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)ws, C, chunks, out);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_maxpool_arg(const float* x, float* y, unsigned char* argmax, int n_img, int H, int W, int C,
+                                       int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, void* stream) {
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)n_img * OH * OW * C;
+    hipLaunchKernelGGL(bn_relu_maxpool_arg_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
+                       n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
+    return mft_launch_status();
+}
+
+extern "C" int mft_maxpool_relu_backward(const float* dy, const unsigned char* argmax, const float* y, float* dx,
+                                         int n_img, int H, int W, int C, void* stream) {
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)n_img * H * W * C;
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, y, dx,
+                       n_img, H, W, C, OH, OW);
+    return mft_launch_status();
+}
+
+extern "C" int mft_masked_softmax_backward(const float* A, const float* dA, float* ds, int ldds, int n_graphs, int N,
+                                           void* stream) {
+    const long long rows = (long long)n_graphs * N;
+    hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, dA,
+                       ds, ldds, n_graphs, N);
+    return mft_launch_status();
+}
+
+extern "C" int mft_pair_absdiff_backward(const float* x, int ldx, const float* dd, int ldd, float* dx, int lddx,
+                                         int n_graphs, int N, int F, void* stream) {
+    hipLaunchKernelGGL(pair_absdiff_bwd_kernel, dim3(bgrid((long long)n_graphs * N * F)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, dd, ldd, dx, lddx, n_graphs, N, F);
+    return mft_launch_status();
+}
+
+extern "C" int mft_graph_aggregate_backward(const float* A, const float* x, int ldx, const float* dy, int lddy, float* dx,
+                                            int lddx, float* dA, int n_graphs, int N, int F, void* stream) {
+    hipLaunchKernelGGL(graph_aggregate_bwd_kernel, dim3(n_graphs * N), dim3(256), 0, (hipStream_t)stream, A, x, ldx, dy,
+                       lddy, dx, lddx, dA, n_graphs, N, F);
+    return mft_launch_status();
+}
+
+extern "C" int mft_build_graph_nodes_backward(const float* dnodes, int ld, float* dz, int zf, int n_episodes, int n_way,
+                                              int n_support, int n_query, int fold, void* stream) {
+    const long long total = (long long)n_episodes * n_way * ((fold ? 2 * n_support : n_support) + n_query) * zf;
+    hipLaunchKernelGGL(build_nodes_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dnodes, ld, dz, zf,
+                       n_episodes, n_way, n_support, n_query, fold);
+    return mft_launch_status();
+}
+
+extern "C" int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,
+                                                int n_support, int n_query, void* stream) {
+    const long long total = (long long)n_episodes * n_query * n_way * (n_support + 1) * ldo;
+    hipLaunchKernelGGL(gather_scores_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dscores, dout, ldo,
+                       n_episodes, n_way, n_support, n_query);
+    return mft_launch_status();
+}

@@ -1,0 +1,347 @@
+"""Taped forward + hand-written backward of the meta-training path, as sequences of HIP launches.
+
+Covers what ``loss.backward()`` differentiates in MetaTemplate.train_loop2 / train_loop_finetune
+(meta_template.py:76-109): the whole ResNet10 (one BatchNorm mini-batch per call, backbone.py:251-261,
+401-439) and the GnnNet head (fc + BatchNorm1d + GNN_nl, gnnnet.py:30,76-87,210-217; gnn.py:16-166).
+Everything is single-group (one episode); gradients come back in the reference's parameter layouts.
+"""
+import torch
+
+from . import functional as Fn
+from . import ops
+
+L = ops._lib
+RELU, LRELU, NONE = ops.ACT_RELU, ops.ACT_LRELU, ops.ACT_NONE
+
+
+def _zeros(shape, dev):
+    return torch.zeros(shape, device=dev, dtype=torch.float32)
+
+
+def _empty(shape, dev):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def bn_stats(x2d, C, rows, running=None):
+    rm, rv = running if running is not None else (None, None)
+    return ops.bn_stats(x2d, C, rows, 1, rm, rv)
+
+
+def bn_bwd(x2d, dy2d, C, rows, mean, rstd, gamma, y_act=None, act=NONE, need_dx=True):
+    """-> dx (or None), dgamma [C], dbeta [C]"""
+    dev = x2d.device
+    dx = None
+    if need_dx:          # padding columns (ld > C) must stay zero: they feed dgrad reductions against zero weight rows
+        dx = _empty(x2d.shape, dev) if x2d.shape[-1] == C else _zeros(x2d.shape, dev)
+    dg, db = _empty((C,), dev), _empty((C,), dev)
+    ws = _empty((int(L.lib().mft_bn_backward_ws_floats(C, rows, 1)),), dev)
+    rc = L.lib().mft_bn_backward_act(ops._p(x2d), x2d.shape[-1], ops._p(dy2d), dy2d.shape[-1], ops._p(y_act),
+                                     0 if y_act is None else y_act.shape[-1], ops._p(dx), 0 if dx is None else dx.shape[-1],
+                                     C, rows, 1, ops._p(mean), ops._p(rstd), ops._p(gamma), 0, ops._p(dg), ops._p(db), act,
+                                     ops.LRELU_SLOPE, ops._p(ws), ops._stream())
+    L.check(rc, "mft_bn_backward_act")
+    return dx, dg, db
+
+
+def act_backward(dy, y, dx, C, act, accumulate, dy_off=0, y_off=0, dx_off=0):
+    """dx[:, dx_off:dx_off+C] (+)= dy[:, dy_off:..] * act'(y[:, y_off:..]) on 2-D tensors with arbitrary row strides."""
+    rows = dy.shape[0]
+    rc = L.lib().mft_act_backward(dy.data_ptr() + 4 * dy_off, dy.shape[1], y.data_ptr() + 4 * y_off, y.shape[1],
+                                  dx.data_ptr() + 4 * dx_off, dx.shape[1], C, rows, act, ops.LRELU_SLOPE,
+                                  1 if accumulate else 0, ops._stream())
+    L.check(rc, "mft_act_backward")
+
+
+def colsum(x2d, C):
+    rows = x2d.shape[0]
+    out = _empty((C,), x2d.device)
+    ws = _empty((((rows + 1023) // 1024) * C,), x2d.device)
+    L.check(L.lib().mft_colsum(ops._p(x2d), x2d.shape[1], C, rows, ops._p(out), ops._p(ws), ops._stream()), "mft_colsum")
+    return out
+
+
+# =========================================================================================== ResNet10
+
+def resnet10_forward_taped(W, x, running=None):
+    """x [n,H,W,3] NHWC, one BatchNorm group.  Returns (features [n,512], tape)."""
+    n = x.shape[0]
+    dev = x.device
+    t = {"x": x, "n": n}
+
+    def run(name):
+        return None if running is None else running.get(name)
+
+    c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3)
+    H0 = c0.shape[1]
+    m0, s0 = bn_stats(c0.view(-1, 64), 64, n * H0 * H0, run("trunk.1"))
+    g0, b0 = W.bn["trunk.1"]
+    PH = (H0 + 2 - 3) // 2 + 1
+    a0 = _empty((n, PH, PH, 64), dev)
+    arg = torch.empty((n, PH, PH, 64), device=dev, dtype=torch.uint8)
+    L.check(L.lib().mft_bn_relu_maxpool_arg(ops._p(c0), ops._p(a0), ops._p(arg), n, H0, H0, 64, n, ops._p(m0), ops._p(s0),
+                                            ops._p(g0), ops._p(b0), ops._stream()), "mft_bn_relu_maxpool_arg")
+    t.update(c0=c0, m0=m0, s0=s0, a0=a0, arg=arg)
+    a = a0
+    blocks = []
+    for idx in (4, 5, 6, 7):
+        cin, cout, stride = Fn.STAGES[idx]
+        p = "trunk.%d" % idx
+        H = a.shape[1]
+        OH = (H + 2 - 3) // stride + 1
+        rows = n * OH * OH
+        b = {"p": p, "x": a, "cin": cin, "cout": cout, "stride": stride, "rows": rows}
+        c1 = ops.conv2d(a, W.conv[p + ".C1"], cout, 3, 3, stride, 1)
+        m1, s1 = bn_stats(c1.view(-1, cout), cout, rows, run(p + ".BN1"))
+        g1, be1 = W.bn[p + ".BN1"]
+        r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, 1, m1, s1, g1, be1, act=RELU).view(n, OH, OH, cout)
+        c2 = ops.conv2d(r1, W.conv[p + ".C2"], cout, 3, 3, 1, 1)
+        m2, s2 = bn_stats(c2.view(-1, cout), cout, rows, run(p + ".BN2"))
+        g2, be2 = W.bn[p + ".BN2"]
+        if cin != cout:
+            sc = ops.conv2d(a, W.conv[p + ".shortcut"], cout, 1, 1, stride, 0)
+            ms, ss = bn_stats(sc.view(-1, cout), cout, rows, run(p + ".BNshortcut"))
+            gs, bs = W.bn[p + ".BNshortcut"]
+            out = ops.bn_apply(c2.view(-1, cout), cout, rows, 1, m2, s2, g2, be2, act=RELU, res=sc.view(-1, cout),
+                               res_bn=(ms, ss, gs, bs)).view(n, OH, OH, cout)
+            b.update(sc=sc, ms=ms, ss=ss)
+        else:
+            out = ops.bn_apply(c2.view(-1, cout), cout, rows, 1, m2, s2, g2, be2, act=RELU,
+                               res=a.view(-1, cin)).view(n, OH, OH, cout)
+        b.update(c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, out=out)
+        blocks.append(b)
+        a = out
+    t["blocks"] = blocks
+    feat = ops.global_avgpool(a)
+    return feat, t
+
+
+def resnet10_backward(W, t, dfeat, need):
+    """Gradients of every ResNet10 parameter named in ``need`` (set of 'trunk.*' keys) in reference layouts."""
+    n = t["n"]
+    dev = dfeat.device
+    grads = {}
+    last = t["blocks"][-1]
+    d_out = ops.avgpool_relu_backward(dfeat.contiguous(), last["out"])
+    for b in reversed(t["blocks"]):
+        p, cin, cout, stride, rows = b["p"], b["cin"], b["cout"], b["stride"], b["rows"]
+        x_in, out = b["x"], b["out"]
+        H_in = x_in.shape[1]
+        o2 = out.view(-1, cout)
+        d2 = d_out.view(-1, cout)
+        g2 = W.bn[p + ".BN2"][0]
+        dc2, dg, db = bn_bwd(b["c2"].view(-1, cout), d2, cout, rows, b["m2"], b["s2"], g2, y_act=o2, act=RELU)
+        grads[p + ".BN2.weight"], grads[p + ".BN2.bias"] = dg, db
+        dc2 = dc2.view(out.shape)
+        grads[p + ".C2.weight"] = ops.unpack_conv_weight(
+            ops.conv2d_wgrad(b["r1"], dc2, cout, 3, 3, 1, 1)[0], (cout, cout, 3, 3))
+        dr1 = ops.conv2d_dgrad(dc2, W.conv[p + ".C2"], cout, 3, 3, 1)
+        g1 = W.bn[p + ".BN1"][0]
+        dc1, dg, db = bn_bwd(b["c1"].view(-1, cout), dr1.view(-1, cout), cout, rows, b["m1"], b["s1"], g1,
+                             y_act=b["r1"].view(-1, cout), act=RELU)
+        grads[p + ".BN1.weight"], grads[p + ".BN1.bias"] = dg, db
+        dc1 = dc1.view(out.shape)
+        grads[p + ".C1.weight"] = ops.unpack_conv_weight(
+            ops.conv2d_wgrad(x_in, dc1, cout, 3, 3, stride, 1)[0], (cout, cin, 3, 3))
+        dx = ops.conv2d_dgrad(dc1, W.conv[p + ".C1"], cin, 3, 3, 1, stride=stride, in_hw=(H_in, H_in))
+        if cin != cout:
+            gs = W.bn[p + ".BNshortcut"][0]
+            dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU)
+            grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dg, db
+            dsc = dsc.view(out.shape)
+            grads[p + ".shortcut.weight"] = ops.unpack_conv_weight(
+                ops.conv2d_wgrad(x_in, dsc, cout, 1, 1, stride, 0)[0], (cout, cin, 1, 1))
+            dxs = ops.conv2d_dgrad(dsc, W.conv[p + ".shortcut"], cin, 1, 1, 0, stride=stride, in_hw=(H_in, H_in))
+            act_backward(dxs.view(-1, cin), dxs.view(-1, cin), dx.view(-1, cin), cin, NONE, True)
+        else:
+            act_backward(d2, o2, dx.view(-1, cin), cin, RELU, True)            # identity shortcut through relu2
+        d_out = dx
+    # stem: maxpool + relu backward, BatchNorm backward, 7x7 wgrad
+    c0, a0 = t["c0"], t["a0"]
+    H0 = c0.shape[1]
+    d_bn0 = _empty(c0.shape, dev)
+    L.check(L.lib().mft_maxpool_relu_backward(ops._p(d_out), ops._p(t["arg"]), ops._p(a0), ops._p(d_bn0), n, H0, H0, 64,
+                                              ops._stream()), "mft_maxpool_relu_backward")
+    g0 = W.bn["trunk.1"][0]
+    dc0, dg, db = bn_bwd(c0.view(-1, 64), d_bn0.view(-1, 64), 64, n * H0 * H0, t["m0"], t["s0"], g0)
+    grads["trunk.1.weight"], grads["trunk.1.bias"] = dg, db
+    dw0 = ops.conv2d_wgrad(t["x"], dc0.view(c0.shape), 64, 7, 7, 2, 3)[0]
+    grads["trunk.0.weight"] = ops.unpack_conv_weight(dw0, (64, 3, 7, 7))
+    return grads
+
+
+# =========================================================================================== GNN head
+
+def _pad_rows32(w_pk):
+    """Weight pack with its row count padded to a multiple of 32 (zero rows): the dgrad reduction runs over Cout."""
+    cout, k = w_pk.shape
+    cp = ops.round_up(cout, 32)
+    if cp == cout:
+        return w_pk
+    out = torch.zeros((cp, k), device=w_pk.device, dtype=torch.float32)
+    out[:cout] = w_pk
+    return out
+
+
+def _linear_fwd(h, K, w, b, cout):
+    """h [rows, >=K] -> raw output [rows, roundup(cout,32)] (extra columns stay zero: they are dgrad/wgrad padding)."""
+    rows = h.shape[0]
+    ld = ops.round_up(cout, 32)
+    o = _zeros((rows, ld), h.device) if ld != cout else _empty((rows, ld), h.device)
+    ops.gemm(h, K, w, cout, bias=b, out=o)
+    return o
+
+
+def _linear_bwd(h, K, w, d_o, cout, need_dx=True):
+    """-> (dx [rows,K] or None, dW [cout, K], db [cout]).  d_o [rows, roundup(cout,32)] with zero padding columns."""
+    rows = h.shape[0]
+    cp = d_o.shape[1]
+    hin = h.view(rows, 1, 1, K) if h.shape[1] == K else _narrow(h, K)
+    dW = ops.conv2d_wgrad(hin, d_o.view(rows, 1, 1, cp), cp, 1, 1, 1, 0)[0][:cout]
+    db = colsum(d_o, cp)[:cout]
+    dx = None
+    if need_dx:
+        dx = ops.conv2d_dgrad(d_o.view(rows, 1, 1, cp), _pad_rows32(w), K, 1, 1, 0).view(rows, K)
+    return dx, dW, db
+
+
+def _narrow(h, K):
+    """[rows, ld] with ld > K -> contiguous [rows,1,1,K] copy (wgrad reads rows of exactly Cin floats)."""
+    return h[:, :K].contiguous().view(h.shape[0], 1, 1, K)
+
+
+def wcompute_taped(G, name, x, F, n_graphs, N):
+    layers, (w5, b5) = G.wc[name]
+    Kp = ops.round_up(F, 32)
+    rows = n_graphs * N * N
+    d = ops.pair_absdiff(x, N, F, Kp)
+    t = {"name": name, "F": F, "Kp": Kp, "d": d, "raw": [], "act": [], "stats": []}
+    h, K = d, Kp
+    for (w, b, g, beta, cout) in layers:
+        o = _linear_fwd(h, K, w, b, cout)
+        m, s = ops.bn_stats(o, cout, rows, 1)
+        oa = ops.bn_apply(o, cout, rows, 1, m, s, g, beta, act=LRELU, out=_empty(o.shape, o.device))
+        t["raw"].append(o); t["act"].append(oa); t["stats"].append((m, s))
+        h, K = oa, cout
+    sc = _linear_fwd(h, K, w5, b5, 1)                     # [rows, 32], column 0 is the score
+    A = ops.masked_softmax(sc, N)
+    t["A"] = A
+    return A, t
+
+
+def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
+    """Accumulates d(x) into dX[:, :F]; writes parameter gradients into ``grads`` under ``prefix``."""
+    layers, (w5, b5) = G.wc[t["name"]]
+    rows = n_graphs * N * N
+    dev = x.device
+    ds = _zeros((rows, 32), dev)
+    L.check(L.lib().mft_masked_softmax_backward(ops._p(t["A"]), ops._p(dA), ops._p(ds), 32, n_graphs, N, ops._stream()),
+            "mft_masked_softmax_backward")
+    h4 = t["act"][3]
+    dh, dW, db = _linear_bwd(h4, 96, w5, ds, 1)
+    grads[prefix + ".conv2d_last.weight"] = dW[:, :96].reshape(1, 96, 1, 1).contiguous()
+    grads[prefix + ".conv2d_last.bias"] = db
+    for li in (3, 2, 1, 0):
+        w, b, g, beta, cout = layers[li]
+        m, s = t["stats"][li]
+        do, dg, dbt = bn_bwd(t["raw"][li], dh, cout, rows, m, s, g, y_act=t["act"][li], act=LRELU)
+        grads[prefix + ".bn_%d.weight" % (li + 1)], grads[prefix + ".bn_%d.bias" % (li + 1)] = dg, dbt
+        hin = t["act"][li - 1] if li > 0 else t["d"]
+        K = layers[li - 1][4] if li > 0 else t["Kp"]
+        dh, dW, db = _linear_bwd(hin, K, w, do, cout)
+        kin = K if li > 0 else t["F"]
+        grads[prefix + ".conv2d_%d.weight" % (li + 1)] = dW[:, :kin].reshape(cout, kin, 1, 1).contiguous()
+        grads[prefix + ".conv2d_%d.bias" % (li + 1)] = db
+    L.check(L.lib().mft_pair_absdiff_backward(ops._p(x), x.shape[1], ops._p(dh), dh.shape[1], ops._p(dX), dX.shape[1],
+                                              n_graphs, N, t["F"], ops._stream()), "mft_pair_absdiff_backward")
+
+
+def gconv_taped(G, name, A, x, F, n_graphs, N):
+    w, b, g, beta, cout = G.gc[name]
+    rows = n_graphs * N
+    ldy = ops.round_up(2 * F, 32)
+    y = ops.graph_aggregate(A, x, F, ldy)
+    o = _linear_fwd(y, ldy, w, b, cout)
+    t = {"name": name, "F": F, "y": y, "raw": o, "A": A}
+    if g is not None:
+        m, s = ops.bn_stats(o, cout, rows, 1)
+        ob = ops.bn_apply(o, cout, rows, 1, m, s, g, beta, act=NONE, out=_empty(o.shape, o.device))
+        t["stats"] = (m, s)
+        return ob, t
+    return o, t
+
+
+def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix):
+    """d_o: gradient w.r.t. the Gconv output (after its BatchNorm when present), [rows, roundup(cout,32)].
+    Accumulates into dX[:, :F]; returns dA."""
+    w, b, g, beta, cout = G.gc[t["name"]]
+    rows = n_graphs * N
+    F = t["F"]
+    if g is not None:
+        m, s = t["stats"]
+        d_o, dg, dbt = bn_bwd(t["raw"], d_o, cout, rows, m, s, g)
+        grads[prefix + ".bn.weight"], grads[prefix + ".bn.bias"] = dg, dbt
+    dy, dW, db = _linear_bwd(t["y"], t["y"].shape[1], w, d_o, cout)
+    grads[prefix + ".fc.weight"] = dW[:, :2 * F].contiguous()
+    grads[prefix + ".fc.bias"] = db
+    dA = _empty((n_graphs, N, N), x.device)
+    L.check(L.lib().mft_graph_aggregate_backward(ops._p(t["A"]), ops._p(x), x.shape[1], ops._p(dy), dy.shape[1],
+                                                 ops._p(dX), dX.shape[1], ops._p(dA), n_graphs, N, F, ops._stream()),
+            "mft_graph_aggregate_backward")
+    return dA
+
+
+def head_forward_taped(G, feats, n_way, n_support, n_query, fold=False):
+    """GnnNet.fc + graph assembly + GNN_nl + score gather for ONE episode, keeping what backward needs."""
+    rows = feats.shape[0]
+    dev = feats.device
+    t = {"feats": feats, "n_way": n_way, "ns": n_support, "nq": n_query, "fold": fold}
+    z_raw = ops.gemm(feats, 512, G.fc_w, 128, bias=G.fc_b)
+    mz, sz = ops.bn_stats(z_raw, 128, rows, 1)
+    z = ops.bn_apply(z_raw, 128, rows, 1, mz, sz, G.fc_g, G.fc_beta, act=NONE, out=_empty(z_raw.shape, dev))
+    t.update(z_raw=z_raw, mz=mz, sz=sz)
+    N = n_way * (n_support + 1)
+    n_graphs = n_query
+    x = ops.build_graph_nodes(z, 1, n_way, n_support, n_query, ld=256, fold=fold)
+    F = 128 + n_way
+    t.update(x=x, N=N, n_graphs=n_graphs, wc=[], gc=[], Fs=[])
+    for i in range(2):
+        A, tw = wcompute_taped(G, "layer_w%d" % i, x, F, n_graphs, N)
+        ob, tg = gconv_taped(G, "layer_l%d" % i, A, x, F, n_graphs, N)
+        ops.copy_cols(ob, x, F, 48, act=LRELU)
+        t["wc"].append(tw); t["gc"].append(tg); t["Fs"].append(F)
+        F += 48
+    A, tw = wcompute_taped(G, "w_comp_last", x, F, n_graphs, N)
+    out, tg = gconv_taped(G, "layer_last", A, x, F, n_graphs, N)
+    t["wc"].append(tw); t["gc"].append(tg); t["Fs"].append(F)
+    scores = ops.gather_query_scores(out, 1, n_way, n_support, n_query)
+    return scores, t
+
+
+def head_backward(G, t, dscores):
+    """-> (dfeats [rows,512], grads keyed 'fc.*' / 'gnn.*' in reference layouts)."""
+    n_way, ns, nq, fold = t["n_way"], t["ns"], t["nq"], t["fold"]
+    x, N, n_graphs = t["x"], t["N"], t["n_graphs"]
+    dev = x.device
+    grads = {}
+    rows = n_graphs * N
+    dX = _zeros((rows, 256), dev)
+    d_out = _empty((rows, 32), dev)
+    L.check(L.lib().mft_gather_query_scores_backward(ops._p(dscores.contiguous()), ops._p(d_out), 32, 1, n_way, ns, nq,
+                                                     ops._stream()), "mft_gather_query_scores_backward")
+    dA = gconv_backward(G, t["gc"][2], d_out, x, dX, n_graphs, N, grads, "gnn.layer_last")
+    wcompute_backward(G, t["wc"][2], dA, x, dX, n_graphs, N, grads, "gnn.w_comp_last")
+    for i in (1, 0):
+        F = t["Fs"][i]
+        d_ob = _zeros((rows, 64), dev)                       # 48 outputs padded to 64 (dgrad reduction width)
+        act_backward(dX, x, d_ob, 48, LRELU, False, dy_off=F, y_off=F)
+        dA = gconv_backward(G, t["gc"][i], d_ob, x, dX, n_graphs, N, grads, "gnn.layer_l%d" % i)
+        wcompute_backward(G, t["wc"][i], dA, x, dX, n_graphs, N, grads, "gnn.layer_w%d" % i)
+    per = n_way * ((2 * ns if fold else ns) + nq)
+    dz = _empty((per, 128), dev)
+    L.check(L.lib().mft_build_graph_nodes_backward(ops._p(dX), 256, ops._p(dz), 128, 1, n_way, ns, nq, 1 if fold else 0,
+                                                   ops._stream()), "mft_build_graph_nodes_backward")
+    dzr, dg, db = bn_bwd(t["z_raw"], dz, 128, per, t["mz"], t["sz"], G.fc_g)
+    grads["fc.1.weight"], grads["fc.1.bias"] = dg, db
+    dfeats, dW, dbias = _linear_bwd(t["feats"], 512, G.fc_w, dzr, 128)
+    grads["fc.0.weight"], grads["fc.0.bias"] = dW[:, :512].contiguous(), dbias
+    return dfeats, grads

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from . import configs, synthetic
+from . import configs, optim, synthetic
 from .io_utils import get_assigned_file, model_dict, parse_args
 from .methods.gnnnet import GnnNet
 
@@ -34,7 +34,7 @@ class SyntheticEpisodeLoader:
 def train(base_loader, model, optimization, start_epoch, stop_epoch, params):
     if optimization != 'Adam':
         raise ValueError('Unknown optimization, please define by yourself')
-    optimizer = torch.optim.Adam(model.parameters())
+    optimizer = optim.Adam(model.parameters())          # torch.optim.Adam semantics, fused HIP update
     for epoch in range(start_epoch, stop_epoch):
         model.train()
         if not params.fine_tune:

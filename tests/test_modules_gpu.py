@@ -127,7 +127,7 @@ def test_gnnnet50_and_baselinefinetune(golden_dir):
     m.n_query = 15
     feats = torch.from_numpy(np.random.RandomState(61).standard_normal((5, 65, 512)).astype(np.float32))
     sc = m.set_forward(feats, is_feature=True)
-    np.testing.assert_allclose(sc.cpu().numpy(), g7["scores"], atol=1e-3)
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), g7["scores"], atol=1e-3)
     g8 = _g(golden_dir, "g8_baselinefinetune.npz")
     b = BaselineFinetune(model_dict['ResNet10'], n_way=5, n_support=5)
     b.n_query = 15
@@ -135,7 +135,7 @@ def test_gnnnet50_and_baselinefinetune(golden_dir):
     torch.manual_seed(123)
     np.random.seed(10)
     sc8 = b.set_forward(f8, is_feature=True)
-    np.testing.assert_allclose(sc8.cpu().numpy(), g8["scores"], atol=2e-3)
+    np.testing.assert_allclose(sc8.detach().cpu().numpy(), g8["scores"], atol=2e-3)
 
 
 @pytest.mark.parametrize("E,G", [(0, 0), (1, 2), (2, 1)])
