@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm, "gloo"
+in the CPU tests).  The reference is single-process; this is new functionality with two modes:
+
+* test-time fine-tuning shards embarrassingly: episode i -> rank i mod W, no data-path collective; one
+  all-gather of per-episode accuracies at the end.  Each episode draws its permutations from its own
+  ``numpy.random.RandomState(f(seed, i))`` so results do not depend on the rank count (deviation from the
+  reference's single sequential stream).
+* meta-training has ONE exchange step: every rank runs one episode from the common parameters, the gradients of
+  all 5,307,706 parameters are summed in a single flat fp32 bucket all-reduce (21.2 MB; ring all-reduce moves
+  2*(W-1)/W of it per GPU, ~0.25 ms on one 153 GB/s xGMI link) and divided by W, then every rank applies the same
+  outer Adam step.  Parity oracle: accumulate W episodes' gradients sequentially, divide by W, one step.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n_items, rank, world_size):
+    """Episode i belongs to rank i mod W."""
+    return list(range(rank, n_items, world_size))
+
+
+def episode_rng(seed, episode_index):
+    """Rank-count-invariant permutation stream of one episode."""
+    return np.random.RandomState((int(seed) * 1000003 + int(episode_index) * 7919) % (2 ** 32 - 1))
+
+
+def gather_episode_values(local_values, n_items, device="cpu"):
+    """All ranks' per-episode values (sharded with ``shard_indices``) -> full array in episode order on every rank."""
+    rank, W = world()
+    if W == 1:
+        return np.asarray(local_values, dtype=np.float64)
+    per = (n_items + W - 1) // W
+    buf = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
+    buf[:len(local_values)] = torch.as_tensor(np.asarray(local_values, dtype=np.float64), device=device)
+    out = [torch.empty_like(buf) for _ in range(W)]
+    dist.all_gather(out, buf)
+    full = np.empty(n_items, dtype=np.float64)
+    for r in range(W):
+        idx = shard_indices(n_items, r, W)
+        full[idx] = out[r][:len(idx)].cpu().numpy()
+    return full
+
+
+class FlatGradBucket:
+    """One flat fp32 buffer holding every parameter's gradient: a single all-reduce per outer step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        self.views = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def allreduce_mean(self):
+        """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place)."""
+        _, W = world()
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        if W > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(W)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def broadcast_buffers(module, src=0):
+    """BatchNorm running statistics diverge per rank (each saw its own episodes) and are never read on the hot path;
+    checkpoints take rank ``src``'s copy."""
+    _, W = world()
+    if W == 1:
+        return
+    for b in module.buffers():
+        dist.broadcast(b, src=src)

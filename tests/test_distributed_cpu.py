@@ -1,0 +1,102 @@
+"""N > 1 paths on CPU with the gloo backend (world_size 2): episode sharding + accuracy gather of the test-time path
+and the flat-bucket gradient all-reduce of the meta-training path against the sequential "accumulate W episodes,
+divide by W, one Adam step" emulation."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import parallel, synthetic
+from oracle import mft_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_state():
+    # GNN head only (fc + gnn): the gradient exchange does not care which parameters it carries
+    return synthetic.gnn_head_state_dict(seed=31)
+
+
+def _episode_grads(sd, seed):
+    rs = np.random.RandomState(seed)
+    feats = torch.from_numpy(rs.standard_normal((5, 21, 512)).astype(np.float32))
+    keys = [k for k in sd]
+    ps = [sd[k] for k in keys]
+    for p in ps:
+        p.requires_grad_(True)
+    z = O.fc_project(sd, feats.view(-1, 512)).view(5, 21, 128)
+    scores = O.gnnnet_scores_from_z(sd, z, 5, 5, 16)
+    loss = torch.nn.functional.cross_entropy(scores, torch.from_numpy(np.repeat(np.arange(5), 16)))
+    g = torch.autograd.grad(loss, ps)
+    for p in ps:
+        p.requires_grad_(False)
+    return keys, g
+
+
+def _worker(rank, world_size, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    # ---- test-time: shard 7 episodes, gather accuracies
+    idx = parallel.shard_indices(7, rank, world_size)
+    vals = [10.0 * i + 1 for i in idx]
+    full = parallel.gather_episode_values(vals, 7)
+    assert np.allclose(full, [10.0 * i + 1 for i in range(7)])
+    # ---- meta-train: one episode per rank, flat-bucket all-reduce, identical Adam step on every rank
+    sd = _small_state()
+    keys, g = _episode_grads(sd, 100 + rank)
+    params = [torch.nn.Parameter(sd[k].clone()) for k in keys]
+    for p, gi in zip(params, g):
+        p.grad = gi.clone()
+    bucket = parallel.FlatGradBucket(params)
+    assert bucket.numel == sum(p.numel() for p in params)
+    bucket.allreduce_mean()
+    opt = torch.optim.Adam(params)
+    opt.step()
+    if rank == 0:
+        torch.save({k: p.detach() for k, p in zip(keys, params)}, out)
+    # all ranks must hold identical parameters
+    flat = torch.cat([p.detach().flatten() for p in params])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref)
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    out = str(tmp_path / "params.pt")
+    W = 2
+    mp.spawn(_worker, args=(W, _free_port(), out), nprocs=W, join=True)
+    got = torch.load(out)
+    # sequential emulation: accumulate the W episodes' gradients from the common parameters, divide by W, one step
+    sd = _small_state()
+    acc = None
+    for r in range(W):
+        keys, g = _episode_grads(sd, 100 + r)
+        acc = [gi.clone() for gi in g] if acc is None else [a + gi for a, gi in zip(acc, g)]
+    params = [sd[k].clone() for k in keys]
+    st = O.adam_init(params)
+    O.adam_step(params, [a / W for a in acc], st, lr=1e-3)
+    for k, p in zip(keys, params):
+        err = (got[k] - p).abs()       # first Adam step = lr*sign(g): thread-count rounding may flip a near-zero gradient
+        assert float((err < 1e-6).float().mean()) > 0.999 and float(err.max()) < 2.1e-3, k
+
+
+def test_rank_invariant_permutations():
+    a = [parallel.episode_rng(10, i).permutation(50) for i in range(6)]
+    for W in (1, 2, 4):
+        for r in range(W):
+            for i in parallel.shard_indices(6, r, W):
+                assert np.array_equal(parallel.episode_rng(10, i).permutation(50), a[i])
+    assert parallel.shard_indices(7, 1, 2) == [1, 3, 5]
