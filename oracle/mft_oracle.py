@@ -50,19 +50,22 @@ def batchnorm_train(x, gamma, beta, sd=None, prefix=None, eps=BN_EPS):
     running buffers under ``prefix`` update them with momentum 0.1 and the
     *unbiased* variance, and bump ``num_batches_tracked``.
     """
-    dims = [d for d in range(x.dim()) if d != 1]
-    shape = [1, -1] + [1] * (x.dim() - 2)
-    mean = x.mean(dim=dims)
-    var = x.var(dim=dims, unbiased=False)
     if sd is not None and prefix is not None and (prefix + ".running_mean") in sd:
-        n = x.numel() // x.shape[1]
+        rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+        if rm.dtype == x.dtype:
+            out = F.batch_norm(x, rm, rv, gamma, beta, True, BN_MOMENTUM, eps)
+        else:                       # fp64 run over fp32 buffers: update copies, write back
+            rm2, rv2 = rm.to(x.dtype), rv.to(x.dtype)
+            out = F.batch_norm(x, rm2, rv2, gamma, beta, True, BN_MOMENTUM, eps)
+            with torch.no_grad():
+                rm.copy_(rm2.to(rm.dtype))
+                rv.copy_(rv2.to(rv.dtype))
         with torch.no_grad():
-            unb = var * (float(n) / float(max(n - 1, 1)))
-            sd[prefix + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach().to(sd[prefix + ".running_mean"].dtype))
-            sd[prefix + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * unb.detach().to(sd[prefix + ".running_var"].dtype))
             sd[prefix + ".num_batches_tracked"] += 1
-    xhat = (x - mean.view(shape)) / torch.sqrt(var.view(shape) + eps)
-    return xhat * gamma.view(shape) + beta.view(shape)
+        return out
+    # same ATen batch-norm kernel the reference's nn.BatchNorm* dispatches to (one fused pass; also what makes the
+    # CPU baseline in bench.py a fair stand-in for the reference's own CPU speed)
+    return F.batch_norm(x, None, None, gamma, beta, True, BN_MOMENTUM, eps)
 
 
 def batchnorm_eval(x, gamma, beta, rmean, rvar, eps=BN_EPS):
