@@ -107,6 +107,20 @@ int mft_var_to_rstd(const float* var, float* rstd, int n, float eps, void* strea
 int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
                         const float* mean, const float* rstd, const float* gamma, const float* beta,
                         void* stream);
+
+/* Stem cache (test-time fine-tune, finetune.py:263-291).  The reference re-runs trunk.0 (conv 7x7/2) on an image every time
+ * it is drawn into a mini-batch (once per epoch); the convolution output does not depend on the mini-batch, only the
+ * BatchNorm statistics of trunk.1 do.  mft_bn_image_moments reduces a cached conv output [n_img, rows_per_img, C] to per-image
+ * (mean, M2 = sum (x-mean)^2); mft_bn_combine_moments turns the moments of the images idx[g*imgs_per_group ..] into the
+ * mini-batch statistics of group g (Chan's combination, fixed order); mft_bn_relu_maxpool_gather is mft_bn_relu_maxpool
+ * reading image n from slot src_idx[n] of the cache (src_idx NULL: identity).                                              */
+int mft_bn_image_moments(const float* x, int ldx, int C, int rows_per_img, long long n_img, float* mean_img, float* m2_img,
+                         void* stream);
+int mft_bn_combine_moments(const float* mean_img, const float* m2_img, const int* idx, int C, int rows_per_img,
+                           int imgs_per_group, int n_groups, float eps, float* mean, float* rstd, void* stream);
+int mft_bn_relu_maxpool_gather(const float* x, const int* src_idx, float* y, int n_img, int H, int W, int C,
+                               int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, void* stream);
 /* trunk[8..9]: global average pool + flatten (backbone.py:427-430) */
 int mft_global_avgpool(const float* x, float* y, int n_img, int HW, int C, void* stream);
 

@@ -33,6 +33,9 @@ SIGNATURES = {
     "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P],
     "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
     "mft_bn_relu_maxpool": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mft_bn_relu_maxpool_gather": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mft_bn_image_moments": [_P, _I, _I, _I, _L, _P, _P, _P],
+    "mft_bn_combine_moments": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "mft_global_avgpool": [_P, _P, _I, _I, _I, _P],
     "mft_bn_backward": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P],
     "mft_avgpool_relu_backward": [_P, _P, _P, _I, _I, _I, _P],

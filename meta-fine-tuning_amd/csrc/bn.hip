@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
                                                               int imgs_per_group, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta) {
+                                                              const float* __restrict__ beta,
+                                                              const int* __restrict__ src_idx) {
     const int cq = C >> 2;
     const long long total = (long long)n_img * OH * OW * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
         const int oh = (int)(t % OH);
         const int n = (int)(t / OH);
         const int g = n / imgs_per_group;
+        const long long ns = src_idx ? (long long)src_idx[n] : (long long)n;   // image slot in the (cached) source
         const f32x4 mu = *(const f32x4*)(mean + (long long)g * C + c);
         const f32x4 rs = *(const f32x4*)(rstd + (long long)g * C + c);
         const f32x4 ga = *(const f32x4*)(gamma + c);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
             for (int dw = 0; dw < 3; ++dw) {
                 const int iw = ow * 2 - 1 + dw;
                 if (iw < 0 || iw >= W) continue;
-                const f32x4 v = *(const f32x4*)(x + (((long long)n * H + ih) * W + iw) * C + c);
+                const f32x4 v = *(const f32x4*)(x + ((ns * H + ih) * W + iw) * C + c);
                 const f32x4 o = (v - mu) * rs * ga + be;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], o[e]);
@@ -276,6 +278,75 @@ __global__ __launch_bounds__(256) void bn_backward_kernel(BwdArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------- per-image moments (stem cache)
+// The stem convolution of an image does not depend on which mini-batch the image lands in, only the BatchNorm
+// statistics do.  Per image and channel we keep (mean_i, M2_i = sum (x - mean_i)^2) over its HW pixels; the
+// statistics of any mini-batch of equally sized images follow from Chan's parallel combination
+//   mean = avg(mean_i),  M2 = sum M2_i + HW * sum (mean_i - mean)^2,  var = M2 / (k * HW)
+// in a fixed order (bit-identical reruns).  One block per (image, 64-channel tile).
+__global__ __launch_bounds__(256) void bn_image_moments_kernel(const float* __restrict__ x, int ldx, int C, int rows,
+                                                               float* __restrict__ mean_img,
+                                                               float* __restrict__ m2_img) {
+    const int cq = threadIdx.x & 15;
+    const int rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    const long long img = blockIdx.x;
+    const long long row0 = img * rows;
+    __shared__ f32x4 red1[ST_ROWS][16];
+    __shared__ f32x4 red2[ST_ROWS][16];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, sh = s1;
+    if (c < C) {
+        sh = *(const f32x4*)(x + row0 * ldx + c);
+        for (int rr = rl; rr < rows; rr += ST_ROWS) {
+            f32x4 v = *(const f32x4*)(x + (row0 + rr) * ldx + c);
+            v -= sh;
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    red1[rl][cq] = s1;
+    red2[rl][cq] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < ST_ROWS; ++k) {
+            s1 += red1[k][cq];
+            s2 += red2[k][cq];
+        }
+        const float inv = 1.f / (float)rows;
+        f32x4 mu, m2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = s1[e] * inv;
+            mu[e] = sh[e] + d;
+            m2[e] = fmaxf(s2[e] - s1[e] * d, 0.f);
+        }
+        *(f32x4*)(mean_img + img * C + c) = mu;
+        *(f32x4*)(m2_img + img * C + c) = m2;
+    }
+}
+
+__global__ void bn_combine_moments_kernel(const float* __restrict__ mean_img, const float* __restrict__ m2_img,
+                                          const int* __restrict__ idx, int C, int rows_per_img, int imgs_per_group,
+                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= C) return;
+    const int* id = idx + (long long)g * imgs_per_group;
+    float mu = 0.f;
+    for (int i = 0; i < imgs_per_group; ++i) mu += mean_img[(long long)id[i] * C + c];
+    mu /= (float)imgs_per_group;
+    float m2 = 0.f, dev = 0.f;
+    for (int i = 0; i < imgs_per_group; ++i) {
+        const float d = mean_img[(long long)id[i] * C + c] - mu;
+        m2 += m2_img[(long long)id[i] * C + c];
+        dev += d * d;
+    }
+    const float var = (m2 + (float)rows_per_img * dev) / ((float)rows_per_img * (float)imgs_per_group);
+    mean[(long long)g * C + c] = mu;
+    rstd[(long long)g * C + c] = 1.0f / sqrtf(var + eps);
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 256 * 8) {
     long long b = (total + block - 1) / block;
     if (b < 1) b = 1;
@@ -328,15 +399,40 @@ extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, i
     return mft_launch_status();
 }
 
-extern "C" int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
-                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                   void* stream) {
+extern "C" int mft_bn_relu_maxpool_gather(const float* x, const int* src_idx, float* y, int n_img, int H, int W, int C,
+                                          int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, void* stream) {
     if (C % 4 != 0) return MFT_EINVAL;
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)n_img * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n_img, H,
-                       W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,
+                                   const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   void* stream) {
+    return mft_bn_relu_maxpool_gather(x, nullptr, y, n_img, H, W, C, imgs_per_group, mean, rstd, gamma, beta, stream);
+}
+
+extern "C" int mft_bn_image_moments(const float* x, int ldx, int C, int rows_per_img, long long n_img, float* mean_img,
+                                    float* m2_img, void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || rows_per_img <= 0 || n_img <= 0 || n_img > 0x7fffffffLL) return MFT_EINVAL;
+    dim3 grid((unsigned)n_img, (C + 63) / 64, 1);
+    hipLaunchKernelGGL(bn_image_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, C, rows_per_img,
+                       mean_img, m2_img);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_combine_moments(const float* mean_img, const float* m2_img, const int* idx, int C,
+                                      int rows_per_img, int imgs_per_group, int n_groups, float eps, float* mean,
+                                      float* rstd, void* stream) {
+    if (imgs_per_group <= 0 || n_groups <= 0 || rows_per_img <= 0) return MFT_EINVAL;
+    dim3 grid((C + 63) / 64, n_groups, 1);
+    hipLaunchKernelGGL(bn_combine_moments_kernel, grid, dim3(64), 0, (hipStream_t)stream, mean_img, m2_img, idx, C,
+                       rows_per_img, imgs_per_group, eps, mean, rstd);
     return mft_launch_status();
 }
 

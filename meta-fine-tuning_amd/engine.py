@@ -41,7 +41,7 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True):
+                 fused_adam=True, pipeline=True, stem_cache=True):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316)."""
         if not torch.cuda.is_available():
@@ -70,6 +70,8 @@ class FinetuneEngine:
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
         ya = np.repeat(np.arange(n_way), n_support)
         self.y_support = np.tile(ya, n_views + 1).astype(np.int32)
+        # every support image is drawn once per epoch: with >1 epoch cache its (mini-batch independent) stem conv
+        self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev) if stem_cache else None
 
     # ------------------------------------------------------------------ ingest
     def load_episode(self, slot, liz_x):
@@ -113,11 +115,19 @@ class FinetuneEngine:
         return tables
 
     # ------------------------------------------------------------------ inner loop
+    def prepare_batch(self):
+        """Once per batch of episodes, after ingest: fill the stem cache for all resident support images."""
+        if self.stem is not None:
+            H = self.size
+            self.stem.fill(self.Xs.view(self.E * self.n_total, H, H, 3))
+
     def trunk_step(self, idx_dev, k, parity):
         """Frozen part of one inner step: gather the mini-batches, run trunk.0-6 (shared weights, per-episode BN
         statistics).  Independent of the adapted weights, hence of the previous step."""
         E, H = self.E, self.size
         a = self.arena_trunk
+        if self.stem is not None:
+            return Fn.resnet10_trunk(self.W, None, a, k, upto=7, tag="tr%d.%d" % (k, parity), stem=(self.stem, idx_dev))
         xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (E * k, H * H * 3)))
         return Fn.resnet10_trunk(self.W, xb.view(E * k, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
 
@@ -194,6 +204,7 @@ class FinetuneEngine:
         for slot in range(self.E):
             self.load_episode(slot, episodes[min(slot, n - 1)])      # pad a short batch by repeating the last episode
         self.adapt.reset(self.W)
+        self.prepare_batch()
         self.inner_loop(self.step_tables(perms, n))
         scores, feats = self.final_scores()
         if return_feats:

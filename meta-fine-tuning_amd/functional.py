@@ -140,19 +140,59 @@ def _bn_stats4(arena, tag, x, ipg, groups, running=None):
     return mean, rstd
 
 
-def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t"):
+class StemCache:
+    """trunk.0 outputs of a set of resident images plus their per-image BatchNorm moments.
+
+    finetune.py:263-291 re-runs the whole backbone on every mini-batch, so each support image passes the (frozen,
+    mini-batch independent) stem convolution once per epoch.  The cache computes it once per image; trunk.1's
+    mini-batch statistics are recombined exactly from per-image moments (csrc/bn.hip)."""
+
+    def __init__(self, W, n_slots, H, device, chunk=8192):
+        self.W = W
+        self.n_slots = n_slots
+        self.OH = (H + 6 - 7) // 2 + 1
+        self.c0 = torch.empty((n_slots, self.OH, self.OH, 64), device=device)
+        self.mean = torch.empty((n_slots, 64), device=device)
+        self.m2 = torch.empty((n_slots, 64), device=device)
+        self.chunk = chunk
+
+    def fill(self, x_nhwc):
+        """x_nhwc [n_slots,H,H,3] -> conv outputs + moments (chunked launches; M = chunk*OH*OW rows each)."""
+        lib = ops._lib.lib()
+        n = x_nhwc.shape[0]
+        assert n == self.n_slots
+        for i in range(0, n, self.chunk):
+            j = min(i + self.chunk, n)
+            ops.conv2d(x_nhwc[i:j], self.W.conv["trunk.0"], 64, 7, 7, 2, 3, out=self.c0[i:j])
+            ops._lib.check(lib.mft_bn_image_moments(ops._p(self.c0[i:j]), 64, 64, self.OH * self.OH, j - i,
+                                                    ops._p(self.mean[i:j]), ops._p(self.m2[i:j]), ops._stream()),
+                           "mft_bn_image_moments")
+
+
+def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None):
     """trunk[0..upto-1] with shared (frozen) weights.  x [n,H,W,3] NHWC -> activation entering trunk[upto].
-    ``running``: optional dict bn-name -> (running_mean, running_var) updated when a single group is run."""
-    n = x.shape[0]
-    groups = n // ipg
+    ``running``: optional dict bn-name -> (running_mean, running_var) updated when a single group is run.
+    ``stem`` = (StemCache, idx_i32): take trunk.0 outputs of images idx from the cache instead of x (x is ignored)."""
 
     def run(name):
         return None if running is None else running.get(name)
 
-    c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3, out=arena.get(tag + ".c0", (n, (x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1, 64)))
-    m, s = _bn_stats4(arena, tag + ".bn0", c0, ipg, groups, run("trunk.1"))
     g, b = W.bn["trunk.1"]
-    a = ops.bn_relu_maxpool(c0, m, s, g, b, imgs_per_group=ipg)
+    if stem is not None:
+        cache, idx = stem
+        n = idx.numel()
+        groups = n // ipg
+        m = arena.get(tag + ".bn0.mean", (groups, 64))
+        s = arena.get(tag + ".bn0.rstd", (groups, 64))
+        ops.bn_combine_moments(cache.mean, cache.m2, idx, cache.OH * cache.OH, ipg, groups, mean=m, rstd=s)
+        PH = (cache.OH + 2 - 3) // 2 + 1
+        a = ops.bn_relu_maxpool_gather(cache.c0, idx, n, m, s, g, b, ipg, out=arena.get(tag + ".p0", (n, PH, PH, 64)))
+    else:
+        n = x.shape[0]
+        groups = n // ipg
+        c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3, out=arena.get(tag + ".c0", (n, (x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1, 64)))
+        m, s = _bn_stats4(arena, tag + ".bn0", c0, ipg, groups, run("trunk.1"))
+        a = ops.bn_relu_maxpool(c0, m, s, g, b, imgs_per_group=ipg)
     for idx in (4, 5, 6, 7):
         if idx >= upto:
             break

@@ -206,6 +206,41 @@ def bn_relu_maxpool(x, mean, rstd, gamma, beta, imgs_per_group=0):
     return y
 
 
+def bn_relu_maxpool_gather(cache, src_idx, n_img, mean, rstd, gamma, beta, imgs_per_group, out=None):
+    """bn_relu_maxpool over images cache[src_idx[n]] (cache [slots,H,W,C]); n_img = src_idx.numel()."""
+    _f32c(cache)
+    _, H, W, C = cache.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    if out is None:
+        out = torch.empty((n_img, OH, OW, C), device=cache.device, dtype=torch.float32)
+    rc = _lib.lib().mft_bn_relu_maxpool_gather(_p(cache), _p(src_idx), _p(out), n_img, H, W, C, imgs_per_group, _p(mean),
+                                               _p(rstd), _p(gamma), _p(beta), _stream())
+    _lib.check(rc, "mft_bn_relu_maxpool_gather")
+    return out
+
+
+def bn_image_moments(x):
+    """x [n_img,H,W,C] -> per-image (mean [n_img,C], M2 [n_img,C]) over the H*W pixels."""
+    _f32c(x)
+    n, H, W, C = x.shape
+    mean = torch.empty((n, C), device=x.device, dtype=torch.float32)
+    m2 = torch.empty_like(mean)
+    _lib.check(_lib.lib().mft_bn_image_moments(_p(x), C, C, H * W, n, _p(mean), _p(m2), _stream()), "mft_bn_image_moments")
+    return mean, m2
+
+
+def bn_combine_moments(mean_img, m2_img, idx_i32, rows_per_img, imgs_per_group, n_groups, mean=None, rstd=None, eps=BN_EPS):
+    """Mini-batch BatchNorm statistics of the groups of images idx[g*k:(g+1)*k] from cached per-image moments."""
+    C = mean_img.shape[1]
+    if mean is None:
+        mean = torch.empty((n_groups, C), device=mean_img.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+    rc = _lib.lib().mft_bn_combine_moments(_p(mean_img), _p(m2_img), _p(idx_i32), C, rows_per_img, imgs_per_group,
+                                           n_groups, eps, _p(mean), _p(rstd), _stream())
+    _lib.check(rc, "mft_bn_combine_moments")
+    return mean, rstd
+
+
 def global_avgpool(x):
     _f32c(x)
     n, H, W, C = x.shape

@@ -192,3 +192,36 @@ def test_two_stream_pipeline_is_bit_identical():
         sc = e.run_batch(eps, perms=perms)
         res.append((sc.clone(), e.adapt.w.flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_stem_cache_matches_recomputed_stem():
+    """Cached trunk.0 outputs + recombined per-image BatchNorm moments must reproduce the per-step stem
+    (conv -> batch statistics -> BN/ReLU/maxpool) to fp32 rounding, and the engine's scores must agree."""
+    W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=27), DEV)
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.standard_normal((40, 84, 84, 3)).astype(np.float32)).to(DEV)
+    cache = Fn.StemCache(W, 40, 84, DEV, chunk=16)          # ragged last chunk
+    cache.fill(x)
+    idx = torch.from_numpy(rs.permutation(40)[:15].astype(np.int32)).to(DEV)
+    a_cached = Fn.resnet10_trunk(W, None, Fn.Arena(DEV), 5, upto=4, tag="a", stem=(cache, idx))
+    a_direct = Fn.resnet10_trunk(W, x[idx.long()].contiguous(), Fn.Arena(DEV), 5, upto=4, tag="b")
+    assert a_cached.shape == a_direct.shape == (15, 21, 21, 64)
+    assert float((a_cached - a_direct).abs().max()) < 2e-5
+    # float64 statement of the per-image moments
+    c0 = cache.c0.double().cpu().view(40, -1, 64)
+    assert float((cache.mean.cpu().double() - c0.mean(1)).abs().max()) < 1e-6
+    m2 = ((c0 - c0.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float(((cache.m2.cpu().double() - m2).abs() / (m2 + 1e-6)).max()) < 1e-5
+
+    sd = synthetic.gnnnet_state_dict(seed=29)
+    eps = [synthetic.test_episode(600 + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)]
+    perms = [[rs.permutation(100), rs.permutation(100)] for _ in range(2)]
+    res = []
+    for sc_on in (False, True):
+        e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, stem_cache=sc_on)
+        res.append(e.run_batch(eps, perms=perms).clone())
+    o64 = [O.finetune_episode(sd, eps[i], 5, 5, total_epoch=2, perms=perms[i], dtype=torch.float64).numpy() for i in range(2)]
+    for i in range(2):
+        d_on = np.abs(res[1][i].cpu().numpy() - o64[i]).max()
+        d_off = np.abs(res[0][i].cpu().numpy() - o64[i]).max()
+        assert d_on <= max(3.0 * d_off, 2e-3), (d_on, d_off)
