@@ -31,6 +31,13 @@ enum { MFT_ACT_NONE = 0, MFT_ACT_RELU = 1, MFT_ACT_LRELU = 2 };
 int mft_version(void);                        /* 100*major + minor                          */
 int mft_device_info(int* cu_count, int* gcn_arch_is_gfx950);
 
+/* CU-partitioned streams (no reference counterpart: the reference is one stream on one GPU).  mask bit i set = the
+ * queue may use CU i (n_words*32 bits); mft_probe_placement writes {XCC_ID, HW_ID} of each workgroup's CU into
+ * out[2*n_blocks] (used to learn the bit -> XCD mapping on the box).                                              */
+int mft_stream_create_cumask(const unsigned* mask_words, int n_words, void** stream_out);
+int mft_stream_destroy(void* stream);
+int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream);
+
 /* layout ---------------------------------------------------------------------------- */
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);

@@ -15,6 +15,9 @@
 // with k=16+t (lanes 32-63) -- a fixed permutation of the reduction order shared by A and B.
 #include "mft_common.h"
 
+int mft_stem_conv_dispatch(const float* in, const float* w, float* out, int n_img, int H, int W, int w_ld,
+                           hipStream_t s);   // csrc/stem.hip
+
 namespace {
 
 struct ConvArgs {
@@ -37,6 +40,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
+int g_stem_fast = 1;   // 0: route the stem through the generic gather kernel (mft_debug_set_conv_tile(2000/2001))
 
 // BT == true is the data-gradient form: dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] *
 // w[co][kh][kw][ci] (taps whose offset is not divisible by the stride contribute nothing).  The B operand is
@@ -432,23 +436,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         constexpr int RP = 256 / Q;           // rows per pass
         const int q = tid % Q, rr = tid / Q;
         const long long gbase = (long long)g * p.dwgs + (long long)khkw * p.Cin + ci0 + 4 * q;
-#pragma unroll 4
-        for (int row = rr; row < BM; row += RP) {
-            const long long gi = gbase + (long long)(co0 + row) * p.Kpad;
-            const f32x4 ge = *(const f32x4*)(Gs + row * GLD + 4 * q);
-            f32x4 mm = *(const f32x4*)(p.m + gi);
-            f32x4 vv = *(const f32x4*)(p.v + gi);
-            f32x4 ww = *(const f32x4*)(p.w + gi);
+        // w, m, v are touched exactly once per step and the slabs (GBs) dwarf every cache: stream them with
+        // nontemporal loads/stores, four rows (12 x 16 B per lane) in flight before the first use.
+        constexpr int NR = BM / RP;           // rows per thread
+        static_assert(NR % 4 == 0, "row blocking");
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mm[e] = p.b1 * mm[e] + (1.f - p.b1) * ge[e];
-                vv[e] = p.b2 * vv[e] + (1.f - p.b2) * ge[e] * ge[e];
-                ww[e] -= p.step_size * (mm[e] / (sqrtf(vv[e]) * p.inv_sqrt_bc2 + p.eps));
+        for (int r0 = 0; r0 < NR; r0 += 4) {
+            f32x4 mm[4], vv[4], ww[4];
+            long long gi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = rr + (r0 + u) * RP;
+                gi[u] = gbase + (long long)(co0 + row) * p.Kpad;
+                mm[u] = __builtin_nontemporal_load((const f32x4*)(p.m + gi[u]));
+                vv[u] = __builtin_nontemporal_load((const f32x4*)(p.v + gi[u]));
+                ww[u] = __builtin_nontemporal_load((const f32x4*)(p.w + gi[u]));
             }
-            *(f32x4*)(p.m + gi) = mm;
-            *(f32x4*)(p.v + gi) = vv;
-            *(f32x4*)(p.w + gi) = ww;
-            if (p.dw) *(f32x4*)(p.dw + gi) = ge;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = rr + (r0 + u) * RP;
+                const f32x4 ge = *(const f32x4*)(Gs + row * GLD + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mm[u][e] = p.b1 * mm[u][e] + (1.f - p.b1) * ge[e];
+                    vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
+                    ww[u][e] -= p.step_size * (mm[u][e] / (sqrtf(vv[u][e]) * p.inv_sqrt_bc2 + p.eps));
+                }
+                __builtin_nontemporal_store(mm[u], (f32x4*)(p.m + gi[u]));
+                __builtin_nontemporal_store(vv[u], (f32x4*)(p.v + gi[u]));
+                __builtin_nontemporal_store(ww[u], (f32x4*)(p.w + gi[u]));
+                if (p.dw) *(f32x4*)(p.dw + gi[u]) = ge;
+            }
         }
     }
 }
@@ -548,7 +566,15 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     a.tiles_n = 0;
     a.bt_stride = 1;
     hipStream_t s = (hipStream_t)stream;
-    if (stem) return launch_conv<128, 64, 2, 2, true>(a, groups, s);
+    if (stem) {
+        // 7x7/2 pad 3 -> 64 channels on 84x84 / 224x224 inputs: LDS-patch kernel (csrc/stem.hip)
+        if (g_stem_fast && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && ldi == 3 && ldo == 64 &&
+            bias == nullptr && (W == 84 || W == 224)) {
+            const int rc = mft_stem_conv_dispatch(in, w, out, n_img, H, W, a.Kpad, s);
+            if (rc != MFT_EINVAL) return rc;
+        }
+        return launch_conv<128, 64, 2, 2, true>(a, groups, s);
+    }
     // tile choice (tools/conv_tune.py, MI355X): with fp32 MFMA the 64x64 tile (58 VGPRs, 36.9 KB LDS, 4 workgroups
     // per CU) beats every larger tile on all ResNet10 shapes (84-97 vs 61-88 TFLOP/s): latency hiding through
     // occupancy matters more than operand reuse, LDS bandwidth is not a constraint at 2 floats per 64-cycle MFMA.
@@ -564,7 +590,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 1000) g_wgrad_tile = tile - 1000;      // 1064 / 1128: choose the wgrad tile
+    if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
+    else if (tile >= 1000) g_wgrad_tile = tile - 1000; // 1064 / 1128: choose the wgrad tile
     else g_conv_tile = tile;
     return 0;
 }

@@ -99,19 +99,24 @@ class FinetuneEngine:
         ops._lib.check(rc, "mft_nchw_to_nhwc")
 
     def step_tables(self, perms, n_active):
-        """Index/label tables for all inner steps.  perms[e][epoch] is a permutation of n_total."""
+        """Index/label tables for all inner steps.  perms[e][epoch] is a permutation of n_total.  Returns a list of
+        (k, idx[E*k] int32 rows of the support store, labels[E*k] int32), one entry per step (finetune.py:270-284)."""
         E, bs, nt = self.E, self.bs, self.n_total
+        P = np.empty((E, self.epochs, nt), dtype=np.int64)
+        for e in range(E):
+            pe = perms[min(e, n_active - 1)]
+            for ep in range(self.epochs):
+                P[e, ep] = pe[ep]
+        base = (np.arange(E, dtype=np.int64) * nt)[:, None]
         tables = []
         for ep in range(self.epochs):
+            sel_all = P[:, ep]                                   # [E, nt]
+            idx_all = (sel_all + base).astype(np.int32)
+            lab_all = self.y_support[sel_all]
             for j in range(0, nt, bs):
                 k = min(bs, nt - j)
-                idx = np.empty((E, k), dtype=np.int32)
-                lab = np.empty((E, k), dtype=np.int32)
-                for e in range(E):
-                    sel = perms[min(e, n_active - 1)][ep][j:j + k]
-                    idx[e] = e * nt + sel
-                    lab[e] = self.y_support[sel]
-                tables.append((k, idx.reshape(-1), lab.reshape(-1)))
+                tables.append((k, np.ascontiguousarray(idx_all[:, j:j + k]).reshape(-1),
+                               np.ascontiguousarray(lab_all[:, j:j + k]).reshape(-1)))
         return tables
 
     # ------------------------------------------------------------------ inner loop
@@ -158,8 +163,13 @@ class FinetuneEngine:
         if not tables:
             return
         dev = self.dev
-        idx_all = [torch.from_numpy(t[1]).to(dev, non_blocking=True) for t in tables]
-        lab_all = [torch.from_numpy(t[2]).to(dev, non_blocking=True) for t in tables]
+        if len({t[0] for t in tables}) == 1:               # uniform mini-batches: two H2D copies for the whole loop
+            idx_dev = torch.from_numpy(np.stack([t[1] for t in tables])).to(dev, non_blocking=True)
+            lab_dev = torch.from_numpy(np.stack([t[2] for t in tables])).to(dev, non_blocking=True)
+            idx_all, lab_all = list(idx_dev.unbind(0)), list(lab_dev.unbind(0))
+        else:
+            idx_all = [torch.from_numpy(t[1]).to(dev, non_blocking=True) for t in tables]
+            lab_all = [torch.from_numpy(t[2]).to(dev, non_blocking=True) for t in tables]
         if not self.pipeline:
             for (k, _, _), idx, lab in zip(tables, idx_all, lab_all):
                 self.inner_step(idx, lab, k)
