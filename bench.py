@@ -41,6 +41,20 @@ def conv_flops(n_img, OH, Cout, K):
     return 2.0 * n_img * OH * OH * Cout * K
 
 
+def pmc_traffic(E):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 corrections applied; profiles/pmc_traffic.json).  None when no pass exists for this E."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            j = json.load(f)
+        if int(j["episodes_per_step"]) == int(E):
+            return {"mb_per_launch": j["traffic_mb_per_launch"], "algorithmic_mb_per_launch": j["algorithmic_mb_per_launch"],
+                    "source": "profiles/pmc_traffic.json (round %s)" % j["round"]}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def host_threads():
     """Threads the CPU baseline may use: the cores this process can actually run on (affinity mask and cgroup CPU
     quota), capped at 32 -- the 5-image convolutions of one inner step do not scale past that, and oversubscribing an
@@ -245,7 +259,7 @@ def main():
         roof = {"bound": "hbm", "kernel": "conv_wgrad_kernel<64,64,ADAM> (trunk.7 weight gradient with torch.optim.Adam fused "
                                           "in the epilogue; per-episode w,m,v streamed once per inner step)",
                 "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                "traffic": None, "launches": n_a, "avg_launch_us": round(a_ms * 1e3 / n_a, 2),
+                "traffic": pmc_traffic(E), "launches": n_a, "avg_launch_us": round(a_ms * 1e3 / n_a, 2),
                 "algorithmic_mb_per_launch": round(a_by / n_a / 1e6, 2),
                 "largest_shape": {"what": "trunk.7.C2 (512x512x3x3) x %d episodes" % E,
                                   "avg_launch_us": round(sum(t for t, _ in big) * 1e3 / len(big), 2),
