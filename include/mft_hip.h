@@ -159,6 +159,17 @@ int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_st
 /* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
 int mft_maml_delta(float* p, const float* p2, const float* p3, long long n, void* stream);
 
+/* finetune_linear's classifier head (finetune.py:33-42,65,103,147-158,171-174), one Linear(D, n_way) per episode (group).
+ * mft_linear_head_step = one inner step for all groups in one launch: logits = feat @ W[g]^T + b[g]; mean cross entropy over
+ * the group's rows (loss[g], nullable); dfeat = dlogits @ W[g] (pre-update weights; the gradient handed to the backbone);
+ * Adam(lr, betas, eps, L2 weight_decay) on W [n_groups,n_way,D], b [n_groups,n_way] with moments mW,vW,mb,vb.
+ * rows_per_group <= 16, n_way <= 16.  mft_linear_head_scores: out[row][:] = softmax(feat[row] @ W[g]^T + b[g]).        */
+int mft_linear_head_step(const float* feat, int ldf, const int* labels, int rows_per_group, int n_groups, int n_way, int D,
+                         float* W, float* b, float* mW, float* vW, float* mb, float* vb, float* dfeat, int lddf, float* loss,
+                         int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+int mft_linear_head_scores(const float* feat, int ldf, int rows_per_group, int n_groups, int n_way, int D, const float* W,
+                           const float* b, float* out, void* stream);
+
 /* GNN head ------------------------------------------------------------------------------ */
 /* Wcompute: W_new = abs(x_i - x_j) (gnn.py:79-82): x [n_graphs*N, ldx] -> d [n_graphs*N*N, ldd]; columns
  * F..ldd-1 of d are zero-filled.                                                              */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_linear_head_step": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _F, _F, _F, _F, _F, _P],
+    "mft_linear_head_scores": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "mft_pair_absdiff": [_P, _I, _P, _I, _I, _I, _I, _P],
     "mft_masked_softmax": [_P, _I, _P, _I, _I, _P],
     "mft_graph_aggregate": [_P, _P, _I, _P, _I, _I, _I, _I, _P],

@@ -179,3 +179,139 @@ extern "C" int mft_var_to_rstd(const float* var, float* rstd, int n, float eps, 
     hipLaunchKernelGGL(var_to_rstd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, var, rstd, n, eps);
     return mft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ linear head
+// finetune_linear's classifier (finetune.py:33-42,65,103,147-158): per episode a Linear(D, n_way) on the backbone
+// feature; one inner step = logits -> cross entropy -> {d feature (pre-update weights), dW, db} -> Adam with L2
+// weight decay on (W, b).  Everything for one episode fits one workgroup, so the whole classifier step is ONE
+// launch over the E episodes: no logits / dlogits / gradient tensors in HBM.  rows_per_group <= 16, n_way <= 16.
+namespace {
+
+constexpr int LH_MAXR = 16, LH_MAXC = 16;
+
+__global__ __launch_bounds__(256) void linear_head_step_kernel(
+    const float* __restrict__ feat, int ldf, const int* __restrict__ labels, int k, int n_way, int D,
+    float* __restrict__ W, float* __restrict__ b, float* __restrict__ mW, float* __restrict__ vW,
+    float* __restrict__ mb, float* __restrict__ vb, float* __restrict__ dfeat, int lddf, float* __restrict__ loss,
+    float step_size, float inv_sqrt_bc2, float b1, float b2, float eps, float wd) {
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_logit[LH_MAXR][LH_MAXC];
+    __shared__ float s_d[LH_MAXR][LH_MAXC];
+    __shared__ float s_loss[LH_MAXR];
+    const float* F = feat + (long long)g * k * ldf;
+    float* Wg = W + (long long)g * n_way * D;
+    float* bg = b + (long long)g * n_way;
+    // logits: one wave per (row, class) pair
+    for (int pr = wave; pr < k * n_way; pr += 4) {
+        const int r = pr / n_way, c = pr - r * n_way;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += F[(long long)r * ldf + d] * Wg[(long long)c * D + d];
+        s = wave_sum(s);
+        if (lane == 0) s_logit[r][c] = s + bg[c];
+    }
+    __syncthreads();
+    if (tid < k) {
+        const int r = tid;
+        float mx = -3.4e38f;
+        for (int c = 0; c < n_way; ++c) mx = fmaxf(mx, s_logit[r][c]);
+        float se = 0.f;
+        for (int c = 0; c < n_way; ++c) se += __expf(s_logit[r][c] - mx);
+        const float lse = mx + __logf(se);
+        const int y = labels[(long long)g * k + r];
+        s_loss[r] = lse - s_logit[r][y];
+        const float inv = 1.f / (float)k;
+        for (int c = 0; c < n_way; ++c) s_d[r][c] = (__expf(s_logit[r][c] - lse) - (c == y ? 1.f : 0.f)) * inv;
+    }
+    __syncthreads();
+    if (tid == 0 && loss) {
+        float s = 0.f;
+        for (int r = 0; r < k; ++r) s += s_loss[r];
+        loss[g] = s / (float)k;
+    }
+    // d feature with the pre-update weights
+    for (int i = tid; i < k * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        float s = 0.f;
+        for (int c = 0; c < n_way; ++c) s += s_d[r][c] * Wg[(long long)c * D + d];
+        dfeat[((long long)g * k + r) * lddf + d] = s;
+    }
+    __syncthreads();
+    // dW, db -> Adam (weight decay folded into the gradient, torch.optim.Adam semantics)
+    float* mWg = mW + (long long)g * n_way * D;
+    float* vWg = vW + (long long)g * n_way * D;
+    for (int i = tid; i < n_way * D; i += 256) {
+        const int c = i / D, d = i - c * D;
+        float gr = 0.f;
+        for (int r = 0; r < k; ++r) gr += s_d[r][c] * F[(long long)r * ldf + d];
+        const float w = Wg[i];
+        gr += wd * w;
+        const float m = b1 * mWg[i] + (1.f - b1) * gr;
+        const float v = b2 * vWg[i] + (1.f - b2) * gr * gr;
+        mWg[i] = m;
+        vWg[i] = v;
+        Wg[i] = w - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+    if (tid < n_way) {
+        const int c = tid;
+        float gr = 0.f;
+        for (int r = 0; r < k; ++r) gr += s_d[r][c];
+        const float w = bg[c];
+        gr += wd * w;
+        const long long i = (long long)g * n_way + c;
+        const float m = b1 * mb[i] + (1.f - b1) * gr;
+        const float v = b2 * vb[i] + (1.f - b2) * gr * gr;
+        mb[i] = m;
+        vb[i] = v;
+        bg[c] = w - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
+
+// scores = softmax(feat @ W[g]^T + b[g]); one wave per row
+__global__ __launch_bounds__(256) void linear_head_scores_kernel(const float* __restrict__ feat, int ldf,
+                                                                 int rows_per_group, int n_groups, int n_way, int D,
+                                                                 const float* __restrict__ W,
+                                                                 const float* __restrict__ b,
+                                                                 float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)rows_per_group * n_groups) return;
+    const int g = (int)(row / rows_per_group);
+    const float* f = feat + row * ldf;
+    float lg[LH_MAXC];
+    float mx = -3.4e38f;
+    for (int c = 0; c < n_way; ++c) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += f[d] * W[((long long)g * n_way + c) * D + d];
+        s = wave_sum(s) + b[(long long)g * n_way + c];
+        lg[c] = s;
+        mx = fmaxf(mx, s);
+    }
+    float se = 0.f;
+    for (int c = 0; c < n_way; ++c) se += __expf(lg[c] - mx);
+    if (lane < n_way) out[row * n_way + lane] = __expf(lg[lane] - mx) / se;
+}
+
+}  // namespace
+
+extern "C" int mft_linear_head_step(const float* feat, int ldf, const int* labels, int rows_per_group, int n_groups,
+                                    int n_way, int D, float* W, float* b, float* mW, float* vW, float* mb, float* vb,
+                                    float* dfeat, int lddf, float* loss, int step, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, void* stream) {
+    if (step < 1 || rows_per_group < 1 || rows_per_group > LH_MAXR || n_way < 1 || n_way > LH_MAXC) return MFT_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(linear_head_step_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, feat, ldf, labels,
+                       rows_per_group, n_way, D, W, b, mW, vW, mb, vb, dfeat, lddf, loss, (float)((double)lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
+    return mft_launch_status();
+}
+
+extern "C" int mft_linear_head_scores(const float* feat, int ldf, int rows_per_group, int n_groups, int n_way, int D,
+                                      const float* W, const float* b, float* out, void* stream) {
+    if (n_way < 1 || n_way > LH_MAXC) return MFT_EINVAL;
+    const long long rows = (long long)rows_per_group * n_groups;
+    hipLaunchKernelGGL(linear_head_scores_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat,
+                       ldf, rows_per_group, n_groups, n_way, D, W, b, out);
+    return mft_launch_status();
+}

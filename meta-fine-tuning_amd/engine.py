@@ -41,9 +41,14 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True, stem_cache=True):
+                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn"):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
-        ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316)."""
+        ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316).
+        ``mode`` "gnn": finetune.finetune (inner loss on the raw feature, GNN scoring);
+        "linear": finetune.finetune_linear (finetune.py:45-174: per-episode Linear(512, n_way) classifier trained together
+        with the last block over the ORIGINAL support images only; scores = softmax(classifier(features)))."""
+        assert mode in ("gnn", "linear")
+        self.mode = mode
         if not torch.cuda.is_available():
             raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
         self.dev = torch.device(device)
@@ -53,12 +58,16 @@ class FinetuneEngine:
         self.fold50 = fold50
         self.fused_adam = fused_adam
         self.n_per_view = n_way * n_support
-        self.n_total = self.n_per_view * (n_views + 1)            # finetune.py:214-233,269
+        # finetune.py:214-233,269: view 0 twice + every other view; finetune_linear permutes support_size only (:139-141)
+        self.n_total = self.n_per_view * (n_views + 1) if mode == "gnn" else self.n_per_view
         self.n_all = n_way * (n_support + n_query)
         fsd = {k[len("feature."):]: v for k, v in state.items()
                if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))}
         self.W = Fn.ResNet10Weights(fsd, self.dev)
-        self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way)
+        self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way) if mode == "gnn" else None
+        if mode == "linear":
+            self.cls = {k: torch.zeros((self.E, n_way, 512) if k.endswith("W") else (self.E, n_way), device=self.dev)
+                        for k in ("W", "b", "mW", "vW", "mb", "vb")}
         self.arena = Fn.Arena(self.dev)
         self.arena_trunk = Fn.Arena(self.dev)      # the frozen-trunk stream owns its own buffers / BN workspace
         self.adapt = AdaptState(self.E, self.dev)
@@ -69,7 +78,7 @@ class FinetuneEngine:
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
         ya = np.repeat(np.arange(n_way), n_support)
-        self.y_support = np.tile(ya, n_views + 1).astype(np.int32)
+        self.y_support = (np.tile(ya, n_views + 1) if mode == "gnn" else ya).astype(np.int32)
         # every support image is drawn once per epoch: with >1 epoch cache its (mini-batch independent) stem conv
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev) if stem_cache else None
 
@@ -90,10 +99,11 @@ class FinetuneEngine:
 
         xa0 = x0[:, :ns].contiguous().view(npv, 3, H, H)
         put(base, xa0, npv)
-        put(base + npv, xa0, npv)
-        for vi, xv in enumerate(liz_x[1:]):
-            xa = xv.to(self.dev, non_blocking=True)[:, :ns].contiguous().view(npv, 3, H, H)
-            put(base + (vi + 2) * npv, xa, npv)
+        if self.mode == "gnn":
+            put(base + npv, xa0, npv)
+            for vi, xv in enumerate(liz_x[1:]):
+                xa = xv.to(self.dev, non_blocking=True)[:, :ns].contiguous().view(npv, 3, H, H)
+                put(base + (vi + 2) * npv, xa, npv)
         xin = x0.contiguous().view(self.n_all, 3, H, H)
         rc = lib.mft_nchw_to_nhwc(ops._p(xin), ops._p(self.Xall[slot * self.n_all]), self.n_all, 3, H, H, ops._stream())
         ops._lib.check(rc, "mft_nchw_to_nhwc")
@@ -142,8 +152,19 @@ class FinetuneEngine:
         E = self.E
         tape = {}
         feat = Fn.last_block_forward(self.W, x6, self.arena, k, slab=self.adapt.w, tape=tape, tag="s%d" % k)
-        loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
         self.adapt.step += 1
+        if self.mode == "linear":
+            # classifier step (logits, CE, d feature, Adam(lr .01, wd .001) on W, b) in one launch; finetune.py:147-158
+            c = self.cls
+            dlogits = self.arena.get("lin.dfeat%d" % k, (E * k, 512))
+            loss = self.arena.get("lin.loss", (E,))
+            rc = ops._lib.lib().mft_linear_head_step(ops._p(feat), 512, ops._p(lab_dev), k, E, self.n_way, 512, ops._p(c["W"]),
+                                                     ops._p(c["b"]), ops._p(c["mW"]), ops._p(c["vW"]), ops._p(c["mb"]),
+                                                     ops._p(c["vb"]), ops._p(dlogits), 512, ops._p(loss), self.adapt.step,
+                                                     self.lr, 0.9, 0.999, 1e-8, 0.001, ops._stream())
+            ops._lib.check(rc, "mft_linear_head_step")
+        else:
+            loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
         if self.fused_adam:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
                                    adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr))
@@ -199,11 +220,31 @@ class FinetuneEngine:
         """finetune.py:306-317: transductive feature pass over all n_way*(n_support+n_query) images, then
         GnnNet.set_forward(is_feature=True) and softmax.  (finetune.py:307's second pass is dead compute.)"""
         feats = Fn.resnet10_forward(self.W, self.Xall, self.arena, ipg=self.n_all, slab=self.adapt.w, tag="fin")
+        if self.mode == "linear":
+            # finetune.py:165-174: features of cat(support, query) in one train-mode pass (BatchNorm statistics over all
+            # n_all images are order independent), classifier + softmax on the query rows (class-major)
+            sc = self.arena.get("lin.scores", (self.E * self.n_all, self.n_way))
+            rc = ops._lib.lib().mft_linear_head_scores(ops._p(feats), 512, self.n_all, self.E, self.n_way, 512,
+                                                       ops._p(self.cls["W"]), ops._p(self.cls["b"]), ops._p(sc), ops._stream())
+            ops._lib.check(rc, "mft_linear_head_scores")
+            sc = sc.view(self.E, self.n_way, self.n_support + self.n_query, self.n_way)[:, :, self.n_support:]
+            return sc.reshape(self.E, self.n_way * self.n_query, self.n_way), feats
         ns = self.n_support // 2 if self.fold50 else self.n_support
         scores = Fn.gnnnet_scores(self.G, feats, self.E, self.n_way, ns, self.n_query, self.arena, fold=self.fold50)
         return ops.softmax_rows(scores).view(self.E, self.n_way * self.n_query, self.n_way), feats
 
-    def run_batch(self, episodes, perms=None, return_feats=False):
+    def set_classifier(self, w0, b0, n_active):
+        """Initial Linear(512, n_way) weights per episode: w0 [n, n_way, 512], b0 [n, n_way] (finetune.py:65)."""
+        c = self.cls
+        for k in ("mW", "vW", "mb", "vb"):
+            c[k].zero_()
+        w0 = torch.as_tensor(w0, dtype=torch.float32).to(self.dev).view(-1, self.n_way, 512)
+        b0 = torch.as_tensor(b0, dtype=torch.float32).to(self.dev).view(-1, self.n_way)
+        idx = torch.clamp(torch.arange(self.E, device=self.dev), max=n_active - 1)
+        c["W"].copy_(w0[idx])
+        c["b"].copy_(b0[idx])
+
+    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None):
         """episodes: list (<= E) of liz_x; perms: per-episode list of per-epoch permutations (default: drawn from
         the global numpy RNG episode by episode, exactly the reference's draw order).  Returns softmax scores
         [len(episodes), n_way*n_query, n_way]."""
@@ -214,6 +255,10 @@ class FinetuneEngine:
         for slot in range(self.E):
             self.load_episode(slot, episodes[min(slot, n - 1)])      # pad a short batch by repeating the last episode
         self.adapt.reset(self.W)
+        if self.mode == "linear":
+            if classifier_init is None:
+                raise RuntimeError("mode='linear' needs classifier_init=(w0 [n,n_way,512], b0 [n,n_way])")
+            self.set_classifier(classifier_init[0], classifier_init[1], n)
         self.prepare_batch()
         self.inner_loop(self.step_tables(perms, n))
         scores, feats = self.final_scores()

@@ -53,6 +53,55 @@ def finetune(liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_q
     return e.run_batch([liz_x])[0].clone()
 
 
+_LIN_ENGINES = {}
+
+
+def classifier_init(n_way, dim=512, n=1):
+    """Initial weights of ``Classifier(dim, n_way)`` (finetune.py:33-42,65): torch's nn.Linear default draw from the
+    global torch RNG, one fresh classifier per episode as in the reference."""
+    ws, bs = [], []
+    for _ in range(n):
+        lin = torch.nn.Linear(dim, n_way)
+        ws.append(lin.weight.detach())
+        bs.append(lin.bias.detach())
+    return torch.stack(ws), torch.stack(bs)
+
+
+def _linear_engine(state_in, n_way, n_support, n_query, size, n_views, E):
+    key = (id(state_in), n_way, n_support, n_query, size, n_views, E)
+    e = _LIN_ENGINES.get(key)
+    if e is None:
+        if len(_LIN_ENGINES) >= 2:
+            _LIN_ENGINES.clear()
+        e = eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=20,
+                               episodes_per_batch=E, mode="linear")
+        _LIN_ENGINES[key] = e
+    return e
+
+
+def finetune_linear(liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+                    pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
+    """finetune.finetune_linear (finetune.py:45-174): the "baseline" branch of the README ensemble.  ``classifier`` =
+    (w0 [n_way,512], b0 [n_way]) pins the initial Linear weights (default: torch's nn.Linear draw, as the reference)."""
+    if not flatten or freeze_backbone:
+        raise NotImplementedError("finetune_linear(): flatten=False / freeze_backbone are outside the HIP hot path")
+    x0 = liz_x[0]
+    n_query = x0.size(1) - n_support
+    e = _linear_engine(state_in, n_way, n_support, n_query, x0.size(-1), len(liz_x), 1)
+    w0, b0 = classifier_init(n_way) if classifier is None else (torch.as_tensor(classifier[0]).view(1, n_way, -1),
+                                                                 torch.as_tensor(classifier[1]).view(1, n_way))
+    return e.run_batch([liz_x], classifier_init=(w0, b0))[0].clone()
+
+
+def finetune_all(liz_x, y, model, state_baseline, state_gnn, n_way=5, n_support=5, classifier=None):
+    """``--method all`` (finetune.py:634-649): scores_out = finetune_linear(baseline state) + finetune(gnnnet state);
+    the numpy permutation stream is consumed in that order."""
+    out = finetune_linear(liz_x, y, state_baseline, None, linear=True, n_way=n_way, n_support=n_support,
+                          classifier=classifier)
+    out = out + finetune(liz_x, y, model, state_gnn, 600, n_way=n_way, n_support=n_support)
+    return out
+
+
 def finetune_batched(episodes, model, state_in, fine_tune_epoch, n_way=5, n_support=5, episodes_per_batch=32,
                      perms=None):
     """Throughput path: ``episodes`` (list of liz_x) processed ``episodes_per_batch`` at a time in lockstep.

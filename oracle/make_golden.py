@@ -316,6 +316,43 @@ def main():
         np.savez(os.path.join(GOLD, "g8_baselinefinetune.npz"), **out)
         print("g8 done")
 
+    # ---------------------------------------------------------------- G10 finetune_linear + "all" ensemble
+    if want("g10"):
+        out = {}
+        size = 84
+        sd = synthetic.gnnnet_state_dict(seed=37)
+        finetune.model_dict["ResNet10"] = make_factory(backbone, size)
+        finetune.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=1)
+        rs = np.random.RandomState(81)
+        w0 = (rs.uniform(-1, 1, size=(5, 512)) / np.sqrt(512)).astype(np.float32)
+        b0 = (rs.uniform(-1, 1, size=(5,)) / np.sqrt(512)).astype(np.float32)
+        RefLinear = nn.Linear
+
+        class SeededLinear(RefLinear):                   # finetune.Classifier's nn.Linear(512, 5) with known initial weights
+            def __init__(self, i, o, *a, **k):           # instead of torch's RNG draw (finetune.py:36-38,65)
+                super().__init__(i, o, *a, **k)
+                if (o, i) == w0.shape:
+                    with torch.no_grad():
+                        self.weight.copy_(torch.from_numpy(w0))
+                        self.bias.copy_(torch.from_numpy(b0))
+
+        nn.Linear = SeededLinear
+        liz = synthetic.test_episode(91, 5, 5, 15, size, gen_examples=1)
+        np.random.seed(10)
+        sc_lin = finetune.finetune_linear(liz, None, state_in=copy.deepcopy(sd), linear=True, save_it=None, n_query=15,
+                                          n_way=5, n_support=5)
+        out["w0"], out["b0"] = w0, b0
+        out["scores_linear"] = sc_lin.numpy()
+        nn.Linear = RefLinear
+        # finetune.py:647-649 ("--method all"): scores_out = finetune_linear(...); scores_out += finetune(...), same numpy stream
+        model = gnnnet.GnnNet(make_factory(backbone, size), n_way=5, n_support=5)
+        model.load_state_dict(sd)
+        model.train()
+        sc_gnn = finetune.finetune(liz, None, model, copy.deepcopy(sd), None, n_query=15, n_way=5, n_support=5)
+        out["scores_all"] = (sc_lin + sc_gnn).numpy()
+        np.savez(os.path.join(GOLD, "g10_finetune_linear.npz"), **out)
+        print("g10 done")
+
 
 if __name__ == "__main__":
     main()

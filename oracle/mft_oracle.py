@@ -372,6 +372,47 @@ def finetune_episode(state, liz_x, n_way=5, n_support=5, total_epoch=5, perms=No
     return out
 
 
+def finetune_linear_episode(state, liz_x, n_way=5, n_support=5, w0=None, b0=None, perms=None, epochs=20,
+                            batch_size=5, dtype=torch.float32):
+    """finetune.finetune_linear (finetune.py:45-174), freeze_backbone=False: a Linear(512, n_way) classifier
+    (initial weight/bias ``w0``/``b0``; the reference draws them from torch's RNG, finetune.py:65) on top of the
+    backbone; 20 epochs over the n_way*n_support ORIGINAL support images only (finetune.py:139-141 permutes
+    ``support_size``, so the augmented views appended at :93-101 are never drawn), mini-batches of 5;
+    Adam(lr .01, weight_decay .001) on the classifier, Adam(lr .01) on the last ResNet block (:107-124).
+    Scores = softmax(classifier(backbone(cat(support, query))[n_support*n_way:])) (:165-174)."""
+    sd_all = clone_state(state, dtype)
+    fsd = feature_state(sd_all)
+    x0 = liz_x[0].to(dtype)
+    n_query = x0.shape[1] - n_support
+    xa = x0[:, :n_support].contiguous().view(n_way * n_support, *x0.shape[2:])
+    xb = x0[:, n_support:].contiguous().view(n_way * n_query, *x0.shape[2:])
+    ya = torch.from_numpy(np.repeat(np.arange(n_way), n_support))
+    support_size = n_way * n_support
+    if perms is None:
+        perms = [np.random.permutation(support_size) for _ in range(epochs)]
+    w = w0.detach().clone().to(dtype)
+    b = b0.detach().clone().to(dtype)
+    params = [fsd[k] for k in ADAPT_KEYS]
+    adam_blk = adam_init(params)
+    adam_cls = adam_init([w, b])
+    for ep in range(epochs):
+        rand_id = perms[ep]
+        for j in range(0, support_size, batch_size):
+            sel = torch.from_numpy(np.asarray(rand_id[j:min(j + batch_size, support_size)]))
+            for t in params + [w, b]:
+                t.requires_grad_(True)
+            feat = resnet10_forward(fsd, xa[sel], "", train=True)
+            loss = F.cross_entropy(F.linear(feat, w, b), ya[sel])
+            grads = torch.autograd.grad(loss, params + [w, b])
+            for t in params + [w, b]:
+                t.requires_grad_(False)
+            adam_step([w, b], list(grads[-2:]), adam_cls, lr=0.01, weight_decay=0.001)
+            adam_step(params, list(grads[:-2]), adam_blk, lr=0.01)
+    with torch.no_grad():
+        out = resnet10_forward(fsd, torch.cat([xa, xb], 0), "", train=True)[support_size:]
+        return F.softmax(F.linear(out, w, b), dim=1)
+
+
 # --------------------------------------------------------------------------- meta-train / meta-fine-tune
 
 def meta_train_loss(sd, x, n_way, n_support, track=True):

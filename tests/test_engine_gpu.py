@@ -225,3 +225,52 @@ def test_stem_cache_matches_recomputed_stem():
         d_on = np.abs(res[1][i].cpu().numpy() - o64[i]).max()
         d_off = np.abs(res[0][i].cpu().numpy() - o64[i]).max()
         assert d_on <= max(3.0 * d_off, 2e-3), (d_on, d_off)
+
+
+def test_finetune_linear_and_all_vs_reference_golden(golden_dir):
+    """finetune_linear (per-episode Linear head + last block, 100 Adam steps) and the README's `--method all` sum
+    (finetune.py:45-174,647-649) against the scores the reference produced for the same episode, weights, classifier
+    initialisation and numpy seed (G10)."""
+    from meta_fine_tuning_amd import finetune as ft
+    from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+    from meta_fine_tuning_amd.io_utils import model_dict
+    import argparse
+    g = _g(golden_dir, "g10_finetune_linear.npz")
+    sd = synthetic.gnnnet_state_dict(seed=37)
+    liz = synthetic.test_episode(91, 5, 5, 15, 84, gen_examples=1)
+    np.random.seed(10)
+    sc = ft.finetune_linear([v.to(DEV) for v in liz], None, sd, None, linear=True, classifier=(g["w0"], g["b0"]))
+    ref = g["scores_linear"]
+    err = np.abs(sc.cpu().numpy() - ref)
+    assert sc.shape == (75, 5)
+    assert err.max() < 2e-2 and (sc.cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.96, err.max()
+    # the same against the float64 oracle envelope
+    np.random.seed(10)
+    o64 = O.finetune_linear_episode(sd, liz, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"]), dtype=torch.float64).numpy()
+    np.random.seed(10)
+    o32 = O.finetune_linear_episode(sd, liz, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"]), dtype=torch.float32).numpy()
+    assert np.abs(sc.cpu().numpy() - o64).max() <= max(4.0 * np.abs(o32 - o64).max(), 2e-3)
+    # --method all: finetune_linear + finetune on the same numpy stream
+    ft.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=1)
+    model = GnnNet(model_dict["ResNet10"], n_way=5, n_support=5)
+    model.load_state_dict(sd)
+    np.random.seed(10)
+    tot = ft.finetune_all([v.to(DEV) for v in liz], None, model, sd, sd, classifier=(g["w0"], g["b0"])).cpu().numpy()
+    ref = g["scores_all"]
+    assert np.abs(tot - ref).max() < 4e-2 and (tot.argmax(1) == ref.argmax(1)).mean() >= 0.96
+
+
+def test_linear_engine_batched_equals_single():
+    """Two episodes in lockstep (linear mode) give each episode the scores it gets alone."""
+    sd = synthetic.gnnnet_state_dict(seed=39)
+    eps = [synthetic.test_episode(700 + i, 5, 5, 15, 84, gen_examples=0) for i in range(2)]
+    rs = np.random.RandomState(9)
+    perms = [[rs.permutation(25) for _ in range(20)] for _ in range(2)]
+    w0 = torch.from_numpy((rs.uniform(-1, 1, (2, 5, 512)) / 22.6).astype(np.float32))
+    b0 = torch.from_numpy((rs.uniform(-1, 1, (2, 5)) / 22.6).astype(np.float32))
+    e2 = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=20, episodes_per_batch=2, device=DEV, mode="linear")
+    both = e2.run_batch(eps, perms=perms, classifier_init=(w0, b0)).clone()
+    e1 = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=20, episodes_per_batch=1, device=DEV, mode="linear")
+    for i in range(2):
+        one = e1.run_batch([eps[i]], perms=[perms[i]], classifier_init=(w0[i:i + 1], b0[i:i + 1]))[0]
+        assert float((one - both[i]).abs().max()) < 1e-5

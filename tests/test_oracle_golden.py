@@ -201,3 +201,16 @@ def test_g8_baselinefinetune(golden_dir):
     np.random.seed(10)
     sc = O.set_forward_adaptation(feats, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"]))
     np.testing.assert_allclose(sc.numpy(), g["scores"], atol=2e-4)
+
+
+def test_g10_finetune_linear_and_all(golden_dir):
+    """Oracle restatement of finetune.finetune_linear / the `--method all` sum against the reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "g10_finetune_linear.npz"))
+    sd = synthetic.gnnnet_state_dict(seed=37)
+    liz = synthetic.test_episode(91, 5, 5, 15, 84, gen_examples=1)
+    np.random.seed(10)
+    sc = O.finetune_linear_episode(sd, liz, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"])).numpy()
+    assert np.abs(sc - g["scores_linear"]).max() < 1e-4
+    sc2 = O.finetune_episode(sd, liz, 5, 5, total_epoch=1).numpy()
+    tot = sc + sc2
+    assert np.abs(tot - g["scores_all"]).max() < 5e-3 and (tot.argmax(1) == g["scores_all"].argmax(1)).mean() >= 0.98
