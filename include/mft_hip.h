@@ -60,6 +60,16 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
                     int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int imgs_per_group, long long w_group_stride, void* stream);
 
+/* The same convolution for FROZEN shared weights on the bf16 matrix cores with fp32 accuracy ("bf16x3", csrc/conv_x3.hip):
+ * every fp32 operand is split exactly into three bf16 pieces and the six leading piece products are accumulated in fp32
+ * (dropped terms <= 2^-24 relative: error at the level of fp32 rounding, 2.67x the fp32-MFMA rate).  mft_split_bf16x3 turns
+ * a packed fp32 weight matrix [n] into three bf16 planes [3][n] once; mft_conv2d_nhwc_x3 consumes them (no bias, no groups;
+ * Cin % 32 == 0, Cout % 64 == 0).  Replaces the same nn.Conv2d.forward call sites as mft_conv2d_nhwc for trunk.4-6.      */
+int mft_split_bf16x3(const float* w, unsigned short* planes, long long n, void* stream);
+int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
+                       int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 2: 128x128 */
+
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
 int mft_debug_set_conv_tile(int tile);
 

@@ -99,6 +99,29 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
     return out
 
 
+def split_weight_x3(w_pk):
+    """packed fp32 weights [Cout, Kpad] -> three bf16 planes [3, Cout, Kpad] (int16 storage) for conv2d_x3."""
+    _f32c(w_pk)
+    planes = torch.empty((3,) + tuple(w_pk.shape), device=w_pk.device, dtype=torch.int16)
+    _lib.check(_lib.lib().mft_split_bf16x3(_p(w_pk), _p(planes), w_pk.numel(), _stream()), "mft_split_bf16x3")
+    return planes
+
+
+def conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out=None):
+    """conv2d for frozen shared weights on bf16 MFMA with fp32 accuracy (6-term bf16x3 products).  x [n,H,W,Cin] fp32,
+    w3 = split_weight_x3(pack_conv_weight(w)) -> [n,OH,OW,Cout] fp32."""
+    _f32c(x)
+    n, H, W, Cin = x.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((n, OH, OW, Cout), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mft_conv2d_nhwc_x3(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout,
+                                       KH, KW, stride, pad, _stream())
+    _lib.check(rc, "mft_conv2d_nhwc_x3")
+    return out
+
+
 def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     """out[m, :N] = a[m, :K] @ w_pk[:N, :K].T + bias.  `a` is [M, lda] with lda >= K, K % 32 == 0."""
     _f32c(a)

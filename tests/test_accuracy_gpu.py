@@ -1,0 +1,63 @@
+"""600-episode accuracy parity (BASELINE.json north_star: +-0.2 % on the 600-episode mean) against per-episode accuracies
+the REFERENCE's own finetune() produced on the same structured synthetic episodes, weights (seeded backbone + the
+meta-trained head fixture g9_head.npz), and numpy permutation stream (oracle/make_golden_g9.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import engine as eng
+from meta_fine_tuning_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _state(golden_dir, g):
+    sd = synthetic.gnnnet_state_dict(seed=int(g["seed_sd"]))
+    hz = np.load(os.path.join(golden_dir, "g9_head.npz"))
+    for k in hz.files:
+        sd[k] = torch.from_numpy(hz[k])
+    return sd
+
+
+def _run(golden_dir, tag, batch):
+    g = np.load(os.path.join(golden_dir, "g9_accuracy.npz"))
+    if "acc_" + tag not in g.files:
+        pytest.skip("golden config %s not generated" % tag)
+    E_ep, G, n = [int(v) for v in g["cfg_" + tag]]
+    ref = g["acc_" + tag]
+    n = len(ref)
+    sd = _state(golden_dir, g)
+    e = eng.FinetuneEngine(sd, 5, 5, 15, 84, n_views=2 + G, fine_tune_epoch=E_ep, episodes_per_batch=batch, device=DEV)
+    y = np.repeat(np.arange(5), 15)
+    accs, chk = [], []
+    np.random.seed(10)                                   # finetune.py:425; permutations are then drawn episode by episode
+    for i in range(0, n, batch):
+        eps = [synthetic.test_episode(int(g["ep_seed0"]) + j, 5, 5, 15, 84, gen_examples=G, noise=float(g["noise"]))
+               for j in range(i, min(i + batch, n))]
+        sc = e.run_batch(eps).cpu().numpy()
+        for s in sc:
+            accs.append(float((s.argmax(1) == y).mean() * 100.0))
+            chk.append(float(s[:, 0].astype(np.float64).sum()))
+    return np.array(accs), np.array(chk), ref, g["chk_" + tag]
+
+
+def test_g9_accuracy_600_episodes_short_config(golden_dir):
+    """fine_tune_epoch=1, gen_examples=2 (20 Adam steps per episode), 600 episodes."""
+    accs, chk, ref, ref_chk = _run(golden_dir, "A", 50)
+    assert len(accs) == 600
+    assert abs(accs.mean() - ref.mean()) <= 0.2, (accs.mean(), ref.mean())
+    # per-episode: identical accuracy for the vast majority, never far off (one query = 1.33 %)
+    same = np.mean(np.abs(accs - ref) < 1e-6)
+    assert same >= 0.85 and np.abs(accs - ref).max() <= 4.1, (same, np.abs(accs - ref).max())
+    assert np.abs(chk - ref_chk).max() < 0.15            # sum over 75 queries of the class-0 probability
+
+
+def test_g9_accuracy_full_config(golden_dir):
+    """BASELINE configs[1]: fine_tune_epoch=5, gen_examples=17 (500 Adam steps per episode)."""
+    accs, chk, ref, ref_chk = _run(golden_dir, "B", 20)
+    assert abs(accs.mean() - ref.mean()) <= 0.7, (accs.mean(), ref.mean())      # +-0.2 % is a 600-episode statement
+    assert np.abs(accs - ref).max() <= 5.4

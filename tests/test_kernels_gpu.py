@@ -326,3 +326,22 @@ def test_gnn_glue(B, N, Fd):
     z = torch.zeros(B * N, ld, device=DEV)
     ops.copy_cols(y, z, 7, 48, act=ops.ACT_LRELU)
     assert float((z.cpu()[:, 7:55].double() - F.leaky_relu(y.cpu()[:, :48].double(), 0.01)).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H", [c for c in CONV_SHAPES if c[1] % 32 == 0 and c[2] % 64 == 0])
+def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
+    """6-term bf16x3 convolution (bf16 MFMA) against float64: same tolerance as the fp32-MFMA kernel, and an error no
+    larger than 2x that kernel's own error (the split is exact, dropped terms are <= 2^-24 relative)."""
+    n = 7 if H < 200 else 2
+    x = rnd((n, Cin, H, H), 11)
+    w = rnd((Cout, Cin, k, k), 12, scale=(2.0 / (k * k * Cout)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    xg = nhwc(x).to(DEV)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    y32 = nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad).cpu()).double()
+    y3 = nchw(ops.conv2d_x3(xg, ops.split_weight_x3(wpk), Cout, k, k, stride, pad).cpu()).double()
+    scale = max(float(ref.abs().max()), 1.0)
+    e32 = float((y32 - ref).abs().max())
+    e3 = float((y3 - ref).abs().max())
+    assert e3 <= 2e-5 * scale, (name, e3)
+    assert e3 <= 2.0 * e32 + 1e-7 * scale, (name, e3, e32)
