@@ -29,6 +29,7 @@ F_IMG_84 = 0.28585e9          # ResNet10 forward per 84x84 image
 F_LB_84 = 0.1086e9            # last-block backward per image (wgrad C1,C2,shortcut + dgrad C2)
 F_GNN_15_30 = 8.08e9          # GNN forward, 15 graphs of 30 nodes
 PEAK_F32_MFMA = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA = 2500e12      # same guide: dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0         # same guide: HBM3E ~8 TB/s peak (spec); ~6.3 TB/s achievable read-only
 
 
@@ -186,8 +187,8 @@ def main():
     # trunk and the last-block half of a step on two different HIP streams).  Dominant kernel of the path = the fused
     # weight-gradient + Adam kernel (HBM-bound: w, m, v of every episode are read and written once per step); the
     # implicit-GEMM convolutions (MFMA-bound) are reported next to it.
-    conv_events, adam_events = [], []
-    orig_conv2d, orig_wgrad_adam = ops.conv2d, ops.conv2d_wgrad_adam
+    conv_events, adam_events, x3_events = [], [], []
+    orig_conv2d, orig_wgrad_adam, orig_conv2d_x3 = ops.conv2d, ops.conv2d_wgrad_adam, ops.conv2d_x3
     timing = {"on": False}
 
     def timed_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=None):
@@ -213,8 +214,20 @@ def main():
         adam_events.append((a, b, 6.0 * 4.0 * w.numel()))      # read w,m,v + write w,m,v; the gradient never reaches HBM
         return None
 
+    def timed_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out=None):
+        if not timing["on"]:
+            return orig_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out)
+        s = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        r = orig_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out)
+        b.record(s)
+        x3_events.append((a, b, conv_flops(x.shape[0], r.shape[1], Cout, KH * KW * x.shape[3])))
+        return r
+
     ops.conv2d = timed_conv2d
     ops.conv2d_wgrad_adam = timed_wgrad_adam
+    ops.conv2d_x3 = timed_conv2d_x3
 
     def sync_all():
         if dist is not None:
@@ -245,7 +258,7 @@ def main():
     # ---- rooflines: one more identical batch (same two-stream pipeline) with an event pair around every launch of the
     # two kernel families.  In-situ durations include the slowdown from the kernel co-running on the other stream; the
     # rocprofv3 kernel-trace of this same command (profiles/) must and does show the same averages.
-    roof = roof_mfma = None
+    roof = roof_mfma = roof_x3 = None
     if rank == 0:
         timing["on"] = True
         e.run_batch(pool)
@@ -270,8 +283,18 @@ def main():
         tot_fl = sum(f for _, _, f in conv_events)
         n_launch = len(conv_events)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        roof_mfma = {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_conv_kernel (fp32 MFMA implicit GEMM, all forward shapes "
-                                                "incl. the weight-streaming per-episode trunk.7 launches)",
+        if x3_events:
+            x_ms = sum(a.elapsed_time(b) for a, b, _ in x3_events)
+            x_fl = sum(f for _, _, f in x3_events)
+            ach3 = x_fl / (x_ms * 1e-3) / 1e12
+            roof_x3 = {"bound": "mfma", "kernel": "conv_x3_kernel (frozen trunk.4-6: fp32-accurate 6-term bf16x3 products on bf16 MFMA)",
+                       "achieved": round(ach3, 2), "peak": round(PEAK_BF16_MFMA / 6e12, 1), "unit": "TFLOP/s (fp32-equivalent: "
+                       "algorithmic 2*M*N*K; the kernel executes 6 bf16 MFMA flops per algorithmic flop, peak = 2500/6)",
+                       "frac": round(ach3 / (PEAK_BF16_MFMA / 6e12), 4), "launches": len(x3_events),
+                       "avg_launch_us": round(x_ms * 1e3 / len(x3_events), 2),
+                       "vs_fp32_mfma_peak": round(ach3 / (PEAK_F32_MFMA / 1e12), 3)}
+        roof_mfma = {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_conv_kernel (fp32 MFMA implicit GEMM: stem, "
+                                                "weight-streaming per-episode trunk.7 launches, GNN GEMMs)",
                      "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "launches": n_launch,
                      "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
@@ -285,7 +308,10 @@ def main():
             "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node",
             "value": round(value, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "all arithmetic is fp32-accurate: fp32 MFMA everywhere except the frozen trunk.4-6 convolutions, which run as "
+                          "exact 3-way bf16 splits with the six leading products accumulated in fp32 (error <= fp32 GEMM rounding; "
+                          "tests/test_kernels_gpu.py::test_conv2d_bf16x3_is_fp32_accurate)", "data": "synthetic",
             "config": {"workload": "5-way 5-shot ResNet10+GNN test-time finetune, 84x84, fine_tune_epoch=%d, "
                                    "gen_examples=%d (%d inner Adam steps/episode), 15 queries" %
                                    (args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
@@ -297,6 +323,7 @@ def main():
             "mean_acc": round(float(acc_ep.mean()), 2),
             "roofline": roof,
             "roofline_mfma": roof_mfma,
+            "roofline_mfma_x3": roof_x3,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.gen_examples)

@@ -41,7 +41,7 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn"):
+                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316).
         ``mode`` "gnn": finetune.finetune (inner loss on the raw feature, GNN scoring);
@@ -63,7 +63,7 @@ class FinetuneEngine:
         self.n_all = n_way * (n_support + n_query)
         fsd = {k[len("feature."):]: v for k, v in state.items()
                if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))}
-        self.W = Fn.ResNet10Weights(fsd, self.dev)
+        self.W = Fn.ResNet10Weights(fsd, self.dev, x3=x3)
         self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way) if mode == "gnn" else None
         if mode == "linear":
             self.cls = {k: torch.zeros((self.E, n_way, 512) if k.endswith("W") else (self.E, n_way), device=self.dev)

@@ -51,9 +51,12 @@ class Arena:
 class ResNet10Weights:
     """Packed device copy of a backbone.ResNet10 state dict (keys 'trunk.*' under ``prefix``)."""
 
-    def __init__(self, sd, device, prefix=""):
+    def __init__(self, sd, device, prefix="", x3=False):
+        """``x3``: also keep bf16x3 planes of the frozen trunk.4-6 weights (csrc/conv_x3.hip: fp32-accurate convolution
+        on the bf16 matrix cores); used wherever these layers run with shared weights."""
         self.device = device
         self.conv = {}
+        self.conv3 = {}
         self.bn = {}
 
         def dev(t):
@@ -61,6 +64,8 @@ class ResNet10Weights:
 
         def conv(name):
             self.conv[name] = ops.pack_conv_weight(dev(sd[prefix + name + ".weight"]))
+            if x3 and name.startswith(("trunk.4", "trunk.5", "trunk.6")):
+                self.conv3[name] = ops.split_weight_x3(self.conv[name])
 
         def bn(name):
             self.bn[name] = (dev(sd[prefix + name + ".weight"]), dev(sd[prefix + name + ".bias"]))
@@ -222,17 +227,24 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         g1, b1, g2, b2, gs, bs = slab.bn1g, slab.bn1b, slab.bn2g, slab.bn2b, slab.bnsg, slab.bnsb
         gbs = cout
     wipg = ipg if slab is not None else 0
-    c1 = ops.conv2d(x, c1w, cout, 3, 3, stride, 1, imgs_per_group=wipg, out=arena.get(tag + ".c1", (n, OH, OH, cout)))
+    w3 = W.conv3 if slab is None else {}
+
+    def conv(name, inp, wpk, k, s, pd, out):
+        if (p + name) in w3:
+            return ops.conv2d_x3(inp, w3[p + name], cout, k, k, s, pd, out=out)
+        return ops.conv2d(inp, wpk, cout, k, k, s, pd, imgs_per_group=wipg, out=out)
+
+    c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
     m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"))
     rows = ipg * OH * OH
     r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
                       out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
-    c2 = ops.conv2d(r1, c2w, cout, 3, 3, 1, 1, imgs_per_group=wipg, out=arena.get(tag + ".c2", (n, OH, OH, cout)))
+    c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
     m2, s2 = _bn_stats4(arena, tag + ".bn2", c2, ipg, groups, run(p + ".BN2"))
     out = arena.get(tag + ".out", (n * OH * OH, cout))
     sc = ms = ss = None
     if cin != cout:
-        sc = ops.conv2d(x, scw, cout, 1, 1, stride, 0, imgs_per_group=wipg, out=arena.get(tag + ".sc", (n, OH, OH, cout)))
+        sc = conv(".shortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)))
         ms, ss = _bn_stats4(arena, tag + ".bns", sc, ipg, groups, run(p + ".BNshortcut"))
         ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc.view(-1, cout),
                      res_bn=(ms, ss, gs, bs), out=out, gb_group_stride=gbs)
