@@ -17,6 +17,12 @@
 
 int mft_stem_conv_dispatch(const float* in, const float* w, float* out, int n_img, int H, int W, int w_ld,
                            hipStream_t s);   // csrc/stem.hip
+int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                            long long w_group_stride, hipStream_t s);   // csrc/skinny.hip
+int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                              int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                              long long w_group_stride, hipStream_t s);
 
 namespace {
 
@@ -40,6 +46,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
+int g_skinny = 1;      // 0: per-episode-weight launches use the generic tiles (mft_debug_set_conv_tile(3000/3001))
 int g_stem_fast = 1;   // 0: route the stem through the generic gather kernel (mft_debug_set_conv_tile(2000/2001))
 
 // BT == true is the data-gradient form: dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] *
@@ -575,6 +582,12 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
         }
         return launch_conv<128, 64, 2, 2, true>(a, groups, s);
     }
+    if (g_skinny && groups > 1 && w_group_stride != 0 && bias == nullptr) {
+        // per-episode weights, <= 48 output pixels per episode: weight-streaming skinny kernel (csrc/skinny.hip)
+        const int rc = mft_skinny_fwd_dispatch(in, ldi, w, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
+                                               imgs_per_group, w_group_stride, s);
+        if (rc != MFT_EINVAL) return rc;
+    }
     // tile choice (tools/conv_tune.py, MI355X): with fp32 MFMA the 64x64 tile (58 VGPRs, 36.9 KB LDS, 4 workgroups
     // per CU) beats every larger tile on all ResNet10 shapes (84-97 vs 61-88 TFLOP/s): latency hiding through
     // occupancy matters more than operand reuse, LDS bandwidth is not a constraint at 2 floats per 64-cycle MFMA.
@@ -590,7 +603,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
+    if (tile >= 3000) g_skinny = tile - 3000;          // 3000 / 3001: generic / skinny per-episode kernels
+    else if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
     else if (tile >= 1000) g_wgrad_tile = tile - 1000; // 1064 / 1128: choose the wgrad tile
     else g_conv_tile = tile;
     return 0;
@@ -604,6 +618,11 @@ extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, f
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     if (n_img % imgs_per_group != 0) return MFT_EINVAL;
     const int groups = n_img / imgs_per_group;
+    if (g_skinny && groups > 1 && w_group_stride != 0) {
+        const int rc = mft_skinny_dgrad_dispatch(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                 imgs_per_group, w_group_stride, (hipStream_t)stream);
+        if (rc != MFT_EINVAL) return rc;
+    }
     ConvArgs a;
     a.in = dy; a.w = w; a.bias = nullptr; a.out = dx;
     a.ldi = ldy; a.ldo = ldx;

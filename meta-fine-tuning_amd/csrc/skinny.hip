@@ -1,0 +1,311 @@
+// Weight-streaming "skinny" convolutions of the adapted last block (trunk.7, backbone.py:216-261 called from
+// finetune.py:286 / gnnnet.py:168, and its data gradient in loss.backward(), finetune.py:293).
+//
+// In the episode-batched inner loop every episode owns its own trunk.7 weights (14.7 MB) but contributes only
+// 5 images = 45 output pixels: each weight element is used for 45 rows and never again in that step.  The generic
+// implicit-GEMM kernel stages weights through LDS tile by tile with one K-step in flight and reaches ~3 TB/s.
+// Here the roles are swapped:
+//   * the episode's ACTIVATIONS (<= 96 KB per channel slice) are staged once in LDS, rows padded by 8 floats so that
+//     the 16-byte fragment reads of 16 different pixels are conflict-free;
+//   * the WEIGHTS go straight from HBM into MFMA operand registers: with v_mfma_f32_16x16x4_f32 the weight matrix is
+//     the "A" operand (16 output channels x 4 k per instruction), lane (m, kq) loads 16 contiguous bytes of its
+//     channel's row and uses one element per MFMA step; 8 such loads per lane are in flight ahead of the MFMAs;
+//   * the 45 pixels are the "B"/N side: 3 blocks of 16 (M padding 48 instead of 64), fp32 MFMA throughout.
+// One 1024-thread workgroup (16 waves) handles one episode x 256 output channels, so a launch over 128 episodes is
+// one workgroup per CU with 64+ KB of weight loads in flight per CU.
+#include "mft_common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct SkinnyArgs {
+    const float* act;      // [groups][rows_in][lda]
+    const float* w;        // [groups][Cout][K]
+    float* out;            // [groups][rows_out][ldo]
+    int lda, ldo;
+    int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+    int ipg, rows_in, rows_out;
+    long long wgs;
+    int K;
+    int CS;                // channel slice staged in LDS (multiple of 128, divides Cin)
+};
+
+constexpr int SK_PADF = 8;     // row padding (floats)
+constexpr int SK_U = 8;        // k16 groups per chunk (loads in flight per lane)
+
+// forward: out[ro][co] = sum_{tap,ci} act[pix(ro,tap)][ci] * w[co][tap][ci]
+__global__ __launch_bounds__(1024) void skinny_conv_fwd_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int RS = p.CS + SK_PADF;
+    const int ohw = p.OH * p.OW;
+    const int gpt = p.CS / 16;                    // k16 groups per tap within a slice
+    const int taps = p.KH * p.KW;
+
+    // the three pixel blocks of this lane's N index
+    int n_img[3], n_ih0[3], n_iw0[3];
+    bool n_ok[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        n_ok[nb] = ro < p.rows_out;
+        const int rr = n_ok[nb] ? ro : 0;
+        const int img = rr / ohw;
+        const int rem = rr - img * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        n_img[nb] = img;
+        n_ih0[nb] = oh * p.stride - p.pad;
+        n_iw0[nb] = ow * p.stride - p.pad;
+    }
+    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    f32x4v acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int n_slices = p.Cin / p.CS;
+    for (int sl = 0; sl < n_slices; ++sl) {
+        __syncthreads();                           // previous slice fully consumed
+        // stage act[:, sl*CS : (sl+1)*CS] -> lds[rows_in][RS]
+        const int q4 = p.CS / 4;
+        for (int i = tid; i < p.rows_in * q4; i += 1024) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            *(f32x4v*)(lds + r * RS + c) = *(const f32x4v*)(actg + (long long)r * p.lda + sl * p.CS + c);
+        }
+        __syncthreads();
+        const int n_groups = taps * gpt;           // k16 groups of this slice; chunks never straddle a tap (gpt % SK_U == 0)
+        f32x4v a_cur[SK_U], a_nxt[SK_U];
+        auto load_chunk = [&](int q0, f32x4v* dst) {
+            const int tap = q0 / gpt;
+            const int cg0 = q0 - tap * gpt;
+            const float* src = wrow + tap * p.Cin + sl * p.CS + cg0 * 16;
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u) dst[u] = __builtin_nontemporal_load((const f32x4v*)(src + u * 16));
+        };
+        load_chunk(0, a_cur);
+        for (int q0 = 0; q0 < n_groups; q0 += SK_U) {
+            if (q0 + SK_U < n_groups) load_chunk(q0 + SK_U, a_nxt);
+            const int tap = q0 / gpt;
+            const int cg0 = q0 - tap * gpt;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            int boff[3];
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                const int ih = n_ih0[nb] + kh, iw = n_iw0[nb] + kw;
+                const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 4 * kq + cg0 * 16 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u) {
+                f32x4v b4[3];
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    b4[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if (boff[nb] >= 0) b4[nb] = *(const f32x4v*)(lds + boff[nb] + u * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][t], b4[nb][t], acc[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u) a_cur[u] = a_nxt[u];
+        }
+    }
+    // D layout of the 16x16 MFMA: lane holds D[i = 4*(lane/16) + e][j = lane%16]; i = output channel, j = pixel
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro < p.rows_out) *(f32x4v*)(outg + (long long)ro * p.ldo + co0 + 4 * kq) = acc[nb];
+    }
+}
+
+// data gradient of a stride-1 convolution: dx[pix][ci] = sum_{tap,co} dy[pix + pad - (kh,kw)][co] * w[co][tap][ci]
+// Weights are read in their forward layout; a lane loads 8 bytes (2 consecutive ci) of row co(kq,t): M index = ci,
+// two 16-wide M blocks per wave with the interleaved assignment ci = ci0 + 2*m + b.
+__global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
+    // here: act = dy [groups][rows_in][lda] (rows_in = ipg*H*W, channels = Cout of the forward conv = p.Cin field),
+    //       out = dx [groups][rows_out = rows_in][ldo] with p.Cout = forward Cin channels
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int ci0 = blockIdx.x * 256 + wave * 32;       // 8 waves x 32 input channels
+    const int RS = p.CS + SK_PADF;
+    const int hw = p.H * p.W;
+    const int taps = p.KH * p.KW;
+    const int Cdy = p.Cin;                          // reduction channels (forward Cout)
+    const int Cdx = p.Cout;                         // output channels (forward Cin)
+    const long long co_stride = (long long)taps * Cdx;   // floats between consecutive co rows of the forward pack
+
+    int n_img[3], n_h[3], n_w[3];
+    bool n_ok[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        n_ok[nb] = ro < p.rows_out;
+        const int rr = n_ok[nb] ? ro : 0;
+        const int img = rr / hw;
+        const int rem = rr - img * hw;
+        n_img[nb] = img;
+        n_h[nb] = rem / p.W;
+        n_w[nb] = rem - n_h[nb] * p.W;
+    }
+    const float* wbase = p.w + (long long)g * p.wgs + ci0 + 2 * m;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    f32x4v acc[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) acc[b][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // stage dy (all Cdy channels: rows_in x Cdy) once
+    {
+        const int q4 = Cdy / 4;
+        for (int i = tid; i < p.rows_in * q4; i += 512) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            *(f32x4v*)(lds + r * RS + c) = *(const f32x4v*)(actg + (long long)r * p.lda + c);
+        }
+    }
+    __syncthreads();
+    const int gpt = Cdy / 16;                       // k16 groups (16 co each) per tap
+    const int n_groups = taps * gpt;
+    constexpr int U = 4;                            // groups per chunk: 4 groups x 4 steps = 16 loads of 8 B in flight
+    f32x2v a_cur[U][4], a_nxt[U][4];
+    auto load_chunk = [&](int q0, f32x2v (*dst)[4]) {
+        const int tap = q0 / gpt;
+        const int cg0 = q0 - tap * gpt;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int co = (cg0 + u) * 16 + 4 * kq + t;
+                dst[u][t] = __builtin_nontemporal_load((const f32x2v*)(wbase + (long long)co * co_stride + (long long)tap * Cdx));
+            }
+    };
+    load_chunk(0, a_cur);
+    for (int q0 = 0; q0 < n_groups; q0 += U) {
+        if (q0 + U < n_groups) load_chunk(q0 + U, a_nxt);
+        const int tap = q0 / gpt;
+        const int cg0 = q0 - tap * gpt;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int boff[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ih = n_h[nb] + p.pad - kh, iw = n_w[nb] + p.pad - kw;     // dy pixel feeding dx(h,w) through tap (kh,kw)
+            const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 4 * kq + cg0 * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4v b4[3];
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                b4[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (boff[nb] >= 0) b4[nb] = *(const f32x4v*)(lds + boff[nb] + u * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+                        acc[b][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][t][b], b4[nb][t], acc[b][nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a_cur[u][t] = a_nxt[u][t];
+    }
+    // D[i][j]: i = 4*kq + e -> M row -> ci = ci0 + 2*i + b ; j = m -> pixel
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro >= p.rows_out) continue;
+        float* o = outg + (long long)ro * p.ldo + ci0 + 8 * kq;     // rows i = 4kq..4kq+3 -> ci0 + 8kq + {0..7}
+        f32x4v lo, hi;
+        lo[0] = acc[0][nb][0]; lo[1] = acc[1][nb][0]; lo[2] = acc[0][nb][1]; lo[3] = acc[1][nb][1];
+        hi[0] = acc[0][nb][2]; hi[1] = acc[1][nb][2]; hi[2] = acc[0][nb][3]; hi[3] = acc[1][nb][3];
+        *(f32x4v*)(o) = lo;
+        *(f32x4v*)(o + 4) = hi;
+    }
+}
+
+int pick_slice(int rows_in, int Cin) {
+    for (int cs = Cin; cs >= 128; cs /= 2) {
+        if (cs % 128 != 0 || Cin % cs != 0) continue;
+        if ((long long)rows_in * (cs + SK_PADF) * 4 <= 100 * 1024) return cs;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
+int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                            long long w_group_stride, hipStream_t s) {
+    if (imgs_per_group <= 0 || w_group_stride == 0 || n_img % imgs_per_group != 0) return MFT_EINVAL;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const int rows_out = imgs_per_group * OH * OW, rows_in = imgs_per_group * H * W;
+    if (rows_out > 48 || Cout % 256 != 0 || Cin % 128 != 0 || ldi % 4 != 0 || ldo % 4 != 0) return MFT_EINVAL;
+    const int cs = pick_slice(rows_in, Cin);
+    // measured (tools/conv_tune.py, E=128): with the whole activation resident (one slice: trunk.7.C2) the skinny kernel
+    // streams weights at 4.1 TB/s vs 3.1 for the generic tiles; sliced shapes (C1, shortcut: 180 input pixels) are slower.
+    if (cs != Cin || KH * KW == 1) return MFT_EINVAL;
+    SkinnyArgs p;
+    p.act = in; p.w = w; p.out = out; p.lda = ldi; p.ldo = ldo;
+    p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.ipg = imgs_per_group; p.rows_in = rows_in; p.rows_out = rows_out; p.wgs = w_group_stride;
+    p.K = KH * KW * Cin; p.CS = cs;
+    const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           110 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(Cout / 256, n_img / imgs_per_group, 1);
+    hipLaunchKernelGGL(skinny_conv_fwd_kernel, grid, dim3(1024), lds, s, p);
+    return mft_launch_status();
+}
+
+int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                              int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                              long long w_group_stride, hipStream_t s) {
+    // forward conv: Cin -> Cout, stride 1, "same" padding: dy and dx have the same H x W
+    if (imgs_per_group <= 0 || w_group_stride == 0 || n_img % imgs_per_group != 0 || stride != 1) return MFT_EINVAL;
+    if (2 * pad != KH - 1 || 2 * pad != KW - 1) return MFT_EINVAL;
+    const int rows = imgs_per_group * H * W;
+    if (rows > 48 || Cin % 256 != 0 || Cout % 64 != 0 || ldy % 4 != 0 || ldx % 4 != 0) return MFT_EINVAL;
+    if ((long long)rows * (Cout + SK_PADF) * 4 > 100 * 1024) return MFT_EINVAL;
+    SkinnyArgs p;
+    p.act = dy; p.w = w; p.out = dx; p.lda = ldy; p.ldo = ldx;
+    p.H = H; p.W = W; p.Cin = Cout; p.OH = H; p.OW = W; p.Cout = Cin; p.KH = KH; p.KW = KW; p.stride = 1; p.pad = pad;
+    p.ipg = imgs_per_group; p.rows_in = rows; p.rows_out = rows; p.wgs = w_group_stride;
+    p.K = KH * KW * Cin; p.CS = Cout;
+    const size_t lds = (size_t)rows * (Cout + SK_PADF) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           110 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(Cin / 256, n_img / imgs_per_group, 1);
+    hipLaunchKernelGGL(skinny_conv_dgrad_kernel, grid, dim3(512), lds, s, p);
+    return mft_launch_status();
+}

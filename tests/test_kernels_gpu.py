@@ -345,3 +345,42 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
     e3 = float((y3 - ref).abs().max())
     assert e3 <= 2e-5 * scale, (name, e3)
     assert e3 <= 2.0 * e32 + 1e-7 * scale, (name, e3, e32)
+
+
+@pytest.mark.parametrize("ipg", [5, 4, 1])
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H", [("trunk.7.C1", 256, 512, 3, 2, 1, 6), ("trunk.7.C2", 512, 512, 3, 1, 1, 3),
+                                                          ("trunk.7.shortcut", 256, 512, 1, 2, 0, 6)])
+def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, ipg):
+    """Weight-streaming skinny kernels (csrc/skinny.hip; per-episode weights, <= 48 pixels per episode) against float64,
+    and bit-for-bit routing check against the generic tiles (same tolerance)."""
+    from meta_fine_tuning_amd import _lib
+    G = 3
+    n = G * ipg
+    x = rnd((n, Cin, H, H), 21)
+    w = rnd((G, Cout, Cin, k, k), 22, scale=(2.0 / (k * k * Cout)) ** 0.5)
+    xg = nhwc(x).to(DEV)
+    wpk = torch.stack([ops.pack_conv_weight(w[g].to(DEV)) for g in range(G)])
+    ref = torch.cat([F.conv2d(x[g * ipg:(g + 1) * ipg].double(), w[g].double(), None, stride, pad) for g in range(G)])
+    outs = []
+    for mode in (3000, 3001):
+        _lib.lib().mft_debug_set_conv_tile(mode)
+        outs.append(nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad, imgs_per_group=ipg).cpu()).double())
+    _lib.lib().mft_debug_set_conv_tile(3001)
+    scale = max(float(ref.abs().max()), 1.0)
+    assert float((outs[1] - ref).abs().max()) <= 2e-5 * scale, name
+    assert float((outs[0] - ref).abs().max()) <= 2e-5 * scale, name
+    if stride == 1:
+        dy = rnd((n, Cout, H, H), 23)
+        dyg = nhwc(dy).to(DEV)
+        xr = x.double().requires_grad_(True)
+        refs = []
+        for g in range(G):
+            xi = x[g * ipg:(g + 1) * ipg].double().requires_grad_(True)
+            F.conv2d(xi, w[g].double(), None, 1, pad).backward(dy[g * ipg:(g + 1) * ipg].double())
+            refs.append(xi.grad)
+        refd = torch.cat(refs)
+        for mode in (3000, 3001):
+            _lib.lib().mft_debug_set_conv_tile(mode)
+            dx = nchw(ops.conv2d_dgrad(dyg, wpk, Cin, k, k, pad, imgs_per_group=ipg).cpu()).double()
+            assert float((dx - refd).abs().max()) <= 2e-5 * max(float(refd.abs().max()), 1.0), (name, mode)
+        _lib.lib().mft_debug_set_conv_tile(3001)

@@ -37,25 +37,35 @@ for (name, cin, cout, k, s, p, H) in LAYERS:
     _lib.lib().mft_debug_set_conv_tile(0)
     print("%-12s M=%-7d N=%-4d K=%-5d | %s" % (name, n * OH * OH, cout, k * k * cin, " | ".join(res)))
 
-print("per-episode (grouped) weights, 5 images per group:")
+print("per-episode (grouped) weights, 5 images per group: generic tiles vs skinny kernel")
 GL = [("trunk.7.C1", 256, 512, 3, 2, 1, 6), ("trunk.7.C2", 512, 512, 3, 1, 1, 3), ("trunk.7.sc", 256, 512, 1, 2, 0, 6)]
+
+
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
 for (name, cin, cout, k, s, p, H) in GL:
     x = torch.randn(n, H, H, cin, device="cuda")
     w = torch.randn(E, cout, k * k * cin, device="cuda") * 0.05
     OH = (H + 2 * p - k) // s + 1
     byt = 4.0 * E * cout * k * k * cin
     res = []
-    for tile in (0, 1, 2, 3, 4):
-        _lib.lib().mft_debug_set_conv_tile(tile)
+    for mode, nm in ((3000, "generic"), (3001, "skinny")):
+        _lib.lib().mft_debug_set_conv_tile(mode)
         out = ops.conv2d(x, w, cout, k, k, s, p, imgs_per_group=5)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            ops.conv2d(x, w, cout, k, k, s, p, imgs_per_group=5, out=out)
-        b.record()
-        torch.cuda.synchronize()
-        us = a.elapsed_time(b) * 1e3 / 10
-        res.append("%s %.0fus %.2fTB/s" % (names[tile], us, byt / us / 1e6))
-    _lib.lib().mft_debug_set_conv_tile(0)
+        us = timeit(lambda: ops.conv2d(x, w, cout, k, k, s, p, imgs_per_group=5, out=out))
+        res.append("fwd %s %.0fus %.2fTB/s" % (nm, us, byt / us / 1e6))
+        if s == 1:
+            dy = torch.randn(n, OH, OH, cout, device="cuda")
+            dx = ops.conv2d_dgrad(dy, w, cin, k, k, p, imgs_per_group=5)
+            us = timeit(lambda: ops.conv2d_dgrad(dy, w, cin, k, k, p, imgs_per_group=5, out=dx))
+            res.append("dgrad %s %.0fus %.2fTB/s" % (nm, us, byt / us / 1e6))
+    _lib.lib().mft_debug_set_conv_tile(3001)
     print("%-12s rows/group=%-4d N=%-4d K=%-5d | %s" % (name, 5 * OH * OH, cout, k * k * cin, " | ".join(res)))
