@@ -33,9 +33,16 @@ PEAK_BF16_MFMA = 2500e12      # same guide: dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0         # same guide: HBM3E ~8 TB/s peak (spec); ~6.3 TB/s achievable read-only
 
 
+def gnn_flops(B, N):
+    """F_gnn(B,N) ~ 596,160*B*N^2 + 64,868*B*N (+ 1,086*B*N^2 for A@x)."""
+    return (596160.0 + 1086.0) * B * N * N + 64868.0 * B * N
+
+
 def episode_flops(n_way, n_shot, n_query, views, epochs):
     passes = epochs * n_way * n_shot * (views + 1)
-    return passes * (F_IMG_84 + F_LB_84) + n_way * (n_shot + n_query) * F_IMG_84 + F_GNN_15_30
+    graph_support = n_shot // 2 if n_shot == 50 else n_shot          # gnnnet_copy.py:34 folds 50 -> 25 nodes per class
+    f_gnn = F_GNN_15_30 if n_shot == 5 else gnn_flops(n_query, n_way * (graph_support + 1))
+    return passes * (F_IMG_84 + F_LB_84) + n_way * (n_shot + n_query) * F_IMG_84 + f_gnn
 
 
 def conv_flops(n_img, OH, Cout, K):
@@ -127,6 +134,60 @@ def cpu_baseline_subprocess(gen_examples, timeout_s=240):
     return {"value": None, "unit": "episodes/s", "cores": host_threads(), "kind": "port", "sample": note}
 
 
+def bench_metatrain(args, rank, world, dev, dist):
+    """BASELINE configs[3]: episode-parallel meta-training, 5-way 5-shot, 16 queries (105 images of 84x84 per episode and
+    rank); a step = loss + full backward on HIP, ONE flat fp32 all-reduce of all 5.3 M gradients over RCCL, fused outer Adam
+    (train.py:28, meta_template.py:76-92; parallel.FlatGradBucket).  Extra measurement, not the headline metric."""
+    from meta_fine_tuning_amd import optim, parallel, synthetic
+    from meta_fine_tuning_amd.io_utils import model_dict
+    from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+    model = GnnNet(model_dict["ResNet10"], n_way=5, n_support=5).cuda()
+    model.load_state_dict(synthetic.gnnnet_state_dict(seed=0))
+    model.train()
+    model.n_query = 16
+    opt = optim.Adam(model.parameters())
+    bucket = parallel.FlatGradBucket(model.parameters())
+    eps = [synthetic.train_episode(5000 + 100 * rank + i, 5, 5, 16, 84).to(dev) for i in range(8)]
+
+    def step(i):
+        opt.zero_grad()
+        loss = model.set_forward_loss(eps[i % len(eps)])
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node", "value": round(world * args.steps / dt, 3),
+            "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "meta-training step (BASELINE configs[3]): 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
+                                   "flat 21.2 MB gradient all-reduce + fused outer Adam", "parallelism": "episode-parallel x%d" % world},
+            "last_loss": round(float(loss.detach().cpu()), 4), "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +196,11 @@ def main():
     ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "128")))
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--gen-examples", type=int, default=17)
+    ap.add_argument("--n-shot", type=int, default=5, help="5 = BASELINE configs[1] (the metric); 20 = configs[2]; 50 = configs[4] "
+                    "(compressed-GNN fold, finetune_50.py).  Non-default shots are extra measurements, not the headline line.")
+    ap.add_argument("--workload", default="finetune", choices=["finetune", "metatrain"],
+                    help="finetune = BASELINE configs[1] (the metric, default); metatrain = configs[3]: one meta-training episode per "
+                         "rank per step (set_forward_loss -> full backward -> flat-bucket RCCL all-reduce -> fused outer Adam)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle on a bounded sample and print its JSON object; never touches the GPU")
@@ -168,15 +234,20 @@ def main():
     from meta_fine_tuning_amd import engine as eng
     from meta_fine_tuning_amd import ops, synthetic
 
+    if args.workload == "metatrain":
+        return bench_metatrain(args, rank, world, dev, dist)
+
     if os.environ.get("MFT_WGRAD_TILE"):
         from meta_fine_tuning_amd import _lib
         _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
     E = args.episodes_per_batch
-    n_way, n_shot, n_query, size = 5, 5, 15, 84
+    n_way, n_shot, n_query, size = 5, args.n_shot, 15, 84
+    if n_shot != 5:
+        args.no_cpu_baseline = True
     views = 2 + args.gen_examples
     state = synthetic.gnnnet_state_dict(seed=0)
     e = eng.FinetuneEngine(state, n_way, n_shot, n_query, size, n_views=views, fine_tune_epoch=args.epochs,
-                           episodes_per_batch=E, device=dev, pipeline=not args.no_pipeline)
+                           episodes_per_batch=E, device=dev, pipeline=not args.no_pipeline, fold50=(n_shot == 50))
     # resident synthetic episodes (class-structured so accuracy is meaningful); distinct per rank
     pool = [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
                                           gen_examples=args.gen_examples) for i in range(E)]
@@ -312,9 +383,9 @@ def main():
             "dtype_note": "all arithmetic is fp32-accurate: fp32 MFMA everywhere except the frozen trunk.4-6 convolutions, which run as "
                           "exact 3-way bf16 splits with the six leading products accumulated in fp32 (error <= fp32 GEMM rounding; "
                           "tests/test_kernels_gpu.py::test_conv2d_bf16x3_is_fp32_accurate)", "data": "synthetic",
-            "config": {"workload": "5-way 5-shot ResNet10+GNN test-time finetune, 84x84, fine_tune_epoch=%d, "
+            "config": {"workload": "5-way %d-shot ResNet10+GNN test-time finetune, 84x84, fine_tune_epoch=%d, "
                                    "gen_examples=%d (%d inner Adam steps/episode), 15 queries" %
-                                   (args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
+                                   (n_shot, args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
                        "episodes_per_step": E, "episodes_total": total_eps, "image_size": size,
                        "parallelism": "episode-parallel x%d" % world},
             "episode_tflop": round(fl / 1e12, 4),

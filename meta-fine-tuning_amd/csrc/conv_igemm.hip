@@ -46,6 +46,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
+int g_wgrad_min_lds_kb = 0;   // experiment: pad the fused wgrad+Adam workgroup's LDS to cap its occupancy (4000 + KB)
 int g_skinny = 1;      // 0: per-episode-weight launches use the generic tiles (mft_debug_set_conv_tile(3000/3001))
 int g_stem_fast = 1;   // 0: route the stem through the generic gather kernel (mft_debug_set_conv_tile(2000/2001))
 
@@ -492,7 +493,9 @@ template <int BM, int BN, bool ADAM, bool STEMW = false>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
     constexpr int lds_ad = BM * (BN + 4) * 4;
-    constexpr int lds = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
+    constexpr int lds0 = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
+    int lds = lds0;
+    if (ADAM && g_wgrad_min_lds_kb * 1024 > lds) lds = g_wgrad_min_lds_kb * 1024;
     auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
@@ -603,7 +606,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 3000) g_skinny = tile - 3000;          // 3000 / 3001: generic / skinny per-episode kernels
+    if (tile >= 4000) g_wgrad_min_lds_kb = tile - 4000;
+    else if (tile >= 3000) g_skinny = tile - 3000;          // 3000 / 3001: generic / skinny per-episode kernels
     else if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
     else if (tile >= 1000) g_wgrad_tile = tile - 1000; // 1064 / 1128: choose the wgrad tile
     else g_conv_tile = tile;
