@@ -168,18 +168,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+            // six piece products per accumulator, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that no
+            // instruction waits on the result of the one issued just before it
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // smallest terms first; (1,1) last
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (kt + 1 < nk) store_tile();
@@ -234,6 +233,184 @@ int launch_x3(X3Args p, hipStream_t s) {
     return mft_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------ 3x3 stride-1 "patch" form
+// The implicit-GEMM form above re-reads (and re-splits) every input element nine times, once per tap, and depends on
+// L2 for that reuse -- beside the HBM-saturating last-block stream it collapses (3x slower in situ).  For 3x3 / stride 1 /
+// pad 1 layers a workgroup instead owns G images x R output rows x all columns (<= 128 pixels) x 64 output channels and
+// walks the input channels in slices of 32: the slice of the input PATCH ((R+2) x (W+2) pixels per image, zero halo) is
+// loaded, split into its three bf16 planes and parked in LDS ONCE, then all nine taps read their A fragments from it
+// at shifted pixel offsets.  The weight fragments go straight from L2/L1 into registers (8 bf16 of one output channel
+// per lane; no LDS, no barrier inside the tap loop), prefetched one tap ahead.
+struct P3Args {
+    const float* in;
+    const unsigned short* w3;
+    long long plane;
+    float* out;
+    int n_img, H, W, Cin, Cout;
+    int G, R;                  // images and output rows per tile
+    int row_blocks;            // ceil(H / R)
+    int tiles_n;               // Cout / 64
+};
+
+__global__ __launch_bounds__(256) void conv3x3_patch_x3_kernel(P3Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int PW = p.W + 2, PH = p.R + 2;
+    const int PP = p.G * PH * PW;                        // patch pixels
+    const int PLANE = PP * X3_RS;                        // bf16 elements per plane
+    int bx = blockIdx.x;
+    const int nt = bx % p.tiles_n; bx /= p.tiles_n;
+    const int rb = bx % p.row_blocks;
+    const int ig = bx / p.row_blocks;
+    const int img0 = ig * p.G, orow0 = rb * p.R;
+    const int n0 = nt * 64;
+    const int rows_tile = p.R * p.W;                     // pixels per image in the tile
+    const int m_tile = p.G * rows_tile;
+
+    // A-fragment lane bases (patch pixel of output pixel m, tap (0,0)) for the wave's two 32-row blocks
+    int a_pix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = wm * 64 + i * 32 + r;
+        if (m >= m_tile) m = m_tile - 1;                 // clamped rows are computed but never stored
+        const int gl = m / rows_tile;
+        const int rem = m - gl * rows_tile;
+        const int orow = rem / p.W, ocol = rem - orow * p.W;
+        a_pix[i] = (gl * PH + orow) * PW + ocol;
+    }
+    const unsigned short* wlane = p.w3 + (long long)(n0 + wn * 32 + r) * (9 * p.Cin) + h * 8;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int n_slices = p.Cin / 32;
+    constexpr int NPRE = 6;                              // patch float4 slots per thread (PP * 8 <= 1536)
+    f32x4 pre[NPRE];
+    auto load_patch = [&](int sl) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int q = tid + k * 256;
+            const int pp = q >> 3, c4 = (q & 7) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pp < PP) {
+                const int gl = pp / (PH * PW);
+                const int rem = pp - gl * (PH * PW);
+                const int pr = rem / PW, pc = rem - pr * PW;
+                const int img = img0 + gl, ih = orow0 - 1 + pr, iw = pc - 1;
+                if (img < p.n_img && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    v = *(const f32x4*)(p.in + (((long long)img * p.H + ih) * p.W + iw) * p.Cin + sl * 32 + c4);
+            }
+            pre[k] = v;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int q = tid + k * 256;
+            const int pp = q >> 3, c4 = (q & 7) * 4;
+            if (pp < PP) {
+                u32x2 p1, p2, p3;
+                split4(pre[k], p1, p2, p3);
+                const int off = pp * X3_RS + c4;
+                *(u32x2*)(smem + off) = p1;
+                *(u32x2*)(smem + PLANE + off) = p2;
+                *(u32x2*)(smem + 2 * PLANE + off) = p3;
+            }
+        }
+    };
+    bf16x8 bcur[3][2], bnxt[3][2];
+    auto load_b = [&](int sl, int tap, bf16x8 (*dst)[2]) {
+        const unsigned short* src = wlane + tap * p.Cin + sl * 32;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) dst[pl][kk] = *(const bf16x8*)(src + pl * p.plane + kk * 16);
+    };
+
+    load_patch(0);
+    load_b(0, 0, bcur);
+    for (int sl = 0; sl < n_slices; ++sl) {
+        __syncthreads();                                 // every wave is done reading the previous slice
+        store_patch();
+        __syncthreads();
+        if (sl + 1 < n_slices) load_patch(sl + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_b(sl, tap + 1, bnxt);
+            else if (sl + 1 < n_slices) load_b(sl + 1, 0, bnxt);
+            const int toff = ((tap / 3) * PW + (tap % 3)) * X3_RS;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[i][pl] = *(const bf16x8*)(smem + pl * PLANE + a_pix[i] * X3_RS + toff + kk * 16 + h * 8);
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bcur[TB[t]][kk], acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) bcur[pl][kk] = bnxt[pl][kk];
+        }
+    }
+    // epilogue
+    const int n = n0 + wn * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int m = wm * 64 + i * 32 + row;
+            if (m >= m_tile) continue;
+            const int gl = m / rows_tile;
+            const int rem = m - gl * rows_tile;
+            const int orow = orow0 + rem / p.W, ocol = rem % p.W;
+            const int img = img0 + gl;
+            if (img < p.n_img && orow < p.H) p.out[(((long long)img * p.H + orow) * p.W + ocol) * p.Cout + n] = acc[i][e];
+        }
+}
+
+// tile geometry for a 3x3/s1/p1 layer on H x W maps; returns false when the patch form does not apply
+bool patch_geometry(int H, int W, int* G, int* R, double* eff_out) {
+    if (W > 64 || H > 64) return false;
+    int best_g = 0, best_r = 0;
+    double best = 0.0;
+    for (int g = 1; g <= 8; ++g)
+        for (int rr = 1; rr <= H; ++rr) {
+            if (g > 1 && rr != H) continue;                     // several images per tile only with whole images
+            const int m = g * rr * W;
+            if (m > 128) continue;
+            const int pp = g * (rr + 2) * (W + 2);
+            if (pp * 8 > 6 * 256) continue;                     // NPRE float4 slots per thread
+            const int blocks = (H + rr - 1) / rr;
+            const double eff = (double)(H * W) * g / ((double)blocks * 128.0);     // useful rows per 128-row tile
+            if (eff > best + 1e-9) { best = eff; best_g = g; best_r = rr; }
+        }
+    if (best < 0.7) return false;
+    *G = best_g; *R = best_r;
+    *eff_out = best;
+    return true;
+}
+
+// Measured (tools/x3_tune.py, tools/phase_times.py, E=128): standalone the patch form wins only on 11x11 maps (157 vs 173 us)
+// and loses on 21x21 / 6x6 (tile utilisation 86 / 84 %); beside the last-block stream it is slower everywhere (61.0 / 59.7
+// vs 62.0 episodes/s) because both forms are bound by VALU + LDS issue, not by operand re-reads.  Kept as an opt-in.
+int g_x3_patch = 0;  // mft_debug_set_x3_tile(10 + v): 0 never use the patch form (default), 1 only when >= 90 % of a tile's
+                     // rows are useful (11x11 maps), 2 whenever it applies
 int g_x3_tile = 0;   // 0 auto; 1: 128x64; 2: 128x128
 
 }  // namespace
@@ -247,7 +424,8 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 }
 
 extern "C" int mft_debug_set_x3_tile(int t) {
-    g_x3_tile = t;
+    if (t >= 10) g_x3_patch = t - 10;
+    else g_x3_tile = t;
     return 0;
 }
 
@@ -266,8 +444,31 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
     p.M = (int)M;
     p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
+    int G = 0, R = 0;
+    double eff = 0.0;
+    if (g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
+        patch_geometry(H, W, &G, &R, &eff) && (g_x3_patch >= 2 || eff >= 0.9)) {
+        P3Args q;
+        q.in = in; q.w3 = w3; q.plane = plane_elems; q.out = out;
+        q.n_img = n_img; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.G = G; q.R = R;
+        q.row_blocks = (H + R - 1) / R;
+        q.tiles_n = Cout / 64;
+        const int img_groups = (n_img + G - 1) / G;
+        const size_t lds = (size_t)3 * G * (R + 2) * (W + 2) * X3_RS * sizeof(unsigned short);
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               64 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(conv3x3_patch_x3_kernel, dim3((unsigned)(img_groups * q.row_blocks * q.tiles_n)), dim3(256), lds, s, q);
+            return mft_launch_status();
+        }
+    }
     int tile = g_x3_tile;
-    if (tile == 0) tile = (Cout % 128 == 0) ? 2 : 1;
+    if (tile == 0) tile = 1;       // 128x64 beats 128x128 on every trunk shape (3 vs 2 workgroups per CU)
     if (tile == 2 && Cout % 128 == 0) return launch_x3<128, 128>(p, s);
     return launch_x3<128, 64>(p, s);
 }

@@ -13,6 +13,10 @@ if os.environ.get("MFT_DEBUG_TILE"):
     from meta_fine_tuning_amd import _lib
     for t in os.environ["MFT_DEBUG_TILE"].split(","):
         _lib.lib().mft_debug_set_conv_tile(int(t))
+if os.environ.get("MFT_X3_TILE"):
+    from meta_fine_tuning_amd import _lib
+    for t in os.environ["MFT_X3_TILE"].split(","):
+        _lib.lib().mft_debug_set_x3_tile(int(t))
 state = synthetic.gnnnet_state_dict(seed=0)
 e = eng.FinetuneEngine(state, 5, 5, 15, 84, n_views=19, fine_tune_epoch=5, episodes_per_batch=E, device=dev, pipeline=pipe)
 pool = [synthetic.test_episode_device(i, dev) for i in range(min(E, 8))]

@@ -25,7 +25,10 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) * 1e3 / iters
 
 
+FILTER = sys.argv[2] if len(sys.argv) > 2 else ""
 for (name, cin, cout, k, s, p, H) in LAYERS:
+    if FILTER and FILTER not in name:
+        continue
     x = torch.randn(n, H, H, cin, device="cuda")
     w = torch.randn(cout, cin, k, k, device="cuda") * (2.0 / (k * k * cout)) ** 0.5
     wpk = ops.pack_conv_weight(w)
@@ -39,13 +42,17 @@ for (name, cin, cout, k, s, p, H) in LAYERS:
     ref = F.conv2d(x[:nv].permute(0, 3, 1, 2).double(), w.double(), None, s, p).permute(0, 2, 3, 1)
     sc = float(ref.abs().max())
     e32 = float((out32[:nv].double() - ref).abs().max()) / sc
-    for tile, tn in ((1, "128x64"), (2, "128x128")):
+    for tile, tn in ((1, "128x64"), (2, "128x128"), (11, "patch")):
         if tile == 2 and cout % 128:
             continue
-        _lib.lib().mft_debug_set_x3_tile(tile)
+        if tile == 11 and not (k == 3 and s == 1):
+            continue
+        _lib.lib().mft_debug_set_x3_tile(10 if tile < 10 else 12)
+        _lib.lib().mft_debug_set_x3_tile(tile if tile < 10 else 0)
         o3 = ops.conv2d_x3(x, w3, cout, k, k, s, p)
         t3 = timeit(lambda: ops.conv2d_x3(x, w3, cout, k, k, s, p, out=o3))
         e3 = float((o3[:nv].double() - ref).abs().max()) / sc
         res.append("x3 %s %.0fus %.0fTF err %.1e" % (tn, t3, fl / t3 / 1e6, e3))
     _lib.lib().mft_debug_set_x3_tile(0)
+    _lib.lib().mft_debug_set_x3_tile(11)
     print("%-11s M=%-7d N=%-4d K=%-5d | %s (err %.1e) | %s" % (name, n * OH * OH, cout, k * k * cin, res[0], e32, " | ".join(res[1:])))
