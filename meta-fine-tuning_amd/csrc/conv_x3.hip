@@ -32,6 +32,7 @@ struct X3Args {
     int Kpad;
     int M;                         // n_img * OH * OW
     int tiles_n;
+    unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
 };
 
 constexpr int X3_RS = 40;          // bf16 per LDS row: 32 data + 8 pad (80 B)
@@ -83,7 +84,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int lrow = tid >> 3;
     const int c4 = (tid & 7) * 4;
     const int ohw = p.OH * p.OW;
-    long long a_base[PA];
+    // Operands are fetched with raw buffer loads: one 32-bit byte offset per lane, and an offset beyond the buffer
+    // (the sentinel 0x80000000) returns zeros -- that IS the zero padding of the convolution and of ragged tiles, so the
+    // im2col gather costs a compare + select per row instead of 64-bit address arithmetic under divergent branches.
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
+    int a_off[PA];                 // byte offset of (img, ih0, iw0, channel c4); meaningful only with a valid tap
     int a_ih0[PA], a_iw0[PA];
     bool a_ok[PA];
 #pragma unroll
@@ -96,12 +102,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
-        a_base[j] = (long long)img * p.H * p.W;
+        a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * 4;
     }
     const int brow = tid >> 2, bseg = tid & 3;
-    const unsigned short* b_ptr[PB];
+    int b_off[PB];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) b_ptr[j] = p.w3 + (long long)(n0 + brow + 64 * j) * p.Kpad + bseg * 8;
+    for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
+    const int plane_bytes = (int)(p.plane * 2);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -117,21 +124,21 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * 32;
-        const int khkw = k0 / p.Cin;
+        const int khkw = k0 / p.Cin;                       // uniform (scalar) tap bookkeeping
         const int ci0 = k0 - khkw * p.Cin;
         const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+        const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * 4;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-            const bool ok = a_ok[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(p.in + (a_base[j] + (long long)ih * p.W + iw) * p.ldi + ci0 + c4);
-            ra[j] = v;
+            const bool ok = a_ok[j] && (unsigned)(a_ih0[j] + kh) < (unsigned)p.H && (unsigned)(a_iw0[j] + kw) < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)(a_off[j] + tap_off) : 0x80000000u;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rb[j][pl] = *(const u32x4*)(b_ptr[j] + pl * p.plane + k0);
+            for (int pl = 0; pl < 3; ++pl)
+                rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -469,6 +476,20 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
     }
     int tile = g_x3_tile;
     if (tile == 0) tile = 1;       // 128x64 beats 128x128 on every trunk shape (3 vs 2 workgroups per CU)
-    if (tile == 2 && Cout % 128 == 0) return launch_x3<128, 128>(p, s);
-    return launch_x3<128, 64>(p, s);
+    p.w_bytes = (unsigned)(3 * plane_elems * 2);
+    // buffer extents must stay below 2^31 bytes: split the batch over images when the input is larger
+    const long long img_bytes = (long long)H * W * ldi * 4;
+    const long long max_imgs = 0x7fff0000LL / img_bytes;
+    if (max_imgs < 1 || 3 * plane_elems * 2 >= 0x7fff0000LL) return MFT_EINVAL;
+    for (long long i0 = 0; i0 < n_img; i0 += max_imgs) {
+        const long long ni = (n_img - i0 < max_imgs) ? (n_img - i0) : max_imgs;
+        X3Args q = p;
+        q.in = in + i0 * H * W * ldi;
+        q.out = out + i0 * p.OH * p.OW * ldo;
+        q.M = (int)(ni * p.OH * p.OW);
+        q.in_bytes = (unsigned)(ni * img_bytes);
+        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128>(q, s) : launch_x3<128, 64>(q, s);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
