@@ -62,10 +62,11 @@ def _worker(rank, world_size, port, out):
     bucket = parallel.FlatGradBucket(params)
     assert bucket.numel == sum(p.numel() for p in params)
     bucket.allreduce_mean()
+    avg_grads = {k: p.grad.detach().clone() for k, p in zip(keys, params)}
     opt = torch.optim.Adam(params)
     opt.step()
     if rank == 0:
-        torch.save({k: p.detach() for k, p in zip(keys, params)}, out)
+        torch.save({"params": {k: p.detach() for k, p in zip(keys, params)}, "grads": avg_grads}, out)
     # all ranks must hold identical parameters
     flat = torch.cat([p.detach().flatten() for p in params])
     ref = flat.clone()
@@ -82,15 +83,23 @@ def test_world_size_2_gloo(tmp_path):
     # sequential emulation: accumulate the W episodes' gradients from the common parameters, divide by W, one step
     sd = _small_state()
     acc = None
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(2)           # same ATen reduction order as the workers (the fused CPU BatchNorm is thread-count sensitive)
     for r in range(W):
         keys, g = _episode_grads(sd, 100 + r)
         acc = [gi.clone() for gi in g] if acc is None else [a + gi for a, gi in zip(acc, g)]
+    torch.set_num_threads(nthreads)
     params = [sd[k].clone() for k in keys]
     st = O.adam_init(params)
     O.adam_step(params, [a / W for a in acc], st, lr=1e-3)
+    for k, a in zip(keys, acc):
+        # the exchange itself: averaged gradients equal the sequential accumulation (thread-count rounding only)
+        ref_g = a / W
+        assert float((got["grads"][k] - ref_g).abs().max()) <= 2e-5 * max(float(ref_g.abs().max()), 1e-3), k
     for k, p in zip(keys, params):
-        err = (got[k] - p).abs()       # first Adam step = lr*sign(g): thread-count rounding may flip a near-zero gradient
-        assert float((err < 1e-6).float().mean()) > 0.999 and float(err.max()) < 2.1e-3, k
+        # first Adam step = lr*sign(g): rounding of a near-zero gradient flips a +-1e-3 move for a small fraction of weights
+        err = (got["params"][k] - p).abs()
+        assert float((err < 1e-6).float().mean()) > 0.99 and float(err.max()) < 2.1e-3, k
 
 
 def test_rank_invariant_permutations():
