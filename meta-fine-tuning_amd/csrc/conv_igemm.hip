@@ -46,6 +46,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
+int g_wgrad_early = 1;        // 1: issue the tile's w/m/v loads before the reduction (mft_debug_set_conv_tile(5000/5001))
 int g_wgrad_min_lds_kb = 0;   // experiment: pad the fused wgrad+Adam workgroup's LDS to cap its occupancy (4000 + KB)
 int g_skinny = 1;      // 0: per-episode-weight launches use the generic tiles (mft_debug_set_conv_tile(3000/3001))
 int g_stem_fast = 1;   // 0: route the stem through the generic gather kernel (mft_debug_set_conv_tile(2000/2001))
@@ -307,7 +308,7 @@ struct WgradArgs {
 // in LDS ([BM][BN+4]) and the w/m/v update streams with 16 B per lane and 4*BN contiguous bytes per row:
 // 3 reads + 3 writes per parameter instead of a gradient write plus Adam's 4 reads + 3 writes.
 // STEMW: the 7x7x3 stem (Cin == 3): the "ci" axis of the tile is the flattened k = (kh*KW+kw)*3+ci (147 -> 160).
-template <int BM, int BN, bool ADAM, bool STEMW>
+template <int BM, int BN, bool ADAM, bool STEMW, bool EARLYT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
     constexpr int QA = BM / 4;                  // float4 per A row
@@ -348,6 +349,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const long long row0 = (long long)g * p.rows_per_group;
     const long long img0 = (long long)g * p.imgs_per_group;
 
+    // ADAM, 64x64 tile: issue the tile's w/m/v loads (12 x 16 B per lane, nontemporal) BEFORE the reduction so that their
+    // HBM latency is covered by the MFMA phase of this same workgroup instead of by other resident workgroups -- the kernel
+    // then keeps its bandwidth when the co-running trunk stream takes CU slots away.
+    constexpr bool EARLY = EARLYT && ADAM && BM == 64 && BN == 64;
+    f32x4 e_m[4], e_v[4], e_w[4];
+    long long e_gi[4];
+    if (EARLY) {
+        const int q = tid % 16, rr = tid / 16;
+        const long long gbase = (long long)g * p.dwgs + (long long)khkw * p.Cin + ci0 + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e_gi[u] = gbase + (long long)(co0 + rr + u * 16) * p.Kpad;
+            e_m[u] = __builtin_nontemporal_load((const f32x4*)(p.m + e_gi[u]));
+            e_v[u] = __builtin_nontemporal_load((const f32x4*)(p.v + e_gi[u]));
+            e_w[u] = __builtin_nontemporal_load((const f32x4*)(p.w + e_gi[u]));
+        }
+    }
     const int m_begin = blockIdx.z * p.chunk_rows;
     const int m_end = min(m_begin + p.chunk_rows, p.rows_per_group);
     const bool a_col_ok = (co0 + acol) < p.Cout;
@@ -455,10 +473,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int row = rr + (r0 + u) * RP;
-                gi[u] = gbase + (long long)(co0 + row) * p.Kpad;
-                mm[u] = __builtin_nontemporal_load((const f32x4*)(p.m + gi[u]));
-                vv[u] = __builtin_nontemporal_load((const f32x4*)(p.v + gi[u]));
-                ww[u] = __builtin_nontemporal_load((const f32x4*)(p.w + gi[u]));
+                if (EARLY) {
+                    gi[u] = e_gi[u]; mm[u] = e_m[u]; vv[u] = e_v[u]; ww[u] = e_w[u];
+                } else {
+                    gi[u] = gbase + (long long)(co0 + row) * p.Kpad;
+                    mm[u] = __builtin_nontemporal_load((const f32x4*)(p.m + gi[u]));
+                    vv[u] = __builtin_nontemporal_load((const f32x4*)(p.v + gi[u]));
+                    ww[u] = __builtin_nontemporal_load((const f32x4*)(p.w + gi[u]));
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -489,14 +511,14 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool ADAM, bool STEMW = false>
+template <int BM, int BN, bool ADAM, bool STEMW = false, bool EARLYT = false>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
     constexpr int lds_ad = BM * (BN + 4) * 4;
     constexpr int lds0 = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
     int lds = lds0;
     if (ADAM && g_wgrad_min_lds_kb * 1024 > lds) lds = g_wgrad_min_lds_kb * 1024;
-    auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW>;
+    auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW, EARLYT>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -545,6 +567,7 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     if (adam) {
         if (a.Cin % 64 != 0 || a.Cout % 64 != 0) return MFT_EINVAL;
         if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64) return launch_wgrad<128, 128, true>(a, taps, groups, s);
+        if (g_wgrad_early) return launch_wgrad<64, 64, true, false, true>(a, taps, groups, s);
         return launch_wgrad<64, 64, true>(a, taps, groups, s);
     }
     return launch_wgrad<64, 64, false>(a, taps, groups, s);
@@ -606,7 +629,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 4000) g_wgrad_min_lds_kb = tile - 4000;
+    if (tile >= 5000) g_wgrad_early = tile - 5000;
+    else if (tile >= 4000) g_wgrad_min_lds_kb = tile - 4000;
     else if (tile >= 3000) g_skinny = tile - 3000;          // 3000 / 3001: generic / skinny per-episode kernels
     else if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
     else if (tile >= 1000) g_wgrad_tile = tile - 1000; // 1064 / 1128: choose the wgrad tile
