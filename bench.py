@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--gen-examples", type=int, default=17)
     ap.add_argument("--n-shot", type=int, default=5, help="5 = BASELINE configs[1] (the metric); 20 = configs[2]; 50 = configs[4] "
                     "(compressed-GNN fold, finetune_50.py).  Non-default shots are extra measurements, not the headline line.")
+    ap.add_argument("--device-aug", action="store_true",
+                    help="generate the 2+G views on the GPU from resident uint8 64x64 (EuroSAT-shaped) source images inside the timed "
+                         "region (mft_augment_views) instead of ingesting pre-made fp32 views; extra measurement")
     ap.add_argument("--workload", default="finetune", choices=["finetune", "metatrain"],
                     help="finetune = BASELINE configs[1] (the metric, default); metatrain = configs[3]: one meta-training episode per "
                          "rank per step (set_forward_loss -> full backward -> flat-bucket RCCL all-reduce -> fused outer Adam)")
@@ -249,8 +252,25 @@ def main():
     e = eng.FinetuneEngine(state, n_way, n_shot, n_query, size, n_views=views, fine_tune_epoch=args.epochs,
                            episodes_per_batch=E, device=dev, pipeline=not args.no_pipeline, fold50=(n_shot == 50))
     # resident synthetic episodes (class-structured so accuracy is meaningful); distinct per rank
-    pool = [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
-                                          gen_examples=args.gen_examples) for i in range(E)]
+    if args.device_aug:
+        from meta_fine_tuning_amd import augment
+        g = torch.Generator(device=dev)
+        g.manual_seed(77 + rank)
+        srcs = [torch.randint(0, 256, (n_way, n_shot + n_query, 64, 64, 3), generator=g, device=dev, dtype=torch.uint8)
+                for _ in range(E)]
+        aug_rs = np.random.RandomState(1234 + rank)
+        pool = None
+    else:
+        pool = [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
+                                              gen_examples=args.gen_examples) for i in range(E)]
+
+    def one_batch():
+        if args.device_aug:        # fresh random views every batch, parameters drawn on the host inside the timed region
+            eps = [(srcs[i], augment.sample_view_params(aug_rs, n_way * (n_shot + n_query), 64, 64, size, args.gen_examples))
+                   for i in range(E)]
+            return e.run_batch(eps, sources=True)
+        return e.run_batch(pool)
+
     y_query = np.repeat(np.arange(n_way), n_query)
     np.random.seed(10 + rank)
 
@@ -307,11 +327,11 @@ def main():
 
     accs = []
     for _ in range(args.warmup):
-        e.run_batch(pool)
+        one_batch()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sc = e.run_batch(pool)
+        sc = one_batch()
         accs.append(sc)
     sync_all()
     dt = time.perf_counter() - t0
@@ -332,7 +352,7 @@ def main():
     roof = roof_mfma = roof_x3 = None
     if rank == 0:
         timing["on"] = True
-        e.run_batch(pool)
+        one_batch()
         torch.cuda.synchronize()
         timing["on"] = False
         a_ms = sum(a.elapsed_time(b) for a, b, _ in adam_events)
@@ -387,6 +407,8 @@ def main():
                                    "gen_examples=%d (%d inner Adam steps/episode), 15 queries" %
                                    (n_shot, args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
                        "episodes_per_step": E, "episodes_total": total_eps, "image_size": size,
+                       "views": "generated on the GPU from uint8 64x64 sources inside the timed region" if args.device_aug
+                       else "pre-made fp32 NCHW views resident in HBM",
                        "parallelism": "episode-parallel x%d" % world},
             "episode_tflop": round(fl / 1e12, 4),
             "whole_path_tflops": round(value * fl / 1e12, 2),

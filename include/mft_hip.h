@@ -38,6 +38,15 @@ int mft_stream_create_cumask(const unsigned* mask_words, int n_words, void** str
 int mft_stream_destroy(void* stream);
 int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream);
 
+/* Device-side test-time views (datasets/EuroSAT_few_shot.py:145-170,240-276; data/additional_transforms.py:16-31): for every
+ * (view, image) resample the crop box params[view][img][0..3] = (y0, x0, h, w) of the uint8 HWC source image to size x size
+ * (bilinear), apply ImageEnhance Brightness / Contrast / Color with factors params[..][4..6] when params[..][9] != 0, flip
+ * horizontally / vertically when params[..][7] / [8] != 0, scale to [0,1] and normalise with mean3 / std3 (HOST pointers).
+ * Output: fp32 NHWC at out + view*view_stride + img*img_stride (floats).  Parameters come from the host sampler.          */
+int mft_augment_views(const unsigned char* src, int n_img, int Hs, int Ws, const float* params, int n_views, float* out,
+                      long long view_stride, long long img_stride, int size, const float* mean3, const float* std3,
+                      void* stream);
+
 /* layout ---------------------------------------------------------------------------- */
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);

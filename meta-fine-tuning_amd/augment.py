@@ -1,0 +1,109 @@
+"""Device-side test-time views: host parameter sampler + launcher for ``mft_augment_views``.
+
+View contract of the reference (datasets/EuroSAT_few_shot.py:240-276 ``SubDataset2``): every episode image yields
+``2 + num_aug`` tensors -- two identical un-augmented views (Scale(1.15*size) + CenterCrop(size)) followed by ``num_aug``
+augmented ones (RandomSizedCrop(size, scale=(0.5, 0.9)), ImageJitter(Brightness .1, Contrast .1, Color .05),
+RandomHorizontalFlip, RandomVerticalFlip), all ToTensor + Normalize(ImageNet).  The transforms themselves live in
+torchvision (pinned 0.8.2, requirements.txt:20; not vendored in the reference); their published parameter draws are
+restated here with numpy's RandomState so that an episode's views are a pure function of (seed, episode index):
+
+* RandomSizedCrop == RandomResizedCrop.get_params: up to 10 tries of area ~ U(scale)*H*W, log-uniform aspect in [3/4, 4/3],
+  w = round(sqrt(area*aspect)), h = round(sqrt(area/aspect)), accepted when it fits, top-left uniform; fallback = the
+  largest centred crop within the aspect bounds.
+* ImageJitter (data/additional_transforms.py:21-31): r_k = alpha_k*(2u-1)+1 for Brightness, Contrast, Color in that order.
+* flips with probability 1/2 each.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import ops
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+JITTER = (0.1, 0.1, 0.05)          # Brightness, Contrast, Color (EuroSAT_few_shot.py:131)
+NPARAM = 10
+
+
+def noaug_box(Hs, Ws, size):
+    """Scale([int(1.15*size)]*2) then CenterCrop(size), expressed as the source-pixel box that lands on the size x size output."""
+    S2 = int(size * 1.15)
+    top = int(round((S2 - size) / 2.0))
+    return top * Hs / S2, top * Ws / S2, size * Hs / S2, size * Ws / S2
+
+
+def random_resized_crop_boxes(rs, n, Hs, Ws, scale=(0.5, 0.9), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """n independent RandomResizedCrop.get_params draws, vectorised: all 10 candidate boxes of every draw are generated at
+    once and the first that fits is taken (same acceptance rule as the sequential loop) -> float32 [n, 4] (y0, x0, h, w)."""
+    area = float(Hs * Ws)
+    target = rs.uniform(scale[0], scale[1], size=(n, 10)) * area
+    aspect = np.exp(rs.uniform(math.log(ratio[0]), math.log(ratio[1]), size=(n, 10)))
+    w = np.rint(np.sqrt(target * aspect)).astype(np.int64)
+    h = np.rint(np.sqrt(target / aspect)).astype(np.int64)
+    ok = (w > 0) & (w <= Ws) & (h > 0) & (h <= Hs)
+    first = np.argmax(ok, axis=1)
+    any_ok = ok.any(axis=1)
+    idx = np.arange(n)
+    w, h = w[idx, first], h[idx, first]
+    # fallback (no candidate fits): the largest centred crop within the aspect bounds
+    in_ratio = Ws / Hs
+    if in_ratio < ratio[0]:
+        fw, fh = Ws, int(round(Ws / ratio[0]))
+    elif in_ratio > ratio[1]:
+        fh, fw = Hs, int(round(Hs * ratio[1]))
+    else:
+        fw, fh = Ws, Hs
+    w = np.where(any_ok, w, fw)
+    h = np.where(any_ok, h, fh)
+    u = rs.uniform(0.0, 1.0, size=(n, 2))
+    i = np.where(any_ok, np.floor(u[:, 0] * (Hs - h + 1)), (Hs - h) // 2)
+    j = np.where(any_ok, np.floor(u[:, 1] * (Ws - w + 1)), (Ws - w) // 2)
+    return np.stack([i, j, h, w], axis=1).astype(np.float32)
+
+
+def sample_view_params(rs, n_img, Hs, Ws, size, num_aug):
+    """-> float32 [2 + num_aug, n_img, 10] rows (y0, x0, h, w, r_brightness, r_contrast, r_color, flip_h, flip_v, enhance)."""
+    P = np.zeros((2 + num_aug, n_img, NPARAM), dtype=np.float32)
+    P[:2, :, 0:4] = noaug_box(Hs, Ws, size)
+    P[:2, :, 4:7] = 1.0
+    if num_aug > 0:
+        n = num_aug * n_img
+        P[2:, :, 0:4] = random_resized_crop_boxes(rs, n, Hs, Ws).reshape(num_aug, n_img, 4)
+        u = rs.uniform(0.0, 1.0, size=(n, 3))
+        P[2:, :, 4:7] = (np.asarray(JITTER)[None] * (2.0 * u - 1.0) + 1.0).reshape(num_aug, n_img, 3)
+        P[2:, :, 7:9] = (rs.uniform(0.0, 1.0, size=(n, 2)) < 0.5).reshape(num_aug, n_img, 2)
+        P[2:, :, 9] = 1.0
+    return P
+
+
+def augment_views(src_u8, params, size, out=None, view_stride=None, img_stride=None):
+    """src_u8 [n_img, Hs, Ws, 3] uint8 device tensor, params [n_views, n_img, 10] (numpy or tensor) ->
+    fp32 NHWC views [n_views, n_img, size, size, 3] (or written into ``out`` with the given strides, in floats)."""
+    if not src_u8.is_cuda or src_u8.dtype != torch.uint8 or not src_u8.is_contiguous():
+        raise RuntimeError("augment_views needs a contiguous uint8 CUDA (HIP) tensor [n_img, Hs, Ws, 3]")
+    n_img, Hs, Ws, _ = src_u8.shape
+    p = torch.as_tensor(params, dtype=torch.float32).to(src_u8.device).contiguous()
+    n_views = p.shape[0]
+    assert p.shape == (n_views, n_img, NPARAM)
+    if out is None:
+        out = torch.empty((n_views, n_img, size, size, 3), device=src_u8.device, dtype=torch.float32)
+        view_stride, img_stride = n_img * size * size * 3, size * size * 3
+    mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
+    std = (ctypes.c_float * 3)(*IMAGENET_STD)
+    rc = _lib.lib().mft_augment_views(ops._p(src_u8), n_img, Hs, Ws, ops._p(p), n_views, ops._p(out), view_stride, img_stride,
+                                      size, ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std, ctypes.c_void_p), ops._stream())
+    _lib.check(rc, "mft_augment_views")
+    return out
+
+
+def episode_views(src_u8, n_way, n_per_class, size, num_aug, rs):
+    """The reference's episode contract from raw images: src_u8 [n_way*n_per_class, Hs, Ws, 3] (class-major) ->
+    list of 2 + num_aug NHWC tensors [n_way, n_per_class, size, size, 3] (views 0 and 1 identical)."""
+    n_img, Hs, Ws, _ = src_u8.shape
+    assert n_img == n_way * n_per_class
+    P = sample_view_params(rs, n_img, Hs, Ws, size, num_aug)
+    v = augment_views(src_u8, P, size)
+    return [v[i].view(n_way, n_per_class, size, size, 3) for i in range(2 + num_aug)], P

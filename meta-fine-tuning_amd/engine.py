@@ -113,6 +113,27 @@ class FinetuneEngine:
         rc = lib.mft_nchw_to_nhwc(ops._p(xin), ops._p(self.Xall[slot * self.n_all]), self.n_all, 3, H, H, ops._stream())
         ops._lib.check(rc, "mft_nchw_to_nhwc")
 
+    def load_episode_source(self, slot, src_u8, params):
+        """Ingest straight from raw images: src_u8 [n_way, n_support+n_query, Hs, Ws, 3] uint8 on the
+        device, params [n_views, n_way*(n_support+n_query), 10] from augment.sample_view_params.  One launch writes the
+        support views into the support store in finetune.py:208-233's order (view 0 twice, then views 1..), one more
+        writes view 0 of every image for the final pass -- no host-side PIL, no NCHW staging copies."""
+        from . import augment
+        ns, npv, H = self.n_support, self.n_per_view, self.size
+        assert self.mode == "gnn" and params.shape[0] == self.n_views
+        src = src_u8.to(self.dev)
+        n_way, per, Hs, Ws, _ = src.shape
+        assert n_way == self.n_way and per == ns + self.n_query
+        P = torch.as_tensor(params, dtype=torch.float32).view(self.n_views, n_way, per, augment.NPARAM)
+        px = H * H * 3
+        sup_src = src[:, :ns].reshape(npv, Hs, Ws, 3).contiguous()
+        Ps = P[:, :, :ns].reshape(self.n_views, npv, augment.NPARAM)
+        Ps = torch.cat([Ps[:1], Ps], 0)                                   # view 0 twice, then views 1.. (x_a_i doubling)
+        augment.augment_views(sup_src, Ps, H, out=self.Xs[slot * self.n_total], view_stride=npv * px, img_stride=px)
+        all_src = src.reshape(self.n_all, Hs, Ws, 3).contiguous()
+        augment.augment_views(all_src, P[:1].reshape(1, self.n_all, augment.NPARAM), H, out=self.Xall[slot * self.n_all],
+                              view_stride=self.n_all * px, img_stride=px)
+
     def step_tables(self, perms, n_active):
         """Index/label tables for all inner steps.  perms[e][epoch] is a permutation of n_total.  Returns a list of
         (k, idx[E*k] int32 rows of the support store, labels[E*k] int32), one entry per step (finetune.py:270-284)."""
@@ -249,16 +270,20 @@ class FinetuneEngine:
         c["W"].copy_(w0[idx])
         c["b"].copy_(b0[idx])
 
-    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None):
-        """episodes: list (<= E) of liz_x; perms: per-episode list of per-epoch permutations (default: drawn from
-        the global numpy RNG episode by episode, exactly the reference's draw order).  Returns softmax scores
-        [len(episodes), n_way*n_query, n_way]."""
+    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False):
+        """episodes: list (<= E) of liz_x -- or, with ``sources=True``, of (src_u8, view_params) pairs for device-side view
+        generation; perms: per-episode list of per-epoch permutations (default: drawn from the global numpy RNG episode by
+        episode, exactly the reference's draw order).  Returns softmax scores [len(episodes), n_way*n_query, n_way]."""
         n = len(episodes)
         assert 0 < n <= self.E
         if perms is None:
             perms = [draw_perms(self.n_total, self.epochs) for _ in range(n)]
         for slot in range(self.E):
-            self.load_episode(slot, episodes[min(slot, n - 1)])      # pad a short batch by repeating the last episode
+            ep = episodes[min(slot, n - 1)]                          # pad a short batch by repeating the last episode
+            if sources:
+                self.load_episode_source(slot, ep[0], ep[1])
+            else:
+                self.load_episode(slot, ep)
         self.adapt.reset(self.W)
         if self.mode == "linear":
             if classifier_init is None:

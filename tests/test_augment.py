@@ -1,0 +1,70 @@
+"""Device-side view generation: host sampler contracts (CPU) and kernel parity against the PIL pipeline (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import meta_fine_tuning_amd  # noqa: F401
+from meta_fine_tuning_amd import augment
+from oracle import augment_oracle as AO
+
+
+def _sources(n, Hs, Ws, seed):
+    rs = np.random.RandomState(seed)
+    low = rs.uniform(0, 255, size=(n, 8, 8, 3))
+    img = np.kron(low, np.ones((1, Hs // 8, Ws // 8, 1))) + rs.normal(0, 12, size=(n, Hs, Ws, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_sampler_contract():
+    rs = np.random.RandomState(3)
+    P = augment.sample_view_params(rs, 7, 64, 64, 84, 5)
+    assert P.shape == (7, 7, 10) and P.dtype == np.float32
+    assert np.array_equal(P[0], P[1]) and np.all(P[:2, :, 9] == 0)               # two identical un-augmented views
+    box = P[2:, :, 0:4]
+    area = box[..., 2] * box[..., 3] / (64 * 64)
+    assert np.all(area > 0.45) and np.all(area < 0.95)                          # scale=(0.5, 0.9) up to rounding
+    assert np.all(box[..., 0] >= 0) and np.all(box[..., 0] + box[..., 2] <= 64)
+    assert np.all(np.abs(P[2:, :, 4] - 1) <= 0.1 + 1e-6) and np.all(np.abs(P[2:, :, 6] - 1) <= 0.05 + 1e-6)
+    # deterministic in the seed
+    assert np.array_equal(P, augment.sample_view_params(np.random.RandomState(3), 7, 64, 64, 84, 5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [84, 224])
+def test_views_match_pil_pipeline(size):
+    """Same parameters -> the kernel's views equal the PIL pipeline of the reference within uint8 resampling noise
+    (PIL's bilinear uses 8-bit fixed-point coefficients): mean |diff| < 0.6/255, max <= 3/255 of the un-normalised value."""
+    src = _sources(6, 64, 64, 5)                                               # EuroSAT-shaped 64x64 sources (upsampled)
+    rs = np.random.RandomState(9)
+    P = augment.sample_view_params(rs, 6, 64, 64, size, 3)
+    v = augment.augment_views(torch.from_numpy(src).cuda(), P, size).cpu().numpy()
+    assert v.shape == (5, 6, size, size, 3)
+    assert np.array_equal(v[0], v[1])
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+    for i in range(6):
+        d0 = np.abs(v[0, i] - AO.noaug_view(src[i], size)) * std * 255
+        assert d0.mean() < 0.6 and d0.max() <= 3.0, (i, d0.mean(), d0.max())
+        for k in range(3):
+            dk = np.abs(v[2 + k, i] - AO.aug_view(src[i], size, P[2 + k, i])) * std * 255
+            assert dk.mean() < 0.8 and dk.max() <= 6.0, (i, k, dk.mean(), dk.max())
+
+
+@pytest.mark.gpu
+def test_engine_ingest_from_sources_equals_view_ingest():
+    """FinetuneEngine.load_episode_source (raw uint8 images -> stores, two launches) fills the support store and the
+    final-pass images exactly like load_episode does with the same views passed as NCHW tensors, and scores agree."""
+    from meta_fine_tuning_amd import engine as eng, synthetic
+    sd = synthetic.gnnnet_state_dict(seed=41)
+    src = torch.from_numpy(_sources(100, 64, 64, 11).reshape(5, 20, 64, 64, 3)).cuda()
+    rs = np.random.RandomState(13)
+    P = augment.sample_view_params(rs, 100, 64, 64, 84, 2)
+    views, _ = augment.episode_views(src.view(100, 64, 64, 3), 5, 20, 84, 2, np.random.RandomState(13))
+    liz = [v.permute(0, 1, 4, 2, 3).contiguous() for v in views]                  # reference layout [5, 20, 3, H, W]
+    perms = [[np.random.RandomState(1).permutation(125)]]
+    e1 = eng.FinetuneEngine(sd, n_views=4, fine_tune_epoch=1, episodes_per_batch=1, device="cuda:0")
+    s1 = e1.run_batch([liz], perms=perms).clone()
+    xs1, xall1 = e1.Xs.clone(), e1.Xall.clone()
+    e2 = eng.FinetuneEngine(sd, n_views=4, fine_tune_epoch=1, episodes_per_batch=1, device="cuda:0")
+    s2 = e2.run_batch([(src, P)], perms=perms, sources=True).clone()
+    assert torch.equal(xs1, e2.Xs) and torch.equal(xall1, e2.Xall)
+    assert torch.equal(s1, s2)
