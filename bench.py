@@ -226,12 +226,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the product path")
+    if os.environ.get("MFT_BENCH_ONE_DEVICE"):          # test hook: run W ranks on one GPU (with MFT_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("MFT_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     import meta_fine_tuning_amd  # noqa: F401
     from meta_fine_tuning_amd import engine as eng
