@@ -176,6 +176,16 @@ int mft_adam_step(float* p, const float* g, float* m, float* v, long long n, int
 int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_step,
                  float lr, float momentum, float dampening, float weight_decay, void* stream);
 /* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
+/* hipGraph support: kernel arguments are frozen when a graph is captured, so Adam's bias corrections must come from device
+ * memory.  mft_adam_hyper_advance does t = ++(*step) and writes hyper = {lr/(1-beta1^t), 1/sqrt(1-beta2^t)} (double precision,
+ * as the host path); the *_dev variants of the Adam launchers read them instead of taking `step`/`lr`.                       */
+int mft_adam_hyper_advance(int* step, float* hyper, float lr, float beta1, float beta2, void* stream);
+int mft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1, float beta2,
+                      float eps, float weight_decay, void* stream);
+int mft_conv2d_wgrad_adam_nhwc_dev(const float* in, int ldi, const float* dy, int ldy, float* w, float* m, float* v,
+                                   float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                   int pad, int imgs_per_group, long long group_stride, const float* hyper, float beta1,
+                                   float beta2, float eps, void* stream);
 int mft_maml_delta(float* p, const float* p2, const float* p3, long long n, void* stream);
 
 /* finetune_linear's classifier head (finetune.py:33-42,65,103,147-158,171-174), one Linear(D, n_way) per episode (group).

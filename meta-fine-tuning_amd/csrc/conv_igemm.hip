@@ -296,6 +296,7 @@ struct WgradArgs {
     // fused Adam epilogue (ADAM == true): the gradient tile never reaches HBM
     float* w; float* m; float* v;
     float step_size, inv_sqrt_bc2, b1, b2, eps;
+    const float* hyper;  // optional device pointer {step_size, inv_sqrt_bc2}: lets a captured hipGraph replay with advancing steps
     // split-M: grid.z chunks of chunk_rows rows each write partial gradients to ws (reduced afterwards)
     int chunk_rows, chunks;
     float* ws;
@@ -466,6 +467,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         // nontemporal loads/stores, four rows (12 x 16 B per lane) in flight before the first use.
         constexpr int NR = BM / RP;           // rows per thread
         static_assert(NR % 4 == 0, "row blocking");
+        const float step_size = p.hyper ? p.hyper[0] : p.step_size;
+        const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
 #pragma unroll
         for (int r0 = 0; r0 < NR; r0 += 4) {
             f32x4 mm[4], vv[4], ww[4];
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     mm[u][e] = p.b1 * mm[u][e] + (1.f - p.b1) * ge[e];
                     vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
-                    ww[u][e] -= p.step_size * (mm[u][e] / (sqrtf(vv[u][e]) * p.inv_sqrt_bc2 + p.eps));
+                    ww[u][e] -= step_size * (mm[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps));
                 }
                 __builtin_nontemporal_store(mm[u], (f32x4*)(p.m + gi[u]));
                 __builtin_nontemporal_store(vv[u], (f32x4*)(p.v + gi[u]));
@@ -693,12 +696,12 @@ extern "C" int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, 
     return wgrad_dispatch(a, n_img, imgs_per_group, false, ws, (hipStream_t)stream);
 }
 
-extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ldy, float* w, float* m,
-                                          float* v, float* dw_or_null, int n_img, int H, int W, int Cin, int Cout,
-                                          int KH, int KW, int stride, int pad, int imgs_per_group,
-                                          long long group_stride, int step, float lr, float beta1, float beta2,
-                                          float eps, void* stream) {
-    if (step < 1 || (KH * KW * Cin) % 32 != 0) return MFT_EINVAL;
+static int wgrad_adam_impl(const float* in, int ldi, const float* dy, int ldy, float* w, float* m, float* v,
+                           float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                           int pad, int imgs_per_group, long long group_stride, int step, const float* hyper, float lr,
+                           float beta1, float beta2, float eps, void* stream) {
+    if ((hyper == nullptr && step < 1) || (KH * KW * Cin) % 32 != 0) return MFT_EINVAL;
+    if (hyper != nullptr) step = 1;
     WgradArgs a = {};
     a.in = in; a.dy = dy; a.dw = dw_or_null; a.ldi = ldi; a.ldy = ldy;
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -709,5 +712,25 @@ extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float*
     a.step_size = (float)((double)lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    a.hyper = hyper;
     return wgrad_dispatch(a, n_img, imgs_per_group, true, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ldy, float* w, float* m,
+                                          float* v, float* dw_or_null, int n_img, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad, int imgs_per_group,
+                                          long long group_stride, int step, float lr, float beta1, float beta2,
+                                          float eps, void* stream) {
+    return wgrad_adam_impl(in, ldi, dy, ldy, w, m, v, dw_or_null, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
+                           imgs_per_group, group_stride, step, nullptr, lr, beta1, beta2, eps, stream);
+}
+
+extern "C" int mft_conv2d_wgrad_adam_nhwc_dev(const float* in, int ldi, const float* dy, int ldy, float* w, float* m,
+                                              float* v, float* dw_or_null, int n_img, int H, int W, int Cin, int Cout,
+                                              int KH, int KW, int stride, int pad, int imgs_per_group,
+                                              long long group_stride, const float* hyper, float beta1, float beta2,
+                                              float eps, void* stream) {
+    if (hyper == nullptr) return MFT_EINVAL;
+    return wgrad_adam_impl(in, ldi, dy, ldy, w, m, v, dw_or_null, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
+                           imgs_per_group, group_stride, 1, hyper, 0.f, beta1, beta2, eps, stream);
 }

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n4,
                                                    long long n, float step_size, float inv_sqrt_bc2, float b1,
-                                                   float b2, float eps, float wd) {
+                                                   float b2, float eps, float wd, const float* __restrict__ hyper) {
+    if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         f32x4 pp = *(const f32x4*)(p + 4 * i);
@@ -152,7 +153,33 @@ extern "C" int mft_adam_step(float* p, const float* g, float* m, float* v, long 
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n,
-                       step_size, inv_sqrt_bc2, beta1, beta2, eps, weight_decay);
+                       step_size, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, (const float*)nullptr);
+    return mft_launch_status();
+}
+
+namespace {
+// hyper[0] = lr / (1 - b1^t), hyper[1] = 1 / sqrt(1 - b2^t) for t = ++(*step): the step counter lives on the device so that
+// a captured graph of one inner step can be replayed for every step (kernel arguments are frozen at capture time)
+__global__ void adam_hyper_advance_kernel(int* step, float* hyper, float lr, float b1, float b2) {
+    const int t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    hyper[0] = (float)((double)lr / bc1);
+    hyper[1] = (float)(1.0 / sqrt(bc2));
+}
+}  // namespace
+
+extern "C" int mft_adam_hyper_advance(int* step, float* hyper, float lr, float beta1, float beta2, void* stream) {
+    hipLaunchKernelGGL(adam_hyper_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, hyper, lr, beta1, beta2);
+    return mft_launch_status();
+}
+
+extern "C" int mft_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
+                                 float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (hyper == nullptr) return MFT_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, 0.f, 0.f,
+                       beta1, beta2, eps, weight_decay, hyper);
     return mft_launch_status();
 }
 

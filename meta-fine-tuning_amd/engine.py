@@ -41,7 +41,7 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True):
+                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True, graph=False):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316).
         ``mode`` "gnn": finetune.finetune (inner loss on the raw feature, GNN scoring);
@@ -49,6 +49,13 @@ class FinetuneEngine:
         with the last block over the ORIGINAL support images only; scores = softmax(classifier(features)))."""
         assert mode in ("gnn", "linear")
         self.mode = mode
+        # ``graph``: capture one inner step (single stream) as a hipGraph and replay it for every step -- ~45 launches
+        # become 3 (index copy, label copy, replay).  For small episode batches, where the loop is launch-bound; the
+        # two-stream pipeline (default) is the better schedule once the GPU is saturated (E >= 64).
+        self.use_graph = bool(graph) and mode == "gnn" and fused_adam
+        if self.use_graph:
+            pipeline = False
+        self._graphs = {}
         if not torch.cuda.is_available():
             raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
         self.dev = torch.device(device)
@@ -71,6 +78,8 @@ class FinetuneEngine:
         self.arena = Fn.Arena(self.dev)
         self.arena_trunk = Fn.Arena(self.dev)      # the frozen-trunk stream owns its own buffers / BN workspace
         self.adapt = AdaptState(self.E, self.dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)     # device-side Adam step counter / bias
+        self.hyper = torch.zeros(2, device=self.dev)                           # corrections (graph replay)
         self.pipeline = pipeline
         # The trunk's convolution workgroups are large (46-61 KB LDS, 128-226 VGPRs); next to the tens of thousands of
         # small weight-gradient workgroups of the other stream they are starved of CU slots unless their queue has
@@ -191,7 +200,11 @@ class FinetuneEngine:
             ops._lib.check(rc, "mft_linear_head_step")
         else:
             loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
-        if self.fused_adam:
+        if self.use_graph:
+            ops.adam_hyper_advance(self.step_dev, self.hyper, lr=self.lr)
+            Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
+                                   adam=(self.adapt.m, self.adapt.v, self.hyper, self.lr))
+        elif self.fused_adam:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
                                    adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr))
         else:
@@ -217,6 +230,27 @@ class FinetuneEngine:
         else:
             idx_all = [torch.from_numpy(t[1]).to(dev, non_blocking=True) for t in tables]
             lab_all = [torch.from_numpy(t[2]).to(dev, non_blocking=True) for t in tables]
+        if self.use_graph and len({t[0] for t in tables}) == 1:
+            k = tables[0][0]
+            ent = self._graphs.get(k)
+            start = 0
+            if ent is None:
+                # step 0 runs eagerly (it also creates every arena buffer); then one step is captured, not executed
+                sidx, slab = torch.empty_like(idx_all[0]), torch.empty_like(lab_all[0])
+                sidx.copy_(idx_all[0]); slab.copy_(lab_all[0])
+                self.inner_step(sidx, slab, k)
+                start = 1
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.inner_step(sidx, slab, k)
+                ent = self._graphs[k] = (g, sidx, slab)
+            g, sidx, slab = ent
+            for t in range(start, len(tables)):
+                sidx.copy_(idx_all[t])
+                slab.copy_(lab_all[t])
+                g.replay()
+            return
         if not self.pipeline:
             for (k, _, _), idx, lab in zip(tables, idx_all, lab_all):
                 self.inner_step(idx, lab, k)
@@ -285,6 +319,7 @@ class FinetuneEngine:
             else:
                 self.load_episode(slot, ep)
         self.adapt.reset(self.W)
+        self.step_dev.zero_()
         if self.mode == "linear":
             if classifier_init is None:
                 raise RuntimeError("mode='linear' needs classifier_init=(w0 [n,n_way,512], b0 [n,n_way])")

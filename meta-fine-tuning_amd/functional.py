@@ -304,8 +304,9 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
             ops.conv2d_wgrad(xin, dy, 512, k, k, stride, pad, imgs_per_group=ipg, out=getattr(grads, name))
         else:
             m, v, step, lr = adam
+            hyper = step if torch.is_tensor(step) else None          # device-resident bias corrections (graph replay)
             ops.conv2d_wgrad_adam(xin, dy, getattr(params, name), getattr(m, name), getattr(v, name), 512, k, k,
-                                  stride, pad, step, imgs_per_group=ipg, lr=lr)
+                                  stride, pad, 1 if hyper is not None else step, imgs_per_group=ipg, lr=lr, hyper=hyper)
 
     dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
     dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
@@ -318,7 +319,9 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     if adam is not None:
         m, v, step, lr = adam
         nb = params.E * 6 * 512                       # BatchNorm affine tail of the tensor-major slab
-        ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], step, lr=lr)
+        hyper = step if torch.is_tensor(step) else None
+        ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], 1 if hyper is not None else step,
+                      lr=lr, hyper=hyper)
 
 
 # ------------------------------------------------------------------------------------------ GNN head

@@ -173,12 +173,19 @@ def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None, l
 
 
 def conv2d_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group=0, lr=0.01, beta1=0.9,
-                      beta2=0.999, eps=1e-8, dw=None):
-    """Weight gradient of a conv with the Adam update of (w, m, v) [groups, Cout, KH*KW*Cin] fused in the epilogue."""
+                      beta2=0.999, eps=1e-8, dw=None, hyper=None):
+    """Weight gradient of a conv with the Adam update of (w, m, v) [groups, Cout, KH*KW*Cin] fused in the epilogue.
+    ``hyper``: device tensor {lr/(1-b1^t), 1/sqrt(1-b2^t)} maintained by adam_hyper_advance (hipGraph replay); replaces step/lr."""
     _f32c(x)
     _f32c(dy)
     n, H, W, Cin = x.shape
     K = KH * KW * Cin
+    if hyper is not None:
+        rc = _lib.lib().mft_conv2d_wgrad_adam_nhwc_dev(_p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dw), n, H, W, Cin,
+                                                       Cout, KH, KW, stride, pad, imgs_per_group, Cout * K, _p(hyper), beta1,
+                                                       beta2, eps, _stream())
+        _lib.check(rc, "mft_conv2d_wgrad_adam_nhwc_dev")
+        return
     rc = _lib.lib().mft_conv2d_wgrad_adam_nhwc(_p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dw), n, H, W, Cin,
                                                Cout, KH, KW, stride, pad, imgs_per_group, Cout * K, step, lr, beta1,
                                                beta2, eps, _stream())
@@ -320,10 +327,20 @@ def softmax_rows(x):
     return y
 
 
-def adam_step(p, g, m, v, step, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+def adam_hyper_advance(step_i32, hyper, lr=0.01, beta1=0.9, beta2=0.999):
+    """Device-side t = ++step; hyper = {lr/(1-beta1^t), 1/sqrt(1-beta2^t)} (one tiny launch; graph-capturable)."""
+    _lib.check(_lib.lib().mft_adam_hyper_advance(_p(step_i32), _p(hyper), lr, beta1, beta2, _stream()), "mft_adam_hyper_advance")
+
+
+def adam_step(p, g, m, v, step, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, hyper=None):
     """In-place fused Adam on flat (contiguous) fp32 tensors of equal numel."""
     for t in (p, g, m, v):
         _f32c(t)
+    if hyper is not None:
+        rc = _lib.lib().mft_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay,
+                                          _stream())
+        _lib.check(rc, "mft_adam_step_dev")
+        return
     rc = _lib.lib().mft_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), step, lr, beta1, beta2, eps, weight_decay,
                                   _stream())
     _lib.check(rc, "mft_adam_step")

@@ -276,3 +276,20 @@ def test_linear_engine_batched_equals_single():
         # the BatchNorm reduction is chunked by launch size, so E=1 and E=2 round differently; 100 Adam steps amplify that
         assert float((one - both[i]).abs().max()) < 2e-2
         assert float((one.argmax(1) == both[i].argmax(1)).float().mean()) >= 0.96
+
+
+def test_hipgraph_inner_step_is_bit_identical():
+    """One inner step captured as a hipGraph (device-side Adam step counter) and replayed for every step must give
+    exactly the eager single-stream result, also on the second batch (pure replay)."""
+    sd = synthetic.gnnnet_state_dict(seed=43)
+    eps = [synthetic.test_episode(800 + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)]
+    rs = np.random.RandomState(15)
+    perms = [[rs.permutation(100), rs.permutation(100)] for _ in range(2)]
+    e0 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, pipeline=False)
+    ref = e0.run_batch(eps, perms=perms).clone()
+    wref = e0.adapt.w.flat.clone()
+    e1 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, graph=True)
+    for rep in range(2):
+        got = e1.run_batch(eps, perms=perms).clone()
+        assert torch.equal(got, ref), rep
+        assert torch.equal(e1.adapt.w.flat, wref), rep
