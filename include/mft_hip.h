@@ -157,6 +157,24 @@ int mft_bn_backward(const float* x, int ldx, const float* dy, int lddy, const fl
                     float* dx, int lddx, int C, int rows_per_group, int n_groups,
                     const float* mean, const float* rstd, const float* gamma, long long gb_group_stride,
                     float* dgamma, float* dbeta, void* stream);
+/* Fused forms for groups of <= 64 rows (the adapted last block: 5 images x 3x3 pixels per episode), one launch instead of
+ * 3-6 (same reference call sites as mft_bn_stats/apply/global_avgpool: backbone.py:224-261,427):
+ * mft_bn_small_forward: y = act(bn(x1) [+ bn(x2) | + res]) with the statistics of x1 (and x2) computed in the same pass
+ *   (returned in mean1, rstd1, mean2, rstd2 for the backward), optional pooled[img][c] = mean over each image's hw rows of y.
+ * mft_bn_backward2: BatchNorm backward of two branches (xa, xb) that share the incoming gradient dy.
+ * mft_ce_pool_backward: per-group cross entropy on feat (finetune.py:286-293) and its gradient pushed through AvgPool and
+ *   the block's final ReLU: d_out = (out > 0) * (softmax(feat) - onehot) / (rows_per_group * hw); loss[g] nullable.      */
+int mft_bn_small_forward(const float* x1, int ld1, const float* x2, int ld2, const float* res, int ldr, float* y, int ldy, int C,
+                         int rows_per_group, int n_groups, const float* gamma1, const float* beta1, const float* gamma2,
+                         const float* beta2, long long gb_group_stride, float* mean1, float* rstd1, float* mean2, float* rstd2,
+                         int act, float slope, float eps, float* pooled, int hw, void* stream);
+int mft_bn_backward2(const float* xa, const float* xb, int ldx, const float* dy, int lddy, float* dxa, float* dxb, int lddx, int C,
+                     int rows_per_group, int n_groups, const float* mean_a, const float* rstd_a, const float* gamma_a,
+                     const float* mean_b, const float* rstd_b, const float* gamma_b, long long gb_group_stride, float* dgamma_a,
+                     float* dbeta_a, float* dgamma_b, float* dbeta_b, void* stream);
+int mft_ce_pool_backward(const float* feat, const int* labels, int rows_per_group, int n_groups, int C, int hw, const float* out,
+                         float* d_out, float* loss, void* stream);
+
 /* d(out)[n,hw,c] = (out>0) * dfeat[n,c] / HW : AvgPool + relu2 backward (backbone.py:260,427) */
 int mft_avgpool_relu_backward(const float* dfeat, const float* out, float* dout, int n_img, int HW, int C, void* stream);
 

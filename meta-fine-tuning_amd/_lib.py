@@ -44,6 +44,9 @@ SIGNATURES = {
     "mft_bn_image_moments": [_P, _I, _I, _I, _L, _P, _P, _P],
     "mft_bn_combine_moments": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "mft_global_avgpool": [_P, _P, _I, _I, _I, _P],
+    "mft_bn_small_forward": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P],
+    "mft_bn_backward2": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P],
+    "mft_ce_pool_backward": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "mft_bn_backward": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P],
     "mft_avgpool_relu_backward": [_P, _P, _P, _I, _I, _I, _P],
     "mft_cross_entropy": [_P, _I, _P, _I, _I, _I, _P, _P, _P],

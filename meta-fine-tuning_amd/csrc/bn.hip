@@ -464,3 +464,196 @@ extern "C" int mft_bn_backward(const float* x, int ldx, const float* dy, int ldd
     hipLaunchKernelGGL(bn_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return mft_launch_status();
 }
+
+// ------------------------------------------------------------------------------- fused small-group kernels
+// The adapted last block sees 45 rows per episode (5 images x 3x3).  Its BatchNorm work was 2 + 1 launches per
+// normalisation (partial sums, finalize, apply) plus pooling -- each a few microseconds of arithmetic behind ~10 us of
+// dependent-launch latency on the critical stream.  With <= 64 rows per group a workgroup can hold its (group, 64-channel)
+// tile in registers: statistics, normalisation, residual (optionally with its own BatchNorm), activation and the global
+// average pool become ONE pass over the data.
+namespace {
+
+struct SmallFwdArgs {
+    const float* x1; int ld1;
+    const float* x2; int ld2;            // optional second branch with its own BatchNorm (shortcut)
+    const float* res; int ldr;           // optional plain residual
+    float* y; int ldy;
+    int C, rows, n_groups;
+    const float* g1; const float* b1; const float* g2; const float* b2; long long gbs;
+    float* mean1; float* rstd1; float* mean2; float* rstd2;
+    int act; float slope; float eps;
+    float* pooled; int hw;               // optional [n_groups * rows/hw, C] mean over each image's hw rows
+};
+
+constexpr int SM_RPT = 4;                // rows per thread: 16 row lanes x 4 = 64 rows max
+
+__device__ __forceinline__ void small_stats(const f32x4 (&v)[SM_RPT], int rl, int cq, int rows, f32x4 (*red1)[16],
+                                            f32x4 (*red2)[16], f32x4& mean, f32x4& rstd, float eps) {
+    // shifted one-pass moments, fixed reduction order (same scheme as bn_stats_partial/finalize)
+    __shared__ f32x4 s_shift[16];
+    if (rl == 0) s_shift[cq] = v[0];
+    __syncthreads();
+    const f32x4 sh = s_shift[cq];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+    for (int k = 0; k < SM_RPT; ++k)
+        if (rl + 16 * k < rows) {
+            const f32x4 d = v[k] - sh;
+            s1 += d;
+            s2 += d * d;
+        }
+    red1[rl][cq] = s1;
+    red2[rl][cq] = s2;
+    __syncthreads();
+    s1 = red1[0][cq];
+    s2 = red2[0][cq];
+#pragma unroll
+    for (int k = 1; k < ST_ROWS; ++k) {
+        s1 += red1[k][cq];
+        s2 += red2[k][cq];
+    }
+    const float inv = 1.f / (float)rows;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = s1[e] * inv;
+        mean[e] = sh[e] + d;
+        rstd[e] = 1.0f / sqrtf(fmaxf(s2[e] * inv - d * d, 0.f) + eps);
+    }
+    __syncthreads();                      // red1/red2/s_shift may be reused
+}
+
+__global__ __launch_bounds__(256) void bn_small_forward_kernel(SmallFwdArgs p) {
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int g = blockIdx.y;
+    const long long row0 = (long long)g * p.rows;
+    __shared__ f32x4 red1[ST_ROWS][16];
+    __shared__ f32x4 red2[ST_ROWS][16];
+    __shared__ f32x4 tile[64][16];
+    if (c >= p.C) return;                 // C is a multiple of 64 on this path (checked by the launcher)
+    f32x4 v1[SM_RPT], v2[SM_RPT];
+#pragma unroll
+    for (int k = 0; k < SM_RPT; ++k) {
+        const int r = rl + 16 * k;
+        v1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v2[k] = v1[k];
+        if (r < p.rows) {
+            v1[k] = *(const f32x4*)(p.x1 + (row0 + r) * p.ld1 + c);
+            if (p.x2) v2[k] = *(const f32x4*)(p.x2 + (row0 + r) * p.ld2 + c);
+        }
+    }
+    f32x4 m1, r1, m2 = {0.f, 0.f, 0.f, 0.f}, r2 = m2;
+    small_stats(v1, rl, cq, p.rows, red1, red2, m1, r1, p.eps);
+    if (p.x2) small_stats(v2, rl, cq, p.rows, red1, red2, m2, r2, p.eps);
+    if (rl == 0) {
+        *(f32x4*)(p.mean1 + (long long)g * p.C + c) = m1;
+        *(f32x4*)(p.rstd1 + (long long)g * p.C + c) = r1;
+        if (p.x2) {
+            *(f32x4*)(p.mean2 + (long long)g * p.C + c) = m2;
+            *(f32x4*)(p.rstd2 + (long long)g * p.C + c) = r2;
+        }
+    }
+    const f32x4 ga1 = *(const f32x4*)(p.g1 + g * p.gbs + c), be1 = *(const f32x4*)(p.b1 + g * p.gbs + c);
+    f32x4 ga2 = {0.f, 0.f, 0.f, 0.f}, be2 = ga2;
+    if (p.x2) {
+        ga2 = *(const f32x4*)(p.g2 + g * p.gbs + c);
+        be2 = *(const f32x4*)(p.b2 + g * p.gbs + c);
+    }
+#pragma unroll
+    for (int k = 0; k < SM_RPT; ++k) {
+        const int r = rl + 16 * k;
+        if (r >= p.rows) continue;
+        f32x4 o = (v1[k] - m1) * r1 * ga1 + be1;
+        if (p.x2) o += (v2[k] - m2) * r2 * ga2 + be2;
+        if (p.res) o += *(const f32x4*)(p.res + (row0 + r) * p.ldr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
+        *(f32x4*)(p.y + (row0 + r) * p.ldy + c) = o;
+        if (p.pooled) tile[r][cq] = o;
+    }
+    if (p.pooled) {
+        __syncthreads();
+        const int n_img = p.rows / p.hw;
+        if (rl < n_img) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < p.hw; ++k) s += tile[rl * p.hw + k][cq];
+            const float inv = 1.f / (float)p.hw;
+            *(f32x4*)(p.pooled + ((long long)g * n_img + rl) * p.C + c) = s * inv;
+        }
+    }
+}
+
+// two BatchNorm backward passes that share dy (main branch + shortcut branch of a residual block)
+__global__ __launch_bounds__(256) void bn_backward2_kernel(BwdArgs a, BwdArgs b) {
+    for (int which = 0; which < 2; ++which) {
+        const BwdArgs& p = which ? b : a;
+        const int cq = threadIdx.x & 15;
+        const int rl = threadIdx.x >> 4;
+        const int c = blockIdx.x * 64 + cq * 4;
+        const int g = blockIdx.y;
+        const long long row0 = (long long)g * p.rows_per_group;
+        __shared__ f32x4 red1[ST_ROWS][16];
+        __shared__ f32x4 red2[ST_ROWS][16];
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        const f32x4 ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+            const f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            s1 += d;
+            s2 += d * xh;
+        }
+        red1[rl][cq] = s1;
+        red2[rl][cq] = s2;
+        __syncthreads();
+        s1 = red1[0][cq];
+        s2 = red2[0][cq];
+#pragma unroll
+        for (int k = 1; k < ST_ROWS; ++k) {
+            s1 += red1[k][cq];
+            s2 += red2[k][cq];
+        }
+        if (rl == 0) {
+            *(f32x4*)(p.dgamma + (long long)g * p.C + c) = s2;
+            *(f32x4*)(p.dbeta + (long long)g * p.C + c) = s1;
+        }
+        const float inv = 1.f / (float)p.rows_per_group;
+        const f32x4 m1 = s1 * inv, m2 = s2 * inv;
+        const f32x4 k = ga * rs;
+        for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+            const f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            *(f32x4*)(p.dx + (row0 + rr) * p.lddx + c) = k * (d - m1 - xh * m2);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int mft_bn_small_forward(const float* x1, int ld1, const float* x2, int ld2, const float* res, int ldr, float* y,
+                                    int ldy, int C, int rows_per_group, int n_groups, const float* gamma1,
+                                    const float* beta1, const float* gamma2, const float* beta2,
+                                    long long gb_group_stride, float* mean1, float* rstd1, float* mean2, float* rstd2,
+                                    int act, float slope, float eps, float* pooled, int hw, void* stream) {
+    if (C % 64 != 0 || rows_per_group < 1 || rows_per_group > 64 || n_groups < 1) return MFT_EINVAL;
+    if ((ld1 | ldy) % 4 != 0 || (x2 && ld2 % 4 != 0) || (res && ldr % 4 != 0)) return MFT_EINVAL;
+    if (pooled && (hw < 1 || rows_per_group % hw != 0 || rows_per_group / hw > 16)) return MFT_EINVAL;
+    SmallFwdArgs p{x1, ld1, x2, ld2, res, ldr, y, ldy, C, rows_per_group, n_groups, gamma1, beta1, gamma2, beta2,
+                   gb_group_stride, mean1, rstd1, mean2, rstd2, act, slope, eps, pooled, hw};
+    hipLaunchKernelGGL(bn_small_forward_kernel, dim3(C / 64, n_groups), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_backward2(const float* xa, const float* xb, int ldx, const float* dy, int lddy, float* dxa, float* dxb,
+                                int lddx, int C, int rows_per_group, int n_groups, const float* mean_a, const float* rstd_a,
+                                const float* gamma_a, const float* mean_b, const float* rstd_b, const float* gamma_b,
+                                long long gb_group_stride, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                                void* stream) {
+    if (C % 64 != 0 || ldx % 4 != 0 || lddy % 4 != 0 || lddx % 4 != 0) return MFT_EINVAL;
+    BwdArgs a{xa, dy, nullptr, dxa, ldx, lddy, 0, lddx, C, rows_per_group, mean_a, rstd_a, gamma_a, gb_group_stride, dgamma_a, dbeta_a};
+    BwdArgs b{xb, dy, nullptr, dxb, ldx, lddy, 0, lddx, C, rows_per_group, mean_b, rstd_b, gamma_b, gb_group_stride, dgamma_b, dbeta_b};
+    hipLaunchKernelGGL(bn_backward2_kernel, dim3(C / 64, n_groups), dim3(256), 0, (hipStream_t)stream, a, b);
+    return mft_launch_status();
+}

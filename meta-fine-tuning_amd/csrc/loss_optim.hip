@@ -342,3 +342,64 @@ extern "C" int mft_linear_head_scores(const float* feat, int ldf, int rows_per_g
                        ldf, rows_per_group, n_groups, n_way, D, W, b, out);
     return mft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------- fused CE + pool backward
+// Inner-loop loss on the pooled feature (finetune.py:286-293): per group, cross entropy over the C-wide feature rows,
+// dlogits = (softmax - onehot)/rows, and straight on through AvgPool + the block's final ReLU:
+// d_out[img*hw + p][c] = out > 0 ? dlogits[img][c] / hw : 0.  One workgroup per group; replaces three launches.
+namespace {
+__global__ __launch_bounds__(256) void ce_pool_backward_kernel(const float* __restrict__ feat, const int* __restrict__ labels,
+                                                               int k, int C, int hw, const float* __restrict__ out,
+                                                               float* __restrict__ d_out, float* __restrict__ loss) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_lse[16];
+    __shared__ float s_loss[16];
+    for (int r = wave; r < k; r += 4) {
+        const float* x = feat + ((long long)g * k + r) * C;
+        float mx = -3.4e38f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+        se = wave_sum(se);
+        if (lane == 0) {
+            const float lse = mx + __logf(se);
+            s_lse[r] = lse;
+            s_loss[r] = lse - x[labels[(long long)g * k + r]];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) {
+        float s = 0.f;
+        for (int r = 0; r < k; ++r) s += s_loss[r];
+        loss[g] = s / (float)k;
+    }
+    const float inv = 1.f / ((float)k * (float)hw);
+    const int cq = C >> 2;
+    for (int i = threadIdx.x; i < k * hw * cq; i += 256) {
+        const int c = (i % cq) * 4;
+        const int pix = i / cq;
+        const int r = pix / hw;
+        const long long row = ((long long)g * k) * hw + pix;
+        const f32x4 o = *(const f32x4*)(out + row * C + c);
+        const f32x4 x = *(const f32x4*)(feat + ((long long)g * k + r) * C + c);
+        const int y = labels[(long long)g * k + r];
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pr = __expf(x[e] - s_lse[r]) - ((c + e) == y ? 1.f : 0.f);
+            d[e] = o[e] > 0.f ? pr * inv : 0.f;
+        }
+        *(f32x4*)(d_out + row * C + c) = d;
+    }
+}
+}  // namespace
+
+extern "C" int mft_ce_pool_backward(const float* feat, const int* labels, int rows_per_group, int n_groups, int C, int hw,
+                                    const float* out, float* d_out, float* loss, void* stream) {
+    if (rows_per_group < 1 || rows_per_group > 16 || C % 4 != 0 || hw < 1) return MFT_EINVAL;
+    hipLaunchKernelGGL(ce_pool_backward_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, feat, labels,
+                       rows_per_group, C, hw, out, d_out, loss);
+    return mft_launch_status();
+}

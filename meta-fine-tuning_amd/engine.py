@@ -198,17 +198,20 @@ class FinetuneEngine:
                                                      ops._p(c["vb"]), ops._p(dlogits), 512, ops._p(loss), self.adapt.step,
                                                      self.lr, 0.9, 0.999, 1e-8, 0.001, ops._stream())
             ops._lib.check(rc, "mft_linear_head_step")
+            ce = None
         else:
-            loss, dlogits = ops.cross_entropy(feat, lab_dev, k, E)
+            # inner loss = CE on the pooled 512-d feature (finetune.py:286-291); fused with the pool/ReLU backward
+            loss = self.arena.get("ce.loss", (E,))
+            dlogits, ce = None, (feat, lab_dev, loss)
         if self.use_graph:
             ops.adam_hyper_advance(self.step_dev, self.hyper, lr=self.lr)
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
-                                   adam=(self.adapt.m, self.adapt.v, self.hyper, self.lr))
+                                   adam=(self.adapt.m, self.adapt.v, self.hyper, self.lr), ce=ce)
         elif self.fused_adam:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
-                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr))
+                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr), ce=ce)
         else:
-            Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k)
+            Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k, ce=ce)
             ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
                           lr=self.lr)
         return loss

@@ -207,8 +207,27 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None):
     return a
 
 
-def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None):
-    """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's."""
+def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=None, b2=None, res=None, pooled=None, hw=0):
+    """stats + normalise (+ second normalised branch | + residual) + ReLU (+ global average pool) in one launch
+    (groups of <= 64 rows, csrc/bn.hip).  Returns (mean1, rstd1, mean2, rstd2)."""
+    m1 = arena.get(tag + ".mean", (groups, C))
+    s1 = arena.get(tag + ".rstd", (groups, C))
+    m2 = s2 = None
+    if x2 is not None:
+        m2 = arena.get(tag + ".mean2", (groups, C))
+        s2 = arena.get(tag + ".rstd2", (groups, C))
+    rc = ops._lib.lib().mft_bn_small_forward(ops._p(x1), C, ops._p(x2), C, ops._p(res), C, ops._p(out), C, C, rows, groups,
+                                             ops._p(g1), ops._p(b1), ops._p(g2), ops._p(b2), gbs, ops._p(m1), ops._p(s1),
+                                             ops._p(m2), ops._p(s2), ops.ACT_RELU, 0.0, ops.BN_EPS, ops._p(pooled), hw,
+                                             ops._stream())
+    ops._lib.check(rc, "mft_bn_small_forward")
+    return m1, s1, m2, s2
+
+
+def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None):
+    """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's.
+    ``pooled``: optional [n, cout] buffer; filled with the global average pool of the block output when the fused
+    small-group path applies (returns True in tape['pooled'] / via the buffer's ``_mft_filled`` flag)."""
     n, H, Wd, _ = x.shape
     groups = n // ipg
     OH = (H + 2 - 3) // stride + 1
@@ -234,9 +253,25 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
             return ops.conv2d_x3(inp, w3[p + name], cout, k, k, s, pd, out=out)
         return ops.conv2d(inp, wpk, cout, k, k, s, pd, imgs_per_group=wipg, out=out)
 
+    rows = ipg * OH * OH
+    if slab is not None and rows <= 64 and cout % 64 == 0 and cin != cout and running is None:
+        # adapted last block in the episode-batched loop: 3 fused launches instead of 10 around the three convolutions
+        c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
+        r1 = arena.get(tag + ".r1", (n * OH * OH, cout))
+        m1, s1, _, _ = _bn_small(arena, tag + ".bn1", c1, g1, b1, rows, groups, cout, gbs, r1)
+        r1 = r1.view(n, OH, OH, cout)
+        c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
+        sc = conv(".shortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)))
+        out = arena.get(tag + ".out", (n * OH * OH, cout))
+        m2, s2, ms, ss = _bn_small(arena, tag + ".bn2", c2, g2, b2, rows, groups, cout, gbs, out, x2=sc, g2=gs, b2=bs,
+                                   pooled=pooled, hw=OH * OH)
+        out = out.view(n, OH, OH, cout)
+        if tape is not None:
+            tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out,
+                        pooled=pooled is not None)
+        return out
     c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
     m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"))
-    rows = ipg * OH * OH
     r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
                       out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
     c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
@@ -260,10 +295,12 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
 def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f"):
     """trunk.7 + global average pool on the activation ``a`` [n,h,w,256] entering the last block -> features [n,512]."""
     n = a.shape[0]
-    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=tape)
     feat = arena.get(tag + ".feat", (n, 512))
-    ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
-                                                     ops._stream()), "mft_global_avgpool")
+    info = tape if tape is not None else {}
+    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=info, pooled=feat)
+    if not info.get("pooled", False):
+        ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
+                                                         ops._stream()), "mft_global_avgpool")
     return feat
 
 
@@ -277,7 +314,7 @@ def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag
     return last_block_forward(W, a, arena, ipg, slab=slab, tape=tape, running=running, tag=tag)
 
 
-def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None):
+def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None):
     """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
     ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
     ``adam`` = (m_slab, v_slab, step, lr): fuse the Adam update of the three conv weights into the wgrad
@@ -287,9 +324,16 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     groups = n // ipg
     rows = ipg * oh * ow
     d_out = arena.get(tag + ".dout", (n, oh, ow, C))
-    ops._lib.check(ops._lib.lib().mft_avgpool_relu_backward(ops._p(dfeat), ops._p(out), ops._p(d_out), n, oh * ow, C,
-                                                            ops._stream()), "mft_avgpool_relu_backward")
     lib = ops._lib.lib()
+    if ce is not None:
+        # ce = (feat, labels_i32, loss_out): cross entropy on the pooled feature and its gradient through AvgPool + ReLU in
+        # one launch (dfeat is not materialised)
+        feat, labels, loss = ce
+        ops._lib.check(lib.mft_ce_pool_backward(ops._p(feat), ops._p(labels), ipg, groups, C, oh * ow, ops._p(out), ops._p(d_out),
+                                                ops._p(loss), ops._stream()), "mft_ce_pool_backward")
+    else:
+        ops._lib.check(lib.mft_avgpool_relu_backward(ops._p(dfeat), ops._p(out), ops._p(d_out), n, oh * ow, C,
+                                                     ops._stream()), "mft_avgpool_relu_backward")
 
     def bn_bwd(xraw, dy, mean, rstd, gamma, dgamma, dbeta, relu_out, name, need_dx=True):
         dx = arena.get(tag + "." + name, tuple(xraw.shape)) if need_dx else None
@@ -308,8 +352,17 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
             ops.conv2d_wgrad_adam(xin, dy, getattr(params, name), getattr(m, name), getattr(v, name), 512, k, k,
                                   stride, pad, 1 if hyper is not None else step, imgs_per_group=ipg, lr=lr, hyper=hyper)
 
-    dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
-    dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
+    if C % 64 == 0:
+        dc2 = arena.get(tag + ".dc2", tuple(c2.shape))
+        dsc = arena.get(tag + ".dsc", tuple(sc.shape))
+        rc = lib.mft_bn_backward2(ops._p(c2), ops._p(sc), C, ops._p(d_out), C, ops._p(dc2), ops._p(dsc), C, C, rows, groups,
+                                  ops._p(tape["m2"]), ops._p(tape["s2"]), ops._p(params.bn2g), ops._p(tape["ms"]),
+                                  ops._p(tape["ss"]), ops._p(params.bnsg), C, ops._p(grads.bn2g), ops._p(grads.bn2b),
+                                  ops._p(grads.bnsg), ops._p(grads.bnsb), ops._stream())
+        ops._lib.check(rc, "mft_bn_backward2")
+    else:
+        dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
+        dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
     # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
     dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
     dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")

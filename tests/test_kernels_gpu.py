@@ -389,3 +389,53 @@ def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, i
             dx = nchw(ops.conv2d_dgrad(dyg, wpk, Cin, k, k, pad, imgs_per_group=ipg).cpu()).double()
             assert float((dx - refd).abs().max()) <= 2e-5 * max(float(refd.abs().max()), 1.0), (name, mode)
         _lib.lib().mft_debug_set_conv_tile(3001)
+
+
+@pytest.mark.parametrize("ipg", [5, 3, 1])
+def test_fused_small_group_kernels_match_unfused(ipg):
+    """mft_bn_small_forward / mft_bn_backward2 / mft_ce_pool_backward (one launch each) against the launch sequences they
+    replace (bn_stats + bn_apply + global_avgpool; two bn_backward; cross_entropy + avgpool_relu_backward)."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    G, C, hw = 4, 512, 9
+    rows = ipg * hw
+    n = G * ipg
+    c2 = rnd((n * hw, C), 31).to(DEV)
+    sc = rnd((n * hw, C), 32).to(DEV) * 0.5 + 0.3
+    g2, b2 = (rnd((G, C), 33) * 0.2 + 1).to(DEV), (rnd((G, C), 34) * 0.1).to(DEV)
+    gs, bs = (rnd((G, C), 35) * 0.2 + 1).to(DEV), (rnd((G, C), 36) * 0.1).to(DEV)
+    # unfused
+    m2, s2 = ops.bn_stats(c2, C, rows, G)
+    ms, ss = ops.bn_stats(sc, C, rows, G)
+    ref = ops.bn_apply(c2, C, rows, G, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc, res_bn=(ms, ss, gs, bs), gb_group_stride=C)
+    ref_feat = ops.global_avgpool(ref.view(n, 3, 3, C))
+    # fused
+    out = torch.empty_like(c2)
+    feat = torch.empty((n, C), device=DEV)
+    fm2, fs2, fms, fss = (torch.empty((G, C), device=DEV) for _ in range(4))
+    rc = lib.mft_bn_small_forward(ops._p(c2), C, ops._p(sc), C, None, 0, ops._p(out), C, C, rows, G, ops._p(g2), ops._p(b2),
+                                  ops._p(gs), ops._p(bs), C, ops._p(fm2), ops._p(fs2), ops._p(fms), ops._p(fss), ops.ACT_RELU,
+                                  0.0, 1e-5, ops._p(feat), hw, ops._stream())
+    assert rc == 0
+    assert float((out - ref).abs().max()) < 2e-5 and float((feat - ref_feat).abs().max()) < 1e-5
+    assert float((fm2 - m2).abs().max()) < 1e-6 and float(((fs2 - s2) / s2).abs().max()) < 1e-5
+    assert float((fms - ms).abs().max()) < 1e-6 and float(((fss - ss) / ss).abs().max()) < 1e-5
+    # CE + pool backward
+    labels = torch.from_numpy(np.random.RandomState(37).randint(0, 5, size=n).astype(np.int32)).to(DEV)
+    loss_ref, dl = ops.cross_entropy(ref_feat, labels, ipg, G)
+    d_ref = ops.avgpool_relu_backward(dl, ref.view(n, 3, 3, C))
+    d_out = torch.empty_like(ref)
+    loss = torch.empty((G,), device=DEV)
+    assert lib.mft_ce_pool_backward(ops._p(ref_feat), ops._p(labels), ipg, G, C, hw, ops._p(ref), ops._p(d_out), ops._p(loss),
+                                    ops._stream()) == 0
+    assert float((d_out.view(-1) - d_ref.reshape(-1)).abs().max()) < 1e-7 and float((loss - loss_ref).abs().max()) < 1e-5
+    # dual BN backward
+    dxa_r, dga_r, dba_r = ops.bn_backward(c2, d_out, C, rows, G, m2, s2, g2, gb_group_stride=C)
+    dxb_r, dgb_r, dbb_r = ops.bn_backward(sc, d_out, C, rows, G, ms, ss, gs, gb_group_stride=C)
+    dxa, dxb = torch.empty_like(c2), torch.empty_like(sc)
+    dga, dba, dgb, dbb = (torch.empty((G, C), device=DEV) for _ in range(4))
+    assert lib.mft_bn_backward2(ops._p(c2), ops._p(sc), C, ops._p(d_out), C, ops._p(dxa), ops._p(dxb), C, C, rows, G, ops._p(m2),
+                                ops._p(s2), ops._p(g2), ops._p(ms), ops._p(ss), ops._p(gs), C, ops._p(dga), ops._p(dba),
+                                ops._p(dgb), ops._p(dbb), ops._stream()) == 0
+    for a, b in ((dxa, dxa_r), (dxb, dxb_r), (dga, dga_r), (dba, dba_r), (dgb, dgb_r), (dbb, dbb_r)):
+        assert torch.equal(a, b)
