@@ -222,16 +222,19 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
+
 template <int BM, int BN>
 int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
-    const size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
+    size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
+    if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     auto kern = conv_x3_kernel<BM, BN>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_done = true;
         }
@@ -431,7 +434,8 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 }
 
 extern "C" int mft_debug_set_x3_tile(int t) {
-    if (t >= 10) g_x3_patch = t - 10;
+    if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 10) g_x3_patch = t - 10;
     else g_x3_tile = t;
     return 0;
 }
