@@ -8,6 +8,8 @@ images with per-episode BatchNorm statistics (the frozen trunk.0-6 weights are s
 per-episode last-block weights / Adam state held in HBM (44 MB per episode).  Host work per batch
 is index tables only; the numpy permutations are drawn in the reference's order.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -84,7 +86,6 @@ class FinetuneEngine:
         # The trunk's convolution workgroups are large (46-61 KB LDS, 128-226 VGPRs); next to the tens of thousands of
         # small weight-gradient workgroups of the other stream they are starved of CU slots unless their queue has
         # priority (measured in situ: 3.2x slower without).
-        import os
         prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "-1"))
         self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio) if pipeline else None
         self.s_last = torch.cuda.Stream(device=self.dev, priority=0) if pipeline else None

@@ -123,3 +123,32 @@ def test_step_tables_shapes():
     assert k == 5 and idx.shape == (10,) and lab.shape == (10,)
     assert np.array_equal(idx[:5], perms[0][1][5:10]) and np.array_equal(idx[5:], 75 + perms[1][1][5:10])
     assert np.array_equal(lab[:5], e.y_support[perms[0][1][5:10]])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout only exists in the build container")
+def test_checkpoints_interchange_with_the_reference(tmp_path):
+    """a checkpoint written by this package ({'epoch','state'} .tar, train.py:46-48) loads strictly
+    into the REFERENCE's own GnnNet(ResNet10) and a reference-written one loads strictly here, including the extra
+    feature2./feature3. copies a meta-fine-tuned reference model carries (train.py:197-202 drops them)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_golden as MG
+    mods = MG.import_reference()
+    ref_gnnnet, ref_backbone = mods["methods.gnnnet"], mods["backbone"]
+    ours = gnnnet.GnnNet(backbone.ResNet10, n_way=5, n_support=5)
+    ours.load_state_dict(synthetic.gnnnet_state_dict(seed=3))
+    f = str(tmp_path / "399.tar")
+    torch.save({"epoch": 399, "state": ours.state_dict()}, f)
+    ref = ref_gnnnet.GnnNet(MG.make_factory(ref_backbone, 84), n_way=5, n_support=5)
+    ref.load_state_dict(torch.load(f)["state"], strict=True)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, ours.state_dict()[k]), k
+    # the other direction, with the meta-fine-tuning copies present
+    sd = ref.state_dict()
+    sd.update({k.replace("feature.", "feature2.", 1): v for k, v in ref.state_dict().items() if k.startswith("feature.")})
+    g = str(tmp_path / "600.tar")
+    torch.save({"epoch": 600, "state": sd}, g)
+    state = {k: v for k, v in torch.load(g)["state"].items() if "feature2." not in k and "feature3." not in k}
+    ours2 = gnnnet.GnnNet(backbone.ResNet10, n_way=5, n_support=5)
+    ours2.load_state_dict(state, strict=True)
+    assert list(ours2.state_dict().keys()) == list(ref.state_dict().keys())
