@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--workload", default="finetune", choices=["finetune", "metatrain"],
                     help="finetune = BASELINE configs[1] (the metric, default); metatrain = configs[3]: one meta-training episode per "
                          "rank per step (set_forward_loss -> full backward -> flat-bucket RCCL all-reduce -> fused outer Adam)")
+    ap.add_argument("--image-size", type=int, default=84, help="84 = BASELINE configs (the metric); 224 = the reference's hard-coded "
+                    "image_size (train.py:72, finetune.py:429) -- extra measurement, FLOP-derived fields then refer to 84")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle on a bounded sample and print its JSON object; never touches the GPU")
@@ -250,8 +252,8 @@ def main():
         from meta_fine_tuning_amd import _lib
         _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
     E = args.episodes_per_batch
-    n_way, n_shot, n_query, size = 5, args.n_shot, 15, 84
-    if n_shot != 5:
+    n_way, n_shot, n_query, size = 5, args.n_shot, 15, args.image_size
+    if n_shot != 5 or size != 84:
         args.no_cpu_baseline = True
     views = 2 + args.gen_examples
     state = synthetic.gnnnet_state_dict(seed=0)

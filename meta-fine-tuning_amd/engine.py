@@ -95,6 +95,13 @@ class FinetuneEngine:
         ya = np.repeat(np.arange(n_way), n_support)
         self.y_support = (np.tile(ya, n_views + 1) if mode == "gnn" else ya).astype(np.int32)
         # every support image is drawn once per epoch: with >1 epoch cache its (mini-batch independent) stem conv
+        if stem_cache:
+            # 64 channels x (H/2)^2 fp32 per resident support image: 226 KB at 84x84, 3.2 MB at 224x224.  Keep the cache
+            # only while it fits comfortably beside the other resident buffers.
+            oh = (image_size + 6 - 7) // 2 + 1
+            need = self.E * self.n_total * oh * oh * 64 * 4
+            total = torch.cuda.get_device_properties(self.dev).total_memory
+            stem_cache = need <= 0.35 * total
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev) if stem_cache else None
 
     # ------------------------------------------------------------------ ingest

@@ -293,3 +293,19 @@ def test_hipgraph_inner_step_is_bit_identical():
         got = e1.run_batch(eps, perms=perms).clone()
         assert torch.equal(got, ref), rep
         assert torch.equal(e1.adapt.w.flat, wref), rep
+
+
+def test_engine_at_reference_image_size_224():
+    """The reference hard-codes image_size = 224 (train.py:72, finetune.py:429): 7x7 last feature map, 245 rows
+    per episode in trunk.7 (the skinny / fused small-group kernels do not apply and the generic paths take over).  One episode,
+    15 Adam steps, against the float64 oracle envelope."""
+    sd = synthetic.gnnnet_state_dict(seed=45)
+    ep = synthetic.test_episode(900, 5, 5, 15, 224, gen_examples=0)
+    perms = [[np.random.RandomState(17).permutation(75)]]
+    e = eng.FinetuneEngine(sd, 5, 5, 15, 224, n_views=2, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    sc = e.run_batch([ep], perms=perms)[0].cpu().numpy()
+    o64 = O.finetune_episode(sd, ep, 5, 5, total_epoch=1, perms=perms[0], dtype=torch.float64).numpy()
+    o32 = O.finetune_episode(sd, ep, 5, 5, total_epoch=1, perms=perms[0], dtype=torch.float32).numpy()
+    d_ref, d_hip = np.abs(o32 - o64).max(), np.abs(sc - o64).max()
+    assert d_hip <= max(4.0 * d_ref, 2e-3), (d_hip, d_ref)
+    assert (sc.argmax(1) == o64.argmax(1)).mean() >= 0.96
