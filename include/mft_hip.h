@@ -194,6 +194,11 @@ int mft_adam_step(float* p, const float* g, float* m, float* v, long long n, int
 int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_step,
                  float lr, float momentum, float dampening, float weight_decay, void* stream);
 /* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
+/* torch.optim.Adam.step over many tensors in one launch (train.py:28, meta_template.py:87): chunk_table is a DEVICE array of
+ * n_chunks records {float* p; const float* g; float* m; float* v; long long n;} (40 bytes each, n <= 65536 elements; 16-byte aligned chunks take the float4 path).        */
+int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, void* stream);
+
 /* hipGraph support: kernel arguments are frozen when a graph is captured, so Adam's bias corrections must come from device
  * memory.  mft_adam_hyper_advance does t = ++(*step) and writes hyper = {lr/(1-beta1^t), 1/sqrt(1-beta2^t)} (double precision,
  * as the host path); the *_dev variants of the Adam launchers read them instead of taking `step`/`lr`.                       */
@@ -255,7 +260,7 @@ int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, cons
 /* dx (+)= dy * act'(y)  (ReLU / leaky-ReLU backward; GNN_nl's F.leaky_relu before the concat, gnn.py:160) */
 int mft_act_backward(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long long rows,
                      int act, float slope, int accumulate, void* stream);
-/* out[c] = sum_r x[r][c] (bias gradients of nn.Linear / 1x1 nn.Conv2d); ws >= ceil(rows/1024)*C floats */
+/* out[c] = sum_r x[r][c] (bias gradients of nn.Linear / 1x1 nn.Conv2d); ws >= ceil(rows/256)*C floats */
 int mft_colsum(const float* x, int ldx, int C, long long rows, float* out, float* ws, void* stream);
 /* trunk[1..3] forward that also records each window's argmax (uint8, first maximum wins) for the backward pass */
 int mft_bn_relu_maxpool_arg(const float* x, float* y, unsigned char* argmax, int n_img, int H, int W, int C,

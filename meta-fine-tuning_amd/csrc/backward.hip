@@ -58,16 +58,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) {
 }
 
 // phase 2: fixed-order sum of the partials -> dgamma, dbeta and the two group means used by phase 3
-__global__ void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 16 channels x 16 chunk lanes; each lane sums every 16th partial, then a fixed xor tree over the 16 lanes
+// (a serial loop over up to ~340 partials per channel cost 50-250 us per BatchNorm in the meta-training step)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
+    const int kl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int g = blockIdx.y;
-    if (c >= p.C) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < p.chunks; ++k) {
-        const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
-        s1 += o[0];
-        s2 += o[1];
+    if (c < p.C)
+        for (int k = kl; k < p.chunks; k += 16) {
+            const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
+            s1 += o[0];
+            s2 += o[1];
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
     }
+    if (c >= p.C || kl != 0) return;
     if (p.dbeta) p.dbeta[(long long)g * p.C + c] = s1;
     if (p.dgamma) p.dgamma[(long long)g * p.C + c] = s2;
     sums[((long long)g * p.C + c) * 2] = s1 / (float)p.rows_per_group;
@@ -136,12 +145,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (rl == 0 && c < C) ws[(long long)blockIdx.x * C + c] = red[0][c & 63] + red[1][c & 63] + red[2][c & 63] + red[3][c & 63];
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int C, int chunks, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int C, int chunks,
+                                                           float* __restrict__ out) {
+    const int kl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += ws[(long long)k * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int k = kl; k < chunks; k += 16) s += ws[(long long)k * C + c];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (c < C && kl == 0) out[c] = s;
 }
 
 // ---------------------------------------------------------------------------------- max pool with argmax
@@ -354,7 +367,7 @@ extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws; p.act = act; p.slope = slope;
     float* sums = ws + 2LL * n_groups * p.chunks * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.chunks, (C + 63) / 64, n_groups), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128, n_groups), dim3(128), 0, s, p, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16, n_groups), dim3(256), 0, s, p, sums);
     if (dx) {
         const long long total = (long long)n_groups * rows_per_group * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bgrid(total, 2048)), dim3(256), 0, s, p, (const float*)sums, n_groups);
@@ -370,11 +383,11 @@ extern "C" int mft_act_backward(const float* dy, int lddy, const float* y, int l
 }
 
 extern "C" int mft_colsum(const float* x, int ldx, int C, long long rows, float* out, float* ws, void* stream) {
-    // ws: >= ceil(rows/1024) * C floats
+    // ws: >= ceil(rows/256) * C floats
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = (int)((rows + 1023) / 1024);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 1024, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)ws, C, chunks, out);
+    const int chunks = (int)((rows + 255) / 256);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 256, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)ws, C, chunks, out);
     return mft_launch_status();
 }
 

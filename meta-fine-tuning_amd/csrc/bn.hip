@@ -57,19 +57,27 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group, int chunks,
-                                  const float* __restrict__ ws, float eps, float* __restrict__ mean,
-                                  float* __restrict__ rstd, float* running_mean, float* running_var,
-                                  float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 16 channels x 16 chunk lanes (fixed xor tree over the lanes: deterministic)
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group,
+                                                         int chunks, const float* __restrict__ ws, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* running_mean, float* running_var, float momentum) {
+    const int kl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int g = blockIdx.y;
-    if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-        const float* o = ws + (((long long)g * chunks + k) * C + c) * 2;
-        s1 += o[0];
-        s2 += o[1];
+    if (c < C)
+        for (int k = kl; k < chunks; k += 16) {
+            const float* o = ws + (((long long)g * chunks + k) * C + c) * 2;
+            s1 += o[0];
+            s2 += o[1];
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
     }
+    if (c >= C || kl != 0) return;
     const float inv = 1.f / (float)rows_per_group;
     const float sh = x[(long long)g * rows_per_group * ldx + c];
     const float d = s1 * inv;
@@ -380,8 +388,8 @@ extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, 
     const int rpc = (rows_per_group + chunks - 1) / chunks;
     dim3 grid(chunks, (C + 63) / 64, n_groups);
     hipLaunchKernelGGL(bn_stats_partial, grid, dim3(256), 0, s, x, ldx, C, rows_per_group, rpc, chunks, ws);
-    dim3 g2((C + 127) / 128, n_groups, 1);
-    hipLaunchKernelGGL(bn_stats_finalize, g2, dim3(128), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps, mean, rstd,
+    dim3 g2((C + 15) / 16, n_groups, 1);
+    hipLaunchKernelGGL(bn_stats_finalize, g2, dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps, mean, rstd,
                        running_mean, running_var, momentum);
     return mft_launch_status();
 }

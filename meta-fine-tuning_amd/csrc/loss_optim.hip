@@ -403,3 +403,51 @@ extern "C" int mft_ce_pool_backward(const float* feat, const int* labels, int ro
                        rows_per_group, C, hw, out, d_out, loss);
     return mft_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ multi-tensor Adam
+// torch.optim.Adam over a whole model (train.py:28: 104 parameter tensors, 5.3 M parameters) as ONE launch: the host
+// passes a table of (p, g, m, v, n) chunks (<= 65536 elements each); workgroup b updates chunk b.
+namespace {
+struct AdamChunk { float* p; const float* g; float* m; float* v; long long n; };
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __restrict__ table, float step_size,
+                                                         float inv_sqrt_bc2, float b1, float b2, float eps, float wd) {
+    const AdamChunk c = table[blockIdx.x];
+    const bool vec = ((((unsigned long long)c.p | (unsigned long long)c.g | (unsigned long long)c.m | (unsigned long long)c.v) & 15ull) == 0);
+    const long long n4 = vec ? (c.n >> 2) : 0;
+    for (long long i = threadIdx.x; i < n4; i += 256) {
+        f32x4 pp = ((const f32x4*)c.p)[i];
+        const f32x4 gg = ((const f32x4*)c.g)[i];
+        f32x4 mm = ((const f32x4*)c.m)[i], vv = ((const f32x4*)c.v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] + wd * pp[e];
+            mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps));
+        }
+        ((f32x4*)c.m)[i] = mm;
+        ((f32x4*)c.v)[i] = vv;
+        ((f32x4*)c.p)[i] = pp;
+    }
+    for (long long i = 4 * n4 + threadIdx.x; i < c.n; i += 256) {
+        const float pp = c.p[i];
+        const float ge = c.g[i] + wd * pp;
+        const float mm = b1 * c.m[i] + (1.f - b1) * ge;
+        const float vv = b2 * c.v[i] + (1.f - b2) * ge * ge;
+        c.m[i] = mm;
+        c.v[i] = vv;
+        c.p[i] = pp - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    }
+}
+}  // namespace
+
+extern "C" int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* stream) {
+    if (step < 1 || n_chunks < 1) return MFT_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunk_table,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
+    return mft_launch_status();
+}

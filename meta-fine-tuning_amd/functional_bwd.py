@@ -55,7 +55,7 @@ def act_backward(dy, y, dx, C, act, accumulate, dy_off=0, y_off=0, dx_off=0):
 def colsum(x2d, C):
     rows = x2d.shape[0]
     out = _empty((C,), x2d.device)
-    ws = _empty((((rows + 1023) // 1024) * C,), x2d.device)
+    ws = _empty((((rows + 255) // 256) * C,), x2d.device)
     L.check(L.lib().mft_colsum(ops._p(x2d), x2d.shape[1], C, rows, ops._p(out), ops._p(ws), ops._stream()), "mft_colsum")
     return out
 

@@ -1,9 +1,13 @@
 """Outer-loop optimiser on the HIP path: torch.optim.Adam semantics (train.py:28: Adam(model.parameters()), lr 1e-3,
-betas (0.9, 0.999), eps 1e-8, no weight decay by default) with the update done by mft_adam_step (one fused
-streaming launch per parameter tensor; parameters and moments never leave HBM)."""
+betas (0.9, 0.999), eps 1e-8, no weight decay by default) with the update of ALL parameter tensors done by one
+multi-tensor launch (mft_adam_multi; parameters and moments never leave HBM)."""
+import numpy as np
 import torch
 
 from . import ops
+
+
+CHUNK = 16384          # elements per workgroup of the multi-tensor launch (multiple of 4: chunks stay 16-byte aligned)
 
 
 class Adam(torch.optim.Optimizer):
@@ -16,22 +20,43 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        touched = False
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            rows = []
+            step = None
+            for p in ps:
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                g = p.grad.contiguous()
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"], beta1=b1, beta2=b2,
-                              eps=group["eps"], weight_decay=group["weight_decay"])
-                p._version  # parameters were updated through raw pointers: bump autograd's counter below
-                p.data.add_(0)              # no-op write that increments the version counter (pack caches key on it)
-                touched = True
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                if step is None:
+                    step = st["step"]
+                if st["step"] != step or not p.is_cuda:
+                    step = -1                      # mixed step counts: fall back to per-tensor launches
+                n = p.numel()
+                pp, gp, mp, vp = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                for off in range(0, n, CHUNK):
+                    rows.append((pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(CHUNK, n - off)))
+            if step is not None and step > 0:
+                # all tensors of the group in ONE launch (104 tensors for GnnNet): a device table of (p, g, m, v, n) chunks
+                table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device)
+                rc = ops._lib.lib().mft_adam_multi(ops._p(table), len(rows), step, group["lr"], b1, b2, group["eps"],
+                                                   group["weight_decay"], ops._stream())
+                ops._lib.check(rc, "mft_adam_multi")
+                self._keep = table                 # the launch is asynchronous: keep the table alive until the next step
+            else:
+                for p in ps:
+                    st = self.state[p]
+                    ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"], beta1=b1,
+                                  beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"])
+            # parameters were updated through raw pointers: bump autograd's version counters (the weight-pack caches key
+            # on them) with one fused no-op write
+            torch._foreach_add_([p.data for p in ps], 0)
         return loss

@@ -63,21 +63,22 @@ class FlatGradBucket:
             off += p.numel()
 
     def allreduce_mean(self):
-        """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place)."""
+        """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place).  With one rank nothing is exchanged
+        and the gradients stay where autograd put them."""
         _, W = world()
-        for p, v in zip(self.params, self.views):
+        if W == 1:
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            return
+        for p in self.params:
             if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        if W > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(W)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
+        torch._foreach_copy_(self.views, grads)                 # fused multi-tensor copies (104 tensors -> a few launches)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(W)
+        torch._foreach_copy_(grads, self.views)
 
 
 def broadcast_buffers(module, src=0):
