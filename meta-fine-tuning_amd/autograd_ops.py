@@ -143,8 +143,13 @@ def resnet10_module_forward(mod, x):
     xn = ops.nchw_to_nhwc(x)
     params = list(mod.parameters())
     if not mod.training:
-        raise NotImplementedError("eval-mode BatchNorm (freeze_backbone) is not on the HIP hot path yet; the reference "
-                                  "keeps the backbone in train() for fine-tuning (finetune.py:263-264)")
+        # eval-mode BatchNorm (finetune(freeze_backbone=True), finetune.py:265-266): running statistics, no buffer updates
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            raise NotImplementedError("autograd through an eval-mode backbone is not on the HIP hot path (the reference only "
+                                      "evaluates it: the frozen-backbone loop has no optimiser, finetune.py:253-299)")
+        W = module_weights(mod)
+        n = xn.shape[0]
+        return Fn.resnet10_forward(W, xn, arena_for(xn.device), ipg=n, fixed=_eval_weights(mod, W), tag="evl%d" % n).clone()
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if any(p.requires_grad for p in params[:-9]):
             out = _ResNet10FullFn.apply(mod, xn, *params)       # meta-training: gradients for the whole backbone

@@ -39,14 +39,27 @@ def finetune(liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_q
              pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5):
     """One episode: liz_x = [x0, x0, aug_1, ...] each [n_way, n_support+n_query, 3, H, W]; returns softmax scores
     [n_way*n_query, n_way] (finetune.py:182-328)."""
-    if linear or not flatten or ds or freeze_backbone:
-        raise NotImplementedError("finetune(): only the GNN scoring branch with an adaptable, flattened backbone is on "
-                                  "the HIP hot path (linear / ds / freeze_backbone are 'next' rows, SURVEY.md §8(f))")
+    if linear or not flatten or ds:
+        raise NotImplementedError("finetune(): only the GNN scoring branch with a flattened backbone is on the HIP hot path "
+                                  "(the linear branch is finetune_linear(); ds = DampNet, out of scope)")
     if params is None or params.model != 'ResNet10':
         raise RuntimeError("finetune.params must be set (Namespace(model='ResNet10', fine_tune_epoch=...))")
     model = model.cuda()
     x0 = liz_x[0]
     n_query = x0.size(1) - n_support
+    if freeze_backbone:
+        # finetune.py:253-266: eval-mode backbone, no backbone optimiser; the classifier gets no gradient either, so the
+        # loop at :270-299 changes nothing -- it only consumes one permutation per epoch.  Scores = GNN on eval features.
+        for _ in range(params.fine_tune_epoch):
+            np.random.permutation(n_way * n_support * (len(liz_x) + 1))
+        feat = model_dict[params.model](flatten=True)
+        feat.load_state_dict({k.replace("feature.", "", 1): v for k, v in state_in.items()
+                              if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))})
+        feat = feat.cuda().eval()
+        with torch.no_grad():
+            out_all = feat(x0.cuda().reshape(-1, *x0.shape[2:])).view(n_way, n_support + n_query, -1)
+            model.n_query = n_query
+            return torch.nn.functional.softmax(model.set_forward(out_all, is_feature=True), dim=1)
     e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(liz_x), params.fine_tune_epoch, 1,
                     fold50=getattr(model, "FOLD50", False))
     model.n_query = n_query                                          # finetune.py:312

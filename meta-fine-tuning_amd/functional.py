@@ -129,7 +129,11 @@ class LastBlockSlab:
         return out
 
 
-def _bn_stats4(arena, tag, x, ipg, groups, running=None):
+def _bn_stats4(arena, tag, x, ipg, groups, running=None, fixed=None):
+    """Mini-batch statistics of x per group; ``fixed`` = (mean [1,C], rstd [1,C]) short-circuits them (eval-mode BatchNorm:
+    running statistics, one group)."""
+    if fixed is not None:
+        return fixed
     n, H, W, C = x.shape
     mean = arena.get(tag + ".mean", (groups, C))
     rstd = arena.get(tag + ".rstd", (groups, C))
@@ -174,13 +178,16 @@ class StemCache:
                            "mft_bn_image_moments")
 
 
-def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None):
+def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, fixed=None):
     """trunk[0..upto-1] with shared (frozen) weights.  x [n,H,W,3] NHWC -> activation entering trunk[upto].
     ``running``: optional dict bn-name -> (running_mean, running_var) updated when a single group is run.
     ``stem`` = (StemCache, idx_i32): take trunk.0 outputs of images idx from the cache instead of x (x is ignored)."""
 
     def run(name):
         return None if running is None else running.get(name)
+
+    def fix(name):
+        return None if fixed is None else fixed[name]
 
     g, b = W.bn["trunk.1"]
     if stem is not None:
@@ -196,14 +203,14 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None):
         n = x.shape[0]
         groups = n // ipg
         c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3, out=arena.get(tag + ".c0", (n, (x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1, 64)))
-        m, s = _bn_stats4(arena, tag + ".bn0", c0, ipg, groups, run("trunk.1"))
+        m, s = _bn_stats4(arena, tag + ".bn0", c0, ipg, groups, run("trunk.1"), fix("trunk.1"))
         a = ops.bn_relu_maxpool(c0, m, s, g, b, imgs_per_group=ipg)
     for idx in (4, 5, 6, 7):
         if idx >= upto:
             break
         cin, cout, stride = STAGES[idx]
         p = "trunk.%d" % idx
-        a = simple_block(W, p, a, arena, ipg, cin, cout, stride, running, tag + "." + p)
+        a = simple_block(W, p, a, arena, ipg, cin, cout, stride, running, tag + "." + p, fixed=fixed)
     return a
 
 
@@ -224,16 +231,19 @@ def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=Non
     return m1, s1, m2, s2
 
 
-def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None):
+def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None, fixed=None):
     """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's.
     ``pooled``: optional [n, cout] buffer; filled with the global average pool of the block output when the fused
-    small-group path applies (returns True in tape['pooled'] / via the buffer's ``_mft_filled`` flag)."""
+    small-group path applies (``tape['pooled']`` is then True and the caller skips its own pooling launch)."""
     n, H, Wd, _ = x.shape
     groups = n // ipg
     OH = (H + 2 - 3) // stride + 1
 
     def run(name):
         return None if running is None else running.get(name)
+
+    def fix(name):
+        return None if fixed is None else fixed[name]
 
     if slab is None:
         c1w, c2w = W.conv[p + ".C1"], W.conv[p + ".C2"]
@@ -271,16 +281,16 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
                         pooled=pooled is not None)
         return out
     c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
-    m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"))
+    m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"), fix(p + ".BN1"))
     r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
                       out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
     c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
-    m2, s2 = _bn_stats4(arena, tag + ".bn2", c2, ipg, groups, run(p + ".BN2"))
+    m2, s2 = _bn_stats4(arena, tag + ".bn2", c2, ipg, groups, run(p + ".BN2"), fix(p + ".BN2"))
     out = arena.get(tag + ".out", (n * OH * OH, cout))
     sc = ms = ss = None
     if cin != cout:
         sc = conv(".shortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)))
-        ms, ss = _bn_stats4(arena, tag + ".bns", sc, ipg, groups, run(p + ".BNshortcut"))
+        ms, ss = _bn_stats4(arena, tag + ".bns", sc, ipg, groups, run(p + ".BNshortcut"), fix(p + ".BNshortcut"))
         ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc.view(-1, cout),
                      res_bn=(ms, ss, gs, bs), out=out, gb_group_stride=gbs)
     else:
@@ -292,26 +302,28 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
     return out
 
 
-def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f"):
+def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f", fixed=None):
     """trunk.7 + global average pool on the activation ``a`` [n,h,w,256] entering the last block -> features [n,512]."""
     n = a.shape[0]
     feat = arena.get(tag + ".feat", (n, 512))
     info = tape if tape is not None else {}
-    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=info, pooled=feat)
+    out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=info, pooled=feat,
+                       fixed=fixed)
     if not info.get("pooled", False):
         ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
                                                          ops._stream()), "mft_global_avgpool")
     return feat
 
 
-def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag="f"):
-    """Full ResNet10(flatten=True) forward in train mode: x [n,H,W,3] NHWC -> features [n,512].
+def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag="f", fixed=None):
+    """Full ResNet10(flatten=True) forward: x [n,H,W,3] NHWC -> features [n,512].  Train mode (mini-batch statistics per
+    group of ``ipg`` images) unless ``fixed`` = {bn name: (mean [1,C], rstd [1,C])} supplies eval-mode statistics.
     ``slab`` selects per-group last-block parameters (episode-batched inner loop)."""
     n = x.shape[0]
-    if ipg <= 0:
+    if ipg <= 0 or fixed is not None:
         ipg = n
-    a = resnet10_trunk(W, x, arena, ipg, upto=7, running=running, tag=tag)
-    return last_block_forward(W, a, arena, ipg, slab=slab, tape=tape, running=running, tag=tag)
+    a = resnet10_trunk(W, x, arena, ipg, upto=7, running=running, tag=tag, fixed=fixed)
+    return last_block_forward(W, a, arena, ipg, slab=slab, tape=tape, running=running, tag=tag, fixed=fixed)
 
 
 def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None):

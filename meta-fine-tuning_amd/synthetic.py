@@ -107,6 +107,19 @@ def gnnnet_state_dict(seed=0, n_way=5, perturb_bn=True):
     return sd
 
 
+def gnnnet_state_dict_with_running_stats(seed=0, n_way=5):
+    """``gnnnet_state_dict`` whose BatchNorm running statistics are not the (0, 1) defaults, so that eval-mode paths
+    (finetune(freeze_backbone=True), finetune.py:262-266) provably read them."""
+    sd = gnnnet_state_dict(seed, n_way)
+    rs = np.random.RandomState(seed + 1)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy((rs.standard_normal(tuple(sd[k].shape)) * 0.2).astype(np.float32))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, size=tuple(sd[k].shape)).astype(np.float32))
+    return sd
+
+
 # ----------------------------------------------------------------------------- episodes
 
 def _templates(rs, n_way, size):

@@ -353,6 +353,24 @@ def main():
         np.savez(os.path.join(GOLD, "g10_finetune_linear.npz"), **out)
         print("g10 done")
 
+    # ---------------------------------------------------------------- G11 finetune(freeze_backbone=True)
+    if want("g11"):
+        out = {}
+        size = 84
+        sd = synthetic.gnnnet_state_dict_with_running_stats(seed=47)
+        finetune.model_dict["ResNet10"] = make_factory(backbone, size)
+        finetune.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=2)
+        model = gnnnet.GnnNet(make_factory(backbone, size), n_way=5, n_support=5)
+        model.load_state_dict(sd)
+        model.train()
+        liz = synthetic.test_episode(95, 5, 5, 15, size, gen_examples=1)
+        np.random.seed(10)
+        sc = finetune.finetune(liz, None, model, copy.deepcopy(sd), None, n_query=15, freeze_backbone=True, n_way=5, n_support=5)
+        out["scores"] = sc.numpy()
+        out["next_perm"] = np.random.permutation(7)          # position of the numpy stream after the call
+        np.savez(os.path.join(GOLD, "g11_finetune_frozen.npz"), **out)
+        print("g11 done")
+
 
 if __name__ == "__main__":
     main()

@@ -372,6 +372,22 @@ def finetune_episode(state, liz_x, n_way=5, n_support=5, total_epoch=5, perms=No
     return out
 
 
+def finetune_frozen_episode(state, liz_x, n_way=5, n_support=5, total_epoch=5, dtype=torch.float32):
+    """finetune.finetune(..., freeze_backbone=True) (finetune.py:253-266,270-299,306-317): the backbone is in eval mode
+    and has no optimiser, the classifier never receives a gradient -- the "fine-tuning" loop only draws its
+    permutations (one per epoch, consumed here for stream parity) -- so the scores are the GNN on eval-mode features."""
+    sd_all = clone_state(state, dtype)
+    fsd = feature_state(sd_all)
+    x0 = liz_x[0].to(dtype)
+    n_query = x0.shape[1] - n_support
+    for _ in range(total_epoch):
+        np.random.permutation(n_way * n_support * (len(liz_x) + 1))
+    with torch.no_grad():
+        feats = resnet10_forward(fsd, x0.reshape(n_way * (n_support + n_query), *x0.shape[2:]), "", train=False)
+        scores = gnnnet_set_forward(sd_all, feats.view(n_way, n_support + n_query, -1), n_way, n_support, n_query, is_feature=True)
+        return F.softmax(scores, dim=1)
+
+
 def finetune_linear_episode(state, liz_x, n_way=5, n_support=5, w0=None, b0=None, perms=None, epochs=20,
                             batch_size=5, dtype=torch.float32):
     """finetune.finetune_linear (finetune.py:45-174), freeze_backbone=False: a Linear(512, n_way) classifier

@@ -220,11 +220,14 @@ def test_stem_cache_matches_recomputed_stem():
     for sc_on in (False, True):
         e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, stem_cache=sc_on)
         res.append(e.run_batch(eps, perms=perms).clone())
-    o64 = [O.finetune_episode(sd, eps[i], 5, 5, total_epoch=2, perms=perms[i], dtype=torch.float64).numpy() for i in range(2)]
     for i in range(2):
-        d_on = np.abs(res[1][i].cpu().numpy() - o64[i]).max()
-        d_off = np.abs(res[0][i].cpu().numpy() - o64[i]).max()
-        assert d_on <= max(3.0 * d_off, 2e-3), (d_on, d_off)
+        o64 = O.finetune_episode(sd, eps[i], 5, 5, total_epoch=2, perms=perms[i], dtype=torch.float64).numpy()
+        o32 = O.finetune_episode(sd, eps[i], 5, 5, total_epoch=2, perms=perms[i], dtype=torch.float32).numpy()
+        d_ref = np.abs(o32 - o64).max()
+        for r in res:                                   # with and without the cache: same envelope around the fp64 oracle
+            d = np.abs(r[i].cpu().numpy() - o64).max()
+            assert d <= max(4.0 * d_ref, 3e-3), (d, d_ref)
+            assert (r[i].cpu().numpy().argmax(1) == o64.argmax(1)).mean() >= 0.96
 
 
 def test_finetune_linear_and_all_vs_reference_golden(golden_dir):

@@ -162,3 +162,23 @@ def test_finetune_dropin(golden_dir, E, G):
 def test_graft_smoke():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_finetune_frozen_backbone_vs_reference_golden(golden_dir):
+    """finetune(freeze_backbone=True) (eval-mode BatchNorm from the running statistics, no adaptation) against the
+    reference's own output (G11), including the position of the numpy permutation stream afterwards."""
+    import argparse
+    import os
+    from meta_fine_tuning_amd import finetune as ft, synthetic
+    from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+    from meta_fine_tuning_amd.io_utils import model_dict
+    g = np.load(os.path.join(golden_dir, "g11_finetune_frozen.npz"))
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=47)
+    liz = synthetic.test_episode(95, 5, 5, 15, 84, gen_examples=1)
+    ft.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=2)
+    model = GnnNet(model_dict["ResNet10"], n_way=5, n_support=5)
+    model.load_state_dict(sd)
+    np.random.seed(10)
+    sc = ft.finetune([v.cuda() for v in liz], None, model, sd, None, n_query=15, freeze_backbone=True).cpu().numpy()
+    assert np.abs(sc - g["scores"]).max() < 1e-4          # forward-only: bar is 1e-3
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])

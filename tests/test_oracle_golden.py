@@ -214,3 +214,14 @@ def test_g10_finetune_linear_and_all(golden_dir):
     sc2 = O.finetune_episode(sd, liz, 5, 5, total_epoch=1).numpy()
     tot = sc + sc2
     assert np.abs(tot - g["scores_all"]).max() < 5e-3 and (tot.argmax(1) == g["scores_all"].argmax(1)).mean() >= 0.98
+
+
+def test_g11_finetune_frozen_backbone(golden_dir):
+    """finetune(freeze_backbone=True): eval-mode features + GNN, permutations consumed (stream position checked)."""
+    g = np.load(os.path.join(golden_dir, "g11_finetune_frozen.npz"))
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=47)
+    liz = synthetic.test_episode(95, 5, 5, 15, 84, gen_examples=1)
+    np.random.seed(10)
+    sc = O.finetune_frozen_episode(sd, liz, 5, 5, total_epoch=2).numpy()
+    assert np.abs(sc - g["scores"]).max() < 1e-5
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])
