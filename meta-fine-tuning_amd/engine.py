@@ -43,7 +43,7 @@ def draw_perms(n_total, total_epoch, rng=np.random):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True, graph=False):
+                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True, graph=False, trunk_chunk=None):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316).
         ``mode`` "gnn": finetune.finetune (inner loss on the raw feature, GNN scoring);
@@ -83,6 +83,10 @@ class FinetuneEngine:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)     # device-side Adam step counter / bias
         self.hyper = torch.zeros(2, device=self.dev)                           # corrections (graph replay)
         self.pipeline = pipeline
+        # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
+        # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
+        # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
+        self.trunk_chunk = int(os.environ.get("MFT_TRUNK_CHUNK", "1")) if trunk_chunk is None else int(trunk_chunk)
         # The trunk's convolution workgroups are large (46-61 KB LDS, 128-226 VGPRs); next to the tens of thousands of
         # small weight-gradient workgroups of the other stream they are starved of CU slots unless their queue has
         # priority (measured in situ: 3.2x slower without).
@@ -186,8 +190,9 @@ class FinetuneEngine:
         a = self.arena_trunk
         if self.stem is not None:
             return Fn.resnet10_trunk(self.W, None, a, k, upto=7, tag="tr%d.%d" % (k, parity), stem=(self.stem, idx_dev))
-        xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (E * k, H * H * 3)))
-        return Fn.resnet10_trunk(self.W, xb.view(E * k, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
+        n = idx_dev.numel()                      # E*k images per step, times the number of steps in the chunk
+        xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (n, H * H * 3)))
+        return Fn.resnet10_trunk(self.W, xb.view(n, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
 
     def last_step(self, x6, lab_dev, k):
         """Adapted part: trunk.7 forward with per-episode weights, CE on the 512-d feature, last-block backward,
@@ -269,18 +274,31 @@ class FinetuneEngine:
         cur = torch.cuda.current_stream(dev)
         self.s_trunk.wait_stream(cur)
         self.s_last.wait_stream(cur)
+        # The frozen trunk does not depend on the adaptation, so it runs AHEAD in chunks of ``trunk_chunk`` steps: one set
+        # of trunk launches covers T steps (T*E*k images, BatchNorm groups of k images as before), then the last-block
+        # stream consumes the T slices.  Bigger launches for the MFMA-bound half, T times fewer of them.
+        T = self.trunk_chunk if len({t[0] for t in tables}) == 1 else 1
         done = [None, None]                          # last-block completion events per x6 buffer
-        for t, ((k, _, _), idx, lab) in enumerate(zip(tables, idx_all, lab_all)):
-            par = t & 1
+        n_steps = len(tables)
+        for c, s0 in enumerate(range(0, n_steps, T)):
+            s1 = min(s0 + T, n_steps)
+            par = c & 1
+            k = tables[s0][0]
             with torch.cuda.stream(self.s_trunk):
                 if done[par] is not None:
                     self.s_trunk.wait_event(done[par])
-                x6 = self.trunk_step(idx, k, par)
+                if T == 1:
+                    idx_cat = idx_all[s0]
+                else:
+                    idx_cat = idx_dev[s0:s1].reshape(-1)           # rows of the table are consecutive: a view
+                x6 = self.trunk_step(idx_cat, k, par)
                 ready = torch.cuda.Event()
                 ready.record(self.s_trunk)
             with torch.cuda.stream(self.s_last):
                 self.s_last.wait_event(ready)
-                self.last_step(x6, lab, k)
+                per = self.E * k
+                for j, t in enumerate(range(s0, s1)):
+                    self.last_step(x6[j * per:(j + 1) * per], lab_all[t], k)
                 ev = torch.cuda.Event()
                 ev.record(self.s_last)
                 done[par] = ev
