@@ -170,63 +170,68 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) acc[b][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    // stage dy (all Cdy channels: rows_in x Cdy) once
-    {
-        const int q4 = Cdy / 4;
-        for (int i = tid; i < p.rows_in * q4; i += 512) {
-            const int r = i / q4, c = (i - r * q4) * 4;
-            *(f32x4v*)(lds + r * RS + c) = *(const f32x4v*)(actg + (long long)r * p.lda + c);
-        }
-    }
-    __syncthreads();
-    const int gpt = Cdy / 16;                       // k16 groups (16 co each) per tap
+    // dy is staged in channel slices of CS = p.CS reduction channels (LDS footprint rows x (CS+8) x 4 B: 47 KB at CS = 256
+    // leaves room for the other stream's workgroups on the CU; one 92 KB slice does not)
+    const int CS = p.CS;
+    const int gpt = CS / 16;                        // k16 groups (16 co each) per tap and slice
     const int n_groups = taps * gpt;
     constexpr int U = 4;                            // groups per chunk: 4 groups x 4 steps = 16 loads of 8 B in flight
     f32x2v a_cur[U][4], a_nxt[U][4];
-    auto load_chunk = [&](int q0, f32x2v (*dst)[4]) {
-        const int tap = q0 / gpt;
-        const int cg0 = q0 - tap * gpt;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int co = (cg0 + u) * 16 + 4 * kq + t;
-                dst[u][t] = __builtin_nontemporal_load((const f32x2v*)(wbase + (long long)co * co_stride + (long long)tap * Cdx));
+    for (int sl = 0; sl < Cdy / CS; ++sl) {
+        __syncthreads();
+        {
+            const int q4 = CS / 4;
+            for (int i = tid; i < p.rows_in * q4; i += 512) {
+                const int r = i / q4, c = (i - r * q4) * 4;
+                *(f32x4v*)(lds + r * RS + c) = *(const f32x4v*)(actg + (long long)r * p.lda + sl * CS + c);
             }
-    };
-    load_chunk(0, a_cur);
-    for (int q0 = 0; q0 < n_groups; q0 += U) {
-        if (q0 + U < n_groups) load_chunk(q0 + U, a_nxt);
-        const int tap = q0 / gpt;
-        const int cg0 = q0 - tap * gpt;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        int boff[3];
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
-            const int ih = n_h[nb] + p.pad - kh, iw = n_w[nb] + p.pad - kw;     // dy pixel feeding dx(h,w) through tap (kh,kw)
-            const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 4 * kq + cg0 * 16 : -1;
         }
+        __syncthreads();
+        auto load_chunk = [&](int q0, f32x2v (*dst)[4]) {
+            const int tap = q0 / gpt;
+            const int cg0 = q0 - tap * gpt;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            f32x4v b4[3];
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int co = sl * CS + (cg0 + u) * 16 + 4 * kq + t;
+                    dst[u][t] = __builtin_nontemporal_load((const f32x2v*)(wbase + (long long)co * co_stride + (long long)tap * Cdx));
+                }
+        };
+        load_chunk(0, a_cur);
+        for (int q0 = 0; q0 < n_groups; q0 += U) {
+            if (q0 + U < n_groups) load_chunk(q0 + U, a_nxt);
+            const int tap = q0 / gpt;
+            const int cg0 = q0 - tap * gpt;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            int boff[3];
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
-                b4[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-                if (boff[nb] >= 0) b4[nb] = *(const f32x4v*)(lds + boff[nb] + u * 16);
+                const int ih = n_h[nb] + p.pad - kh, iw = n_w[nb] + p.pad - kw;     // dy pixel feeding dx(h,w) through tap (kh,kw)
+                const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 4 * kq + cg0 * 16 : -1;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int u = 0; u < U; ++u) {
+                f32x4v b4[3];
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int nb = 0; nb < 3; ++nb) {
+                    b4[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if (boff[nb] >= 0) b4[nb] = *(const f32x4v*)(lds + boff[nb] + u * 16);
+                }
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb)
-                        acc[b][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][t][b], b4[nb][t], acc[b][nb], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+                            acc[b][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][t][b], b4[nb][t], acc[b][nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a_cur[u][t] = a_nxt[u][t];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a_cur[u][t] = a_nxt[u][t];
     }
     // D[i][j]: i = 4*kq + e -> M row -> ci = ci0 + 2*i + b ; j = m -> pixel
     float* outg = p.out + (long long)g * p.rows_out * p.ldo;
@@ -243,6 +248,8 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
     }
 }
 
+int g_skinny_dgrad_slices = 1;   // reduction-channel slices of the data-gradient kernel (mft_debug_set_conv_tile(6000 + n))
+
 int pick_slice(int rows_in, int Cin) {
     for (int cs = Cin; cs >= 128; cs /= 2) {
         if (cs % 128 != 0 || Cin % cs != 0) continue;
@@ -252,6 +259,8 @@ int pick_slice(int rows_in, int Cin) {
 }
 
 }  // namespace
+
+void mft_skinny_set_dgrad_slices(int n) { g_skinny_dgrad_slices = n; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
 int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
@@ -291,13 +300,15 @@ int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* d
     if (2 * pad != KH - 1 || 2 * pad != KW - 1) return MFT_EINVAL;
     const int rows = imgs_per_group * H * W;
     if (rows > 48 || Cin % 256 != 0 || Cout % 64 != 0 || ldy % 4 != 0 || ldx % 4 != 0) return MFT_EINVAL;
-    if ((long long)rows * (Cout + SK_PADF) * 4 > 100 * 1024) return MFT_EINVAL;
+    int cs = Cout;
+    if (g_skinny_dgrad_slices > 1 && Cout % (64 * g_skinny_dgrad_slices) == 0) cs = Cout / g_skinny_dgrad_slices;
+    if ((long long)rows * (cs + SK_PADF) * 4 > 100 * 1024) return MFT_EINVAL;
     SkinnyArgs p;
     p.act = dy; p.w = w; p.out = dx; p.lda = ldy; p.ldo = ldx;
     p.H = H; p.W = W; p.Cin = Cout; p.OH = H; p.OW = W; p.Cout = Cin; p.KH = KH; p.KW = KW; p.stride = 1; p.pad = pad;
     p.ipg = imgs_per_group; p.rows_in = rows; p.rows_out = rows; p.wgs = w_group_stride;
-    p.K = KH * KW * Cin; p.CS = Cout;
-    const size_t lds = (size_t)rows * (Cout + SK_PADF) * sizeof(float);
+    p.K = KH * KW * Cin; p.CS = cs;
+    const size_t lds = (size_t)rows * (cs + SK_PADF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

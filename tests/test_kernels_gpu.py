@@ -384,10 +384,11 @@ def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, i
             F.conv2d(xi, w[g].double(), None, 1, pad).backward(dy[g * ipg:(g + 1) * ipg].double())
             refs.append(xi.grad)
         refd = torch.cat(refs)
-        for mode in (3000, 3001):
+        for mode in (3000, 3001, 6002):               # generic tiles, skinny kernel, skinny kernel with two LDS slices
             _lib.lib().mft_debug_set_conv_tile(mode)
             dx = nchw(ops.conv2d_dgrad(dyg, wpk, Cin, k, k, pad, imgs_per_group=ipg).cpu()).double()
             assert float((dx - refd).abs().max()) <= 2e-5 * max(float(refd.abs().max()), 1.0), (name, mode)
+        _lib.lib().mft_debug_set_conv_tile(6001)
         _lib.lib().mft_debug_set_conv_tile(3001)
 
 
