@@ -94,6 +94,13 @@ def lib():
             raise RuntimeError(
                 "libmft_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "this package has no CPU or PyTorch fallback" % LIB_PATH)
+        # Load order matters on this stack: the library's static initialisers register its code objects with the HIP runtime
+        # (the one PyTorch already loaded, same SONAME); if that happens before PyTorch has initialised the device, every
+        # later launch from this library fails with hipErrorNoDevice.  So bring the device up through PyTorch first.
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.empty(1, device="cuda")
         h = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
