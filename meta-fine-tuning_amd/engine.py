@@ -58,6 +58,7 @@ class FinetuneEngine:
         if self.use_graph:
             pipeline = False
         self._graphs = {}
+        self._alt = None
         if not torch.cuda.is_available():
             raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
         self.dev = torch.device(device)
@@ -305,21 +306,26 @@ class FinetuneEngine:
         cur.wait_stream(self.s_trunk)
         cur.wait_stream(self.s_last)
 
-    def final_scores(self):
+    def final_scores(self, arena=None):
         """finetune.py:306-317: transductive feature pass over all n_way*(n_support+n_query) images, then
         GnnNet.set_forward(is_feature=True) and softmax.  (finetune.py:307's second pass is dead compute.)"""
-        feats = Fn.resnet10_forward(self.W, self.Xall, self.arena, ipg=self.n_all, slab=self.adapt.w, tag="fin")
+        if arena is not None:
+            return self._final_scores(arena)
+        return self._final_scores(self.arena)
+
+    def _final_scores(self, arena):
+        feats = Fn.resnet10_forward(self.W, self.Xall, arena, ipg=self.n_all, slab=self.adapt.w, tag="fin")
         if self.mode == "linear":
             # finetune.py:165-174: features of cat(support, query) in one train-mode pass (BatchNorm statistics over all
             # n_all images are order independent), classifier + softmax on the query rows (class-major)
-            sc = self.arena.get("lin.scores", (self.E * self.n_all, self.n_way))
+            sc = arena.get("lin.scores", (self.E * self.n_all, self.n_way))
             rc = ops._lib.lib().mft_linear_head_scores(ops._p(feats), 512, self.n_all, self.E, self.n_way, 512,
                                                        ops._p(self.cls["W"]), ops._p(self.cls["b"]), ops._p(sc), ops._stream())
             ops._lib.check(rc, "mft_linear_head_scores")
             sc = sc.view(self.E, self.n_way, self.n_support + self.n_query, self.n_way)[:, :, self.n_support:]
             return sc.reshape(self.E, self.n_way * self.n_query, self.n_way), feats
         ns = self.n_support // 2 if self.fold50 else self.n_support
-        scores = Fn.gnnnet_scores(self.G, feats, self.E, self.n_way, ns, self.n_query, self.arena, fold=self.fold50)
+        scores = Fn.gnnnet_scores(self.G, feats, self.E, self.n_way, ns, self.n_query, arena, fold=self.fold50)
         return ops.softmax_rows(scores).view(self.E, self.n_way * self.n_query, self.n_way), feats
 
     def set_classifier(self, w0, b0, n_active):
@@ -333,12 +339,33 @@ class FinetuneEngine:
         c["W"].copy_(w0[idx])
         c["b"].copy_(b0[idx])
 
-    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False):
+    def _flip_buffers(self):
+        """Deferred final pass: the adapted weights and final-pass images of batch i must survive while batch i+1 is ingested
+        and adapted, so both live in two alternating buffers (m, v, g are only used inside the inner loop and stay single)."""
+        if self._alt is None:
+            self._alt = [(self.adapt.w, self.Xall),
+                         (Fn.LastBlockSlab(self.E, self.dev, zero=False), torch.empty_like(self.Xall))]
+            self._final_done = [None, None]
+            self._bi = 0
+            self.arena_final = Fn.Arena(self.dev)
+            self.s_final = torch.cuda.Stream(device=self.dev)
+        self._bi ^= 1
+        self.adapt.w, self.Xall = self._alt[self._bi]
+        if self._final_done[self._bi] is not None:                 # the final pass that last read these buffers is done
+            torch.cuda.current_stream(self.dev).wait_event(self._final_done[self._bi])
+
+    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False, defer_final=False):
         """episodes: list (<= E) of liz_x -- or, with ``sources=True``, of (src_u8, view_params) pairs for device-side view
         generation; perms: per-episode list of per-epoch permutations (default: drawn from the global numpy RNG episode by
-        episode, exactly the reference's draw order).  Returns softmax scores [len(episodes), n_way*n_query, n_way]."""
+        episode, exactly the reference's draw order).  Returns softmax scores [len(episodes), n_way*n_query, n_way].
+        ``defer_final``: enqueue the final 100-image pass + GNN head on a third stream and return at once, so that it
+        overlaps the ingest / stem cache / first inner steps of the NEXT run_batch call (the returned scores are valid
+        after a device synchronisation or ``engine.s_final.synchronize()``)."""
         n = len(episodes)
         assert 0 < n <= self.E
+        defer_final = defer_final and self.mode == "gnn" and not self.use_graph and not return_feats
+        if defer_final:
+            self._flip_buffers()
         if perms is None:
             perms = [draw_perms(self.n_total, self.epochs) for _ in range(n)]
         for slot in range(self.E):
@@ -355,6 +382,15 @@ class FinetuneEngine:
             self.set_classifier(classifier_init[0], classifier_init[1], n)
         self.prepare_batch()
         self.inner_loop(self.step_tables(perms, n))
+        if defer_final:
+            cur = torch.cuda.current_stream(self.dev)
+            self.s_final.wait_stream(cur)
+            with torch.cuda.stream(self.s_final):
+                scores, _ = self.final_scores(arena=self.arena_final)
+                ev = torch.cuda.Event()
+                ev.record(self.s_final)
+            self._final_done[self._bi] = ev
+            return scores[:n]
         scores, feats = self.final_scores()
         if return_feats:
             return scores[:n], feats.view(self.E, self.n_all, 512)[:n]

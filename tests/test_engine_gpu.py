@@ -312,3 +312,20 @@ def test_engine_at_reference_image_size_224():
     d_ref, d_hip = np.abs(o32 - o64).max(), np.abs(sc - o64).max()
     assert d_hip <= max(4.0 * d_ref, 2e-3), (d_hip, d_ref)
     assert (sc.argmax(1) == o64.argmax(1)).mean() >= 0.96
+
+
+def test_deferred_final_pass_is_bit_identical():
+    """run_batch(defer_final=True): the final pass + GNN of batch i runs on a third stream while batch i+1 is ingested and
+    adapted (double-buffered adapted weights / final-pass images).  Three consecutive batches must give exactly the
+    synchronous results."""
+    sd = synthetic.gnnnet_state_dict(seed=51)
+    batches = [[synthetic.test_episode(1000 + 10 * b + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)] for b in range(3)]
+    rs = np.random.RandomState(19)
+    perms = [[[rs.permutation(100)] for _ in range(2)] for _ in range(3)]
+    e0 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    ref = [e0.run_batch(batches[b], perms=perms[b]).clone() for b in range(3)]
+    e1 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    got = [e1.run_batch(batches[b], perms=perms[b], defer_final=True) for b in range(3)]
+    torch.cuda.synchronize()
+    for b in range(3):
+        assert torch.equal(got[b], ref[b]), b
