@@ -229,6 +229,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the product path")
+    if world > 1:
+        torch.set_num_threads(max(1, host_threads() // world))     # W ranks share the host: no oversubscribed OpenMP pools
     if os.environ.get("MFT_BENCH_ONE_DEVICE"):          # test hook: run W ranks on one GPU (with MFT_DIST_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
