@@ -128,6 +128,108 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_kernel(SkinnyArgs p) {
     }
 }
 
+// forward, per-tap staging: for strided / wide-input layers the episode's whole activation does not fit LDS (trunk.7.C1:
+// 5 x 6 x 6 pixels x 256 channels = 184 KB), but one TAP's im2col rows do (48 x Cin floats): they are gathered into a dense
+// [48][Cin + 8] LDS tile (zero rows where the tap falls into the padding), double buffered so the gather of tap t+1
+// overlaps the MFMAs of tap t.  The weight stream is then fully sequential per output channel (K order = (tap, ci)).
+__global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int RS = p.Cin + SK_PADF;
+    const int ohw = p.OH * p.OW;
+    const int taps = p.KH * p.KW;
+    const int gpt = p.Cin / 16;
+    const int q4 = p.Cin / 4;                      // float4 per staged row
+    constexpr int NST = 3;                         // float4 slots per thread: 48 rows x (Cin <= 256)/4 <= 3072
+    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    // staging descriptors: slot k of this thread covers row sr[k], channels sc[k]..+3
+    int s_row[NST], s_c[NST], s_img[NST], s_ih0[NST], s_iw0[NST];
+    bool s_use[NST], s_rowok[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 1024;
+        s_use[k] = i < 48 * q4;
+        const int r = s_use[k] ? i / q4 : 0;
+        s_row[k] = r;
+        s_c[k] = (i - r * q4) * 4;
+        s_rowok[k] = s_use[k] && r < p.rows_out;
+        const int rr = s_rowok[k] ? r : 0;
+        const int img = rr / ohw;
+        const int rem = rr - img * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        s_img[k] = img;
+        s_ih0[k] = oh * p.stride - p.pad;
+        s_iw0[k] = ow * p.stride - p.pad;
+    }
+    f32x4v st[NST];
+    auto gather = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            const int ih = s_ih0[k] + kh, iw = s_iw0[k] + kw;
+            if (s_rowok[k] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                v = *(const f32x4v*)(actg + (long long)((s_img[k] * p.H + ih) * p.W + iw) * p.lda + s_c[k]);
+            st[k] = v;
+        }
+    };
+    auto scatter = [&](int buf) {
+        float* L = lds + buf * 48 * RS;
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+            if (s_use[k]) *(f32x4v*)(L + s_row[k] * RS + s_c[k]) = st[k];
+    };
+
+    f32x4v acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v a_cur[SK_U], a_nxt[SK_U];
+    auto load_chunk = [&](int q0, f32x4v* dst) {
+#pragma unroll
+        for (int u = 0; u < SK_U; ++u) dst[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + u) * 16));
+    };
+    const int n_groups = taps * gpt;               // weights of one output channel are contiguous over (tap, ci)
+    gather(0);
+    scatter(0);
+    load_chunk(0, a_cur);
+    __syncthreads();
+    for (int tap = 0; tap < taps; ++tap) {
+        if (tap + 1 < taps) gather(tap + 1);
+        const float* L = lds + (tap & 1) * 48 * RS + 4 * kq;
+        for (int cg0 = 0; cg0 < gpt; cg0 += SK_U) {
+            const int q0 = tap * gpt + cg0;
+            if (q0 + SK_U < n_groups) load_chunk(q0 + SK_U, a_nxt);
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u) {
+                f32x4v b4[3];
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) b4[nb] = *(const f32x4v*)(L + (nb * 16 + m) * RS + (cg0 + u) * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][t], b4[nb][t], acc[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < SK_U; ++u) a_cur[u] = a_nxt[u];
+        }
+        if (tap + 1 < taps) scatter((tap + 1) & 1);
+        __syncthreads();
+    }
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro < p.rows_out) *(f32x4v*)(outg + (long long)ro * p.ldo + co0 + 4 * kq) = acc[nb];
+    }
+}
+
 // data gradient of a stride-1 convolution: dx[pix][ci] = sum_{tap,co} dy[pix + pad - (kh,kw)][co] * w[co][tap][ci]
 // Weights are read in their forward layout; a lane loads 8 bytes (2 consecutive ci) of row co(kq,t): M index = ci,
 // two 16-wide M blocks per wave with the interleaved assignment ci = ci0 + 2*m + b.
@@ -248,6 +350,7 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
     }
 }
 
+int g_skinny_tap = 1;            // per-tap staged forward for shapes whose activation exceeds LDS (mft_debug_set_conv_tile(7000/7001))
 int g_skinny_dgrad_slices = 1;   // reduction-channel slices of the data-gradient kernel (mft_debug_set_conv_tile(6000 + n))
 
 int pick_slice(int rows_in, int Cin) {
@@ -261,6 +364,7 @@ int pick_slice(int rows_in, int Cin) {
 }  // namespace
 
 void mft_skinny_set_dgrad_slices(int n) { g_skinny_dgrad_slices = n; }
+void mft_skinny_set_tap(int v) { g_skinny_tap = v; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
 int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
@@ -271,14 +375,26 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
     const int rows_out = imgs_per_group * OH * OW, rows_in = imgs_per_group * H * W;
     if (rows_out > 48 || Cout % 256 != 0 || Cin % 128 != 0 || ldi % 4 != 0 || ldo % 4 != 0) return MFT_EINVAL;
     const int cs = pick_slice(rows_in, Cin);
-    // measured (tools/conv_tune.py, E=128): with the whole activation resident (one slice: trunk.7.C2) the skinny kernel
-    // streams weights at 4.1 TB/s vs 3.1 for the generic tiles; sliced shapes (C1, shortcut: 180 input pixels) are slower.
-    if (cs != Cin || KH * KW == 1) return MFT_EINVAL;
     SkinnyArgs p;
     p.act = in; p.w = w; p.out = out; p.lda = ldi; p.ldo = ldo;
     p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.ipg = imgs_per_group; p.rows_in = rows_in; p.rows_out = rows_out; p.wgs = w_group_stride;
     p.K = KH * KW * Cin; p.CS = cs;
+    dim3 grid(Cout / 256, n_img / imgs_per_group, 1);
+    if (cs != Cin) {
+        // the whole activation does not fit one LDS slice (trunk.7.C1 / shortcut: 180 input pixels): per-tap staging
+        if (Cin > 256 || Cin % (16 * SK_U) != 0 || g_skinny_tap == 0) return MFT_EINVAL;
+        const size_t lds_t = (size_t)2 * 48 * (Cin + SK_PADF) * sizeof(float);
+        static bool attr_t = false;
+        if (!attr_t) {
+            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_tap_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_t = true;
+        }
+        hipLaunchKernelGGL(skinny_conv_fwd_tap_kernel, grid, dim3(1024), lds_t, s, p);
+        return mft_launch_status();
+    }
     const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -287,7 +403,6 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    dim3 grid(Cout / 256, n_img / imgs_per_group, 1);
     hipLaunchKernelGGL(skinny_conv_fwd_kernel, grid, dim3(1024), lds, s, p);
     return mft_launch_status();
 }
