@@ -72,8 +72,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
-    const int nt = blockIdx.x % p.tiles_n;
-    const int mt = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order for single-group launches (see csrc/conv_x3.hip): workgroup ids are dealt round-robin to the 8
+    // XCDs; give each XCD one contiguous range of tiles (n fastest) so that operand re-use stays inside one L2
+    int tile_id = blockIdx.x;
+    if (gridDim.y == 1) {
+        const int nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7;
+        const int xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = xcd * q + (xcd < rmd ? xcd : rmd) + slot;
+    }
+    const int nt = tile_id % p.tiles_n;
+    const int mt = tile_id / p.tiles_n;
     const int g = blockIdx.y;
     const int m0 = mt * BM, n0 = nt * BN;
 

@@ -33,6 +33,7 @@ struct X3Args {
     int M;                         // n_img * OH * OW
     int tiles_n;
     unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
+    int xcd_swizzle;
 };
 
 constexpr int X3_RS = 40;          // bf16 per LDS row: 32 data + 8 pad (80 B)
@@ -77,8 +78,19 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int nt = blockIdx.x % p.tiles_n;
-    const int mt = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  With the
+    // natural order the n-tiles of one m-tile (which read the SAME im2col rows) and neighbouring m-tiles (which share
+    // halo rows) land on different XCDs and every L2 fetches the activation separately -- PMC showed ~6x the input size
+    // in fabric reads.  Remap: XCD x works through one contiguous range of tiles (n fastest), so operand re-use stays
+    // inside one L2.
+    int tile_id = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7;
+        const int xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = xcd * q + (xcd < rmd ? xcd : rmd) + slot;
+    }
+    const int nt = tile_id % p.tiles_n;
+    const int mt = tile_id / p.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int lrow = tid >> 3;
@@ -222,12 +234,14 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
 template <int BM, int BN>
 int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
+    p.xcd_swizzle = g_x3_xcd;
     size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     auto kern = conv_x3_kernel<BM, BN>;
@@ -435,6 +449,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 20) g_x3_xcd = t - 20;
     else if (t >= 10) g_x3_patch = t - 10;
     else g_x3_tile = t;
     return 0;
