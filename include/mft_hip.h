@@ -77,6 +77,14 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
 int mft_split_bf16x3(const float* w, unsigned short* planes, long long n, void* stream);
 int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
                        int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* mft_conv2d_nhwc_x3 with the statistics of the train-mode BatchNorm that follows it (backbone.py:224-227) produced in the
+ * epilogue: per-tile (sum, sum of squares) of the <= 2 groups a 128-row tile touches go to stats_ws
+ * (mft_conv2d_x3_stats_ws_floats floats), then mean/rstd [n_groups, Cout] are merged per group with Chan's formula in tile
+ * order.  Groups = imgs_per_group consecutive images; needs imgs_per_group*OH*OW >= 128.  Replaces conv + mft_bn_stats.      */
+long long mft_conv2d_x3_stats_ws_floats(int n_img, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
+                               int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd, void* stream);
 int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 2: 128x128 */
 
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mft_split_bf16x3": [_P, _P, _L, _P],
     "mft_conv2d_nhwc_x3": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mft_debug_set_x3_tile": [_I],
+    "mft_conv2d_x3_stats_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "mft_conv2d_nhwc_x3_bnstats": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_conv2d_dgrad_nhwc": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_conv2d_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
@@ -81,7 +83,7 @@ SIGNATURES = {
     "mft_build_graph_nodes_backward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L}
+_RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L}
 
 _lib = None
 

@@ -34,6 +34,8 @@ struct X3Args {
     int tiles_n;
     unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
     int xcd_swizzle;
+    float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
+    int rows_per_group;            // >= BM when stats_ws is set
 };
 
 constexpr int X3_RS = 40;          // bf16 per LDS row: 32 data + 8 pad (80 B)
@@ -217,6 +219,79 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
             }
         }
+    // Fused BatchNorm statistics (the consumer of every trunk convolution is a train-mode BatchNorm, backbone.py:224-227):
+    // the tile is still in registers, so its per-channel (sum x, sum x^2) cost no memory traffic -- the separate statistics
+    // pass re-read every convolution output (1.1 GB per lockstep step at E = 128).  A tile of BM <= rows_per_group rows
+    // touches at most two groups: segment 0 = rows of the group the tile starts in, segment 1 = rows of the next group.
+    // Partials are combined by x3_stats_finalize_kernel with Chan's formula in a fixed order (deterministic).
+    if (p.stats_ws != nullptr) {
+        static_assert(TN == 1 || TN == 2, "stats epilogue");
+        const int split = (m0 / p.rows_per_group + 1) * p.rows_per_group;     // first row of the next group
+        float* sred = reinterpret_cast<float*>(smem);                         // [2 wm][2 wn][TN][32 r][4]
+        __syncthreads();                                                      // all fragment reads of the last K-step are done
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[i][j][e];
+                    if (m < p.M) {
+                        if (m < split) { a1 += v; a2 += v * v; }
+                        else { b1 += v; b2 += v * v; }
+                    }
+                }
+            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+            b1 += __shfl_xor(b1, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+            if (h == 0) {
+                float* o = sred + ((((wm * 2 + wn) * TN + j) * 32 + r) << 2);
+                o[0] = a1; o[1] = a2; o[2] = b1; o[3] = b2;
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && h == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* o0 = sred + ((((0 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const float* o1 = sred + ((((1 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const int n = n0 + wn * (BN / 2) + j * 32 + r;
+                float* w0 = p.stats_ws + (((long long)mt * 2 + 0) * p.Cout + n) * 2;
+                float* w1 = p.stats_ws + (((long long)mt * 2 + 1) * p.Cout + n) * 2;
+                w0[0] = o0[0] + o1[0]; w0[1] = o0[1] + o1[1];
+                w1[0] = o0[2] + o1[2]; w1[1] = o0[3] + o1[3];
+            }
+        }
+    }
+}
+
+// mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
+// (n_t, mean_t = s1/n_t, M2_t = s2 - s1^2/n_t) are merged in tile order with Chan's update.
+__global__ void x3_stats_finalize_kernel(const float* __restrict__ ws, int C, int M, int R, int BM, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= C) return;
+    const int r0 = g * R, r1 = min(r0 + R, M);
+    const int t0 = r0 / BM, t1 = (r1 - 1) / BM;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int t = t0; t <= t1; ++t) {
+        const int lo = max(t * BM, r0), hi = min(t * BM + BM, r1);
+        const float nt = (float)(hi - lo);
+        const int seg = ((t * BM) / R == g) ? 0 : 1;
+        const float* o = ws + (((long long)t * 2 + seg) * C + c) * 2;
+        const float s1 = o[0], s2 = o[1];
+        const float mt = s1 / nt;
+        const float m2t = fmaxf(s2 - s1 * mt, 0.f);
+        const float tot = n + nt;
+        const float d = mt - mu;
+        m2 += m2t + d * d * (n * nt / tot);
+        mu += d * (nt / tot);
+        n = tot;
+    }
+    mean[(long long)g * C + c] = mu;
+    rstd[(long long)g * C + c] = 1.0f / sqrtf(m2 / n + eps);
 }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
@@ -455,11 +530,13 @@ extern "C" int mft_debug_set_x3_tile(int t) {
     return 0;
 }
 
-extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out,
-                                  int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                                  int pad, void* stream) {
+static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
+                       int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* stats_ws,
+                       int rows_per_group, void* stream) {
     if (n_img <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || ldi % 4 != 0) return MFT_EINVAL;
     X3Args p;
+    p.stats_ws = stats_ws;
+    p.rows_per_group = rows_per_group;
     p.in = in; p.w3 = w3; p.plane = plane_elems; p.out = out; p.ldi = ldi; p.ldo = ldo;
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.OH = (H + 2 * pad - KH) / stride + 1;
@@ -472,7 +549,7 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
     hipStream_t s = (hipStream_t)stream;
     int G = 0, R = 0;
     double eff = 0.0;
-    if (g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
+    if (stats_ws == nullptr && g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
         patch_geometry(H, W, &G, &R, &eff) && (g_x3_patch >= 2 || eff >= 0.9)) {
         P3Args q;
         q.in = in; q.w3 = w3; q.plane = plane_elems; q.out = out;
@@ -500,6 +577,8 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
     const long long img_bytes = (long long)H * W * ldi * 4;
     const long long max_imgs = 0x7fff0000LL / img_bytes;
     if (max_imgs < 1 || 3 * plane_elems * 2 >= 0x7fff0000LL) return MFT_EINVAL;
+    if (stats_ws != nullptr && (max_imgs < n_img || rows_per_group < 128)) return MFT_EINVAL;   // tile numbering needs one launch
+    if (stats_ws != nullptr) tile = 1;
     for (long long i0 = 0; i0 < n_img; i0 += max_imgs) {
         const long long ni = (n_img - i0 < max_imgs) ? (n_img - i0) : max_imgs;
         X3Args q = p;
@@ -511,4 +590,31 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
         if (rc != 0) return rc;
     }
     return 0;
+}
+
+extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out,
+                                  int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                  int pad, void* stream) {
+    return x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, 0, stream);
+}
+
+extern "C" long long mft_conv2d_x3_stats_ws_floats(int n_img, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+    const long long OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    return ((long long)n_img * OH * OW + 127) / 128 * 2 * Cout * 2;
+}
+
+extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems,
+                                          float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                                          int stride, int pad, int imgs_per_group, float eps, float* stats_ws,
+                                          float* mean, float* rstd, void* stream) {
+    if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || stats_ws == nullptr) return MFT_EINVAL;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const int R = imgs_per_group * OH * OW;
+    const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, stats_ws, R,
+                               stream);
+    if (rc != 0) return rc;
+    const int groups = n_img / imgs_per_group;
+    hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, groups), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)stats_ws, Cout, n_img * OH * OW, R, 128, eps, mean, rstd);
+    return mft_launch_status();
 }

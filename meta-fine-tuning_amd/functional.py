@@ -8,9 +8,13 @@ Reference call sites restated: backbone.ResNet.forward / SimpleBlock.forward
 gnnnet.py:168-177), gnn.GNN_nl / Wcompute / Gconv (gnn.py:16-166), GnnNet.fc and forward_gnn
 (gnnnet.py:30,82-87,210-217).
 """
+import os
+
 import torch
 
 from . import ops
+
+X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm statistics from the bf16x3 convolution epilogue
 
 STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
 
@@ -280,17 +284,32 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
             tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out,
                         pooled=pooled is not None)
         return out
-    c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
-    m1, s1 = _bn_stats4(arena, tag + ".bn1", c1, ipg, groups, run(p + ".BN1"), fix(p + ".BN1"))
+    # frozen shared-weight blocks on the bf16x3 kernels: the statistics of the BatchNorm behind each convolution come out
+    # of the convolution's own epilogue (no separate pass over its output)
+    fuse_stats = (slab is None and running is None and fixed is None and rows >= 128 and X3_FUSED_STATS)
+
+    def conv_bn(name, bnname, inp, wpk, k, s, pd, obuf, stag):
+        if fuse_stats and (p + name) in w3:
+            H_in = inp.shape[1]
+            nws = int(ops._lib.lib().mft_conv2d_x3_stats_ws_floats(n, H_in, H_in, cout, k, k, s, pd))
+            ws = arena.get("x3.statws", (max(nws, 1 << 20),)) if nws <= (1 << 20) else arena.get(stag + ".statws", (nws,))
+            mean = arena.get(stag + ".mean", (groups, cout))
+            rstd = arena.get(stag + ".rstd", (groups, cout))
+            o, mean, rstd = ops.conv2d_x3_bnstats(inp, w3[p + name], cout, k, k, s, pd, ipg, obuf, ws, mean, rstd)
+            return o, mean, rstd
+        o = conv(name, inp, wpk, k, s, pd, obuf)
+        mm, ss_ = _bn_stats4(arena, stag, o, ipg, groups, run(p + bnname), fix(p + bnname))
+        return o, mm, ss_
+
+    c1, m1, s1 = conv_bn(".C1", ".BN1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)), tag + ".bn1")
     r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
                       out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
-    c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
-    m2, s2 = _bn_stats4(arena, tag + ".bn2", c2, ipg, groups, run(p + ".BN2"), fix(p + ".BN2"))
+    c2, m2, s2 = conv_bn(".C2", ".BN2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)), tag + ".bn2")
     out = arena.get(tag + ".out", (n * OH * OH, cout))
     sc = ms = ss = None
     if cin != cout:
-        sc = conv(".shortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)))
-        ms, ss = _bn_stats4(arena, tag + ".bns", sc, ipg, groups, run(p + ".BNshortcut"), fix(p + ".BNshortcut"))
+        sc, ms, ss = conv_bn(".shortcut", ".BNshortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)),
+                             tag + ".bns")
         ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc.view(-1, cout),
                      res_bn=(ms, ss, gs, bs), out=out, gb_group_stride=gbs)
     else:

@@ -122,6 +122,18 @@ def conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out=None):
     return out
 
 
+def conv2d_x3_bnstats(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, eps=BN_EPS):
+    """conv2d_x3 that also returns the following train-mode BatchNorm's statistics per group of ``imgs_per_group`` images
+    (computed from the output tiles while they are still in registers).  ``ws``: >= mft_conv2d_x3_stats_ws_floats floats."""
+    _f32c(x)
+    n, H, W, Cin = x.shape
+    rc = _lib.lib().mft_conv2d_nhwc_x3_bnstats(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin,
+                                               Cout, KH, KW, stride, pad, imgs_per_group, eps, _p(ws), _p(mean), _p(rstd),
+                                               _stream())
+    _lib.check(rc, "mft_conv2d_nhwc_x3_bnstats")
+    return out, mean, rstd
+
+
 def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     """out[m, :N] = a[m, :K] @ w_pk[:N, :K].T + bias.  `a` is [M, lda] with lda >= K, K % 32 == 0."""
     _f32c(a)

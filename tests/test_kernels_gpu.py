@@ -440,3 +440,29 @@ def test_fused_small_group_kernels_match_unfused(ipg):
                                 ops._p(dgb), ops._p(dbb), ops._stream()) == 0
     for a, b in ((dxa, dxa_r), (dxb, dxb_r), (dga, dga_r), (dba, dba_r), (dgb, dgb_r), (dbb, dbb_r)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H,ipg", [("trunk.4.C1", 64, 64, 3, 1, 1, 21, 5), ("trunk.5.C1", 64, 128, 3, 2, 1, 21, 5),
+                                                             ("trunk.6.C2", 256, 256, 3, 1, 1, 6, 5), ("trunk.5.sc", 64, 128, 1, 2, 0, 21, 3)])
+def test_conv_x3_fused_bn_statistics(name, Cin, Cout, k, stride, pad, H, ipg):
+    """BatchNorm statistics produced in the bf16x3 convolution epilogue (tiles straddling group boundaries, ragged last tile,
+    Chan merge) against float64 statistics of the convolution output, and the same convolution output as the plain launch."""
+    from meta_fine_tuning_amd import _lib
+    G = 7
+    n = G * ipg
+    x = nhwc(rnd((n, Cin, H, H), 41) + 0.3).to(DEV)
+    w = rnd((Cout, Cin, k, k), 42, scale=(2.0 / (k * k * Cout)) ** 0.5)
+    w3 = ops.split_weight_x3(ops.pack_conv_weight(w.to(DEV)))
+    OH = (H + 2 * pad - k) // stride + 1
+    ref_out = ops.conv2d_x3(x, w3, Cout, k, k, stride, pad)
+    out = torch.empty_like(ref_out)
+    nws = int(_lib.lib().mft_conv2d_x3_stats_ws_floats(n, H, H, Cout, k, k, stride, pad))
+    ws = torch.empty(nws, device=DEV)
+    mean, rstd = torch.empty((G, Cout), device=DEV), torch.empty((G, Cout), device=DEV)
+    ops.conv2d_x3_bnstats(x, w3, Cout, k, k, stride, pad, ipg, out, ws, mean, rstd)
+    assert torch.equal(out, ref_out)
+    o = ref_out.double().cpu().view(G, ipg * OH * OH, Cout)
+    m_ref = o.mean(1)
+    r_ref = 1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
+    assert float((mean.cpu().double() - m_ref).abs().max()) < 2e-6 * max(1.0, float(m_ref.abs().max()))
+    assert float(((rstd.cpu().double() - r_ref) / r_ref).abs().max()) < 2e-5
