@@ -140,3 +140,53 @@ def test_fused_outer_adam_matches_torch_adam():
         oa.step(); ob.step()
     for pa, pb in zip(a, b):
         assert float((pa - pb).abs().max()) < 1e-6
+
+
+def test_baselinetrain_step_matches_torch():
+    """BaselineTrain (supervised pre-training of the ensemble's baseline checkpoint, methods/baselinetrain.py:10-59): loss and
+    gradients of one mini-batch (backbone on the HIP forward/backward, classifier on the HIP GEMM kernels) against the same
+    model evaluated with PyTorch's own CPU kernels in float64 (the oracle's ResNet10 + F.linear)."""
+    import torch.nn.functional as F
+    from meta_fine_tuning_amd.methods.baselinetrain import BaselineTrain
+    from meta_fine_tuning_amd import backbone, synthetic
+    from oracle import mft_oracle as O
+    torch.manual_seed(3)
+    m = BaselineTrain(backbone.ResNet10, num_class=200).cuda()
+    sd = synthetic.resnet10_state_dict(seed=53)
+    m.feature.load_state_dict(sd)
+    m.train()
+    rs = np.random.RandomState(21)
+    x = torch.from_numpy(rs.standard_normal((16, 3, 84, 84)).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, 200, size=16))
+    loss = m.forward_loss(x, y)
+    loss.backward()
+    # float64 reference
+    fsd = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in O.clone_state(sd).items()}
+    w = m.classifier.weight.detach().cpu().double().requires_grad_(True)
+    b = m.classifier.bias.detach().cpu().double().requires_grad_(True)
+    feat = O.resnet10_forward(fsd, x.double(), "", train=True, track=False)
+    ref = F.cross_entropy(F.linear(feat, w, b), y)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4
+    assert float((m.classifier.weight.grad.cpu().double() - w.grad).abs().max()) < 2e-5 * max(1.0, float(w.grad.abs().max()))
+    assert float((m.classifier.bias.grad.cpu().double() - b.grad).abs().max()) < 2e-5
+    g_hip = m.feature.trunk[0].weight.grad.cpu().double()
+    g_ref = fsd["trunk.0.weight"].grad
+    assert float((g_hip - g_ref).abs().max()) < 3e-4 * max(1.0, float(g_ref.abs().max()))
+    assert m.top1.count == 16
+
+
+def test_train_driver_baseline_method(tmp_path, monkeypatch):
+    """`train.py --method baseline` (train.py:101-108,41-48): two epochs of 3 synthetic mini-batches through BaselineTrain,
+    checkpoints under <save_dir>/checkpoints/<dataset>/ResNet10_baseline/ with 'feature.' + 'classifier.' keys; the loss falls."""
+    from meta_fine_tuning_amd import configs, train as tr
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    torch.manual_seed(0)
+    m = tr.main(["--method", "baseline", "--model", "ResNet10", "--num_classes", "10", "--stop_epoch", "2", "--save_freq", "1"],
+                n_episode=3, size=84)
+    d = os.path.join(str(tmp_path), "checkpoints", "miniImagenet", "ResNet10_baseline")
+    ck = torch.load(os.path.join(d, "1.tar"))
+    assert ck["epoch"] == 1
+    keys = list(ck["state"].keys())
+    assert "feature.trunk.0.weight" in keys and "classifier.weight" in keys and ck["state"]["classifier.weight"].shape == (10, 512)
+    assert m.top1.count == 2 * 3 * 16
