@@ -107,3 +107,39 @@ def episode_views(src_u8, n_way, n_per_class, size, num_aug, rs):
     P = sample_view_params(rs, n_img, Hs, Ws, size, num_aug)
     v = augment_views(src_u8, P, size)
     return [v[i].view(n_way, n_per_class, size, size, 3) for i in range(2 + num_aug)], P
+
+
+class EpisodeSampler:
+    """Test-time episode source over a dataset resident in HBM (second half).
+
+    Reference semantics (datasets/EuroSAT_few_shot.py:75-124,187-205,329-351): an episode's classes are
+    ``torch.randperm(n_classes)[:n_way]`` (EpisodicBatchSampler2.generate_perm) and, per class, the first batch of a freshly
+    shuffled DataLoader over that class's images, i.e. ``n_support + n_query`` distinct random images; every image then
+    yields the 2 + num_aug views.  Here the uint8 images live on the device as ``data[n_classes, n_per_class, H, W, 3]``;
+    the draws come from ``numpy.random.RandomState(f(seed, episode index))`` (not torch's global stream), so episode i is
+    the same on every rank and for every batch size -- a documented deviation, like parallel.episode_rng."""
+
+    def __init__(self, data_u8, n_way=5, n_per_episode=20, seed=7):
+        if data_u8.dtype != torch.uint8 or data_u8.dim() != 5:
+            raise ValueError("data_u8 must be uint8 [n_classes, n_per_class, H, W, 3]")
+        self.data = data_u8
+        self.n_classes, self.n_per_class = data_u8.shape[:2]
+        if n_way > self.n_classes or n_per_episode > self.n_per_class:
+            raise ValueError("dataset too small for %d-way episodes of %d images per class" % (n_way, n_per_episode))
+        self.n_way, self.n_per_episode, self.seed = n_way, n_per_episode, seed
+
+    def indices(self, episode):
+        rs = np.random.RandomState((int(self.seed) * 1000003 + int(episode) * 7919) % (2 ** 32 - 1))
+        classes = rs.permutation(self.n_classes)[:self.n_way]
+        images = np.stack([rs.permutation(self.n_per_class)[:self.n_per_episode] for _ in range(self.n_way)])
+        return classes, images, rs
+
+    def episode(self, episode, size, num_aug):
+        """-> (src_u8 [n_way, n_per_episode, H, W, 3] on the data's device, view params [2+num_aug, n_way*n_per_episode, 10],
+        classes): exactly what FinetuneEngine.run_batch(..., sources=True) ingests."""
+        classes, images, rs = self.indices(episode)
+        ci = torch.from_numpy(np.repeat(classes, self.n_per_episode)).to(self.data.device)
+        ii = torch.from_numpy(images.reshape(-1)).to(self.data.device)
+        src = self.data[ci, ii].view(self.n_way, self.n_per_episode, *self.data.shape[2:]).contiguous()
+        P = sample_view_params(rs, self.n_way * self.n_per_episode, self.data.shape[2], self.data.shape[3], size, num_aug)
+        return src, P, classes

@@ -68,3 +68,36 @@ def test_engine_ingest_from_sources_equals_view_ingest():
     s2 = e2.run_batch([(src, P)], perms=perms, sources=True).clone()
     assert torch.equal(xs1, e2.Xs) and torch.equal(xall1, e2.Xall)
     assert torch.equal(s1, s2)
+
+
+def test_episode_sampler_contract():
+    data = torch.from_numpy(_sources(10 * 30, 16, 16, 3).reshape(10, 30, 16, 16, 3))
+    s = augment.EpisodeSampler(data, n_way=5, n_per_episode=20, seed=7)
+    c0, i0, _ = s.indices(3)
+    c1, i1, _ = s.indices(3)
+    assert np.array_equal(c0, c1) and np.array_equal(i0, i1)                      # pure function of (seed, episode)
+    assert len(set(c0.tolist())) == 5 and all(len(set(r.tolist())) == 20 for r in i0)   # distinct classes / images
+    src, P, classes = s.episode(3, 84, 2)
+    assert src.shape == (5, 20, 16, 16, 3) and src.dtype == torch.uint8 and P.shape == (4, 100, 10)
+    assert torch.equal(src[2, 7], data[int(classes[2]), int(i0[2, 7])])
+    assert not np.array_equal(s.indices(4)[1], i0)
+
+
+@pytest.mark.gpu
+def test_dataset_to_scores_end_to_end():
+    """Resident uint8 dataset -> sampled episodes -> device-side views -> fine-tune -> scores, two episodes in lockstep;
+    class-structured data, so the GNN-free sanity check is only shape/finite-ness plus determinism of a rerun."""
+    from meta_fine_tuning_amd import engine as eng, synthetic
+    rs = np.random.RandomState(5)
+    templ = rs.uniform(40, 215, size=(10, 1, 8, 8, 3))
+    data = np.clip(np.kron(templ, np.ones((1, 30, 8, 8, 1))) + rs.normal(0, 25, size=(10, 30, 64, 64, 3)), 0, 255).astype(np.uint8)
+    sampler = augment.EpisodeSampler(torch.from_numpy(data).cuda(), 5, 20, seed=7)
+    sd = synthetic.gnnnet_state_dict(seed=55)
+    perms = [[np.random.RandomState(e).permutation(125)] for e in range(2)]
+    outs = []
+    for rep in range(2):
+        e = eng.FinetuneEngine(sd, n_views=4, fine_tune_epoch=1, episodes_per_batch=2, device="cuda:0")
+        eps = [sampler.episode(i, 84, 2)[:2] for i in range(2)]
+        outs.append(e.run_batch(eps, perms=perms, sources=True).clone())
+    assert outs[0].shape == (2, 75, 5) and bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1])
