@@ -51,9 +51,9 @@ class FinetuneEngine:
         with the last block over the ORIGINAL support images only; scores = softmax(classifier(features)))."""
         assert mode in ("gnn", "linear")
         self.mode = mode
-        # ``graph``: capture one inner step (single stream) as a hipGraph and replay it for every step -- ~45 launches
-        # become 3 (index copy, label copy, replay).  For small episode batches, where the loop is launch-bound; the
-        # two-stream pipeline (default) is the better schedule once the GPU is saturated (E >= 64).
+        # ``graph``: capture one inner step (single stream) as a hipGraph and replay it for every step -- ~40 launches
+        # become 3 (index copy, label copy, replay).  Measured: no gain (a step is a chain of dependent kernels bound by
+        # per-kernel latency on the GPU, not by the host launch rate; DESIGN.md section 2); off by default.
         self.use_graph = bool(graph) and mode == "gnn" and fused_adam
         if self.use_graph:
             pipeline = False
@@ -88,9 +88,8 @@ class FinetuneEngine:
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
         self.trunk_chunk = int(os.environ.get("MFT_TRUNK_CHUNK", "1")) if trunk_chunk is None else int(trunk_chunk)
-        # The trunk's convolution workgroups are large (46-61 KB LDS, 128-226 VGPRs); next to the tens of thousands of
-        # small weight-gradient workgroups of the other stream they are starved of CU slots unless their queue has
-        # priority (measured in situ: 3.2x slower without).
+        # Queue priority for the trunk stream (its convolution workgroups are the large ones: 46 KB LDS).  Measured: no effect
+        # on this stack (4.03 vs 4.01 ms per step with / without); kept as a knob.
         prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "-1"))
         self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio) if pipeline else None
         self.s_last = torch.cuda.Stream(device=self.dev, priority=0) if pipeline else None
