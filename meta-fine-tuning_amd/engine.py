@@ -396,6 +396,10 @@ class FinetuneEngine:
         return scores[:n]
 
 
+_ADAPT_STREAMS = {}
+_ADAPT_ARENAS = {}
+
+
 def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=None):
     """The inner loop of GnnNet.set_forward_finetune (gnnnet.py:126-177) for one episode: Adam(lr=0.01) on the last
     ResNet block of a *copy* of ``feature_mod`` over ``epochs`` permutations of the support set in mini-batches of
@@ -414,23 +418,51 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
             running[name] = (m.running_mean.detach().clone(), m.running_var.detach().clone())
             nbt[name] = m.num_batches_tracked.detach().clone()
     Xs = ops.nchw_to_nhwc(x_a.contiguous().float()).view(n, -1)
-    steps = 0
+    # all index / label tables go to the device in ONE copy each before the loop: a per-step pageable host-to-device
+    # copy is stream-ordered and would drain the queue every step
+    plan, flat_idx, flat_lab = [], [], []
     for ep in range(epochs):
         rand_id = np.random.permutation(n) if perms is None else perms[ep]
         for j in range(0, n, batch_size):
             ids = np.asarray(rand_id[j:min(j + batch_size, n)])
-            k = len(ids)
-            idx = torch.from_numpy(ids.astype(np.int32)).to(dev)
-            lab = torch.from_numpy(np.asarray(y_a)[ids].astype(np.int32)).to(dev)
-            xb = ops.gather_rows(Xs, idx)
-            tape = {}
-            feat = Fn.resnet10_forward(W, xb.view(k, H, H, 3), arena, ipg=k, slab=ad.w, tape=tape, running=running,
-                                       tag="ad%d" % k)
-            _, dl = ops.cross_entropy(feat, lab, k, 1)
-            Fn.last_block_backward(tape, dl, ad.w, ad.g, arena, ipg=k, tag="adbw%d" % k)
-            ad.step += 1
-            ops.adam_step(ad.w.flat, ad.g.flat, ad.m.flat, ad.v.flat, ad.step, lr=lr)
-            steps += 1
+            plan.append((len(flat_idx), len(ids)))
+            flat_idx.extend(ids.tolist())
+            flat_lab.extend(np.asarray(y_a)[ids].tolist())
+    idx_all = torch.from_numpy(np.asarray(flat_idx, dtype=np.int32)).to(dev)
+    lab_all = torch.from_numpy(np.asarray(flat_lab, dtype=np.int32)).to(dev)
+    # frozen trunk.0-6 of step t+1 on a second stream while the last block of step t is adapted (as in FinetuneEngine)
+    cur = torch.cuda.current_stream(dev)
+    s_trunk = _ADAPT_STREAMS.get(dev)
+    if s_trunk is None:
+        s_trunk = _ADAPT_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    arena_t = _ADAPT_ARENAS.get(dev)
+    if arena_t is None:
+        arena_t = _ADAPT_ARENAS[dev] = Fn.Arena(dev)
+    s_trunk.wait_stream(cur)
+    done = [None, None]
+    steps = 0
+    for t, (off, k) in enumerate(plan):
+        idx, lab = idx_all[off:off + k], lab_all[off:off + k]
+        par = t & 1
+        with torch.cuda.stream(s_trunk):
+            if done[par] is not None:
+                s_trunk.wait_event(done[par])
+            xb = ops.gather_rows(Xs, idx, out=arena_t.get("ad.xb%d.%d" % (k, par), (k, Xs.shape[1])))
+            x6 = Fn.resnet10_trunk(W, xb.view(k, H, H, 3), arena_t, k, upto=7, running=running, tag="adt%d.%d" % (k, par))
+            ready = torch.cuda.Event()
+            ready.record(s_trunk)
+        cur.wait_event(ready)
+        tape = {}
+        feat = Fn.last_block_forward(W, x6, arena, k, slab=ad.w, tape=tape, running=running, tag="ad%d" % k)
+        ad.step += 1
+        # CE on the pooled feature fused with the pool/ReLU backward; Adam fused into the weight-gradient epilogues
+        Fn.last_block_backward(tape, None, ad.w, ad.g, arena, ipg=k, tag="adbw%d" % k,
+                               adam=(ad.m, ad.v, ad.step, lr), ce=(feat, lab, arena.get("ad.loss", (1,))))
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        done[par] = ev
+        steps += 1
+    cur.wait_stream(s_trunk)
     out = ad.w.export(0)
     for name, (rm, rv) in running.items():
         out[name + ".running_mean"] = rm

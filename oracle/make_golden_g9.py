@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--train-episodes", type=int, default=300)
     ap.add_argument("--nA", type=int, default=600)
     ap.add_argument("--nB", type=int, default=40)
+    ap.add_argument("--only", default="AB", help="which configs to (re)compute; the other one is kept from the existing file")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     mods = MG.import_reference()
@@ -72,7 +73,13 @@ def main():
     finetune.model_dict["ResNet10"] = fac
     y = np.repeat(np.arange(5), 15)
     res = {}
+    acc_path = os.path.join(MG.GOLD, "g9_accuracy.npz")
+    if os.path.exists(acc_path):
+        old = np.load(acc_path)
+        res = {k: old[k] for k in old.files if k[:4] in ("acc_", "chk_", "cfg_")}
     for tag, E, G, n in (("A", 1, 2, args.nA), ("B", 5, 17, args.nB)):
+        if tag not in args.only:
+            continue
         finetune.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=E)
         accs, chk = [], []
         np.random.seed(10)                     # finetune.py:425
