@@ -202,6 +202,15 @@ int mft_adam_step(float* p, const float* g, float* m, float* v, long long n, int
 int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_step,
                  float lr, float momentum, float dampening, float weight_decay, void* stream);
 /* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
+/* MetaTemplate.set_forward_adaptation / BaselineFinetune.set_forward (meta_template.py:153-186, baselinefinetune.py:17-58) as ONE
+ * launch: per group (episode) a Linear(D, n_way) head (W [n_groups,n_way,D], b [n_groups,n_way], updated in place) is trained on
+ * the frozen support features z_support [n_groups, n_support_rows, D] with torch.optim.SGD(lr, momentum, dampening, L2
+ * weight_decay) semantics for n_steps mini-batches; idx_table [n_groups, n_steps, batch_size] holds the support row of every
+ * mini-batch slot (-1 = empty slot of a ragged batch), y_support [n_groups, n_support_rows] the labels.                      */
+int mft_linear_head_sgd_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups, int n_support_rows,
+                            int D, int n_way, int n_steps, int batch_size, float* W, float* b, float lr, float momentum,
+                            float dampening, float weight_decay, void* stream);
+
 /* torch.optim.Adam.step over many tensors in one launch (train.py:28, meta_template.py:87): chunk_table is a DEVICE array of
  * n_chunks records {float* p; const float* g; float* m; float* v; long long n;} (40 bytes each, n <= 65536 elements; 16-byte aligned chunks take the float4 path).        */
 int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_linear_head_sgd_run": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _P],
     "mft_adam_multi": [_P, _I, _I, _F, _F, _F, _F, _F, _P],
     "mft_adam_hyper_advance": [_P, _P, _F, _F, _F, _P],
     "mft_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],

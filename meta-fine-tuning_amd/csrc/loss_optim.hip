@@ -451,3 +451,94 @@ extern "C" int mft_adam_multi(const void* chunk_table, int n_chunks, int step, f
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
     return mft_launch_status();
 }
+
+// ------------------------------------------------------------------------------- linear-head SGD adaptation, whole run
+// MetaTemplate.set_forward_adaptation / BaselineFinetune.set_forward (meta_template.py:153-186, baselinefinetune.py:17-58):
+// a fresh Linear(D, n_way) trained on the frozen support features with SGD(lr .01, momentum .9, dampening .9,
+// weight_decay .001) for 100 epochs of mini-batches of 4 -- 700 dependent steps of ~10 kFLOP each.  One workgroup per
+// episode keeps the support features, W, b and the momentum buffers in LDS / registers and runs ALL steps in one launch.
+namespace {
+__global__ __launch_bounds__(256) void linear_head_sgd_kernel(const float* __restrict__ z, const int* __restrict__ y,
+                                                              const int* __restrict__ idx, int S, int D, int n_way, int T,
+                                                              int bs, float* __restrict__ W, float* __restrict__ b, float lr,
+                                                              float mom, float damp, float wd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* zs = sm;                              // [S][D]
+    float* Ws = zs + S * D;                      // [n_way][D]
+    float* Bw = Ws + n_way * D;                  // momentum buffer of W
+    float* sl = Bw + n_way * D;                  // logits / dlogits [bs][16]
+    __shared__ float bsm[16], bbuf[16];
+    for (int i = tid; i < S * D; i += 256) zs[i] = z[(long long)g * S * D + i];
+    for (int i = tid; i < n_way * D; i += 256) { Ws[i] = W[(long long)g * n_way * D + i]; Bw[i] = 0.f; }
+    if (tid < n_way) { bsm[tid] = b[(long long)g * n_way + tid]; bbuf[tid] = 0.f; }
+    __syncthreads();
+    const int* yg = y + (long long)g * S;
+    const int* ig = idx + (long long)g * T * bs;
+    for (int t = 0; t < T; ++t) {
+        int k = 0;
+        while (k < bs && ig[t * bs + k] >= 0) ++k;             // ragged tail: -1 padded
+        for (int pr = wave; pr < k * n_way; pr += 4) {
+            const int r = pr / n_way, c = pr - r * n_way;
+            const float* zr = zs + ig[t * bs + r] * D;
+            float s = 0.f;
+            for (int d = lane; d < D; d += 64) s += zr[d] * Ws[c * D + d];
+            s = wave_sum(s);
+            if (lane == 0) sl[r * 16 + c] = s + bsm[c];
+        }
+        __syncthreads();
+        if (tid < k) {
+            const int r = tid;
+            float mx = -3.4e38f;
+            for (int c = 0; c < n_way; ++c) mx = fmaxf(mx, sl[r * 16 + c]);
+            float se = 0.f;
+            for (int c = 0; c < n_way; ++c) se += __expf(sl[r * 16 + c] - mx);
+            const float lse = mx + __logf(se);
+            const int yy = yg[ig[t * bs + r]];
+            const float inv = 1.f / (float)k;
+            for (int c = 0; c < n_way; ++c) sl[r * 16 + c] = (__expf(sl[r * 16 + c] - lse) - (c == yy ? 1.f : 0.f)) * inv;
+        }
+        __syncthreads();
+        for (int i = tid; i < n_way * D; i += 256) {
+            const int c = i / D, d = i - c * D;
+            float gr = 0.f;
+            for (int r = 0; r < k; ++r) gr += sl[r * 16 + c] * zs[ig[t * bs + r] * D + d];
+            const float w = Ws[i];
+            gr += wd * w;
+            const float bu = (t == 0) ? gr : mom * Bw[i] + (1.f - damp) * gr;
+            Bw[i] = bu;
+            Ws[i] = w - lr * bu;
+        }
+        if (tid < n_way) {
+            float gr = 0.f;
+            for (int r = 0; r < k; ++r) gr += sl[r * 16 + tid];
+            const float w = bsm[tid];
+            gr += wd * w;
+            const float bu = (t == 0) ? gr : mom * bbuf[tid] + (1.f - damp) * gr;
+            bbuf[tid] = bu;
+            bsm[tid] = w - lr * bu;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n_way * D; i += 256) W[(long long)g * n_way * D + i] = Ws[i];
+    if (tid < n_way) b[(long long)g * n_way + tid] = bsm[tid];
+}
+}  // namespace
+
+extern "C" int mft_linear_head_sgd_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups,
+                                       int n_support_rows, int D, int n_way, int n_steps, int batch_size, float* W, float* b,
+                                       float lr, float momentum, float dampening, float weight_decay, void* stream) {
+    if (n_way < 1 || n_way > 16 || batch_size < 1 || batch_size > 16 || n_steps < 1) return MFT_EINVAL;
+    const size_t lds = ((size_t)n_support_rows * D + 2 * (size_t)n_way * D + 16 * 16) * sizeof(float);
+    if (lds > 150 * 1024) return MFT_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(linear_head_sgd_kernel, dim3(n_groups), dim3(256), lds, (hipStream_t)stream, z_support, y_support,
+                       idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, momentum, dampening, weight_decay);
+    return mft_launch_status();
+}

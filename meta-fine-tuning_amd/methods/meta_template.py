@@ -111,34 +111,30 @@ class MetaTemplate(nn.Module):
 
 
 def linear_head_adapt(z_support, y_support, z_query, w, b, n_way, n_support, epochs=100, batch_size=4):
-    """SGD-with-dampening head training as HIP launches: GEMM fwd, CE fwd/bwd, GEMM wgrad, fused SGD."""
+    """SGD-with-dampening head training (meta_template.py:160-186) as ONE launch: the permutations of all epochs are drawn
+    first (same numpy stream order as the reference's per-epoch draws), uploaded as an index table, and
+    mft_linear_head_sgd_run executes the 100 x 7 dependent steps inside a single workgroup; then one GEMM scores the queries."""
     dev = z_support.device
     K = z_support.shape[1]
     assert K % 32 == 0
     support_size = n_way * n_support
-    wpad = torch.zeros((32, K), device=dev)               # rows >= n_way stay zero (N padded to the 32-wide tile)
-    wpad[:n_way] = w
-    bias = b.clone().float().contiguous()
-    bufw = torch.zeros_like(wpad[:n_way])
-    bufb = torch.zeros_like(bias)
-    first = True
+    steps = []
     for epoch in range(epochs):
         rand_id = np.random.permutation(support_size)
         for i in range(0, support_size, batch_size):
             ids = rand_id[i:min(i + batch_size, support_size)]
-            sel = torch.from_numpy(ids.astype(np.int32)).to(dev)
-            k = sel.numel()
-            zb = ops.gather_rows(z_support, sel)
-            yb = torch.from_numpy(y_support[ids]).to(dev)
-            scores = ops.gemm(zb, K, wpad[:n_way].contiguous(), n_way, bias=bias)
-            _, d = ops.cross_entropy(scores, yb, k, 1)
-            gw = small_tn(d, zb)                           # [n_way, K] = d^T @ zb
-            gb = small_tn(d, torch.ones((k, 4), device=dev))[:, 0].contiguous()
-            wv = wpad[:n_way]
-            ops.sgd_step(wv, gw, bufw, first)
-            ops.sgd_step(bias, gb, bufb, first)
-            first = False
-    return ops.gemm(z_query, K, wpad[:n_way].contiguous(), n_way, bias=bias)
+            steps.append(np.concatenate([ids, -np.ones(batch_size - len(ids), dtype=ids.dtype)]))
+    table = torch.from_numpy(np.stack(steps).astype(np.int32)).to(dev)
+    W = w.detach().clone().float().contiguous().view(1, n_way, K)
+    bias = b.detach().clone().float().contiguous().view(1, n_way)
+    y_dev = torch.from_numpy(np.asarray(y_support).astype(np.int32)).to(dev)
+    rc = ops._lib.lib().mft_linear_head_sgd_run(ops._p(z_support.contiguous()), ops._p(y_dev), ops._p(table), 1, support_size, K,
+                                                n_way, table.shape[0], batch_size, ops._p(W), ops._p(bias), 0.01, 0.9, 0.9, 0.001,
+                                                ops._stream())
+    ops._lib.check(rc, "mft_linear_head_sgd_run")
+    wpad = torch.zeros((32, K), device=dev)               # rows >= n_way stay zero (N padded to the 32-wide tile)
+    wpad[:n_way] = W[0]
+    return ops.gemm(z_query, K, wpad[:n_way].contiguous(), n_way, bias=bias[0].contiguous())
 
 
 def small_tn(a, b):
