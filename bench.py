@@ -254,6 +254,10 @@ def main():
     if os.environ.get("MFT_WGRAD_TILE"):
         from meta_fine_tuning_amd import _lib
         _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
+    for knob in os.environ.get("MFT_CONV_KNOBS", "").split(","):          # A/B hook: mft_debug_set_conv_tile codes
+        if knob.strip():
+            from meta_fine_tuning_amd import _lib
+            _lib.lib().mft_debug_set_conv_tile(int(knob))
     E = args.episodes_per_batch
     n_way, n_shot, n_query, size = 5, args.n_shot, 15, args.image_size
     if n_shot != 5 or size != 84:

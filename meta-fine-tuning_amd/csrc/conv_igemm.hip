@@ -22,6 +22,7 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
                             long long w_group_stride, hipStream_t s);   // csrc/skinny.hip
 void mft_skinny_set_dgrad_slices(int n);
 void mft_skinny_set_tap(int v);
+void mft_skinny_set_x3(int v);
 int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
                               long long w_group_stride, hipStream_t s);
@@ -642,7 +643,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 7000) mft_skinny_set_tap(tile - 7000);
+    if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
+    else if (tile >= 7000) mft_skinny_set_tap(tile - 7000);
     else if (tile >= 6000) mft_skinny_set_dgrad_slices(tile - 6000);
     else if (tile >= 5000) g_wgrad_early = tile - 5000;
     else if (tile >= 4000) g_wgrad_min_lds_kb = tile - 4000;

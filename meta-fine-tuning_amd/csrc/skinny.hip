@@ -128,6 +128,171 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_kernel(SkinnyArgs p) {
     }
 }
 
+// ---- bf16x3 forms ----------------------------------------------------------------------------------------------------------
+// At 45 pixels per episode the fp32 MFMA work of these layers (2 x 48 x 512 x 4608 FLOP per episode, 157 TFLOP/s peak) takes
+// about as long as streaming the weights (9.4 MB per episode), so the fp32 kernels above are co-limited by the matrix pipe and
+// HBM and stop at ~4 TB/s.  The x3 forms do the same product with six bf16 MFMAs per fp32-equivalent (csrc/conv_x3.hip: every
+// fp32 value is the exact sum of three bf16 pieces; the three lowest-order cross terms are dropped; error at the level of fp32
+// rounding) at 16/6 of the fp32 rate: weights are split in registers right after their load, the activations are split ONCE
+// while they are staged into three bf16 LDS planes.  K order inside a 32-element group is permuted so that a lane's eight
+// operand elements are the two float4 it already loads (k = 16*uu + 4*kq + t -> slot 8*kq + 4*uu + t).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int SK_PADH = 16;    // row padding of the bf16 planes (elements): row stride = 32 B mod 256 B like the fp32 tiles
+
+__device__ __forceinline__ unsigned sk_pk_bf16(float a, float b) {
+    f32x2s v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+
+// 4 floats -> three planes of 4 bf16 (round-to-nearest-even pieces, exact residuals); same split as csrc/conv_x3.hip
+__device__ __forceinline__ void sk_split4(const f32x4v x, u32x2v& p1, u32x2v& p2, u32x2v& p3) {
+    f32x4v r;
+    p1[0] = sk_pk_bf16(x[0], x[1]);
+    p1[1] = sk_pk_bf16(x[2], x[3]);
+    r[0] = x[0] - __builtin_bit_cast(float, p1[0] << 16);
+    r[1] = x[1] - __builtin_bit_cast(float, p1[0] & 0xffff0000u);
+    r[2] = x[2] - __builtin_bit_cast(float, p1[1] << 16);
+    r[3] = x[3] - __builtin_bit_cast(float, p1[1] & 0xffff0000u);
+    p2[0] = sk_pk_bf16(r[0], r[1]);
+    p2[1] = sk_pk_bf16(r[2], r[3]);
+    r[0] -= __builtin_bit_cast(float, p2[0] << 16);
+    r[1] -= __builtin_bit_cast(float, p2[0] & 0xffff0000u);
+    r[2] -= __builtin_bit_cast(float, p2[1] << 16);
+    r[3] -= __builtin_bit_cast(float, p2[1] & 0xffff0000u);
+    p3[0] = sk_pk_bf16(r[0], r[1]);
+    p3[1] = sk_pk_bf16(r[2], r[3]);
+}
+
+// slot of channel c (multiple of 4) inside its row of a permuted bf16 plane
+__device__ __forceinline__ int sk_perm(int c) {
+    const int kl = c & 31;
+    return (c & ~31) + ((kl & 15) >> 2) * 8 + (kl >> 4) * 4;
+}
+
+// split one staged float4 and store its pieces into the three planes (plane stride PL elements)
+__device__ __forceinline__ void sk_store3(unsigned short* L, int off, int PL, const f32x4v v) {
+    u32x2v p1, p2, p3;
+    sk_split4(v, p1, p2, p3);
+    *(u32x2v*)(L + off) = p1;
+    *(u32x2v*)(L + PL + off) = p2;
+    *(u32x2v*)(L + 2 * PL + off) = p3;
+}
+
+// two weight float4 (k16 groups u, u+1 of one lane) -> the three bf16x8 A operands
+__device__ __forceinline__ void sk_split_a(const f32x4v w0, const f32x4v w1, bf16x8 a[3]) {
+    u32x2v p0[3], p1[3];
+    sk_split4(w0, p0[0], p0[1], p0[2]);
+    sk_split4(w1, p1[0], p1[1], p1[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const u32x4v q = {p0[pl][0], p0[pl][1], p1[pl][0], p1[pl][1]};
+        a[pl] = __builtin_bit_cast(bf16x8, q);
+    }
+}
+
+// six piece products, smallest first (same order as conv_x3_kernel); weights are the A side
+#define SK_X3_MFMA(ACC, A, B)                                                              \
+    {                                                                                      \
+        constexpr int TA_[6] = {2, 0, 1, 1, 0, 0};                                         \
+        constexpr int TB_[6] = {0, 2, 1, 0, 1, 0};                                         \
+        _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_)                                   \
+            _Pragma("unroll") for (int nb_ = 0; nb_ < 3; ++nb_)                            \
+                ACC[nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA_[t_]], B[nb_][TB_[t_]], ACC[nb_], 0, 0, 0); \
+    }
+
+// forward, whole activation in LDS (trunk.7.C2: 45 input pixels x 512 channels = 3 x 46 KB of bf16 planes)
+__global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int RS = p.Cin + SK_PADH;
+    const int PL = p.rows_in * RS;
+    const int ohw = p.OH * p.OW;
+    const int gpt = p.Cin / 16;
+    const int taps = p.KH * p.KW;
+
+    int n_img[3], n_ih0[3], n_iw0[3];
+    bool n_ok[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        n_ok[nb] = ro < p.rows_out;
+        const int rr = n_ok[nb] ? ro : 0;
+        const int img = rr / ohw;
+        const int rem = rr - img * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        n_img[nb] = img;
+        n_ih0[nb] = oh * p.stride - p.pad;
+        n_iw0[nb] = ow * p.stride - p.pad;
+    }
+    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    // weights of one output channel are contiguous over (tap, ci); SK_U float4 per lane stay in flight: a register pair is
+    // re-issued for the next chunk as soon as its pieces have been split off
+    f32x4v a_cur[SK_U];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    {
+        const int q4 = p.Cin / 4;
+        for (int i = tid; i < p.rows_in * q4; i += 1024) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            sk_store3(ldh, r * RS + sk_perm(c), PL, *(const f32x4v*)(actg + (long long)r * p.lda + c));
+        }
+    }
+    __syncthreads();
+
+    f32x4v acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int n_groups = taps * gpt;               // chunks never straddle a tap (gpt % SK_U == 0)
+    for (int q0 = 0; q0 < n_groups; q0 += SK_U) {
+        const bool more = q0 + SK_U < n_groups;
+        const int tap = q0 / gpt;
+        const int cg0 = q0 - tap * gpt;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int boff[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ih = n_ih0[nb] + kh, iw = n_iw0[nb] + kw;
+            const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 8 * kq + cg0 * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SK_U; u += 2) {
+            bf16x8 a[3], b[3][3];
+            sk_split_a(a_cur[u], a_cur[u + 1], a);
+            if (more) {
+                a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u) * 16));
+                a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u + 1) * 16));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    u32x4v z = {0u, 0u, 0u, 0u};
+                    if (boff[nb] >= 0) z = *(const u32x4v*)(ldh + pl * PL + boff[nb] + u * 16);
+                    b[nb][pl] = __builtin_bit_cast(bf16x8, z);
+                }
+            SK_X3_MFMA(acc, a, b)
+        }
+    }
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro < p.rows_out) *(f32x4v*)(outg + (long long)ro * p.ldo + co0 + 4 * kq) = acc[nb];
+    }
+}
+
 // forward, per-tap staging: for strided / wide-input layers the episode's whole activation does not fit LDS (trunk.7.C1:
 // 5 x 6 x 6 pixels x 256 channels = 184 KB), but one TAP's im2col rows do (48 x Cin floats): they are gathered into a dense
 // [48][Cin + 8] LDS tile (zero rows where the tap falls into the padding), double buffered so the gather of tap t+1
@@ -350,6 +515,220 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
     }
 }
 
+// forward, per-tap staging, bf16x3 (trunk.7.C1 / shortcut): the gathered [48][Cin] im2col rows of one tap are split while
+// they are scattered into the three bf16 planes (double buffered: 2 x 3 x 48 x (Cin + 16) x 2 B = 153 KB at Cin = 256)
+__global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int RS = p.Cin + SK_PADH;
+    const int PL = 48 * RS;
+    const int ohw = p.OH * p.OW;
+    const int taps = p.KH * p.KW;
+    const int gpt = p.Cin / 16;
+    const int q4 = p.Cin / 4;
+    constexpr int NST = 3;
+    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    int s_off[NST], s_c[NST], s_img[NST], s_ih0[NST], s_iw0[NST];
+    bool s_use[NST], s_rowok[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 1024;
+        s_use[k] = i < 48 * q4;
+        const int r = s_use[k] ? i / q4 : 0;
+        s_c[k] = (i - r * q4) * 4;
+        s_off[k] = r * RS + sk_perm(s_c[k]);
+        s_rowok[k] = s_use[k] && r < p.rows_out;
+        const int rr = s_rowok[k] ? r : 0;
+        const int img = rr / ohw;
+        const int rem = rr - img * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        s_img[k] = img;
+        s_ih0[k] = oh * p.stride - p.pad;
+        s_iw0[k] = ow * p.stride - p.pad;
+    }
+    f32x4v st[NST];
+    auto gather = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            const int ih = s_ih0[k] + kh, iw = s_iw0[k] + kw;
+            if (s_rowok[k] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                v = *(const f32x4v*)(actg + (long long)((s_img[k] * p.H + ih) * p.W + iw) * p.lda + s_c[k]);
+            st[k] = v;
+        }
+    };
+    auto scatter = [&](int buf) {
+        unsigned short* L = ldh + buf * 3 * PL;
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+            if (s_use[k]) sk_store3(L, s_off[k], PL, st[k]);
+    };
+
+    f32x4v acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v a_cur[SK_U];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    const int n_groups = taps * gpt;
+    gather(0);
+    scatter(0);
+    __syncthreads();
+    for (int tap = 0; tap < taps; ++tap) {
+        if (tap + 1 < taps) gather(tap + 1);
+        const unsigned short* L = ldh + (tap & 1) * 3 * PL + 8 * kq;
+        for (int cg0 = 0; cg0 < gpt; cg0 += SK_U) {
+            const int q0 = tap * gpt + cg0;
+            const bool more = q0 + SK_U < n_groups;
+#pragma unroll
+            for (int u = 0; u < SK_U; u += 2) {
+                bf16x8 a[3], b[3][3];
+                sk_split_a(a_cur[u], a_cur[u + 1], a);
+                if (more) {
+                    a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u) * 16));
+                    a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u + 1) * 16));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[nb][pl] = __builtin_bit_cast(bf16x8, *(const u32x4v*)(L + pl * PL + (nb * 16 + m) * RS + (cg0 + u) * 16));
+                SK_X3_MFMA(acc, a, b)
+            }
+        }
+        if (tap + 1 < taps) scatter((tap + 1) & 1);
+        __syncthreads();
+    }
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro < p.rows_out) *(f32x4v*)(outg + (long long)ro * p.ldo + co0 + 4 * kq) = acc[nb];
+    }
+}
+
+// data gradient, bf16x3: dy is split once into the three LDS planes (reduction index = forward output channel, same slot
+// permutation); a lane's four 8-byte weight loads of a k16 group give it 4 consecutive reduction rows of 2 input channels.
+__global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int ci0 = blockIdx.x * 256 + wave * 32;
+    const int Cdy = p.Cin, Cdx = p.Cout;
+    const int RS = Cdy + SK_PADH;
+    const int PL = p.rows_in * RS;
+    const int hw = p.H * p.W;
+    const int taps = p.KH * p.KW;
+    const long long co_stride = (long long)taps * Cdx;
+
+    int n_img[3], n_h[3], n_w[3];
+    bool n_ok[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        n_ok[nb] = ro < p.rows_out;
+        const int rr = n_ok[nb] ? ro : 0;
+        const int img = rr / hw;
+        const int rem = rr - img * hw;
+        n_img[nb] = img;
+        n_h[nb] = rem / p.W;
+        n_w[nb] = rem - n_h[nb] * p.W;
+    }
+    const float* wbase = p.w + (long long)g * p.wgs + ci0 + 2 * m;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    constexpr int U = 4;                            // k16 groups per chunk: 16 loads of 8 B per lane in flight
+    const int gpt = Cdy / 16;
+    const int n_groups = taps * gpt;
+    f32x2v a_cur[U][4];
+    auto load_group = [&](int q, f32x2v* dst) {
+        const int tap = q / gpt;
+        const int cg = q - tap * gpt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int co = cg * 16 + 4 * kq + t;
+            dst[t] = __builtin_nontemporal_load((const f32x2v*)(wbase + (long long)co * co_stride + (long long)tap * Cdx));
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_group(u, a_cur[u]);
+    {
+        const int q4 = Cdy / 4;
+        for (int i = tid; i < p.rows_in * q4; i += 512) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            sk_store3(ldh, r * RS + sk_perm(c), PL, *(const f32x4v*)(actg + (long long)r * p.lda + c));
+        }
+    }
+    __syncthreads();
+
+    f32x4v acc[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) acc[b][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < n_groups; q0 += U) {
+        const bool more = q0 + U < n_groups;
+        const int tap = q0 / gpt;
+        const int cg0 = q0 - tap * gpt;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int boff[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ih = n_h[nb] + p.pad - kh, iw = n_w[nb] + p.pad - kw;
+            const bool ok = n_ok[nb] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            boff[nb] = ok ? ((n_img[nb] * p.H + ih) * p.W + iw) * RS + 8 * kq + cg0 * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            bf16x8 a[2][3], b[3][3];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const f32x4v w0 = {a_cur[u][0][bb], a_cur[u][1][bb], a_cur[u][2][bb], a_cur[u][3][bb]};
+                const f32x4v w1 = {a_cur[u + 1][0][bb], a_cur[u + 1][1][bb], a_cur[u + 1][2][bb], a_cur[u + 1][3][bb]};
+                sk_split_a(w0, w1, a[bb]);
+            }
+            if (more) {
+                load_group(q0 + U + u, a_cur[u]);
+                load_group(q0 + U + u + 1, a_cur[u + 1]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    u32x4v z = {0u, 0u, 0u, 0u};
+                    if (boff[nb] >= 0) z = *(const u32x4v*)(ldh + pl * PL + boff[nb] + u * 16);
+                    b[nb][pl] = __builtin_bit_cast(bf16x8, z);
+                }
+            SK_X3_MFMA(acc[0], a[0], b)
+            SK_X3_MFMA(acc[1], a[1], b)
+        }
+    }
+    float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro >= p.rows_out) continue;
+        float* o = outg + (long long)ro * p.ldo + ci0 + 8 * kq;
+        f32x4v lo, hi;
+        lo[0] = acc[0][nb][0]; lo[1] = acc[1][nb][0]; lo[2] = acc[0][nb][1]; lo[3] = acc[1][nb][1];
+        hi[0] = acc[0][nb][2]; hi[1] = acc[1][nb][2]; hi[2] = acc[0][nb][3]; hi[3] = acc[1][nb][3];
+        *(f32x4v*)(o) = lo;
+        *(f32x4v*)(o + 4) = hi;
+    }
+}
+
+int g_skinny_x3 = 1;             // bf16x3 forms of the weight-streaming kernels (mft_debug_set_conv_tile(8000/8001))
 int g_skinny_tap = 1;            // per-tap staged forward for shapes whose activation exceeds LDS (mft_debug_set_conv_tile(7000/7001))
 int g_skinny_dgrad_slices = 1;   // reduction-channel slices of the data-gradient kernel (mft_debug_set_conv_tile(6000 + n))
 
@@ -365,6 +744,7 @@ int pick_slice(int rows_in, int Cin) {
 
 void mft_skinny_set_dgrad_slices(int n) { g_skinny_dgrad_slices = n; }
 void mft_skinny_set_tap(int v) { g_skinny_tap = v; }
+void mft_skinny_set_x3(int v) { g_skinny_x3 = v; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
 int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
@@ -384,6 +764,18 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
     if (cs != Cin) {
         // the whole activation does not fit one LDS slice (trunk.7.C1 / shortcut: 180 input pixels): per-tap staging
         if (Cin > 256 || Cin % (16 * SK_U) != 0 || g_skinny_tap == 0) return MFT_EINVAL;
+        if (g_skinny_x3) {
+            const size_t lds_h = (size_t)2 * 3 * 48 * (Cin + SK_PADH) * 2;
+            static bool attr_tx = false;
+            if (!attr_tx) {
+                hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_tap_x3_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_tx = true;
+            }
+            hipLaunchKernelGGL(skinny_conv_fwd_tap_x3_kernel, grid, dim3(1024), lds_h, s, p);
+            return mft_launch_status();
+        }
         const size_t lds_t = (size_t)2 * 48 * (Cin + SK_PADF) * sizeof(float);
         static bool attr_t = false;
         if (!attr_t) {
@@ -393,6 +785,18 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
             attr_t = true;
         }
         hipLaunchKernelGGL(skinny_conv_fwd_tap_kernel, grid, dim3(1024), lds_t, s, p);
+        return mft_launch_status();
+    }
+    if (g_skinny_x3 && (size_t)3 * rows_in * (Cin + SK_PADH) * 2 <= 150 * 1024 && Cin % (16 * SK_U) == 0) {
+        const size_t lds3 = (size_t)3 * rows_in * (Cin + SK_PADH) * 2;
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_x3 = true;
+        }
+        hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel, grid, dim3(1024), lds3, s, p);
         return mft_launch_status();
     }
     const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
@@ -423,6 +827,19 @@ int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* d
     p.H = H; p.W = W; p.Cin = Cout; p.OH = H; p.OW = W; p.Cout = Cin; p.KH = KH; p.KW = KW; p.stride = 1; p.pad = pad;
     p.ipg = imgs_per_group; p.rows_in = rows; p.rows_out = rows; p.wgs = w_group_stride;
     p.K = KH * KW * Cin; p.CS = cs;
+    dim3 grid(Cin / 256, n_img / imgs_per_group, 1);
+    if (g_skinny_x3 && g_skinny_dgrad_slices <= 1 && (size_t)3 * rows * (Cout + SK_PADH) * 2 <= 150 * 1024 && Cout % 64 == 0) {
+        const size_t lds3 = (size_t)3 * rows * (Cout + SK_PADH) * 2;
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_x3 = true;
+        }
+        hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel, grid, dim3(512), lds3, s, p);
+        return mft_launch_status();
+    }
     const size_t lds = (size_t)rows * (cs + SK_PADF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -431,7 +848,6 @@ int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* d
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    dim3 grid(Cin / 256, n_img / imgs_per_group, 1);
     hipLaunchKernelGGL(skinny_conv_dgrad_kernel, grid, dim3(512), lds, s, p);
     return mft_launch_status();
 }

@@ -367,13 +367,17 @@ def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, i
     wpk = torch.stack([ops.pack_conv_weight(w[g].to(DEV)) for g in range(G)])
     ref = torch.cat([F.conv2d(x[g * ipg:(g + 1) * ipg].double(), w[g].double(), None, stride, pad) for g in range(G)])
     outs = []
-    for mode in (3000, 3001):
+    for mode in (3000, 3001, 8000):                   # generic tiles, skinny bf16x3 form (default), skinny fp32-MFMA form
         _lib.lib().mft_debug_set_conv_tile(mode)
         outs.append(nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad, imgs_per_group=ipg).cpu()).double())
     _lib.lib().mft_debug_set_conv_tile(3001)
+    _lib.lib().mft_debug_set_conv_tile(8001)
     scale = max(float(ref.abs().max()), 1.0)
-    assert float((outs[1] - ref).abs().max()) <= 2e-5 * scale, name
-    assert float((outs[0] - ref).abs().max()) <= 2e-5 * scale, name
+    e32 = float((outs[2] - ref).abs().max())
+    for o in outs:
+        assert float((o - ref).abs().max()) <= 2e-5 * scale, name
+    # the six-term bf16 product is as accurate as the fp32 matrix instruction it replaces
+    assert float((outs[1] - ref).abs().max()) <= 2.0 * e32 + 1e-7 * scale, (name, e32)
     if stride == 1:
         dy = rnd((n, Cout, H, H), 23)
         dyg = nhwc(dy).to(DEV)
@@ -384,11 +388,15 @@ def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, i
             F.conv2d(xi, w[g].double(), None, 1, pad).backward(dy[g * ipg:(g + 1) * ipg].double())
             refs.append(xi.grad)
         refd = torch.cat(refs)
-        for mode in (3000, 3001, 6002):               # generic tiles, skinny kernel, skinny kernel with two LDS slices
+        errs = {}
+        for mode in (3000, 3001, 8000, 6002):         # generic tiles, skinny x3, skinny fp32, skinny fp32 with two LDS slices
             _lib.lib().mft_debug_set_conv_tile(mode)
             dx = nchw(ops.conv2d_dgrad(dyg, wpk, Cin, k, k, pad, imgs_per_group=ipg).cpu()).double()
-            assert float((dx - refd).abs().max()) <= 2e-5 * max(float(refd.abs().max()), 1.0), (name, mode)
+            errs[mode] = float((dx - refd).abs().max())
+            assert errs[mode] <= 2e-5 * max(float(refd.abs().max()), 1.0), (name, mode)
+        assert errs[3001] <= 2.0 * errs[8000] + 1e-7 * max(float(refd.abs().max()), 1.0), (name, errs)
         _lib.lib().mft_debug_set_conv_tile(6001)
+        _lib.lib().mft_debug_set_conv_tile(8001)
         _lib.lib().mft_debug_set_conv_tile(3001)
 
 
