@@ -202,6 +202,35 @@ int mft_adam_step(float* p, const float* g, float* m, float* v, long long n, int
 int mft_sgd_step(float* p, const float* g, float* buf, long long n, int first_step,
                  float lr, float momentum, float dampening, float weight_decay, void* stream);
 /* GnnNet.MAML_update (gnnnet.py:90-103): p -= (p3 - p2) */
+/* Entry half of a down-sampling SimpleBlock for per-episode weights in one launch (backbone.py:251-256 + the shortcut of
+ * :258): c1 = C1(x) (3x3, stride, pad 1), r1 = ReLU(BatchNorm_train(c1)) with the statistics of each episode's own
+ * imgs_per_group images (mean1/rstd1 [groups, Cout] returned for the backward), sc = shortcut(x) (1x1, stride, pad 0).  Domain:
+ * <= 48 output pixels per episode, Cin <= 256 (multiple of 128), Cout multiple of 256; MFT_EINVAL outside it (callers then use
+ * mft_conv2d_nhwc + mft_bn_small_forward).                                                                                   */
+int mft_block_entry_small_forward(const float* x, int ldx, const float* w_c1, long long w1_group_stride, const float* w_sc,
+                                  long long wsc_group_stride, float* c1, float* r1, float* sc, int n_img, int H, int W, int Cin,
+                                  int Cout, int stride, int imgs_per_group, const float* gamma1, const float* beta1,
+                                  long long gb_group_stride, float* mean1, float* rstd1, float eps, void* stream);
+
+/* Exit half of the same block + ResNet's global average pool in one launch (backbone.py:256-261, :309): c2 = C2(r1) (3x3,
+ * stride 1, pad 1, C -> C), out = ReLU(BatchNorm_train(c2) + BatchNorm_train(sc)) with per-episode statistics of both branches
+ * (returned in mean2/rstd2/mean_sc/rstd_sc [groups, C]), pooled [n_img, C] = mean of out over each image's H*W pixels.
+ * MFT_EINVAL outside the per-episode kernel's domain (callers then use mft_conv2d_nhwc + mft_bn_small_forward).                */
+int mft_block_exit_small_forward(const float* r1, const float* w_c2, long long w_group_stride, const float* sc, float* c2,
+                                 float* out, float* pooled, int n_img, int H, int W, int C, int imgs_per_group,
+                                 const float* gamma2, const float* beta2, const float* gamma_sc, const float* beta_sc,
+                                 long long gb_group_stride, float* mean2, float* rstd2, float* mean_sc, float* rstd_sc, float eps,
+                                 void* stream);
+
+/* loss.backward() through C2 and the BatchNorm + ReLU in front of it (finetune.py:293 over backbone.py:253-256) in one launch:
+ * dx_conv = dgrad(dy, w) as mft_conv2d_dgrad_nhwc, then the BatchNorm/ReLU backward over each episode's rows:
+ * dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dx_conv*(relu_out > 0), xhat = (x_raw - mean)*rstd; dgamma/dbeta
+ * [groups, Cin].  Same domain as the per-episode data-gradient kernel (stride 1, "same" padding, <= 48 pixels per episode). */
+int mft_conv2d_dgrad_bn_backward_small(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                                       int Cin, int Cout, int KH, int KW, int pad, int imgs_per_group, long long w_group_stride,
+                                       const float* x_raw, const float* relu_out, const float* mean, const float* rstd,
+                                       const float* gamma, long long gb_group_stride, float* dgamma, float* dbeta, void* stream);
+
 /* MetaTemplate.set_forward_adaptation / BaselineFinetune.set_forward (meta_template.py:153-186, baselinefinetune.py:17-58) as ONE
  * launch: per group (episode) a Linear(D, n_way) head (W [n_groups,n_way,D], b [n_groups,n_way], updated in place) is trained on
  * the frozen support features z_support [n_groups, n_support_rows, D] with torch.optim.SGD(lr, momentum, dampening, L2

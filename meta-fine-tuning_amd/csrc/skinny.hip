@@ -205,8 +205,49 @@ __device__ __forceinline__ void sk_split_a(const f32x4v w0, const f32x4v w1, bf1
                 ACC[nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[TA_[t_]], B[nb_][TB_[t_]], ACC[nb_], 0, 0, 0); \
     }
 
+// sum over the 16 lanes that share a kq (the 16 pixels of one MFMA column block)
+__device__ __forceinline__ float sk_row16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// mean / rstd of 4 channels over the episode's valid pixels held as v[nb] (pixel nb*16 + m) by the 16 lanes of a kq group
+__device__ __forceinline__ void sk_stats(const f32x4v v[3], int m, int rows, float eps, f32x4v& mu, f32x4v& rs) {
+    const float inv = 1.f / (float)rows;
+    f32x4v s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+        if (nb * 16 + m < rows) s += v[nb];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mu[e] = sk_row16_sum(s[e]) * inv;
+    s = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+        if (nb * 16 + m < rows) {
+            const f32x4v d = v[nb] - mu;
+            s += d * d;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(sk_row16_sum(s[e]) * inv + eps);
+}
+
+// EXIT: second half of the residual block in the same launch (SimpleBlock.forward, backbone.py:256-261, + the AvgPool2d of
+// ResNet.forward): out = ReLU(BN2(c2) + BNshortcut(sc)) with per-episode statistics of both branches, and the global average
+// pool of `out` per image -- the wave already holds all pixels of its 16 channels.
+struct SkinnyExitArgs {
+    const float* sc;           // raw shortcut conv output [groups][rows_out][ldo]
+    float* y;                  // block output [groups][rows_out][ldo]
+    float* pooled;             // [groups][ipg][Cout]
+    const float* g2; const float* b2; const float* gs; const float* bs; long long gbs;
+    float* mean2; float* rstd2; float* means; float* rstds;
+    float eps;
+    int hw;                    // pixels per image
+};
+
 // forward, whole activation in LDS (trunk.7.C2: 45 input pixels x 512 channels = 3 x 46 KB of bf16 planes)
-__global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p) {
+template <bool EXIT>
+__global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p, SkinnyExitArgs x) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -290,6 +331,52 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p) 
     for (int nb = 0; nb < 3; ++nb) {
         const int ro = nb * 16 + m;
         if (ro < p.rows_out) *(f32x4v*)(outg + (long long)ro * p.ldo + co0 + 4 * kq) = acc[nb];
+    }
+    if constexpr (EXIT) {
+        const int co = co0 + 4 * kq;
+        const long long ob = (long long)g * p.rows_out * p.ldo;
+        f32x4v sv[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ro = nb * 16 + m;
+            sv[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (ro < p.rows_out) sv[nb] = *(const f32x4v*)(x.sc + ob + (long long)ro * p.ldo + co);
+        }
+        f32x4v m2, r2, ms, rs;
+        sk_stats(acc, m, p.rows_out, x.eps, m2, r2);
+        sk_stats(sv, m, p.rows_out, x.eps, ms, rs);
+        if (m == 0) {
+            *(f32x4v*)(x.mean2 + (long long)g * p.Cout + co) = m2;
+            *(f32x4v*)(x.rstd2 + (long long)g * p.Cout + co) = r2;
+            *(f32x4v*)(x.means + (long long)g * p.Cout + co) = ms;
+            *(f32x4v*)(x.rstds + (long long)g * p.Cout + co) = rs;
+        }
+        const f32x4v ga2 = *(const f32x4v*)(x.g2 + g * x.gbs + co), be2 = *(const f32x4v*)(x.b2 + g * x.gbs + co);
+        const f32x4v gas = *(const f32x4v*)(x.gs + g * x.gbs + co), bes = *(const f32x4v*)(x.bs + g * x.gbs + co);
+        __syncthreads();                           // every wave is done with the activation planes: reuse them for the pool
+        float* T = (float*)ldh + wave * 48 * 16;   // this wave's [48 pixels][16 channels] output tile
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ro = nb * 16 + m;
+            if (ro >= p.rows_out) continue;
+            f32x4v o = (acc[nb] - m2) * r2 * ga2 + be2;
+            o += (sv[nb] - ms) * rs * gas + bes;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            *(f32x4v*)(x.y + ob + (long long)ro * p.ldo + co) = o;
+            *(f32x4v*)(T + ro * 16 + 4 * kq) = o;
+        }
+        __syncthreads();
+        const int n_img = p.rows_out / x.hw;
+        const float invp = 1.f / (float)x.hw;
+        for (int i0 = 0; i0 < n_img; i0 += 4) {
+            const int img = i0 + (lane >> 4);
+            if (img < n_img) {
+                float sum = 0.f;
+                for (int k2 = 0; k2 < x.hw; ++k2) sum += T[(img * x.hw + k2) * 16 + m];
+                x.pooled[((long long)g * n_img + img) * p.Cout + co0 + m] = sum * invp;
+            }
+        }
     }
 }
 
@@ -614,9 +701,171 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs
     }
 }
 
+// Entry of a down-sampling residual block for one episode in ONE launch (SimpleBlock.forward, backbone.py:251-261, first
+// half): c1 = C1(x) (3x3, stride s, pad 1), r1 = ReLU(BN1(c1)) with the episode's own mini-batch statistics, and
+// sc = shortcut(x) (1x1, stride s, pad 0).  The shortcut samples exactly the pixels of C1's centre tap, so it runs as a tenth
+// "tap" pass over the re-gathered centre tile with its own weight stream and accumulators; every wave holds all <= 48 pixels
+// of its 16 output channels, so the BatchNorm statistics are an in-register reduction (two-pass mean / variance).
+struct SkinnyEntryArgs {
+    SkinnyArgs c;              // C1 geometry; c.out = raw c1
+    const float* w_sc;         // [groups][Cout][Cin]
+    long long wscs;            // group stride of w_sc
+    float* sc;                 // raw shortcut output [groups][rows_out][ldo]
+    float* r1;                 // ReLU(BN1(c1))
+    const float* gamma; const float* beta; long long gbs;
+    float* mean; float* rstd;  // [groups][Cout]
+    float eps;
+};
+
+__global__ __launch_bounds__(1024) void skinny_block_entry_x3_kernel(SkinnyEntryArgs q) {
+    const SkinnyArgs& p = q.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.y;
+    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int RS = p.Cin + SK_PADH;
+    const int PL = 48 * RS;
+    const int ohw = p.OH * p.OW;
+    const int taps = p.KH * p.KW;
+    const int gpt = p.Cin / 16;
+    const int q4 = p.Cin / 4;
+    constexpr int NST = 3;
+    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* wsrow = q.w_sc + (long long)g * q.wscs + (long long)(co0 + m) * p.Cin + 4 * kq;
+    const float* actg = p.act + (long long)g * p.rows_in * p.lda;
+
+    const int centre = (p.KH / 2) * p.KW + p.KW / 2;
+    f32x4v st[NST];
+    // staging slot k of this thread: row (tid + 1024 k) / q4 of the 48-row im2col tile, 4 channels; the descriptors are
+    // recomputed per pass (10 times per kernel) instead of living in registers through the MFMA loop
+    auto gather = [&](int pass) {
+        const int tap = pass < taps ? pass : centre;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 1024;
+            const int r = i / q4;
+            const int c = (i - r * q4) * 4;
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (r < p.rows_out) {
+                const int img = r / ohw;
+                const int rem = r - img * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    v = *(const f32x4v*)(actg + (long long)((img * p.H + ih) * p.W + iw) * p.lda + c);
+            }
+            st[k] = v;
+        }
+    };
+    auto scatter = [&](int buf) {
+        unsigned short* L = ldh + buf * 3 * PL;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 1024;
+            const int r = i / q4;
+            if (r < 48) sk_store3(L, r * RS + sk_perm((i - r * q4) * 4), PL, st[k]);
+        }
+    };
+
+    f32x4v acc[3], acs[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = acs[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int n_groups = taps * gpt;               // C1's k16 groups; the shortcut's gpt groups follow as pass `taps`
+    auto wptr = [&](int qq) { return qq < n_groups ? wrow + (long long)qq * 16 : wsrow + (long long)(qq - n_groups) * 16; };
+    f32x4v a_cur[SK_U];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    gather(0);
+    scatter(0);
+    __syncthreads();
+    auto pass_body = [&](int pass, f32x4v (&A)[3]) {
+        const unsigned short* L = ldh + (pass & 1) * 3 * PL + 8 * kq;
+        for (int cg0 = 0; cg0 < gpt; cg0 += SK_U) {
+            const int q0 = pass * gpt + cg0;
+            const bool more = q0 + SK_U < n_groups + gpt;
+#pragma unroll
+            for (int u = 0; u < SK_U; u += 2) {
+                bf16x8 a[3], b[3][3];
+                sk_split_a(a_cur[u], a_cur[u + 1], a);
+                if (more) {
+                    a_cur[u] = __builtin_nontemporal_load((const f32x4v*)wptr(q0 + SK_U + u));
+                    a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)wptr(q0 + SK_U + u + 1));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[nb][pl] = __builtin_bit_cast(bf16x8, *(const u32x4v*)(L + pl * PL + (nb * 16 + m) * RS + (cg0 + u) * 16));
+                SK_X3_MFMA(A, a, b)
+            }
+        }
+    };
+    for (int pass = 0; pass < taps; ++pass) {
+        gather(pass + 1);
+        pass_body(pass, acc);
+        scatter((pass + 1) & 1);
+        __syncthreads();
+    }
+    pass_body(taps, acs);
+
+    // ---- epilogue: raw outputs, BatchNorm statistics of c1 over the episode's pixels, r1 = ReLU(BN1(c1))
+    const float inv = 1.f / (float)p.rows_out;
+    f32x4v s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+        if (nb * 16 + m < p.rows_out) s += acc[nb];
+    f32x4v mu, rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mu[e] = sk_row16_sum(s[e]) * inv;
+    s = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+        if (nb * 16 + m < p.rows_out) {
+            const f32x4v d = acc[nb] - mu;
+            s += d * d;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rs[e] = 1.0f / sqrtf(sk_row16_sum(s[e]) * inv + q.eps);
+    const int co = co0 + 4 * kq;
+    const f32x4v ga = *(const f32x4v*)(q.gamma + g * q.gbs + co), be = *(const f32x4v*)(q.beta + g * q.gbs + co);
+    if (m == 0) {
+        *(f32x4v*)(q.mean + (long long)g * p.Cout + co) = mu;
+        *(f32x4v*)(q.rstd + (long long)g * p.Cout + co) = rs;
+    }
+    const long long ob = (long long)g * p.rows_out * p.ldo;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int ro = nb * 16 + m;
+        if (ro >= p.rows_out) continue;
+        const long long o = ob + (long long)ro * p.ldo + co;
+        *(f32x4v*)(p.out + o) = acc[nb];
+        *(f32x4v*)(q.sc + o) = acs[nb];
+        f32x4v y = (acc[nb] - mu) * rs * ga + be;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        *(f32x4v*)(q.r1 + o) = y;
+    }
+}
+
 // data gradient, bf16x3: dy is split once into the three LDS planes (reduction index = forward output channel, same slot
 // permutation); a lane's four 8-byte weight loads of a k16 group give it 4 consecutive reduction rows of 2 input channels.
-__global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p) {
+//
+// BNB: the BatchNorm + ReLU in front of the convolution is differentiated in the epilogue (SimpleBlock: r1 = ReLU(BN1(c1)) feeds
+// C2, backbone.py:253-255): with g = dx * (r1 > 0) and xhat = (c1 - mean) * rstd the kernel writes
+// dc1 = gamma * rstd * (g - mean_rows(g) - xhat * mean_rows(g * xhat)), dgamma = sum_rows(g * xhat), dbeta = sum_rows(g)
+// over the episode's rows, all of which sit in this wave's accumulators (16 lanes x 3 blocks per channel).
+struct SkinnyBnArgs {
+    const float* x_raw;        // c1 [groups][rows][ldo]
+    const float* relu_out;     // r1 [groups][rows][ldo]
+    const float* mean; const float* rstd; const float* gamma; long long gbs;
+    float* dgamma; float* dbeta;                   // [groups][C]
+};
+
+template <bool BNB>
+__global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p, SkinnyBnArgs bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
@@ -715,16 +964,67 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p)
         }
     }
     float* outg = p.out + (long long)g * p.rows_out * p.ldo;
+    // channels of this lane: ci0 + 8 kq + j, j = 2 e + b  <->  acc[b][nb][e]
+    f32x4v d[3][2];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        d[nb][0][0] = acc[0][nb][0]; d[nb][0][1] = acc[1][nb][0]; d[nb][0][2] = acc[0][nb][1]; d[nb][0][3] = acc[1][nb][1];
+        d[nb][1][0] = acc[0][nb][2]; d[nb][1][1] = acc[1][nb][2]; d[nb][1][2] = acc[0][nb][3]; d[nb][1][3] = acc[1][nb][3];
+    }
+    const int cc = ci0 + 8 * kq;
+    if constexpr (BNB) {
+        const long long gb = (long long)g * p.rows_out * p.ldo;
+        f32x4v mu[2], rs[2], ga[2], xh[3][2], s1[2], s2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            mu[h] = *(const f32x4v*)(bn.mean + (long long)g * Cdx + cc + 4 * h);
+            rs[h] = *(const f32x4v*)(bn.rstd + (long long)g * Cdx + cc + 4 * h);
+            ga[h] = *(const f32x4v*)(bn.gamma + g * bn.gbs + cc + 4 * h);
+            s1[h] = s2[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int ro = nb * 16 + m;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xh[nb][h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (ro < p.rows_out) {
+                    const long long o = gb + (long long)ro * p.ldo + cc + 4 * h;
+                    const f32x4v r = *(const f32x4v*)(bn.relu_out + o);
+                    xh[nb][h] = (*(const f32x4v*)(bn.x_raw + o) - mu[h]) * rs[h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[nb][h][e] = r[e] > 0.f ? d[nb][h][e] : 0.f;
+                    s1[h] += d[nb][h];
+                    s2[h] += d[nb][h] * xh[nb][h];
+                } else {
+                    d[nb][h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        const float inv = 1.f / (float)p.rows_out;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[h][e] = sk_row16_sum(s1[h][e]);
+                s2[h][e] = sk_row16_sum(s2[h][e]);
+            }
+            if (m == 0) {
+                *(f32x4v*)(bn.dgamma + (long long)g * Cdx + cc + 4 * h) = s2[h];
+                *(f32x4v*)(bn.dbeta + (long long)g * Cdx + cc + 4 * h) = s1[h];
+            }
+            const f32x4v m1 = s1[h] * inv, m2 = s2[h] * inv, kk = ga[h] * rs[h];
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) d[nb][h] = kk * (d[nb][h] - m1 - xh[nb][h] * m2);
+        }
+    }
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
         const int ro = nb * 16 + m;
         if (ro >= p.rows_out) continue;
-        float* o = outg + (long long)ro * p.ldo + ci0 + 8 * kq;
-        f32x4v lo, hi;
-        lo[0] = acc[0][nb][0]; lo[1] = acc[1][nb][0]; lo[2] = acc[0][nb][1]; lo[3] = acc[1][nb][1];
-        hi[0] = acc[0][nb][2]; hi[1] = acc[1][nb][2]; hi[2] = acc[0][nb][3]; hi[3] = acc[1][nb][3];
-        *(f32x4v*)(o) = lo;
-        *(f32x4v*)(o + 4) = hi;
+        float* o = outg + (long long)ro * p.ldo + cc;
+        *(f32x4v*)(o) = d[nb][0];
+        *(f32x4v*)(o + 4) = d[nb][1];
     }
 }
 
@@ -747,9 +1047,9 @@ void mft_skinny_set_tap(int v) { g_skinny_tap = v; }
 void mft_skinny_set_x3(int v) { g_skinny_x3 = v; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
-int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
-                            int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
-                            long long w_group_stride, hipStream_t s) {
+static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
+                           int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                           long long w_group_stride, const SkinnyExitArgs* ex, hipStream_t s) {
     if (imgs_per_group <= 0 || w_group_stride == 0 || n_img % imgs_per_group != 0) return MFT_EINVAL;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     const int rows_out = imgs_per_group * OH * OW, rows_in = imgs_per_group * H * W;
@@ -762,6 +1062,7 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
     p.K = KH * KW * Cin; p.CS = cs;
     dim3 grid(Cout / 256, n_img / imgs_per_group, 1);
     if (cs != Cin) {
+        if (ex != nullptr) return MFT_EINVAL;
         // the whole activation does not fit one LDS slice (trunk.7.C1 / shortcut: 180 input pixels): per-tap staging
         if (Cin > 256 || Cin % (16 * SK_U) != 0 || g_skinny_tap == 0) return MFT_EINVAL;
         if (g_skinny_x3) {
@@ -788,17 +1089,25 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
         return mft_launch_status();
     }
     if (g_skinny_x3 && (size_t)3 * rows_in * (Cin + SK_PADH) * 2 <= 150 * 1024 && Cin % (16 * SK_U) == 0) {
-        const size_t lds3 = (size_t)3 * rows_in * (Cin + SK_PADH) * 2;
+        size_t lds3 = (size_t)3 * rows_in * (Cin + SK_PADH) * 2;
+        if (ex != nullptr && lds3 < (size_t)16 * 48 * 16 * 4) lds3 = (size_t)16 * 48 * 16 * 4;    // the pool's per-wave output tiles
         static bool attr_x3 = false;
         if (!attr_x3) {
-            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel,
+            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel<false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_x3 = true;
         }
-        hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel, grid, dim3(1024), lds3, s, p);
+        if (ex != nullptr)
+            hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel<true>, grid, dim3(1024), lds3, s, p, *ex);
+        else
+            hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel<false>, grid, dim3(1024), lds3, s, p, SkinnyExitArgs{});
         return mft_launch_status();
     }
+    if (ex != nullptr) return MFT_EINVAL;          // the fused block exit exists in the bf16x3 form only
     const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -811,9 +1120,9 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
     return mft_launch_status();
 }
 
-int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
-                              int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
-                              long long w_group_stride, hipStream_t s) {
+static int skinny_dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                             long long w_group_stride, const SkinnyBnArgs* bn, hipStream_t s) {
     // forward conv: Cin -> Cout, stride 1, "same" padding: dy and dx have the same H x W
     if (imgs_per_group <= 0 || w_group_stride == 0 || n_img % imgs_per_group != 0 || stride != 1) return MFT_EINVAL;
     if (2 * pad != KH - 1 || 2 * pad != KW - 1) return MFT_EINVAL;
@@ -832,14 +1141,21 @@ int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* d
         const size_t lds3 = (size_t)3 * rows * (Cout + SK_PADH) * 2;
         static bool attr_x3 = false;
         if (!attr_x3) {
-            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel,
+            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel<false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_x3 = true;
         }
-        hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel, grid, dim3(512), lds3, s, p);
+        if (bn != nullptr)
+            hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel<true>, grid, dim3(512), lds3, s, p, *bn);
+        else
+            hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel<false>, grid, dim3(512), lds3, s, p, SkinnyBnArgs{});
         return mft_launch_status();
     }
+    if (bn != nullptr) return MFT_EINVAL;          // the fused BatchNorm epilogue exists in the bf16x3 form only
     const size_t lds = (size_t)rows * (cs + SK_PADF) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -849,5 +1165,74 @@ int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* d
         attr_done = true;
     }
     hipLaunchKernelGGL(skinny_conv_dgrad_kernel, grid, dim3(512), lds, s, p);
+    return mft_launch_status();
+}
+
+int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                            long long w_group_stride, hipStream_t s) {
+    return skinny_fwd_impl(in, ldi, w, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride,
+                           nullptr, s);
+}
+
+extern "C" int mft_block_exit_small_forward(const float* r1, const float* w_c2, long long w_group_stride, const float* sc,
+                                            float* c2, float* out, float* pooled, int n_img, int H, int W, int C,
+                                            int imgs_per_group, const float* gamma2, const float* beta2, const float* gamma_sc,
+                                            const float* beta_sc, long long gb_group_stride, float* mean2, float* rstd2,
+                                            float* mean_sc, float* rstd_sc, float eps, void* stream) {
+    if (!sc || !out || !pooled || imgs_per_group <= 0) return MFT_EINVAL;
+    SkinnyExitArgs ex{sc, out, pooled, gamma2, beta2, gamma_sc, beta_sc, gb_group_stride, mean2, rstd2, mean_sc, rstd_sc, eps,
+                      H * W};
+    return skinny_fwd_impl(r1, C, w_c2, c2, C, n_img, H, W, C, C, 3, 3, 1, 1, imgs_per_group, w_group_stride, &ex,
+                           (hipStream_t)stream);
+}
+
+int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                              int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                              long long w_group_stride, hipStream_t s) {
+    return skinny_dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride,
+                             nullptr, s);
+}
+
+extern "C" int mft_conv2d_dgrad_bn_backward_small(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
+                                                  int W, int Cin, int Cout, int KH, int KW, int pad, int imgs_per_group,
+                                                  long long w_group_stride, const float* x_raw, const float* relu_out,
+                                                  const float* mean, const float* rstd, const float* gamma,
+                                                  long long gb_group_stride, float* dgamma, float* dbeta, void* stream) {
+    if (!x_raw || !relu_out || !mean || !rstd || !gamma || !dgamma || !dbeta || ldx != Cin) return MFT_EINVAL;
+    SkinnyBnArgs bn{x_raw, relu_out, mean, rstd, gamma, gb_group_stride, dgamma, dbeta};
+    return skinny_dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, 1, pad, imgs_per_group, w_group_stride, &bn,
+                             (hipStream_t)stream);
+}
+
+extern "C" int mft_block_entry_small_forward(const float* x, int ldx, const float* w_c1, long long w1_group_stride,
+                                             const float* w_sc, long long wsc_group_stride, float* c1, float* r1, float* sc,
+                                             int n_img, int H, int W, int Cin, int Cout, int stride, int imgs_per_group,
+                                             const float* gamma1, const float* beta1, long long gb_group_stride, float* mean1,
+                                             float* rstd1, float eps, void* stream) {
+    if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || w1_group_stride == 0 || wsc_group_stride == 0) return MFT_EINVAL;
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    // the 1x1 / stride s / pad 0 shortcut must sample the centre tap of the 3x3 / stride s / pad 1 convolution
+    if ((H - 1) / stride + 1 != OH || (W - 1) / stride + 1 != OW) return MFT_EINVAL;
+    const int rows_out = imgs_per_group * OH * OW;
+    if (!g_skinny_x3 || rows_out > 48 || Cout % 256 != 0 || Cin % (16 * SK_U) != 0 || Cin > 256 || ldx % 4 != 0) return MFT_EINVAL;
+    SkinnyEntryArgs q;
+    SkinnyArgs& p = q.c;
+    p.act = x; p.w = w_c1; p.out = c1; p.lda = ldx; p.ldo = Cout;
+    p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = 3; p.KW = 3; p.stride = stride; p.pad = 1;
+    p.ipg = imgs_per_group; p.rows_in = imgs_per_group * H * W; p.rows_out = rows_out; p.wgs = w1_group_stride;
+    p.K = 9 * Cin; p.CS = Cin;
+    q.w_sc = w_sc; q.wscs = wsc_group_stride; q.sc = sc; q.r1 = r1; q.gamma = gamma1; q.beta = beta1; q.gbs = gb_group_stride;
+    q.mean = mean1; q.rstd = rstd1; q.eps = eps;
+    const size_t lds_h = (size_t)2 * 3 * 48 * (Cin + SK_PADH) * 2;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)skinny_block_entry_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           156 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(skinny_block_entry_x3_kernel, dim3(Cout / 256, n_img / imgs_per_group, 1), dim3(1024), lds_h,
+                       (hipStream_t)stream, q);
     return mft_launch_status();
 }

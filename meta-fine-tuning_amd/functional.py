@@ -14,6 +14,7 @@ import torch
 
 from . import ops
 
+FUSED_LAST_BLOCK = os.environ.get("MFT_FUSED_LAST_BLOCK", "1") == "1"   # conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)
 X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm statistics from the bf16x3 convolution epilogue
 
 STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
@@ -270,15 +271,41 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
     rows = ipg * OH * OH
     if slab is not None and rows <= 64 and cout % 64 == 0 and cin != cout and running is None:
         # adapted last block in the episode-batched loop: 3 fused launches instead of 10 around the three convolutions
-        c1 = conv(".C1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)))
+        c1 = arena.get(tag + ".c1", (n, OH, OH, cout))
         r1 = arena.get(tag + ".r1", (n * OH * OH, cout))
-        m1, s1, _, _ = _bn_small(arena, tag + ".bn1", c1, g1, b1, rows, groups, cout, gbs, r1)
+        sc = arena.get(tag + ".sc", (n, OH, OH, cout))
+        rc = ops._lib.MFT_EINVAL
+        if FUSED_LAST_BLOCK and c1w.dim() == 3 and scw.dim() == 3:
+            # C1 + BatchNorm + ReLU and the shortcut convolution (which samples C1's centre tap) in one launch
+            m1 = arena.get(tag + ".bn1.mean", (groups, cout))
+            s1 = arena.get(tag + ".bn1.rstd", (groups, cout))
+            rc = ops._lib.lib().mft_block_entry_small_forward(
+                ops._p(x), x.shape[-1], ops._p(c1w), c1w.shape[1] * c1w.shape[2], ops._p(scw), scw.shape[1] * scw.shape[2],
+                ops._p(c1), ops._p(r1), ops._p(sc), n, H, Wd, cin, cout, stride, ipg, ops._p(g1), ops._p(b1), gbs, ops._p(m1),
+                ops._p(s1), ops.BN_EPS, ops._stream())
+            if rc != ops._lib.MFT_EINVAL:
+                ops._lib.check(rc, "mft_block_entry_small_forward")
+        if rc == ops._lib.MFT_EINVAL:                      # outside the fused kernel's domain: three launches
+            conv(".C1", x, c1w, 3, stride, 1, c1)
+            m1, s1, _, _ = _bn_small(arena, tag + ".bn1", c1, g1, b1, rows, groups, cout, gbs, r1)
+            conv(".shortcut", x, scw, 1, stride, 0, sc)
         r1 = r1.view(n, OH, OH, cout)
-        c2 = conv(".C2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)))
-        sc = conv(".shortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)))
+        c2 = arena.get(tag + ".c2", (n, OH, OH, cout))
         out = arena.get(tag + ".out", (n * OH * OH, cout))
-        m2, s2, ms, ss = _bn_small(arena, tag + ".bn2", c2, g2, b2, rows, groups, cout, gbs, out, x2=sc, g2=gs, b2=bs,
-                                   pooled=pooled, hw=OH * OH)
+        rc = ops._lib.MFT_EINVAL
+        if FUSED_LAST_BLOCK and pooled is not None and c2w.dim() == 3:
+            # C2 + both BatchNorms + residual add + ReLU + global average pool in one launch
+            m2, s2, ms, ss = (arena.get(tag + ".bn2." + k, (groups, cout)) for k in ("mean", "rstd", "mean2", "rstd2"))
+            rc = ops._lib.lib().mft_block_exit_small_forward(
+                ops._p(r1), ops._p(c2w), c2w.shape[1] * c2w.shape[2], ops._p(sc), ops._p(c2), ops._p(out), ops._p(pooled), n, OH,
+                OH, cout, ipg, ops._p(g2), ops._p(b2), ops._p(gs), ops._p(bs), gbs, ops._p(m2), ops._p(s2), ops._p(ms),
+                ops._p(ss), ops.BN_EPS, ops._stream())
+            if rc != ops._lib.MFT_EINVAL:
+                ops._lib.check(rc, "mft_block_exit_small_forward")
+        if rc == ops._lib.MFT_EINVAL:
+            conv(".C2", r1, c2w, 3, 1, 1, c2)
+            m2, s2, ms, ss = _bn_small(arena, tag + ".bn2", c2, g2, b2, rows, groups, cout, gbs, out, x2=sc, g2=gs, b2=bs,
+                                       pooled=pooled, hw=OH * OH)
         out = out.view(n, OH, OH, cout)
         if tape is not None:
             tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out,
@@ -395,8 +422,20 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
         dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
         dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
     # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
-    dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
-    dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
+    rc = ops._lib.MFT_EINVAL
+    if FUSED_LAST_BLOCK:
+        # data gradient of C2 with the BatchNorm1 + ReLU backward in its epilogue (dr1 is not materialised)
+        dc1 = arena.get(tag + ".dc1", tuple(c1.shape))
+        w2 = params.c2w
+        rc = lib.mft_conv2d_dgrad_bn_backward_small(ops._p(dc2), C, ops._p(w2), ops._p(dc1), C, n, oh, ow, C, C, 3, 3, 1, ipg,
+                                                    w2.shape[1] * w2.shape[2], ops._p(c1), ops._p(r1), ops._p(tape["m1"]),
+                                                    ops._p(tape["s1"]), ops._p(params.bn1g), C, ops._p(grads.bn1g),
+                                                    ops._p(grads.bn1b), ops._stream())
+        if rc != ops._lib.MFT_EINVAL:
+            ops._lib.check(rc, "mft_conv2d_dgrad_bn_backward_small")
+    if rc == ops._lib.MFT_EINVAL:
+        dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
+        dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
     wgrad(r1, dc2, "c2w", 3, 1, 1)
     wgrad(x, dc1, "c1w", 3, 2, 1)
     wgrad(x, dsc, "scw", 1, 2, 0)

@@ -450,6 +450,76 @@ def test_fused_small_group_kernels_match_unfused(ipg):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ipg", [5, 4, 1])
+def test_fused_block_entry_and_dgrad_bn_backward(ipg):
+    """mft_block_entry_small_forward (C1 + BatchNorm + ReLU + shortcut conv in one launch) and
+    mft_conv2d_dgrad_bn_backward_small (C2 data gradient + BatchNorm/ReLU backward) against the launch sequences they replace."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    G, Cin, C, H = 3, 256, 512, 6
+    n = G * ipg
+    rows = ipg * 9
+    x = nhwc(rnd((n, Cin, H, H), 41)).to(DEV)
+    w1 = torch.stack([ops.pack_conv_weight(rnd((C, Cin, 3, 3), 42 + g, scale=0.03).to(DEV)) for g in range(G)])
+    wsc = torch.stack([ops.pack_conv_weight(rnd((C, Cin, 1, 1), 52 + g, scale=0.08).to(DEV)) for g in range(G)])
+    g1, b1 = (rnd((G, C), 61) * 0.2 + 1).to(DEV), (rnd((G, C), 62) * 0.1).to(DEV)
+    # unfused reference sequence
+    c1_r = ops.conv2d(x, w1, C, 3, 3, 2, 1, imgs_per_group=ipg)
+    sc_r = ops.conv2d(x, wsc, C, 1, 1, 2, 0, imgs_per_group=ipg)
+    m_r, s_r = ops.bn_stats(c1_r.view(-1, C), C, rows, G)
+    r1_r = ops.bn_apply(c1_r.view(-1, C), C, rows, G, m_r, s_r, g1, b1, act=ops.ACT_RELU, gb_group_stride=C)
+    c1, sc, r1 = torch.empty_like(c1_r), torch.empty_like(sc_r), torch.empty_like(r1_r)
+    m1, s1 = torch.empty((G, C), device=DEV), torch.empty((G, C), device=DEV)
+    rc = lib.mft_block_entry_small_forward(ops._p(x), Cin, ops._p(w1), C * 9 * Cin, ops._p(wsc), C * Cin, ops._p(c1), ops._p(r1),
+                                           ops._p(sc), n, H, H, Cin, C, 2, ipg, ops._p(g1), ops._p(b1), C, ops._p(m1), ops._p(s1),
+                                           1e-5, ops._stream())
+    assert rc == 0
+    assert torch.equal(c1, c1_r) and torch.equal(sc, sc_r)            # same bf16x3 arithmetic in the same order
+    assert float((m1 - m_r).abs().max()) < 1e-6 and float(((s1 - s_r) / s_r).abs().max()) < 1e-5
+    assert float((r1 - r1_r).abs().max()) < 2e-5
+    # exit half: C2 + BN2 + BN(shortcut) + add + ReLU + average pool
+    w2 = torch.stack([ops.pack_conv_weight(rnd((C, C, 3, 3), 72 + g, scale=0.02).to(DEV)) for g in range(G)])
+    g2, b2 = (rnd((G, C), 63) * 0.2 + 1).to(DEV), (rnd((G, C), 64) * 0.1).to(DEV)
+    gs, bs = (rnd((G, C), 65) * 0.2 + 1).to(DEV), (rnd((G, C), 66) * 0.1).to(DEV)
+    r1v = r1_r.view(n, 3, 3, C)
+    c2_r = ops.conv2d(r1v, w2, C, 3, 3, 1, 1, imgs_per_group=ipg)
+    out_r, feat_r = torch.empty((n * 9, C), device=DEV), torch.empty((n, C), device=DEV)
+    st_r = [torch.empty((G, C), device=DEV) for _ in range(4)]
+    assert lib.mft_bn_small_forward(ops._p(c2_r), C, ops._p(sc_r), C, None, 0, ops._p(out_r), C, C, rows, G, ops._p(g2), ops._p(b2),
+                                    ops._p(gs), ops._p(bs), C, ops._p(st_r[0]), ops._p(st_r[1]), ops._p(st_r[2]), ops._p(st_r[3]),
+                                    ops.ACT_RELU, 0.0, 1e-5, ops._p(feat_r), 9, ops._stream()) == 0
+    c2, out, feat = torch.empty_like(c2_r), torch.empty_like(out_r), torch.empty_like(feat_r)
+    st = [torch.empty((G, C), device=DEV) for _ in range(4)]
+    rc = lib.mft_block_exit_small_forward(ops._p(r1v), ops._p(w2), C * 9 * C, ops._p(sc_r), ops._p(c2), ops._p(out), ops._p(feat), n,
+                                          3, 3, C, ipg, ops._p(g2), ops._p(b2), ops._p(gs), ops._p(bs), C, ops._p(st[0]),
+                                          ops._p(st[1]), ops._p(st[2]), ops._p(st[3]), 1e-5, ops._stream())
+    assert rc == 0
+    assert torch.equal(c2, c2_r)
+    for a, b in ((st[0], st_r[0]), (st[2], st_r[2])):
+        assert float((a - b).abs().max()) < 1e-6
+    for a, b in ((st[1], st_r[1]), (st[3], st_r[3])):
+        assert float(((a - b) / b).abs().max()) < 1e-5
+    assert float((out - out_r).abs().max()) < 2e-5 and float((feat - feat_r).abs().max()) < 1e-5
+    # backward half
+    dc2 = nhwc(rnd((n, C, 3, 3), 81)).to(DEV)
+    dr1 = ops.conv2d_dgrad(dc2, w2, C, 3, 3, 1, imgs_per_group=ipg)
+    dx_r, dg_r, db_r = ops.bn_backward(c1_r.view(-1, C), dr1.view(-1, C), C, rows, G, m_r, s_r, g1, relu_out=r1_r,
+                                       gb_group_stride=C)
+    dx, dg, db = torch.empty_like(dx_r), torch.empty_like(dg_r), torch.empty_like(db_r)
+    rc = lib.mft_conv2d_dgrad_bn_backward_small(ops._p(dc2), C, ops._p(w2), ops._p(dx), C, n, 3, 3, C, C, 3, 3, 1, ipg,
+                                                C * 9 * C, ops._p(c1_r), ops._p(r1_r), ops._p(m_r), ops._p(s_r), ops._p(g1), C,
+                                                ops._p(dg), ops._p(db), ops._stream())
+    assert rc == 0
+    sc_ = max(float(dx_r.abs().max()), 1e-6)
+    assert float((dx - dx_r).abs().max()) <= 2e-5 * sc_
+    assert float((dg - dg_r).abs().max()) <= 2e-5 * max(float(dg_r.abs().max()), 1.0)
+    assert float((db - db_r).abs().max()) <= 2e-5 * max(float(db_r.abs().max()), 1.0)
+    # out-of-domain shapes are refused (callers fall back to the separate launches)
+    assert lib.mft_block_entry_small_forward(ops._p(x), Cin, ops._p(w1), C * 9 * Cin, ops._p(wsc), C * Cin, ops._p(c1), ops._p(r1),
+                                             ops._p(sc), n, H, H, Cin, C, 2, n, ops._p(g1), ops._p(b1), C, ops._p(m1),
+                                             ops._p(s1), 1e-5, ops._stream()) == (-22 if n * 9 > 48 else 0)
+
+
 @pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H,ipg", [("trunk.4.C1", 64, 64, 3, 1, 1, 21, 5), ("trunk.5.C1", 64, 128, 3, 2, 1, 21, 5),
                                                              ("trunk.6.C2", 256, 256, 3, 1, 1, 6, 5), ("trunk.5.sc", 64, 128, 1, 2, 0, 21, 3)])
 def test_conv_x3_fused_bn_statistics(name, Cin, Cout, k, stride, pad, H, ipg):
