@@ -50,6 +50,13 @@ int mft_augment_views(const unsigned char* src, int n_img, int Hs, int Ws, const
 /* layout ---------------------------------------------------------------------------- */
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);
+
+/* Episode ingest, finetune.py:208-233 (x_a_i = cat(view 0, view 0, view 1, ...) of the support images; x of view 0 for the
+ * final pass): views[v] = device pointer of augmentation view v, an fp32 [n_way, per_class, C, H, W] tensor (host array of
+ * n_views <= 32 device pointers).  support_store receives [(n_views + double_first) * n_way * n_support, H, W, C] (NHWC,
+ * view-major, class-major inside a view), all_store (optional) [n_way * per_class, H, W, C] from view 0.  One launch.       */
+int mft_ingest_episode_views(const float* const* views, int n_views, int double_first, int n_way, int per_class, int n_support,
+                             int C, int H, int W, float* support_store, float* all_store, void* stream);
 /* nn.Conv2d weight OIHW -> packed [Cout][KH][KW][Cin] padded to k_pad floats per row (zeros) */
 int mft_pack_oihw(const float* w_oihw, float* w_pk, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);
 int mft_unpack_oihw(const float* w_pk, float* w_oihw, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);

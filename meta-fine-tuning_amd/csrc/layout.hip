@@ -68,6 +68,61 @@ inline int lgrid(long long total) {
 
 }  // namespace
 
+// Episode ingest (finetune.py:208-233): the support images of every augmentation view -- view 0 twice (x_a_i doubling),
+// then views 1.. -- go from the loader's [n_way, per_class, C, H, W] tensors into the NHWC support store in ONE launch, and
+// view 0 of all images into the final-pass store.  One thread per pixel: C coalesced reads, one contiguous C-float write.
+namespace {
+constexpr int MAX_VIEWS = 32;
+struct IngestArgs {
+    const float* view[MAX_VIEWS];
+    float* support;            // [(n_views + dbl) * n_way * n_support][HW][C]
+    float* all;                // [n_way * per_class][HW][C] or nullptr
+    int n_views, dbl, n_way, per_class, n_support, C, HW;
+};
+
+__global__ __launch_bounds__(256) void ingest_views_kernel(IngestArgs p) {
+    const long long npv = (long long)p.n_way * p.n_support;
+    const long long n_sup = (long long)(p.n_views + p.dbl) * npv * p.HW;
+    const long long n_all = p.all ? (long long)p.n_way * p.per_class * p.HW : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_sup + n_all;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float* src;
+        float* dst;
+        int hw;
+        if (i < n_sup) {
+            hw = (int)(i % p.HW);
+            const long long img = i / p.HW;                       // slot * npv + way * n_support + s
+            const int slot = (int)(img / npv);
+            const int r = (int)(img - slot * npv);
+            const int way = r / p.n_support, sidx = r - way * p.n_support;
+            const int v = slot - p.dbl < 0 ? 0 : slot - p.dbl;
+            src = p.view[v] + ((long long)way * p.per_class + sidx) * p.C * p.HW;
+            dst = p.support + i * p.C;
+        } else {
+            const long long j = i - n_sup;
+            hw = (int)(j % p.HW);
+            src = p.view[0] + (j / p.HW) * p.C * p.HW;
+            dst = p.all + j * p.C;
+        }
+        for (int c = 0; c < p.C; ++c) dst[c] = src[(long long)c * p.HW + hw];
+    }
+}
+}  // namespace
+
+extern "C" int mft_ingest_episode_views(const float* const* views, int n_views, int double_first, int n_way, int per_class,
+                                        int n_support, int C, int H, int W, float* support_store, float* all_store,
+                                        void* stream) {
+    if (n_views < 1 || n_views > MAX_VIEWS || n_support > per_class || !support_store) return MFT_EINVAL;
+    IngestArgs p;
+    for (int v = 0; v < n_views; ++v) p.view[v] = views[v];
+    for (int v = n_views; v < MAX_VIEWS; ++v) p.view[v] = nullptr;
+    p.support = support_store; p.all = all_store; p.n_views = n_views; p.dbl = double_first ? 1 : 0;
+    p.n_way = n_way; p.per_class = per_class; p.n_support = n_support; p.C = C; p.HW = H * W;
+    const long long total = ((long long)(n_views + p.dbl) * n_way * n_support + (all_store ? (long long)n_way * per_class : 0)) * H * W;
+    hipLaunchKernelGGL(ingest_views_kernel, dim3(lgrid(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
 extern "C" int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(lgrid((long long)n_img * C * H * W)), dim3(256), 0,
                        (hipStream_t)stream, src, dst, n_img, C, H * W);

@@ -10,6 +10,8 @@ is index tables only; the numpy permutations are drawn in the reference's order.
 """
 import os
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -113,26 +115,16 @@ class FinetuneEngine:
         """finetune.py:208-233: support images of view 0 twice, then of views 1.. (device NCHW -> NHWC store)."""
         ns, npv, H = self.n_support, self.n_per_view, self.size
         assert len(liz_x) == self.n_views
-        x0 = liz_x[0].to(self.dev, non_blocking=True)
-        assert x0.shape[1] == ns + self.n_query
-        base = slot * self.n_total
-        store = self.Xs.view(self.E * self.n_total, H, H, 3)
-        lib = ops._lib.lib()
-
-        def put(dst_row, src_nchw, n):
-            rc = lib.mft_nchw_to_nhwc(ops._p(src_nchw), ops._p(store[dst_row]), n, 3, H, H, ops._stream())
-            ops._lib.check(rc, "mft_nchw_to_nhwc")
-
-        xa0 = x0[:, :ns].contiguous().view(npv, 3, H, H)
-        put(base, xa0, npv)
+        views = [liz_x[0].to(self.dev, non_blocking=True)]
+        assert views[0].shape[1] == ns + self.n_query
         if self.mode == "gnn":
-            put(base + npv, xa0, npv)
-            for vi, xv in enumerate(liz_x[1:]):
-                xa = xv.to(self.dev, non_blocking=True)[:, :ns].contiguous().view(npv, 3, H, H)
-                put(base + (vi + 2) * npv, xa, npv)
-        xin = x0.contiguous().view(self.n_all, 3, H, H)
-        rc = lib.mft_nchw_to_nhwc(ops._p(xin), ops._p(self.Xall[slot * self.n_all]), self.n_all, 3, H, H, ops._stream())
-        ops._lib.check(rc, "mft_nchw_to_nhwc")
+            views += [xv.to(self.dev, non_blocking=True) for xv in liz_x[1:]]
+        views = [v if (v.dtype == torch.float32 and v.is_contiguous()) else v.float().contiguous() for v in views]
+        ptrs = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        rc = ops._lib.lib().mft_ingest_episode_views(ptrs, len(views), 1 if self.mode == "gnn" else 0, self.n_way,
+                                                     ns + self.n_query, ns, 3, H, H, ops._p(self.Xs[slot * self.n_total]),
+                                                     ops._p(self.Xall[slot * self.n_all]), ops._stream())
+        ops._lib.check(rc, "mft_ingest_episode_views")
 
     def load_episode_source(self, slot, src_u8, params):
         """Ingest straight from raw images: src_u8 [n_way, n_support+n_query, Hs, Ws, 3] uint8 on the
