@@ -51,6 +51,25 @@ int mft_augment_views(const unsigned char* src, int n_img, int Hs, int Ws, const
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);
 
+/* Pre-split activation planes for the bf16x3 convolutions: the frozen trunk convolutions consume every activation 9-36 times
+ * (taps x output-channel tiles); the producers below split each fp32 value once into its three bf16 pieces
+ * ([3][rows][C] unsigned short, plane_stride elements between planes) so the convolution's operand path is a plain copy.
+ *   mft_bn_apply_planes               = mft_bn_apply with an additional planes output (y may be NULL)
+ *   mft_bn_relu_maxpool_gather_planes = mft_bn_relu_maxpool_gather writing y AND planes
+ *   mft_conv2d_nhwc_x3p_bnstats       = mft_conv2d_nhwc_x3_bnstats reading in_planes ([3][n_img*H*W][ldi]) instead of fp32 */
+int mft_bn_apply_planes(const float* x, int ldx, float* y, int ldy, unsigned short* planes, long long plane_stride, int C,
+                        int rows_per_group, int n_groups, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, long long gb_group_stride, const float* res, int ldr, const float* res_mean,
+                        const float* res_rstd, const float* res_gamma, const float* res_beta, int act, float slope,
+                        void* stream);
+int mft_bn_relu_maxpool_gather_planes(const float* x, const int* src_idx, float* y, unsigned short* planes,
+                                      long long plane_stride, int n_img, int H, int W, int C, int imgs_per_group,
+                                      const float* mean, const float* rstd, const float* gamma, const float* beta, void* stream);
+int mft_conv2d_nhwc_x3p_bnstats(const unsigned short* in_planes, long long in_plane_elems, int ldi, const unsigned short* w3,
+                                long long plane_elems, float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH,
+                                int KW, int stride, int pad, int imgs_per_group, float eps, float* stats_ws, float* mean,
+                                float* rstd, void* stream);
+
 /* Episode ingest, finetune.py:208-233 (x_a_i = cat(view 0, view 0, view 1, ...) of the support images; x of view 0 for the
  * final pass): views[v] = device pointer of augmentation view v, an fp32 [n_way, per_class, C, H, W] tensor (host array of
  * n_views <= 32 device pointers).  support_store receives [(n_views + double_first) * n_way * n_support, H, W, C] (NHWC,

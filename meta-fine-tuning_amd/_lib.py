@@ -56,6 +56,9 @@ SIGNATURES = {
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_bn_apply_planes": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
+    "mft_bn_relu_maxpool_gather_planes": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mft_conv2d_nhwc_x3p_bnstats": [_P, _L, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_ingest_episode_views": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "mft_block_entry_small_forward": [_P, _I, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _F, _P],
     "mft_block_exit_small_forward": [_P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _F, _P],

@@ -99,6 +99,7 @@ struct ApplyArgs {
     const float* mean; const float* rstd; const float* gamma; const float* beta; long long gbs;
     const float* res; int ldr; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta;
     int act; float slope;
+    unsigned short* planes; long long plane_stride;      // optional bf16x3 planes of y ([3][rows][C], csrc/conv_x3.hip operand)
 };
 
 __device__ __forceinline__ float act_f(float v, int act, float slope) {
@@ -134,7 +135,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
-        *(f32x4*)(p.y + row * p.ldy + c) = o;
+        if (p.y) *(f32x4*)(p.y + row * p.ldy + c) = o;
+        if (p.planes) {
+            mft_u32x2 p1, p2, p3;
+            mft_split4_bf16(o, p1, p2, p3);
+            unsigned short* q = p.planes + row * p.C + c;
+            *(mft_u32x2*)(q) = p1;
+            *(mft_u32x2*)(q + p.plane_stride) = p2;
+            *(mft_u32x2*)(q + 2 * p.plane_stride) = p3;
+        }
     }
 }
 
@@ -145,7 +154,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
-                                                              const int* __restrict__ src_idx) {
+                                                              const int* __restrict__ src_idx,
+                                                              unsigned short* __restrict__ planes, long long plane_stride) {
     const int cq = C >> 2;
     const long long total = (long long)n_img * OH * OW * cq;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -179,6 +189,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], 0.f);
         *(f32x4*)(y + i * 4) = best;
+        if (planes) {
+            mft_u32x2 p1, p2, p3;
+            mft_split4_bf16(best, p1, p2, p3);
+            unsigned short* q = planes + i * 4;
+            *(mft_u32x2*)(q) = p1;
+            *(mft_u32x2*)(q + plane_stride) = p2;
+            *(mft_u32x2*)(q + 2 * plane_stride) = p3;
+        }
     }
 }
 
@@ -401,22 +419,44 @@ extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, i
                             void* stream) {
     if (C % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || (res && ldr % 4 != 0)) return MFT_EINVAL;
     ApplyArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, mean, rstd, gamma, beta, gb_group_stride,
-                res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope};
+                res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope, nullptr, 0};
     const long long total = (long long)n_groups * rows_per_group * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_apply_planes(const float* x, int ldx, float* y, int ldy, unsigned short* planes, long long plane_stride,
+                                   int C, int rows_per_group, int n_groups, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, long long gb_group_stride, const float* res, int ldr,
+                                   const float* res_mean, const float* res_rstd, const float* res_gamma,
+                                   const float* res_beta, int act, float slope, void* stream) {
+    if (C % 4 != 0 || ldx % 4 != 0 || (y && ldy % 4 != 0) || (res && ldr % 4 != 0) || !planes) return MFT_EINVAL;
+    if (plane_stride < (long long)n_groups * rows_per_group * C) return MFT_EINVAL;
+    ApplyArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, mean, rstd, gamma, beta, gb_group_stride,
+                res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope, planes, plane_stride};
+    const long long total = (long long)n_groups * rows_per_group * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_maxpool_gather_planes(const float* x, const int* src_idx, float* y, unsigned short* planes,
+                                                 long long plane_stride, int n_img, int H, int W, int C, int imgs_per_group,
+                                                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                 void* stream) {
+    if (C % 4 != 0) return MFT_EINVAL;
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)n_img * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx, planes, plane_stride);
     return mft_launch_status();
 }
 
 extern "C" int mft_bn_relu_maxpool_gather(const float* x, const int* src_idx, float* y, int n_img, int H, int W, int C,
                                           int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
                                           const float* beta, void* stream) {
-    if (C % 4 != 0) return MFT_EINVAL;
-    if (imgs_per_group <= 0) imgs_per_group = n_img;
-    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    const long long total = (long long)n_img * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx);
-    return mft_launch_status();
+    return mft_bn_relu_maxpool_gather_planes(x, src_idx, y, nullptr, 0, n_img, H, W, C, imgs_per_group, mean, rstd, gamma, beta,
+                                             stream);
 }
 
 extern "C" int mft_bn_relu_maxpool(const float* x, float* y, int n_img, int H, int W, int C, int imgs_per_group,

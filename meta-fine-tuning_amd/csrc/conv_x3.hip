@@ -34,6 +34,8 @@ struct X3Args {
     int tiles_n;
     unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
     int xcd_swizzle;
+    const unsigned short* in3;     // AP kernels: pre-split input planes [3][n_img*H*W][ldi] bf16 (written by mft_bn_apply_planes)
+    unsigned in_plane_bytes;
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
     int rows_per_group;            // >= BM when stats_ws is set
 };
@@ -64,11 +66,14 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
     p3[1] = pk_bf16(r[2], r[3]);
 }
 
-template <int BM, int BN>
+// AP = true: the activation arrives already split into its three bf16 planes (the producing BatchNorm-apply / pooling kernel
+// split every element ONCE, instead of this loader re-splitting it for each of the 9 taps and each n-tile): the A path is
+// then the same plain 16-byte copy into LDS as the weight path, with no VALU work between the loads and the MFMAs.
+template <int BM, int BN, bool AP>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
-    constexpr int PA = BM / 32;           // A passes: 32 rows per pass, 8 threads x float4 per row
+    constexpr int PA = AP ? BM / 64 : BM / 32;   // A passes: fp32: 32 rows x 8 threads x float4; planes: 64 rows x 4 threads x 16 B
     constexpr int PB = BN / 64;           // B passes: 64 rows per pass, 4 threads x 16 B per row and plane
     constexpr int A_PLANE = BM * X3_RS;   // bf16 elements
     constexpr int B_PLANE = BN * X3_RS;
@@ -95,20 +100,23 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int mt = tile_id / p.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 3;
-    const int c4 = (tid & 7) * 4;
+    const int lrow = AP ? tid >> 2 : tid >> 3;
+    const int c4 = AP ? (tid & 3) * 8 : (tid & 7) * 4;         // first channel of this thread's 16-byte piece
+    constexpr int RPP = AP ? 64 : 32;                          // rows per A pass
+    constexpr int ESZ = AP ? 2 : 4;                            // bytes per stored activation element
     const int ohw = p.OH * p.OW;
     // Operands are fetched with raw buffer loads: one 32-bit byte offset per lane, and an offset beyond the buffer
     // (the sentinel 0x80000000) returns zeros -- that IS the zero padding of the convolution and of ragged tiles, so the
     // im2col gather costs a compare + select per row instead of 64-bit address arithmetic under divergent branches.
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = AP ? __builtin_amdgcn_make_buffer_rsrc((void*)p.in3, 0, 3 * p.in_plane_bytes, 0x00020000)
+                                         : __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
     int a_off[PA];                 // byte offset of (img, ih0, iw0, channel c4); meaningful only with a valid tap
     int a_ih0[PA], a_iw0[PA];
     bool a_ok[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
-        const int m = m0 + lrow + 32 * j;
+        const int m = m0 + lrow + RPP * j;
         a_ok[j] = m < p.M;
         const int mm = a_ok[j] ? m : 0;
         const int img = mm / ohw;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
-        a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * 4;
+        a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * ESZ;
     }
     const int brow = tid >> 2, bseg = tid & 3;
     int b_off[PB];
@@ -132,7 +140,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 ra[PA];
+    f32x4 ra[AP ? 1 : PA];
+    u32x4 ra3[AP ? PA : 1][3];
     u32x4 rb[PB][3];
     const int nk = p.Kpad / 32;
 
@@ -141,12 +150,18 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         const int khkw = k0 / p.Cin;                       // uniform (scalar) tap bookkeeping
         const int ci0 = k0 - khkw * p.Cin;
         const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-        const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * 4;
+        const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * ESZ;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const bool ok = a_ok[j] && (unsigned)(a_ih0[j] + kh) < (unsigned)p.H && (unsigned)(a_iw0[j] + kw) < (unsigned)p.W;
             const unsigned voff = ok ? (unsigned)(a_off[j] + tap_off) : 0x80000000u;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
+            if constexpr (AP) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ra3[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, pl * (int)p.in_plane_bytes, 0);
+            } else {
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
+            }
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j)
@@ -157,12 +172,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            u32x2 p1, p2, p3;
-            split4(ra[j], p1, p2, p3);
-            const int off = (lrow + 32 * j) * X3_RS + c4;
-            *(u32x2*)(As + off) = p1;
-            *(u32x2*)(As + A_PLANE + off) = p2;
-            *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+            const int off = (lrow + RPP * j) * X3_RS + c4;
+            if constexpr (AP) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = ra3[j][pl];
+            } else {
+                u32x2 p1, p2, p3;
+                split4(ra[j], p1, p2, p3);
+                *(u32x2*)(As + off) = p1;
+                *(u32x2*)(As + A_PLANE + off) = p2;
+                *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+            }
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j)
@@ -312,14 +332,14 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
-template <int BM, int BN>
+template <int BM, int BN, bool AP>
 int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
-    auto kern = conv_x3_kernel<BM, BN>;
+    auto kern = conv_x3_kernel<BM, BN, AP>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -532,9 +552,11 @@ extern "C" int mft_debug_set_x3_tile(int t) {
 
 static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
                        int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* stats_ws,
-                       int rows_per_group, void* stream) {
+                       int rows_per_group, void* stream, const unsigned short* in3 = nullptr, long long in_plane_elems = 0) {
     if (n_img <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || ldi % 4 != 0) return MFT_EINVAL;
     X3Args p;
+    p.in3 = in3;
+    p.in_plane_bytes = 0;
     p.stats_ws = stats_ws;
     p.rows_per_group = rows_per_group;
     p.in = in; p.w3 = w3; p.plane = plane_elems; p.out = out; p.ldi = ldi; p.ldo = ldo;
@@ -549,6 +571,17 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
     hipStream_t s = (hipStream_t)stream;
     int G = 0, R = 0;
     double eff = 0.0;
+    if (in3 != nullptr) {
+        // pre-split input planes: one launch, 32-bit byte offsets over the three planes
+        const long long need = (long long)n_img * H * W * ldi;
+        if (ldi % 8 != 0 || in_plane_elems < need || 3 * in_plane_elems * 2 >= 0x7fff0000LL || 3 * plane_elems * 2 >= 0x7fff0000LL)
+            return MFT_EINVAL;
+        if (stats_ws != nullptr && rows_per_group < 128) return MFT_EINVAL;
+        p.in_plane_bytes = (unsigned)(in_plane_elems * 2);
+        p.in_bytes = 0;
+        p.w_bytes = (unsigned)(3 * plane_elems * 2);
+        return launch_x3<128, 64, true>(p, (hipStream_t)stream);
+    }
     if (stats_ws == nullptr && g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
         patch_geometry(H, W, &G, &R, &eff) && (g_x3_patch >= 2 || eff >= 0.9)) {
         P3Args q;
@@ -586,7 +619,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.out = out + i0 * p.OH * p.OW * ldo;
         q.M = (int)(ni * p.OH * p.OW);
         q.in_bytes = (unsigned)(ni * img_bytes);
-        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128>(q, s) : launch_x3<128, 64>(q, s);
+        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false>(q, s) : launch_x3<128, 64, false>(q, s);
         if (rc != 0) return rc;
     }
     return 0;
@@ -612,6 +645,23 @@ extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsign
     const int R = imgs_per_group * OH * OW;
     const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, stats_ws, R,
                                stream);
+    if (rc != 0) return rc;
+    const int groups = n_img / imgs_per_group;
+    hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, groups), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)stats_ws, Cout, n_img * OH * OW, R, 128, eps, mean, rstd);
+    return mft_launch_status();
+}
+
+extern "C" int mft_conv2d_nhwc_x3p_bnstats(const unsigned short* in_planes, long long in_plane_elems, int ldi,
+                                           const unsigned short* w3, long long plane_elems, float* out, int ldo, int n_img,
+                                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                           int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd,
+                                           void* stream) {
+    if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || stats_ws == nullptr || in_planes == nullptr) return MFT_EINVAL;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const int R = imgs_per_group * OH * OW;
+    const int rc = x3_dispatch(nullptr, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, stats_ws, R,
+                               stream, in_planes, in_plane_elems);
     if (rc != 0) return rc;
     const int groups = n_img / imgs_per_group;
     hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, groups), dim3(64), 0, (hipStream_t)stream,

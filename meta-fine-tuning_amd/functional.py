@@ -15,6 +15,10 @@ import torch
 from . import ops
 
 FUSED_LAST_BLOCK = os.environ.get("MFT_FUSED_LAST_BLOCK", "1") == "1"   # conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)
+# opt-in: trunk activations travel pre-split into bf16x3 planes between the x3 convolutions.  Bit-identical, but measured
+# SLOWER (66.5 vs 69.0 episodes/s): the convolutions are not bound by the in-loader split (161 vs 160 us standalone) while the
+# producers write 1.5x the bytes -- kept for the record (tests/test_engine_gpu.py::test_presplit_activation_planes_are_bit_identical)
+X3_PLANES = os.environ.get("MFT_X3_PLANES", "0") == "1"
 X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm statistics from the bf16x3 convolution epilogue
 
 STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
@@ -203,6 +207,25 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
         s = arena.get(tag + ".bn0.rstd", (groups, 64))
         ops.bn_combine_moments(cache.mean, cache.m2, idx, cache.OH * cache.OH, ipg, groups, mean=m, rstd=s)
         PH = (cache.OH + 2 - 3) // 2 + 1
+        if (X3_PLANES and X3_FUSED_STATS and upto == 7 and running is None and fixed is None and ipg * ((PH + 3) // 4) ** 2 >= 128
+                and all(("trunk.%d.C1" % i) in W.conv3 for i in (4, 5, 6))):
+            # frozen trunk on pre-split activations: each tensor between two bf16x3 convolutions is written once as three
+            # bf16 planes by its producer (pool / BatchNorm-apply) instead of being re-split by every consumer tile
+            ap = arena.get(tag + ".p0p", (3, n * PH * PH, 64), torch.int16)
+            a = ops.bn_relu_maxpool_gather(cache.c0, idx, n, m, s, g, b, ipg, out=arena.get(tag + ".p0", (n, PH, PH, 64)),
+                                           planes=ap)
+            shape = (n, PH, PH, 64)
+            for bi in (4, 5, 6):
+                cin, cout, stride = STAGES[bi]
+                p = "trunk.%d" % bi
+                mode = "f32" if bi == 6 else "planes"
+                r = simple_block(W, p, a if bi == 4 else None, arena, ipg, cin, cout, stride, None, tag + "." + p, xp=ap,
+                                 xshape=shape, out_mode=mode)
+                if mode == "f32":
+                    return r
+                _, ap = r
+                OHb = (shape[1] + 2 - 3) // stride + 1
+                shape = (n, OHb, OHb, cout)
         a = ops.bn_relu_maxpool_gather(cache.c0, idx, n, m, s, g, b, ipg, out=arena.get(tag + ".p0", (n, PH, PH, 64)))
     else:
         n = x.shape[0]
@@ -236,11 +259,15 @@ def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=Non
     return m1, s1, m2, s2
 
 
-def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None, fixed=None):
+def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None, fixed=None,
+                 xp=None, xshape=None, out_mode="f32"):
     """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's.
     ``pooled``: optional [n, cout] buffer; filled with the global average pool of the block output when the fused
-    small-group path applies (``tape['pooled']`` is then True and the caller skips its own pooling launch)."""
-    n, H, Wd, _ = x.shape
+    small-group path applies (``tape['pooled']`` is then True and the caller skips its own pooling launch).
+    ``xp``: the block input pre-split into bf16x3 planes (int16 [3, n*H*W, cin]); frozen x3 blocks then keep their internal
+    activation in planes too, and ``out_mode`` ("f32" | "planes" | "both") selects the form(s) of the block output
+    (returns ``out`` or ``(out, out_planes)``; ``x`` may be None when only its planes are needed, with ``xshape`` = its shape)."""
+    n, H, Wd, _ = x.shape if x is not None else xshape
     groups = n // ipg
     OH = (H + 2 - 3) // stride + 1
 
@@ -327,6 +354,39 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         o = conv(name, inp, wpk, k, s, pd, obuf)
         mm, ss_ = _bn_stats4(arena, stag, o, ipg, groups, run(p + bnname), fix(p + bnname))
         return o, mm, ss_
+
+    if xp is not None and fuse_stats and tape is None and all((p + nm) in w3 for nm in ((".C1", ".C2", ".shortcut") if cin != cout
+                                                                                      else (".C1", ".C2"))):
+        # pre-split activation chain: every x3 convolution reads bf16 planes written once by its producer
+        def conv_bn_p(name, inp_p, h_in, k, s, pd, obuf, stag):
+            nws = int(ops._lib.lib().mft_conv2d_x3_stats_ws_floats(n, h_in, h_in, cout, k, k, s, pd))
+            ws = arena.get("x3.statws", (max(nws, 1 << 20),)) if nws <= (1 << 20) else arena.get(stag + ".statws", (nws,))
+            mean = arena.get(stag + ".mean", (groups, cout))
+            rstd = arena.get(stag + ".rstd", (groups, cout))
+            return ops.conv2d_x3p_bnstats(inp_p, n, h_in, h_in, w3[p + name], cout, k, k, s, pd, ipg, obuf, ws, mean, rstd)
+
+        c1, m1, s1 = conv_bn_p(".C1", xp, H, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)), tag + ".bn1")
+        r1p = arena.get(tag + ".r1p", (3, n * OH * OH, cout), torch.int16)
+        ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU, gb_group_stride=gbs, planes=r1p,
+                     write_y=False)
+        c2, m2, s2 = conv_bn_p(".C2", r1p, OH, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)), tag + ".bn2")
+        want_f32 = out_mode in ("f32", "both")
+        out = arena.get(tag + ".out", (n * OH * OH, cout)) if want_f32 else None
+        outp = arena.get(tag + ".outp", (3, n * OH * OH, cout), torch.int16) if out_mode in ("planes", "both") else None
+        if cin != cout:
+            sc, ms, ss = conv_bn_p(".shortcut", xp, H, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)), tag + ".bns")
+            res, res_bn = sc.view(-1, cout), (ms, ss, gs, bs)
+        else:
+            res, res_bn = x.view(-1, cin), None
+        if outp is not None:
+            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=res, res_bn=res_bn, out=out,
+                         gb_group_stride=gbs, planes=outp, write_y=want_f32)
+        else:
+            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=res, res_bn=res_bn, out=out,
+                         gb_group_stride=gbs)
+        out = out.view(n, OH, OH, cout) if out is not None else None
+        return out if out_mode == "f32" else (out, outp)
+    assert out_mode == "f32" or xp is None or not fuse_stats, "planes output requested outside the pre-split chain"
 
     c1, m1, s1 = conv_bn(".C1", ".BN1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)), tag + ".bn1")
     r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,

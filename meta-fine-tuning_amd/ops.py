@@ -134,6 +134,17 @@ def conv2d_x3_bnstats(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws,
     return out, mean, rstd
 
 
+def conv2d_x3p_bnstats(xp, n, H, W, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, eps=BN_EPS):
+    """conv2d_x3_bnstats on a pre-split input: ``xp`` int16 [3, n*H*W, Cin] (bf16x3 planes written by bn_apply(planes=) /
+    bn_relu_maxpool_gather(planes=)); the operand path of the convolution is then a plain copy."""
+    Cin = xp.shape[2]
+    rc = _lib.lib().mft_conv2d_nhwc_x3p_bnstats(_p(xp), xp.shape[1] * Cin, Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout,
+                                                n, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, eps, _p(ws), _p(mean),
+                                                _p(rstd), _stream())
+    _lib.check(rc, "mft_conv2d_nhwc_x3p_bnstats")
+    return out, mean, rstd
+
+
 def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     """out[m, :N] = a[m, :K] @ w_pk[:N, :K].T + bias.  `a` is [M, lda] with lda >= K, K % 32 == 0."""
     _f32c(a)
@@ -221,14 +232,24 @@ def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=No
 
 
 def bn_apply(x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act=ACT_NONE, res=None, res_bn=None,
-             out=None, gb_group_stride=0, slope=LRELU_SLOPE):
-    """y = act(bn(x) [+ res | + bn(res)]).  res_bn = (mean, rstd, gamma, beta) of the residual branch."""
+             out=None, gb_group_stride=0, slope=LRELU_SLOPE, planes=None, write_y=True):
+    """y = act(bn(x) [+ res | + bn(res)]).  res_bn = (mean, rstd, gamma, beta) of the residual branch.
+    ``planes``: int16 [3, rows, C] buffer that receives y split into its three bf16 pieces (operand of conv2d_x3p_bnstats);
+    with ``write_y=False`` the fp32 y is not written at all."""
     _f32c(x2d)
-    if out is None:
+    if out is None and (planes is None or write_y):
         out = torch.empty_like(x2d)
     rm = rr = rg = rb = None
     if res_bn is not None:
         rm, rr, rg, rb = res_bn
+    if planes is not None:
+        y = out if write_y else None
+        rc = _lib.lib().mft_bn_apply_planes(_p(x2d), x2d.shape[-1], _p(y), 0 if y is None else y.shape[-1], _p(planes),
+                                            planes.shape[1] * planes.shape[2], C, rows_per_group, n_groups, _p(mean), _p(rstd),
+                                            _p(gamma), _p(beta), gb_group_stride, _p(res), 0 if res is None else res.shape[-1],
+                                            _p(rm), _p(rr), _p(rg), _p(rb), act, slope, _stream())
+        _lib.check(rc, "mft_bn_apply_planes")
+        return y
     rc = _lib.lib().mft_bn_apply(_p(x2d), x2d.shape[-1], _p(out), out.shape[-1], C, rows_per_group, n_groups,
                                  _p(mean), _p(rstd), _p(gamma), _p(beta), gb_group_stride,
                                  _p(res), 0 if res is None else res.shape[-1], _p(rm), _p(rr), _p(rg), _p(rb),
@@ -248,13 +269,20 @@ def bn_relu_maxpool(x, mean, rstd, gamma, beta, imgs_per_group=0):
     return y
 
 
-def bn_relu_maxpool_gather(cache, src_idx, n_img, mean, rstd, gamma, beta, imgs_per_group, out=None):
-    """bn_relu_maxpool over images cache[src_idx[n]] (cache [slots,H,W,C]); n_img = src_idx.numel()."""
+def bn_relu_maxpool_gather(cache, src_idx, n_img, mean, rstd, gamma, beta, imgs_per_group, out=None, planes=None):
+    """bn_relu_maxpool over images cache[src_idx[n]] (cache [slots,H,W,C]); n_img = src_idx.numel().
+    ``planes``: optional int16 [3, n_img*OH*OW, C] buffer receiving the bf16x3 split of the output as well."""
     _f32c(cache)
     _, H, W, C = cache.shape
     OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     if out is None:
         out = torch.empty((n_img, OH, OW, C), device=cache.device, dtype=torch.float32)
+    if planes is not None:
+        rc = _lib.lib().mft_bn_relu_maxpool_gather_planes(_p(cache), _p(src_idx), _p(out), _p(planes),
+                                                          planes.shape[1] * planes.shape[2], n_img, H, W, C, imgs_per_group,
+                                                          _p(mean), _p(rstd), _p(gamma), _p(beta), _stream())
+        _lib.check(rc, "mft_bn_relu_maxpool_gather_planes")
+        return out
     rc = _lib.lib().mft_bn_relu_maxpool_gather(_p(cache), _p(src_idx), _p(out), n_img, H, W, C, imgs_per_group, _p(mean),
                                                _p(rstd), _p(gamma), _p(beta), _stream())
     _lib.check(rc, "mft_bn_relu_maxpool_gather")

@@ -194,6 +194,30 @@ def test_two_stream_pipeline_is_bit_identical():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_presplit_activation_planes_are_bit_identical():
+    """Frozen trunk on pre-split bf16x3 activation planes (producers split once: mft_bn_apply_planes /
+    mft_bn_relu_maxpool_gather_planes, consumer mft_conv2d_nhwc_x3p_bnstats) against the same trunk splitting inside every
+    convolution tile: the pieces are the same numbers, so the activation entering trunk.7 must match bit for bit."""
+    W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=31), DEV, x3=True)
+    rs = np.random.RandomState(9)
+    x = torch.from_numpy(rs.standard_normal((60, 84, 84, 3)).astype(np.float32)).to(DEV)
+    cache = Fn.StemCache(W, 60, 84, DEV, chunk=32)
+    cache.fill(x)
+    idx = torch.from_numpy(rs.permutation(60)[:35].astype(np.int32)).to(DEV)
+    outs = []
+    old = Fn.X3_PLANES
+    try:
+        for planes in (False, True):
+            Fn.X3_PLANES = planes
+            arena = Fn.Arena(DEV)
+            outs.append(Fn.resnet10_trunk(W, None, arena, 5, upto=7, tag="p%d" % planes, stem=(cache, idx)).clone())
+            assert any(k[0].endswith(".r1p") for k in arena.bufs) == planes          # the chain really ran / did not run
+    finally:
+        Fn.X3_PLANES = old
+    assert outs[0].shape == (35, 6, 6, 256)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_stem_cache_matches_recomputed_stem():
     """Cached trunk.0 outputs + recombined per-image BatchNorm moments must reproduce the per-step stem
     (conv -> batch statistics -> BN/ReLU/maxpool) to fp32 rounding, and the engine's scores must agree."""
