@@ -258,6 +258,10 @@ def main():
         if knob.strip():
             from meta_fine_tuning_amd import _lib
             _lib.lib().mft_debug_set_conv_tile(int(knob))
+    for knob in os.environ.get("MFT_X3_KNOBS", "").split(","):            # same for mft_debug_set_x3_tile
+        if knob.strip():
+            from meta_fine_tuning_amd import _lib
+            _lib.lib().mft_debug_set_x3_tile(int(knob))
     E = args.episodes_per_batch
     n_way, n_shot, n_query, size = 5, args.n_shot, 15, args.image_size
     if n_shot != 5 or size != 84:

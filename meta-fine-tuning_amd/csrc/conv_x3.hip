@@ -34,6 +34,8 @@ struct X3Args {
     int tiles_n;
     unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
     int xcd_swizzle;
+    int row_swz;                   // staging-row assignment that avoids LDS write bank conflicts
+    int depth2;                    // 1: two K-steps of operands in flight (register stages), 0: one
     const unsigned short* in3;     // AP kernels: pre-split input planes [3][n_img*H*W][ldi] bf16 (written by mft_bn_apply_planes)
     unsigned in_plane_bytes;
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
+    const bool g_swz = p.row_swz != 0;
     // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  With the
     // natural order the n-tiles of one m-tile (which read the SAME im2col rows) and neighbouring m-tiles (which share
     // halo rows) land on different XCDs and every L2 fetches the activation separately -- PMC showed ~6x the input size
@@ -100,7 +103,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int mt = tile_id / p.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = AP ? tid >> 2 : tid >> 3;
+    // Row owned by a thread in the staging passes.  LDS rows are 80 B = 20 banks apart, so four CONSECUTIVE rows written by one
+    // 32-lane (ds_write_b64) or 16-lane (ds_write_b128) group wrap around the 64 banks and collide 2-way; rows 4 apart start
+    // at banks 0/16/32/48.  Each group therefore owns rows {q, q+4, q+8, q+12} (PMC: 1/3 of the LDS-active cycles were conflicts).
+    const int g_id = AP ? tid >> 4 : tid >> 5;                 // 16-lane groups of 4 threads/row, 32-lane groups of 8 threads/row
+    const int g_rr = AP ? (tid >> 2) & 3 : (tid >> 3) & 3;
+    const int lrow = g_swz ? g_rr * 4 + (g_id & 3) + 16 * (g_id >> 2) : (AP ? tid >> 2 : tid >> 3);
     const int c4 = AP ? (tid & 3) * 8 : (tid & 7) * 4;         // first channel of this thread's 16-byte piece
     constexpr int RPP = AP ? 64 : 32;                          // rows per A pass
     constexpr int ESZ = AP ? 2 : 4;                            // bytes per stored activation element
@@ -126,7 +134,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         a_iw0[j] = ow * p.stride - p.pad;
         a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * ESZ;
     }
-    const int brow = tid >> 2, bseg = tid & 3;
+    const int bseg = tid & 3;
+    const int brow = g_swz ? ((tid >> 2) & 3) * 4 + ((tid >> 4) & 3) + 16 * (tid >> 6) : tid >> 2;
     int b_off[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
@@ -140,12 +149,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 ra[AP ? 1 : PA];
-    u32x4 ra3[AP ? PA : 1][3];
-    u32x4 rb[PB][3];
+    // two register stages: the operands of K-steps kt+1 and kt+2 are in flight while kt is multiplied (one stage in flight
+    // does not cover the L2 / fabric latency beside the HBM-saturating last-block stream)
+    struct Stage {
+        f32x4 ra[AP ? 1 : PA];
+        u32x4 ra3[AP ? PA : 1][3];
+        u32x4 rb[PB][3];
+    };
+    Stage st0, st1;
     const int nk = p.Kpad / 32;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, Stage& S) {
         const int k0 = kt * 32;
         const int khkw = k0 / p.Cin;                       // uniform (scalar) tap bookkeeping
         const int ci0 = k0 - khkw * p.Cin;
@@ -158,27 +172,27 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
             if constexpr (AP) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    ra3[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, pl * (int)p.in_plane_bytes, 0);
+                    S.ra3[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, pl * (int)p.in_plane_bytes, 0);
             } else {
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
+                S.ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
             }
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
+                S.rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const Stage& S) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int off = (lrow + RPP * j) * X3_RS + c4;
             if constexpr (AP) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = ra3[j][pl];
+                for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = S.ra3[j][pl];
             } else {
                 u32x2 p1, p2, p3;
-                split4(ra[j], p1, p2, p3);
+                split4(S.ra[j], p1, p2, p3);
                 *(u32x2*)(As + off) = p1;
                 *(u32x2*)(As + A_PLANE + off) = p2;
                 *(u32x2*)(As + 2 * A_PLANE + off) = p3;
@@ -188,14 +202,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         for (int j = 0; j < PB; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = rb[j][pl];
+                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = S.rb[j][pl];
     };
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[TM][3], b[TN][3];
@@ -221,9 +231,25 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
         }
+    };
+    // K-step kt: LDS holds tile kt; `nxt` holds tile kt+1 (loaded during kt-1), tile kt+2 is requested into `far` -- the stage
+    // whose contents went to LDS before this step
+    const bool g_depth2 = p.depth2 != 0;
+    auto step = [&](int kt, Stage& nxt, Stage& far) {
+        if (g_depth2 && kt + 2 < nk) load_tile(kt + 2, far);
+        if (!g_depth2 && kt + 1 < nk) load_tile(kt + 1, nxt);
+        compute();
         __syncthreads();
-        if (kt + 1 < nk) store_tile();
+        if (kt + 1 < nk) store_tile(nxt);
         __syncthreads();
+    };
+    load_tile(0, st0);
+    store_tile(st0);
+    if (g_depth2 && nk > 1) load_tile(1, st1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, st1, st0);
+        if (kt + 1 < nk) step(kt + 1, st0, st1);
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -329,6 +355,8 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+int g_x3_row_swz = 1;      // conflict-free staging-row assignment (mft_debug_set_x3_tile(40/41))
+int g_x3_depth2 = 0;       // 1: two K-steps of operands in flight instead of one (mft_debug_set_x3_tile(30/31)); measured neutral
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
@@ -337,6 +365,8 @@ int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
+    p.depth2 = g_x3_depth2;
+    p.row_swz = g_x3_row_swz;
     size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     auto kern = conv_x3_kernel<BM, BN, AP>;
@@ -544,6 +574,8 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 40) g_x3_row_swz = t - 40;
+    else if (t >= 30) g_x3_depth2 = t - 30;
     else if (t >= 20) g_x3_xcd = t - 20;
     else if (t >= 10) g_x3_patch = t - 10;
     else g_x3_tile = t;
