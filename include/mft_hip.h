@@ -51,6 +51,16 @@ int mft_augment_views(const unsigned char* src, int n_img, int Hs, int Ws, const
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);
 
+/* mft_ce_pool_backward + mft_bn_backward2 in one launch (finetune.py:286-293 over backbone.py:256-261): the gradient of the
+ * cross entropy on the pooled feature [n_groups*imgs_per_group, C] through AvgPool(hw) and the block's final ReLU (mask: out > 0)
+ * is formed on the fly and pushed through the two BatchNorms of the residual join (main branch xa = c2, shortcut xb = sc):
+ * dxa/dxb [rows, C], dgamma/dbeta [n_groups, C] each, loss [n_groups].  Bit-identical to the two launches it replaces.          */
+int mft_ce_pool_bn_backward2(const float* feat, const int* labels, int imgs_per_group, int n_groups, int C, int hw,
+                             const float* out, const float* xa, const float* xb, float* dxa, float* dxb, const float* mean_a,
+                             const float* rstd_a, const float* gamma_a, const float* mean_b, const float* rstd_b,
+                             const float* gamma_b, long long gb_group_stride, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                             float* dbeta_b, float* loss, void* stream);
+
 /* Pre-split activation planes for the bf16x3 convolutions: the frozen trunk convolutions consume every activation 9-36 times
  * (taps x output-channel tiles); the producers below split each fp32 value once into its three bf16 pieces
  * ([3][rows][C] unsigned short, plane_stride elements between planes) so the convolution's operand path is a plain copy.

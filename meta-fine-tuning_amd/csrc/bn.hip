@@ -678,6 +678,102 @@ __global__ __launch_bounds__(256) void bn_backward2_kernel(BwdArgs a, BwdArgs b)
     }
 }
 
+// bn_backward2 with the incoming gradient computed on the fly from the loss: the inner-loop loss is the cross entropy on the
+// pooled feature (finetune.py:286-293), so dy[row][c] = out > 0 ? (softmax(feat[img])[c] - onehot[c]) / (k * hw) : 0 needs only
+// the k log-sum-exps of the group (recomputed by each of the C/64 workgroups of a group: k x C floats) -- d_out is never written.
+// Same arithmetic, in the same order, as ce_pool_backward_kernel followed by bn_backward2_kernel.
+struct CeArgs { const float* feat; const int* labels; const float* out; float* loss; int k, hw; };
+
+__global__ __launch_bounds__(256) void bn_backward2_ce_kernel(BwdArgs a, BwdArgs b, CeArgs ce) {
+    const int g = blockIdx.y;
+    const int C = a.C;
+    __shared__ float s_lse[16];
+    __shared__ float s_loss[16];
+    __shared__ int s_lab[16];
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int r = wave; r < ce.k; r += 4) {
+            const float* x = ce.feat + ((long long)g * ce.k + r) * C;
+            float mx = -3.4e38f;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+            se = wave_sum(se);
+            if (lane == 0) {
+                const float lse = mx + __logf(se);
+                const int y = ce.labels[(long long)g * ce.k + r];
+                s_lse[r] = lse;
+                s_lab[r] = y;
+                s_loss[r] = lse - x[y];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x == 0 && ce.loss) {
+            float s = 0.f;
+            for (int r = 0; r < ce.k; ++r) s += s_loss[r];
+            ce.loss[g] = s / (float)ce.k;
+        }
+    }
+    const float inv_ce = 1.f / ((float)ce.k * (float)ce.hw);
+    const int cq = threadIdx.x & 15;
+    const int rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const long long row0 = (long long)g * a.rows_per_group;
+    auto dy_at = [&](int rr) {
+        const int img = rr / ce.hw;
+        const f32x4 o = *(const f32x4*)(ce.out + (row0 + rr) * C + c);
+        const f32x4 x = *(const f32x4*)(ce.feat + ((long long)g * ce.k + img) * C + c);
+        const int y = s_lab[img];
+        const float lse = s_lse[img];
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pr = __expf(x[e] - lse) - ((c + e) == y ? 1.f : 0.f);
+            d[e] = o[e] > 0.f ? pr * inv_ce : 0.f;
+        }
+        return d;
+    };
+    for (int which = 0; which < 2; ++which) {
+        const BwdArgs& p = which ? b : a;
+        __shared__ f32x4 red1[ST_ROWS][16];
+        __shared__ f32x4 red2[ST_ROWS][16];
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
+        const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        const f32x4 ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+            const f32x4 d = dy_at(rr);
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            s1 += d;
+            s2 += d * xh;
+        }
+        red1[rl][cq] = s1;
+        red2[rl][cq] = s2;
+        __syncthreads();
+        s1 = red1[0][cq];
+        s2 = red2[0][cq];
+#pragma unroll
+        for (int k = 1; k < ST_ROWS; ++k) {
+            s1 += red1[k][cq];
+            s2 += red2[k][cq];
+        }
+        if (rl == 0) {
+            *(f32x4*)(p.dgamma + (long long)g * p.C + c) = s2;
+            *(f32x4*)(p.dbeta + (long long)g * p.C + c) = s1;
+        }
+        const float inv = 1.f / (float)p.rows_per_group;
+        const f32x4 m1 = s1 * inv, m2 = s2 * inv;
+        const f32x4 k = ga * rs;
+        for (int rr = rl; rr < p.rows_per_group; rr += ST_ROWS) {
+            const f32x4 d = dy_at(rr);
+            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+            *(f32x4*)(p.dx + (row0 + rr) * p.lddx + c) = k * (d - m1 - xh * m2);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int mft_bn_small_forward(const float* x1, int ld1, const float* x2, int ld2, const float* res, int ldr, float* y,
@@ -703,5 +799,19 @@ extern "C" int mft_bn_backward2(const float* xa, const float* xb, int ldx, const
     BwdArgs a{xa, dy, nullptr, dxa, ldx, lddy, 0, lddx, C, rows_per_group, mean_a, rstd_a, gamma_a, gb_group_stride, dgamma_a, dbeta_a};
     BwdArgs b{xb, dy, nullptr, dxb, ldx, lddy, 0, lddx, C, rows_per_group, mean_b, rstd_b, gamma_b, gb_group_stride, dgamma_b, dbeta_b};
     hipLaunchKernelGGL(bn_backward2_kernel, dim3(C / 64, n_groups), dim3(256), 0, (hipStream_t)stream, a, b);
+    return mft_launch_status();
+}
+
+extern "C" int mft_ce_pool_bn_backward2(const float* feat, const int* labels, int imgs_per_group, int n_groups, int C, int hw,
+                                        const float* out, const float* xa, const float* xb, float* dxa, float* dxb,
+                                        const float* mean_a, const float* rstd_a, const float* gamma_a, const float* mean_b,
+                                        const float* rstd_b, const float* gamma_b, long long gb_group_stride, float* dgamma_a,
+                                        float* dbeta_a, float* dgamma_b, float* dbeta_b, float* loss, void* stream) {
+    if (C % 64 != 0 || imgs_per_group < 1 || imgs_per_group > 16 || hw < 1) return MFT_EINVAL;
+    const int rows = imgs_per_group * hw;
+    BwdArgs a{xa, nullptr, nullptr, dxa, C, C, 0, C, C, rows, mean_a, rstd_a, gamma_a, gb_group_stride, dgamma_a, dbeta_a};
+    BwdArgs b{xb, nullptr, nullptr, dxb, C, C, 0, C, C, rows, mean_b, rstd_b, gamma_b, gb_group_stride, dgamma_b, dbeta_b};
+    CeArgs ce{feat, labels, out, loss, imgs_per_group, hw};
+    hipLaunchKernelGGL(bn_backward2_ce_kernel, dim3(C / 64, n_groups), dim3(256), 0, (hipStream_t)stream, a, b, ce);
     return mft_launch_status();
 }

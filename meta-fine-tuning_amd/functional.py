@@ -441,15 +441,20 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     n, oh, ow, C = out.shape
     groups = n // ipg
     rows = ipg * oh * ow
-    d_out = arena.get(tag + ".dout", (n, oh, ow, C))
     lib = ops._lib.lib()
-    if ce is not None:
+    fused_ce = FUSED_LAST_BLOCK and ce is not None and C % 64 == 0 and ipg <= 16
+    d_out = None
+    if fused_ce:
+        pass                                    # the loss gradient is formed inside the fused BatchNorm-backward launch below
+    elif ce is not None:
         # ce = (feat, labels_i32, loss_out): cross entropy on the pooled feature and its gradient through AvgPool + ReLU in
         # one launch (dfeat is not materialised)
+        d_out = arena.get(tag + ".dout", (n, oh, ow, C))
         feat, labels, loss = ce
         ops._lib.check(lib.mft_ce_pool_backward(ops._p(feat), ops._p(labels), ipg, groups, C, oh * ow, ops._p(out), ops._p(d_out),
                                                 ops._p(loss), ops._stream()), "mft_ce_pool_backward")
     else:
+        d_out = arena.get(tag + ".dout", (n, oh, ow, C))
         ops._lib.check(lib.mft_avgpool_relu_backward(ops._p(dfeat), ops._p(out), ops._p(d_out), n, oh * ow, C,
                                                      ops._stream()), "mft_avgpool_relu_backward")
 
@@ -470,7 +475,17 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
             ops.conv2d_wgrad_adam(xin, dy, getattr(params, name), getattr(m, name), getattr(v, name), 512, k, k,
                                   stride, pad, 1 if hyper is not None else step, imgs_per_group=ipg, lr=lr, hyper=hyper)
 
-    if C % 64 == 0:
+    if fused_ce:
+        # CE + AvgPool/ReLU backward + both BatchNorm backwards of the residual join in one launch (d_out never reaches HBM)
+        feat, labels, loss = ce
+        dc2 = arena.get(tag + ".dc2", tuple(c2.shape))
+        dsc = arena.get(tag + ".dsc", tuple(sc.shape))
+        rc = lib.mft_ce_pool_bn_backward2(ops._p(feat), ops._p(labels), ipg, groups, C, oh * ow, ops._p(out), ops._p(c2), ops._p(sc),
+                                          ops._p(dc2), ops._p(dsc), ops._p(tape["m2"]), ops._p(tape["s2"]), ops._p(params.bn2g),
+                                          ops._p(tape["ms"]), ops._p(tape["ss"]), ops._p(params.bnsg), C, ops._p(grads.bn2g),
+                                          ops._p(grads.bn2b), ops._p(grads.bnsg), ops._p(grads.bnsb), ops._p(loss), ops._stream())
+        ops._lib.check(rc, "mft_ce_pool_bn_backward2")
+    elif C % 64 == 0:
         dc2 = arena.get(tag + ".dc2", tuple(c2.shape))
         dsc = arena.get(tag + ".dsc", tuple(sc.shape))
         rc = lib.mft_bn_backward2(ops._p(c2), ops._p(sc), C, ops._p(d_out), C, ops._p(dc2), ops._p(dsc), C, C, rows, groups,

@@ -448,6 +448,16 @@ def test_fused_small_group_kernels_match_unfused(ipg):
                                 ops._p(dgb), ops._p(dbb), ops._stream()) == 0
     for a, b in ((dxa, dxa_r), (dxb, dxb_r), (dga, dga_r), (dba, dba_r), (dgb, dgb_r), (dbb, dbb_r)):
         assert torch.equal(a, b)
+    # CE + pool backward + dual BN backward in one launch: same arithmetic in the same order
+    dxa2, dxb2 = torch.empty_like(c2), torch.empty_like(sc)
+    dga2, dba2, dgb2, dbb2 = (torch.empty((G, C), device=DEV) for _ in range(4))
+    loss2 = torch.empty((G,), device=DEV)
+    assert lib.mft_ce_pool_bn_backward2(ops._p(ref_feat), ops._p(labels), ipg, G, C, hw, ops._p(ref), ops._p(c2), ops._p(sc),
+                                        ops._p(dxa2), ops._p(dxb2), ops._p(m2), ops._p(s2), ops._p(g2), ops._p(ms), ops._p(ss),
+                                        ops._p(gs), C, ops._p(dga2), ops._p(dba2), ops._p(dgb2), ops._p(dbb2), ops._p(loss2),
+                                        ops._stream()) == 0
+    for a, b in ((dxa2, dxa), (dxb2, dxb), (dga2, dga), (dba2, dba), (dgb2, dgb), (dbb2, dbb), (loss2, loss)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("ipg", [5, 4, 1])
