@@ -405,6 +405,28 @@ def main():
                                   "achieved": round(big[0][1] * len(big) / (sum(t for t, _ in big) * 1e-3) / 1e9, 1)},
                 "practical_ceiling_note": "a pure 3-read/3-write Adam stream tops out at ~5.5 TB/s on this part "
                                           "(tools/microbench/adam_stream.hip)"}
+        # the same kernel with the GPU to itself (no trunk stream beside it): what the overlap costs the HBM-bound launch
+        try:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(5)
+            xs = torch.randn(E * 5, 3, 3, 512, device=dev, generator=gen)
+            dys = torch.randn(E * 5, 3, 3, 512, device=dev, generator=gen) * 1e-3
+            ws = torch.randn(E, 512, 4608, device=dev, generator=gen) * 0.02
+            ms_, vs_ = torch.zeros_like(ws), torch.zeros_like(ws)
+            orig_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 1, 5)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for it in range(5):
+                orig_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 2 + it, 5)
+            e1.record()
+            torch.cuda.synchronize()
+            t_us = e0.elapsed_time(e1) * 1e3 / 5
+            roof["standalone"] = {"what": "trunk.7.C2 x %d episodes, no co-running stream" % E, "avg_launch_us": round(t_us, 2),
+                                  "achieved": round(24.0 * ws.numel() / (t_us * 1e-6) / 1e9, 1)}
+            del xs, dys, ws, ms_, vs_
+        except RuntimeError as ex:          # e.g. not enough free memory next to a large engine
+            roof["standalone"] = {"error": str(ex)[:120]}
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
         tot_fl = sum(f for _, _, f in conv_events)
         n_launch = len(conv_events)
