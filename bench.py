@@ -347,7 +347,8 @@ def main():
         a.record(s)
         r = orig_x3_bn(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, **kw)
         b.record(s)
-        x3_events.append((a, b, conv_flops(x.shape[0], out.shape[1], Cout, KH * KW * x.shape[3])))
+        if r is not None:                   # None: outside the fused form's domain, the caller falls back to conv2d_x3 + bn_stats
+            x3_events.append((a, b, conv_flops(x.shape[0], out.shape[1], Cout, KH * KW * x.shape[3])))
         return r
 
     ops.conv2d = timed_conv2d

@@ -349,8 +349,9 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
             ws = arena.get("x3.statws", (max(nws, 1 << 20),)) if nws <= (1 << 20) else arena.get(stag + ".statws", (nws,))
             mean = arena.get(stag + ".mean", (groups, cout))
             rstd = arena.get(stag + ".rstd", (groups, cout))
-            o, mean, rstd = ops.conv2d_x3_bnstats(inp, w3[p + name], cout, k, k, s, pd, ipg, obuf, ws, mean, rstd)
-            return o, mean, rstd
+            r = ops.conv2d_x3_bnstats(inp, w3[p + name], cout, k, k, s, pd, ipg, obuf, ws, mean, rstd)
+            if r is not None:
+                return r
         o = conv(name, inp, wpk, k, s, pd, obuf)
         mm, ss_ = _bn_stats4(arena, stag, o, ipg, groups, run(p + bnname), fix(p + bnname))
         return o, mm, ss_

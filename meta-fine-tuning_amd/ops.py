@@ -130,6 +130,8 @@ def conv2d_x3_bnstats(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws,
     rc = _lib.lib().mft_conv2d_nhwc_x3_bnstats(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin,
                                                Cout, KH, KW, stride, pad, imgs_per_group, eps, _p(ws), _p(mean), _p(rstd),
                                                _stream())
+    if rc == _lib.MFT_EINVAL:
+        return None                       # outside the fused form's domain (e.g. an input of 2 GiB or more): caller uses conv + bn_stats
     _lib.check(rc, "mft_conv2d_nhwc_x3_bnstats")
     return out, mean, rstd
 
