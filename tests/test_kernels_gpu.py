@@ -554,3 +554,62 @@ def test_conv_x3_fused_bn_statistics(name, Cin, Cout, k, stride, pad, H, ipg):
     r_ref = 1.0 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)
     assert float((mean.cpu().double() - m_ref).abs().max()) < 2e-6 * max(1.0, float(m_ref.abs().max()))
     assert float(((rstd.cpu().double() - r_ref) / r_ref).abs().max()) < 2e-5
+
+
+def test_ingest_episode_views_matches_layout_copies():
+    """mft_ingest_episode_views (one launch) against the reference's x_a_i assembly (finetune.py:208-233): view 0 twice, then
+    views 1.., support images only, NCHW -> NHWC; and view 0 of every image for the final pass."""
+    import ctypes
+    from meta_fine_tuning_amd import _lib
+    n_way, per, ns, H, V = 5, 7, 3, 12, 4
+    views = [rnd((n_way, per, 3, H, H), 90 + v).to(DEV) for v in range(V)]
+    ptrs = (ctypes.c_void_p * V)(*[v.data_ptr() for v in views])
+    npv = n_way * ns
+    sup = torch.empty(((V + 1) * npv, H, H, 3), device=DEV)
+    allv = torch.empty((n_way * per, H, H, 3), device=DEV)
+    assert _lib.lib().mft_ingest_episode_views(ptrs, V, 1, n_way, per, ns, 3, H, H, ops._p(sup), ops._p(allv), ops._stream()) == 0
+    ref = torch.cat([views[0][:, :ns].reshape(npv, 3, H, H)] + [v[:, :ns].reshape(npv, 3, H, H) for v in views]).permute(0, 2, 3, 1)
+    assert torch.equal(sup, ref.contiguous())
+    assert torch.equal(allv, views[0].reshape(n_way * per, 3, H, H).permute(0, 2, 3, 1).contiguous())
+    sup1 = torch.empty((npv, H, H, 3), device=DEV)                      # single view, no doubling, no final-pass store
+    assert _lib.lib().mft_ingest_episode_views(ptrs, 1, 0, n_way, per, ns, 3, H, H, ops._p(sup1), None, ops._stream()) == 0
+    assert torch.equal(sup1, ref[:npv].contiguous())
+    assert _lib.lib().mft_ingest_episode_views(ptrs, 33, 0, n_way, per, ns, 3, H, H, ops._p(sup1), None, ops._stream()) == -22
+
+
+def test_linear_head_sgd_run_matches_torch_sgd():
+    """mft_linear_head_sgd_run (all epochs x mini-batches of the set_forward_adaptation head training in one launch, two
+    episodes at once, ragged last mini-batch) against torch.optim.SGD(lr .01, momentum .9, dampening .9, weight_decay .001)."""
+    from meta_fine_tuning_amd import _lib
+    G, S, D, n_way, bs, epochs = 2, 25, 512, 5, 4, 6
+    rs = np.random.RandomState(17)
+    z = torch.from_numpy(np.abs(rs.standard_normal((G, S, D))).astype(np.float32))
+    y = torch.from_numpy(np.stack([np.repeat(np.arange(n_way), S // n_way)[rs.permutation(S)] for _ in range(G)]).astype(np.int64))
+    W0 = torch.from_numpy((rs.standard_normal((G, n_way, D)) * 0.04).astype(np.float32))
+    b0 = torch.from_numpy((rs.standard_normal((G, n_way)) * 0.01).astype(np.float32))
+    steps = [[] for _ in range(G)]
+    for g in range(G):
+        for _ in range(epochs):
+            pm = rs.permutation(S)
+            for i in range(0, S, bs):
+                ids = pm[i:i + bs]
+                steps[g].append(np.concatenate([ids, -np.ones(bs - len(ids), dtype=ids.dtype)]))
+    table = torch.from_numpy(np.stack([np.stack(st) for st in steps]).astype(np.int32)).to(DEV)
+    W, b = W0.clone().to(DEV), b0.clone().to(DEV)
+    z_dev, y_dev = z.to(DEV), y.to(torch.int32).to(DEV)            # named: the launch is asynchronous, temporaries would be freed
+    rc = _lib.lib().mft_linear_head_sgd_run(ops._p(z_dev), ops._p(y_dev), ops._p(table), G, S, D, n_way,
+                                            table.shape[1], bs, ops._p(W), ops._p(b), 0.01, 0.9, 0.9, 0.001, ops._stream())
+    assert rc == 0
+    for g in range(G):
+        lin = torch.nn.Linear(D, n_way).double()
+        lin.weight.data.copy_(W0[g])
+        lin.bias.data.copy_(b0[g])
+        opt = torch.optim.SGD(lin.parameters(), lr=0.01, momentum=0.9, dampening=0.9, weight_decay=0.001)
+        for st in steps[g]:
+            ids = torch.from_numpy(st[st >= 0])
+            opt.zero_grad()
+            F.cross_entropy(lin(z[g][ids].double()), y[g][ids]).backward()
+            opt.step()
+        dw = float((W[g].cpu().double() - lin.weight.data).abs().max())
+        db = float((b[g].cpu().double() - lin.bias.data).abs().max())
+        assert dw < 2e-5 and db < 2e-5, (g, dw, db, float((W0[g].double() - lin.weight.data).abs().max()))
