@@ -90,11 +90,12 @@ class FinetuneEngine:
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
         self.trunk_chunk = int(os.environ.get("MFT_TRUNK_CHUNK", "1")) if trunk_chunk is None else int(trunk_chunk)
-        # Queue priority for the trunk stream (its convolution workgroups are the large ones: 46 KB LDS).  Measured: no effect
-        # on this stack (4.03 vs 4.01 ms per step with / without); kept as a knob.
-        prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "-1"))
+        # Queue priorities: the last-block stream is the critical path (its 8 launches per step are serial and HBM-bound), the
+        # trunk stream only has to stay one step ahead.  A/B (one session, two runs each): last high / trunk normal 68.1, 68.1;
+        # trunk high / last normal 67.4; both normal 67.2, 67.2 episodes/s.
+        prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "0"))
         self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio) if pipeline else None
-        self.s_last = torch.cuda.Stream(device=self.dev, priority=0) if pipeline else None
+        self.s_last = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("MFT_LAST_PRIORITY", "-1"))) if pipeline else None
         px = image_size * image_size * 3
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
