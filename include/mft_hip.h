@@ -35,6 +35,10 @@ int mft_device_info(int* cu_count, int* gcn_arch_is_gfx950);
  * queue may use CU i (n_words*32 bits); mft_probe_placement writes {XCC_ID, HW_ID} of each workgroup's CU into
  * out[2*n_blocks] (used to learn the bit -> XCD mapping on the box).                                              */
 int mft_stream_create_cumask(const unsigned* mask_words, int n_words, void** stream_out);
+/* hipStreamCreateWithPriority with the device's full priority range (range_out = {least, greatest}; stream_out may be NULL to
+ * query only).  The engine puts the frozen-trunk stream at the least and the last-block (critical path) stream at the
+ * greatest priority.                                                                                                          */
+int mft_stream_create_priority(int priority, void** stream_out, int* range_out);
 int mft_stream_destroy(void* stream);
 int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream);
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_stream_create_priority": [_I, _P, _P],
     "mft_ce_pool_bn_backward2": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "mft_bn_apply_planes": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
     "mft_bn_relu_maxpool_gather_planes": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -34,6 +34,21 @@ extern "C" int mft_stream_create_cumask(const unsigned* mask_words, int n_words,
     return 0;
 }
 
+// HIP exposes three queue priorities on this part (hipDeviceGetStreamPriorityRange: least .. greatest); torch.cuda.Stream
+// clamps to two of them.  *range_out = {least, greatest} when non-null.
+extern "C" int mft_stream_create_priority(int priority, void** stream_out, int* range_out) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    if (range_out) { range_out[0] = least; range_out[1] = greatest; }
+    if (!stream_out) return 0;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    if (e != hipSuccess) return (int)e;
+    *stream_out = (void*)s;
+    return 0;
+}
+
 extern "C" int mft_stream_destroy(void* stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
 
 extern "C" int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream) {

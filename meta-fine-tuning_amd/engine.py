@@ -93,8 +93,16 @@ class FinetuneEngine:
         # Queue priorities: the last-block stream is the critical path (its 8 launches per step are serial and HBM-bound), the
         # trunk stream only has to stay one step ahead.  A/B (one session, two runs each): last high / trunk normal 68.1, 68.1;
         # trunk high / last normal 67.4; both normal 67.2, 67.2 episodes/s.
-        prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "0"))
-        self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio) if pipeline else None
+        # (trunk at the device's least priority, below torch's range: 68.2 / 68.1 / 67.7 vs 67.8 / 68.0 / 67.5 at normal)
+        prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "1"))
+        self.s_trunk = None
+        if pipeline and prio > 0:              # below torch's range: a HIP stream at the device's least priority
+            out = ctypes.c_void_p()
+            with torch.cuda.device(self.dev):
+                ops._lib.check(ops._lib.lib().mft_stream_create_priority(prio, ctypes.byref(out), None), "mft_stream_create_priority")
+            self.s_trunk = torch.cuda.ExternalStream(out.value, device=self.dev)
+        elif pipeline:
+            self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio)
         self.s_last = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("MFT_LAST_PRIORITY", "-1"))) if pipeline else None
         px = image_size * image_size * 3
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
