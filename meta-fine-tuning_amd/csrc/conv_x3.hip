@@ -34,9 +34,7 @@ struct X3Args {
     int tiles_n;
     unsigned in_bytes, w_bytes;    // buffer-resource extents (< 2^31: out-of-range offsets are used as the zero-fill sentinel)
     int xcd_swizzle;
-    int prio;                      // 1: s_setprio 1 over the MFMA block, 2: over the split/store block (mft_debug_set_x3_tile(50 + v))
     int row_swz;                   // staging-row assignment that avoids LDS write bank conflicts
-    int depth2;                    // 1: two K-steps of operands in flight (register stages), 0: one
     const unsigned short* in3;     // AP kernels: pre-split input planes [3][n_img*H*W][ldi] bf16 (written by mft_bn_apply_planes)
     unsigned in_plane_bytes;
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
@@ -150,14 +148,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // two register stages: the operands of K-steps kt+1 and kt+2 are in flight while kt is multiplied (one stage in flight
-    // does not cover the L2 / fabric latency beside the HBM-saturating last-block stream)
+    // register stage: the operands of K-step kt+1 are in flight while kt is multiplied
     struct Stage {
         f32x4 ra[AP ? 1 : PA];
         u32x4 ra3[AP ? PA : 1][3];
         u32x4 rb[PB][3];
     };
-    Stage st0, st1;
+    Stage st0;
     const int nk = p.Kpad / 32;
 
     auto load_tile = [&](int kt, Stage& S) {
@@ -233,29 +230,18 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
         }
     };
-    // K-step kt: LDS holds tile kt; `nxt` holds tile kt+1 (loaded during kt-1), tile kt+2 is requested into `far` -- the stage
-    // whose contents went to LDS before this step
-    const bool g_depth2 = p.depth2 != 0;
-    const int prio = p.prio;
-    auto step = [&](int kt, Stage& nxt, Stage& far) {
-        if (g_depth2 && kt + 2 < nk) load_tile(kt + 2, far);
-        if (!g_depth2 && kt + 1 < nk) load_tile(kt + 1, nxt);
-        if (prio == 1) __builtin_amdgcn_s_setprio(1);
-        compute();
-        if (prio == 1) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-        if (prio == 2) __builtin_amdgcn_s_setprio(1);
-        if (kt + 1 < nk) store_tile(nxt);
-        if (prio == 2) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-    };
+    // Rejected variants of this loop (measured, removed again): two K-steps of operands in flight (second register stage):
+    // neutral in situ, +3 % standalone time from the extra registers; s_setprio around the MFMA block or around the split/store
+    // block: no gain from the priority, and the run-time branches alone cost 40 % -- keep the K-step body branch-free.
     load_tile(0, st0);
     store_tile(st0);
-    if (g_depth2 && nk > 1) load_tile(1, st1);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, st1, st0);
-        if (kt + 1 < nk) step(kt + 1, st0, st1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1, st0);
+        compute();
+        __syncthreads();
+        if (kt + 1 < nk) store_tile(st0);
+        __syncthreads();
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -361,9 +347,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
-int g_x3_prio = 0;         // wave priority experiment (mft_debug_set_x3_tile(50/51/52))
 int g_x3_row_swz = 1;      // conflict-free staging-row assignment (mft_debug_set_x3_tile(40/41))
-int g_x3_depth2 = 0;       // 1: two K-steps of operands in flight instead of one (mft_debug_set_x3_tile(30/31)); measured neutral
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
@@ -372,9 +356,7 @@ int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
-    p.depth2 = g_x3_depth2;
     p.row_swz = g_x3_row_swz;
-    p.prio = g_x3_prio;
     size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     auto kern = conv_x3_kernel<BM, BN, AP>;
@@ -582,9 +564,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 100) g_x3_min_lds_kb = t - 100;
-    else if (t >= 50) g_x3_prio = t - 50;
     else if (t >= 40) g_x3_row_swz = t - 40;
-    else if (t >= 30) g_x3_depth2 = t - 30;
     else if (t >= 20) g_x3_xcd = t - 20;
     else if (t >= 10) g_x3_patch = t - 10;
     else g_x3_tile = t;
