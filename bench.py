@@ -207,6 +207,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=84, help="84 = BASELINE configs (the metric); 224 = the reference's hard-coded "
                     "image_size (train.py:72, finetune.py:429) -- extra measurement, FLOP-derived fields then refer to 84")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-standalone", action="store_true", help="skip the extra standalone launches of the dominant kernel "
+                    "(roofline.standalone); used for the PMC passes so that per-launch counter means cover the step mix only")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle on a bounded sample and print its JSON object; never touches the GPU")
     ap.add_argument("--no-defer-final", action="store_true", help="run each batch's final pass synchronously (A/B)")
@@ -408,6 +410,8 @@ def main():
                                           "(tools/microbench/adam_stream.hip)"}
         # the same kernel with the GPU to itself (no trunk stream beside it): what the overlap costs the HBM-bound launch
         try:
+            if args.no_standalone:
+                raise RuntimeError("skipped (--no-standalone)")
             gen = torch.Generator(device=dev)
             gen.manual_seed(5)
             xs = torch.randn(E * 5, 3, 3, 512, device=dev, generator=gen)

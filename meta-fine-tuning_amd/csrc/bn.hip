@@ -108,6 +108,7 @@ __device__ __forceinline__ float act_f(float v, int act, float slope) {
     return v;
 }
 
+template <bool PLANES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
     const int cq = p.C >> 2;
     const long long total = (long long)p.n_groups * p.rows_per_group * cq;
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
-        if (p.y) *(f32x4*)(p.y + row * p.ldy + c) = o;
-        if (p.planes) {
+        if (!PLANES || p.y) *(f32x4*)(p.y + row * p.ldy + c) = o;
+        if constexpr (PLANES) {
             mft_u32x2 p1, p2, p3;
             mft_split4_bf16(o, p1, p2, p3);
             unsigned short* q = p.planes + row * p.C + c;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
 }
 
 // BN -> ReLU -> MaxPool(3,2,1), NHWC.  relu(max(.)) == max(relu(.)); padding never wins (>= 1 valid tap).
+template <bool PLANES>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int n_img, int H, int W, int C, int OH, int OW,
                                                               int imgs_per_group, const float* __restrict__ mean,
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], 0.f);
         *(f32x4*)(y + i * 4) = best;
-        if (planes) {
+        if constexpr (PLANES) {
             mft_u32x2 p1, p2, p3;
             mft_split4_bf16(best, p1, p2, p3);
             unsigned short* q = planes + i * 4;
@@ -421,7 +423,7 @@ extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, i
     ApplyArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, mean, rstd, gamma, beta, gb_group_stride,
                 res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope, nullptr, 0};
     const long long total = (long long)n_groups * rows_per_group * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
     return mft_launch_status();
 }
 
@@ -435,7 +437,7 @@ extern "C" int mft_bn_apply_planes(const float* x, int ldx, float* y, int ldy, u
     ApplyArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, mean, rstd, gamma, beta, gb_group_stride,
                 res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope, planes, plane_stride};
     const long long total = (long long)n_groups * rows_per_group * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
     return mft_launch_status();
 }
 
@@ -447,8 +449,12 @@ extern "C" int mft_bn_relu_maxpool_gather_planes(const float* x, const int* src_
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)n_img * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx, planes, plane_stride);
+    if (planes)
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<true>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                           x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx, planes, plane_stride);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<false>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                           x, y, n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta, src_idx, planes, plane_stride);
     return mft_launch_status();
 }
 
