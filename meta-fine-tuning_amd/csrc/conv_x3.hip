@@ -70,7 +70,11 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // AP = true: the activation arrives already split into its three bf16 planes (the producing BatchNorm-apply / pooling kernel
 // split every element ONCE, instead of this loader re-splitting it for each of the 9 taps and each n-tile): the A path is
 // then the same plain 16-byte copy into LDS as the weight path, with no VALU work between the loads and the MFMAs.
-template <int BM, int BN, bool AP>
+// DB = true: two LDS buffers and ONE barrier per K-step: the split + LDS store of tile kt+1 goes to the other buffer, so it
+// sits in the same basic block as the MFMAs of tile kt and the scheduler can issue it in their shadow (the single-buffer loop
+// has barrier - store - barrier between two MFMA blocks; PMC: waves 47 % issue-stalled / 24 % parked, matrix pipes 40 % busy).
+// Costs 92 KB of LDS per workgroup (one workgroup per CU instead of three).
+template <int BM, int BN, bool AP, bool DB>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* As = smem;                    // [3][BM][RS]
     unsigned short* Bs = smem + 3 * A_PLANE;      // [3][BN][RS]
+    constexpr int BUF = 3 * (A_PLANE + B_PLANE);  // elements per LDS buffer (DB: two of them)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -181,7 +186,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
             for (int pl = 0; pl < 3; ++pl)
                 S.rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
     };
-    auto store_tile = [&](const Stage& S) {
+    auto store_tile = [&](const Stage& S, int buf) {
+        unsigned short* As = smem + buf * BUF;
+        unsigned short* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int off = (lrow + RPP * j) * X3_RS + c4;
@@ -203,7 +210,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = S.rb[j][pl];
     };
 
-    auto compute = [&]() {
+    auto compute = [&](int buf) {
+        const unsigned short* As = smem + buf * BUF;
+        const unsigned short* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[TM][3], b[TN][3];
@@ -233,15 +242,29 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     // Rejected variants of this loop (measured, removed again): two K-steps of operands in flight (second register stage):
     // neutral in situ, +3 % standalone time from the extra registers; s_setprio around the MFMA block or around the split/store
     // block: no gain from the priority, and the run-time branches alone cost 40 % -- keep the K-step body branch-free.
-    load_tile(0, st0);
-    store_tile(st0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1, st0);
-        compute();
+    if constexpr (DB) {
+        load_tile(0, st0);
+        store_tile(st0, 0);
         __syncthreads();
-        if (kt + 1 < nk) store_tile(st0);
+        load_tile(nk > 1 ? 1 : 0, st0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {      // branch-free body: the last tile is simply requested twice
+            compute(kt & 1);
+            store_tile(st0, (kt + 1) & 1);
+            load_tile(kt + 2 < nk ? kt + 2 : nk - 1, st0);
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
+    } else {
+        load_tile(0, st0);
+        store_tile(st0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1, st0);
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) store_tile(st0, 0);
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -347,19 +370,20 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+int g_x3_db = 0;           // double-buffered LDS form of the 128x64 kernel (mft_debug_set_x3_tile(60/61))
 int g_x3_row_swz = 1;      // conflict-free staging-row assignment (mft_debug_set_x3_tile(40/41))
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
-template <int BM, int BN, bool AP>
+template <int BM, int BN, bool AP, bool DB>
 int launch_x3(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz;
-    size_t lds = (size_t)3 * (BM + BN) * X3_RS * sizeof(unsigned short);
+    size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
-    auto kern = conv_x3_kernel<BM, BN, AP>;
+    auto kern = conv_x3_kernel<BM, BN, AP, DB>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -564,6 +588,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 60) g_x3_db = t - 60;
     else if (t >= 40) g_x3_row_swz = t - 40;
     else if (t >= 20) g_x3_xcd = t - 20;
     else if (t >= 10) g_x3_patch = t - 10;
@@ -601,7 +626,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         p.in_plane_bytes = (unsigned)(in_plane_elems * 2);
         p.in_bytes = 0;
         p.w_bytes = (unsigned)(3 * plane_elems * 2);
-        return launch_x3<128, 64, true>(p, (hipStream_t)stream);
+        return launch_x3<128, 64, true, false>(p, (hipStream_t)stream);
     }
     if (stats_ws == nullptr && g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
         patch_geometry(H, W, &G, &R, &eff) && (g_x3_patch >= 2 || eff >= 0.9)) {
@@ -640,7 +665,9 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.out = out + i0 * p.OH * p.OW * ldo;
         q.M = (int)(ni * p.OH * p.OW);
         q.in_bytes = (unsigned)(ni * img_bytes);
-        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false>(q, s) : launch_x3<128, 64, false>(q, s);
+        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
+                       : g_x3_db                      ? launch_x3<128, 64, false, true>(q, s)
+                                                      : launch_x3<128, 64, false, false>(q, s);
         if (rc != 0) return rc;
     }
     return 0;
