@@ -211,6 +211,8 @@ def main():
                     "(roofline.standalone); used for the PMC passes so that per-launch counter means cover the step mix only")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) time the CPU oracle on a bounded sample and print its JSON object; never touches the GPU")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not enqueue the next batch's ingest + stem cache beside "
+                    "the current inner loop (A/B)")
     ap.add_argument("--no-defer-final", action="store_true", help="run each batch's final pass synchronously (A/B)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream inner loop (A/B against the 2-stream pipeline)")
     args = ap.parse_args()
@@ -292,7 +294,7 @@ def main():
             return e.run_batch(eps, sources=True, defer_final=not args.no_defer_final)
         # the final pass + GNN of a batch is enqueued on a third stream and overlaps the next batch's ingest / first steps;
         # everything is complete before the closing barrier + device synchronisation of the timed region
-        return e.run_batch(pool, defer_final=not args.no_defer_final)
+        return e.run_batch(pool, defer_final=not args.no_defer_final, prefetch=None if args.no_prefetch else pool)
 
     y_query = np.repeat(np.arange(n_way), n_query)
     np.random.seed(10 + rank)

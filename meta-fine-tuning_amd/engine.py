@@ -61,6 +61,8 @@ class FinetuneEngine:
             pipeline = False
         self._graphs = {}
         self._alt = None
+        self._pre = None            # ingest + stem cache of the NEXT batch, enqueued on their own stream (run_batch(prefetch=))
+        self._pre_bufs = None
         if not torch.cuda.is_available():
             raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
         self.dev = torch.device(device)
@@ -120,8 +122,11 @@ class FinetuneEngine:
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev) if stem_cache else None
 
     # ------------------------------------------------------------------ ingest
-    def load_episode(self, slot, liz_x):
-        """finetune.py:208-233: support images of view 0 twice, then of views 1.. (device NCHW -> NHWC store)."""
+    def load_episode(self, slot, liz_x, Xs=None, Xall=None):
+        """finetune.py:208-233: support images of view 0 twice, then of views 1.. (device NCHW -> NHWC store).
+        ``Xs`` / ``Xall``: target stores (default: the engine's current ones; the prefetch path fills the alternate pair)."""
+        Xs = self.Xs if Xs is None else Xs
+        Xall = self.Xall if Xall is None else Xall
         ns, npv, H = self.n_support, self.n_per_view, self.size
         assert len(liz_x) == self.n_views
         views = [liz_x[0].to(self.dev, non_blocking=True)]
@@ -131,16 +136,18 @@ class FinetuneEngine:
         views = [v if (v.dtype == torch.float32 and v.is_contiguous()) else v.float().contiguous() for v in views]
         ptrs = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
         rc = ops._lib.lib().mft_ingest_episode_views(ptrs, len(views), 1 if self.mode == "gnn" else 0, self.n_way,
-                                                     ns + self.n_query, ns, 3, H, H, ops._p(self.Xs[slot * self.n_total]),
-                                                     ops._p(self.Xall[slot * self.n_all]), ops._stream())
+                                                     ns + self.n_query, ns, 3, H, H, ops._p(Xs[slot * self.n_total]),
+                                                     ops._p(Xall[slot * self.n_all]), ops._stream())
         ops._lib.check(rc, "mft_ingest_episode_views")
 
-    def load_episode_source(self, slot, src_u8, params):
+    def load_episode_source(self, slot, src_u8, params, Xs=None, Xall=None):
         """Ingest straight from raw images: src_u8 [n_way, n_support+n_query, Hs, Ws, 3] uint8 on the
         device, params [n_views, n_way*(n_support+n_query), 10] from augment.sample_view_params.  One launch writes the
         support views into the support store in finetune.py:208-233's order (view 0 twice, then views 1..), one more
         writes view 0 of every image for the final pass -- no host-side PIL, no NCHW staging copies."""
         from . import augment
+        Xs = self.Xs if Xs is None else Xs
+        Xall = self.Xall if Xall is None else Xall
         ns, npv, H = self.n_support, self.n_per_view, self.size
         assert self.mode == "gnn" and params.shape[0] == self.n_views
         src = src_u8.to(self.dev)
@@ -151,9 +158,9 @@ class FinetuneEngine:
         sup_src = src[:, :ns].reshape(npv, Hs, Ws, 3).contiguous()
         Ps = P[:, :, :ns].reshape(self.n_views, npv, augment.NPARAM)
         Ps = torch.cat([Ps[:1], Ps], 0)                                   # view 0 twice, then views 1.. (x_a_i doubling)
-        augment.augment_views(sup_src, Ps, H, out=self.Xs[slot * self.n_total], view_stride=npv * px, img_stride=px)
+        augment.augment_views(sup_src, Ps, H, out=Xs[slot * self.n_total], view_stride=npv * px, img_stride=px)
         all_src = src.reshape(self.n_all, Hs, Ws, 3).contiguous()
-        augment.augment_views(all_src, P[:1].reshape(1, self.n_all, augment.NPARAM), H, out=self.Xall[slot * self.n_all],
+        augment.augment_views(all_src, P[:1].reshape(1, self.n_all, augment.NPARAM), H, out=Xall[slot * self.n_all],
                               view_stride=self.n_all * px, img_stride=px)
 
     def step_tables(self, perms, n_active):
@@ -354,13 +361,50 @@ class FinetuneEngine:
         if self._final_done[self._bi] is not None:                 # the final pass that last read these buffers is done
             torch.cuda.current_stream(self.dev).wait_event(self._final_done[self._bi])
 
-    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False, defer_final=False):
+    def _ingest(self, episodes, sources, Xs=None, Xall=None):
+        n = len(episodes)
+        for slot in range(self.E):
+            ep = episodes[min(slot, n - 1)]                          # pad a short batch by repeating the last episode
+            if sources:
+                self.load_episode_source(slot, ep[0], ep[1], Xs, Xall)
+            else:
+                self.load_episode(slot, ep, Xs, Xall)
+
+    def _enqueue_prefetch(self, episodes, sources):
+        """Ingest + stem cache of the next batch on their own stream, into the alternate support store / stem cache / final-pass
+        store, while this batch's inner loop runs: the stem convolution is matrix-bound, the inner loop HBM-bound."""
+        if self._pre_bufs is None:
+            need = self.Xs.numel() * 4 + (self.stem.c0.numel() + 2 * self.stem.mean.numel()) * 4
+            free, total = torch.cuda.mem_get_info(self.dev)
+            if need > 0.8 * free:
+                return                                           # not enough room for a second support store + stem cache
+            self._pre_bufs = {"Xs": torch.empty_like(self.Xs),
+                              "stem": Fn.StemCache(self.W, self.E * self.n_total, self.size, self.dev),
+                              "stream": torch.cuda.Stream(device=self.dev)}
+        b = self._pre_bufs
+        sp = b["stream"]
+        cur = torch.cuda.current_stream(self.dev)
+        nxt = self._bi ^ 1                                        # the weight / final-pass buffers the next batch will flip to
+        sp.wait_stream(cur)                                       # previous readers of the alternate store are behind `cur`
+        if self._final_done[nxt] is not None:
+            sp.wait_event(self._final_done[nxt])                  # the deferred final pass that still reads that Xall
+        with torch.cuda.stream(sp):
+            self._ingest(episodes, sources, b["Xs"], self._alt[nxt][1])
+            b["stem"].fill(b["Xs"].view(self.E * self.n_total, self.size, self.size, 3))
+            ev = torch.cuda.Event()
+            ev.record(sp)
+        self._pre = {"token": episodes, "sources": sources, "done": ev, "n": len(episodes)}
+
+    def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False, defer_final=False,
+                  prefetch=None):
         """episodes: list (<= E) of liz_x -- or, with ``sources=True``, of (src_u8, view_params) pairs for device-side view
         generation; perms: per-episode list of per-epoch permutations (default: drawn from the global numpy RNG episode by
         episode, exactly the reference's draw order).  Returns softmax scores [len(episodes), n_way*n_query, n_way].
         ``defer_final``: enqueue the final 100-image pass + GNN head on a third stream and return at once, so that it
         overlaps the ingest / stem cache / first inner steps of the NEXT run_batch call (the returned scores are valid
-        after a device synchronisation or ``engine.s_final.synchronize()``)."""
+        after a device synchronisation or ``engine.s_final.synchronize()``).
+        ``prefetch``: the episode list of the NEXT call (same ``sources``; needs ``defer_final`` in both calls): its ingest and
+        stem cache are enqueued now on a fourth stream and swapped in when that call arrives with the same list object."""
         n = len(episodes)
         assert 0 < n <= self.E
         defer_final = defer_final and self.mode == "gnn" and not self.use_graph and not return_feats
@@ -368,19 +412,28 @@ class FinetuneEngine:
             self._flip_buffers()
         if perms is None:
             perms = [draw_perms(self.n_total, self.epochs) for _ in range(n)]
-        for slot in range(self.E):
-            ep = episodes[min(slot, n - 1)]                          # pad a short batch by repeating the last episode
-            if sources:
-                self.load_episode_source(slot, ep[0], ep[1])
-            else:
-                self.load_episode(slot, ep)
+        pre, self._pre = self._pre, None
+        if pre is not None and defer_final and pre["token"] is episodes and pre["sources"] == sources and pre["n"] == n:
+            b = self._pre_bufs
+            self.Xs, b["Xs"] = b["Xs"], self.Xs
+            self.stem, b["stem"] = b["stem"], self.stem
+            torch.cuda.current_stream(self.dev).wait_event(pre["done"])
+            prepared = True
+        else:
+            if pre is not None:                                   # a prefetch that is not consumed: let it finish before reuse
+                torch.cuda.current_stream(self.dev).wait_event(pre["done"])
+            self._ingest(episodes, sources)
+            prepared = False
         self.adapt.reset(self.W)
         self.step_dev.zero_()
         if self.mode == "linear":
             if classifier_init is None:
                 raise RuntimeError("mode='linear' needs classifier_init=(w0 [n,n_way,512], b0 [n,n_way])")
             self.set_classifier(classifier_init[0], classifier_init[1], n)
-        self.prepare_batch()
+        if not prepared:
+            self.prepare_batch()
+        if prefetch is not None and defer_final and self.stem is not None and self.pipeline:
+            self._enqueue_prefetch(prefetch, sources)
         self.inner_loop(self.step_tables(perms, n))
         if defer_final:
             cur = torch.cuda.current_stream(self.dev)

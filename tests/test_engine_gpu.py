@@ -381,3 +381,22 @@ def test_deferred_final_pass_is_bit_identical():
     torch.cuda.synchronize()
     for b in range(3):
         assert torch.equal(got[b], ref[b]), b
+
+
+def test_prefetched_next_batch_is_bit_identical():
+    """run_batch(prefetch=next): the next batch's ingest + stem cache run on a fourth stream beside the current inner loop
+    (alternate support store / stem cache / final-pass store).  Four consecutive batches -- the third call is handed a list
+    other than the one that was prefetched, which must be discarded -- give exactly the synchronous results."""
+    sd = synthetic.gnnnet_state_dict(seed=53)
+    batches = [[synthetic.test_episode(1100 + 10 * b + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)] for b in range(4)]
+    rs = np.random.RandomState(23)
+    perms = [[[rs.permutation(100)] for _ in range(2)] for _ in range(4)]
+    e0 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    ref = [e0.run_batch(batches[b], perms=perms[b]).clone() for b in range(4)]
+    e1 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=2, device=DEV)
+    nxt = [batches[1], batches[3], batches[3], None]          # call 1 prefetches batch 3 but batch 2 arrives: re-ingested
+    got = [e1.run_batch(batches[b], perms=perms[b], defer_final=True, prefetch=nxt[b]) for b in range(4)]
+    torch.cuda.synchronize()
+    assert e1._pre_bufs is not None                           # the alternate buffers exist, i.e. the prefetch path ran
+    for b in range(4):
+        assert torch.equal(got[b], ref[b]), b
