@@ -55,6 +55,25 @@ int mft_augment_views(const unsigned char* src, int n_img, int Hs, int Ws, const
 /* x.view(-1,3,H,W) NCHW -> NHWC (boundary ingest; gnnnet.py:69-79, finetune.py:210) */
 int mft_nchw_to_nhwc(const float* src, float* dst, int n_img, int C, int H, int W, void* stream);
 
+/* loss.backward() + optimizer.step() for a per-episode 3x3 / stride 1 / pad 1 convolution with ONE pass over its weights
+ * (finetune.py:293-297 over backbone.py:255-256): mft_conv2d_wgrad_adam_nhwc (weight gradient + Adam on w, m, v) that also
+ * multiplies every OLD weight tile with dy before it is overwritten, i.e. the data gradient without re-reading the weights.
+ * dx_partials [groups, 9, rows, Cin] (rows = imgs_per_group*H*W <= 64; mft_conv2d_wgrad_adam_dgrad_ws_floats floats) holds one
+ * partial per tap; mft_col2im_bn_backward_small sums them into the gradient of the convolution input and applies the
+ * BatchNorm + ReLU backward of the layer in front (x_raw, relu_out, mean, rstd, gamma as in mft_bn_backward).  `_dev`: step
+ * size / bias correction from a device pointer (hipGraph replay).                                                            */
+long long mft_conv2d_wgrad_adam_dgrad_ws_floats(int n_img, int H, int W, int Cin);
+int mft_conv2d_wgrad_adam_dgrad_nhwc(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
+                                     float* dx_partials, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group,
+                                     long long group_stride, int step, float lr, float beta1, float beta2, float eps, void* stream);
+int mft_conv2d_wgrad_adam_dgrad_nhwc_dev(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
+                                         float* dx_partials, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group,
+                                         long long group_stride, const float* hyper, float beta1, float beta2, float eps,
+                                         void* stream);
+int mft_col2im_bn_backward_small(const float* dx_partials, const float* x_raw, const float* relu_out, float* dx, int n_img, int H,
+                                 int W, int C, int imgs_per_group, const float* mean, const float* rstd, const float* gamma,
+                                 long long gb_group_stride, float* dgamma, float* dbeta, void* stream);
+
 /* mft_ce_pool_backward + mft_bn_backward2 in one launch (finetune.py:286-293 over backbone.py:256-261): the gradient of the
  * cross entropy on the pooled feature [n_groups*imgs_per_group, C] through AvgPool(hw) and the block's final ReLU (mask: out > 0)
  * is formed on the fly and pushed through the two BatchNorms of the residual join (main branch xa = c2, shortcut xb = sc):

@@ -56,6 +56,10 @@ SIGNATURES = {
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
+    "mft_conv2d_wgrad_adam_dgrad_ws_floats": [_I, _I, _I, _I],
+    "mft_conv2d_wgrad_adam_dgrad_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F, _F, _P],
+    "mft_conv2d_wgrad_adam_dgrad_nhwc_dev": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _P, _F, _F, _F, _P],
+    "mft_col2im_bn_backward_small": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P],
     "mft_stream_create_priority": [_I, _P, _P],
     "mft_ce_pool_bn_backward2": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "mft_bn_apply_planes": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
@@ -94,7 +98,8 @@ SIGNATURES = {
     "mft_build_graph_nodes_backward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L}
+_RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L,
+            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L}
 
 _lib = None
 

@@ -14,6 +14,11 @@ import torch
 
 from . import ops
 
+# opt-in: data gradient of trunk.7.C2 from inside its weight-gradient + Adam launch (csrc/wgrad_dgrad.hip: one pass over the
+# weights instead of two).  Standalone 1.60-1.63 ms + 31 us (col2im + BN1 backward) vs 1.71-1.72 ms for the two passes, but with
+# 3 workgroups x 48 KB of w/m/v in flight per CU (8x fewer, longer workgroups) it loses more beside the trunk stream than the
+# 64x64-tile kernel does: 70.8 / 71.5 / 69.4 vs 71.0 / 71.4 / 71.1 episodes/s -- off by default.
+FUSED_DGRAD = os.environ.get("MFT_FUSED_DGRAD", "0") == "1"
 FUSED_LAST_BLOCK = os.environ.get("MFT_FUSED_LAST_BLOCK", "1") == "1"   # conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)
 # opt-in: trunk activations travel pre-split into bf16x3 planes between the x3 convolutions.  Bit-identical, but measured
 # SLOWER (66.5 vs 69.0 episodes/s): the convolutions are not bound by the in-loader split (161 vs 160 us standalone) while the
@@ -433,6 +438,26 @@ def resnet10_forward(W, x, arena, ipg=0, slab=None, tape=None, running=None, tag
     return last_block_forward(W, a, arena, ipg, slab=slab, tape=tape, running=running, tag=tag, fixed=fixed)
 
 
+def _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd):
+    """Data gradient of trunk.7.C2 followed by the BatchNorm1 + ReLU backward -> dc1 (separate pass over C2's weights)."""
+    # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
+    rc = ops._lib.MFT_EINVAL
+    if FUSED_LAST_BLOCK:
+        # data gradient of C2 with the BatchNorm1 + ReLU backward in its epilogue (dr1 is not materialised)
+        dc1 = arena.get(tag + ".dc1", tuple(c1.shape))
+        w2 = params.c2w
+        rc = lib.mft_conv2d_dgrad_bn_backward_small(ops._p(dc2), C, ops._p(w2), ops._p(dc1), C, n, oh, ow, C, C, 3, 3, 1, ipg,
+                                                    w2.shape[1] * w2.shape[2], ops._p(c1), ops._p(r1), ops._p(tape["m1"]),
+                                                    ops._p(tape["s1"]), ops._p(params.bn1g), C, ops._p(grads.bn1g),
+                                                    ops._p(grads.bn1b), ops._stream())
+        if rc != ops._lib.MFT_EINVAL:
+            ops._lib.check(rc, "mft_conv2d_dgrad_bn_backward_small")
+    if rc == ops._lib.MFT_EINVAL:
+        dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
+        dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
+    return dc1
+
+
 def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None):
     """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
     ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
@@ -497,22 +522,25 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     else:
         dc2 = bn_bwd(c2, d_out, tape["m2"], tape["s2"], params.bn2g, grads.bn2g, grads.bn2b, None, "dc2")
         dsc = bn_bwd(sc, d_out, tape["ms"], tape["ss"], params.bnsg, grads.bnsg, grads.bnsb, None, "dsc")
-    # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
-    rc = ops._lib.MFT_EINVAL
-    if FUSED_LAST_BLOCK:
-        # data gradient of C2 with the BatchNorm1 + ReLU backward in its epilogue (dr1 is not materialised)
-        dc1 = arena.get(tag + ".dc1", tuple(c1.shape))
+    done_c2 = False
+    if FUSED_DGRAD and FUSED_LAST_BLOCK and adam is not None and rows <= 64 and C % 64 == 0:
+        # weight gradient + Adam of C2 that also forms the data gradient from the weight tiles it streams (one partial per tap),
+        # then col2im + BatchNorm1/ReLU backward in a small launch: C2's weights are read once per backward instead of twice
+        m_, v_, step, lr = adam
+        hyper = step if torch.is_tensor(step) else None
         w2 = params.c2w
-        rc = lib.mft_conv2d_dgrad_bn_backward_small(ops._p(dc2), C, ops._p(w2), ops._p(dc1), C, n, oh, ow, C, C, 3, 3, 1, ipg,
-                                                    w2.shape[1] * w2.shape[2], ops._p(c1), ops._p(r1), ops._p(tape["m1"]),
-                                                    ops._p(tape["s1"]), ops._p(params.bn1g), C, ops._p(grads.bn1g),
-                                                    ops._p(grads.bn1b), ops._stream())
-        if rc != ops._lib.MFT_EINVAL:
-            ops._lib.check(rc, "mft_conv2d_dgrad_bn_backward_small")
-    if rc == ops._lib.MFT_EINVAL:
-        dr1 = ops.conv2d_dgrad(dc2, params.c2w, 512, 3, 3, 1, imgs_per_group=ipg, out=arena.get(tag + ".dr1", (n, oh, ow, C)))
-        dc1 = bn_bwd(c1, dr1, tape["m1"], tape["s1"], params.bn1g, grads.bn1g, grads.bn1b, r1, "dc1")
-    wgrad(r1, dc2, "c2w", 3, 1, 1)
+        dxp = arena.get(tag + ".dxp", (groups, 9, rows, C))
+        dc1 = arena.get(tag + ".dc1", tuple(c1.shape))
+        if ops.conv2d_wgrad_adam_dgrad(r1, dc2, w2, m_.c2w, v_.c2w, dxp, 1 if hyper is not None else step, ipg, lr=lr,
+                                       hyper=hyper):
+            ops._lib.check(lib.mft_col2im_bn_backward_small(ops._p(dxp), ops._p(c1), ops._p(r1), ops._p(dc1), n, oh, ow, C, ipg,
+                                                            ops._p(tape["m1"]), ops._p(tape["s1"]), ops._p(params.bn1g), C,
+                                                            ops._p(grads.bn1g), ops._p(grads.bn1b), ops._stream()),
+                           "mft_col2im_bn_backward_small")
+            done_c2 = True
+    if not done_c2:
+        dc1 = _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd)
+        wgrad(r1, dc2, "c2w", 3, 1, 1)
     wgrad(x, dc1, "c1w", 3, 2, 1)
     wgrad(x, dsc, "scw", 1, 2, 0)
     if adam is not None:

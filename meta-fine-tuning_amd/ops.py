@@ -217,6 +217,24 @@ def conv2d_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_
     _lib.check(rc, "mft_conv2d_wgrad_adam_nhwc")
 
 
+def conv2d_wgrad_adam_dgrad(x, dy, w, m, v, dxp, step, imgs_per_group, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, hyper=None):
+    """Weight gradient + Adam of a per-episode 3x3/s1/p1 convolution that also leaves the data gradient as 9 per-tap partials
+    in ``dxp`` [groups, 9, rows, Cin] (csrc/wgrad_dgrad.hip).  Returns False when the shape is outside the kernel's domain."""
+    n, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    gs = w.shape[1] * w.shape[2]
+    if hyper is not None:
+        rc = _lib.lib().mft_conv2d_wgrad_adam_dgrad_nhwc_dev(_p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dxp), n, H, W, Cin,
+                                                             Cout, imgs_per_group, gs, _p(hyper), beta1, beta2, eps, _stream())
+    else:
+        rc = _lib.lib().mft_conv2d_wgrad_adam_dgrad_nhwc(_p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dxp), n, H, W, Cin, Cout,
+                                                         imgs_per_group, gs, step, lr, beta1, beta2, eps, _stream())
+    if rc == _lib.MFT_EINVAL:
+        return False
+    _lib.check(rc, "mft_conv2d_wgrad_adam_dgrad_nhwc")
+    return True
+
+
 # ------------------------------------------------------------------------------------ batch norm
 
 def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=None, momentum=0.1, eps=BN_EPS):

@@ -613,3 +613,46 @@ def test_linear_head_sgd_run_matches_torch_sgd():
         dw = float((W[g].cpu().double() - lin.weight.data).abs().max())
         db = float((b[g].cpu().double() - lin.bias.data).abs().max())
         assert dw < 2e-5 and db < 2e-5, (g, dw, db, float((W0[g].double() - lin.weight.data).abs().max()))
+
+
+@pytest.mark.parametrize("ipg", [5, 4, 1])
+def test_wgrad_adam_with_fused_data_gradient(ipg):
+    """mft_conv2d_wgrad_adam_dgrad_nhwc + mft_col2im_bn_backward_small (one pass over trunk.7.C2's weights) against
+    mft_conv2d_dgrad_nhwc + mft_bn_backward + mft_conv2d_wgrad_adam_nhwc: same weight gradient bit for bit (same reduction
+    order), (w, m, v) to the last ulp, the input gradient / dgamma / dbeta to fp32 rounding (different summation order over output channels and taps)."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    G, C, H = 3, 512, 3
+    n, rows = G * ipg, ipg * 9
+    r1 = torch.relu(nhwc(rnd((n, C, H, H), 101))).to(DEV)
+    c1 = nhwc(rnd((n, C, H, H), 102)).to(DEV)
+    dc2 = (nhwc(rnd((n, C, H, H), 103)) * 1e-2).to(DEV)
+    w0 = torch.stack([ops.pack_conv_weight(rnd((C, C, 3, 3), 104 + g, scale=0.02).to(DEV)) for g in range(G)])
+    m0, v0 = (rnd((G, C, 9 * C), 110) * 1e-3).to(DEV), (rnd((G, C, 9 * C), 111).abs() * 1e-6).to(DEV)
+    g1 = (rnd((G, C), 112) * 0.2 + 1).to(DEV)
+    mean, rstd = ops.bn_stats(c1.view(-1, C), C, rows, G)
+    # separate launches
+    dr1 = ops.conv2d_dgrad(dc2, w0, C, 3, 3, 1, imgs_per_group=ipg)
+    dx_r, dg_r, db_r = ops.bn_backward(c1.view(-1, C), dr1.view(-1, C), C, rows, G, mean, rstd, g1, relu_out=r1.view(-1, C),
+                                       gb_group_stride=C)
+    w_r, m_r, v_r = w0.clone(), m0.clone(), v0.clone()
+    ops.conv2d_wgrad_adam(r1, dc2, w_r, m_r, v_r, C, 3, 3, 1, 1, 7, imgs_per_group=ipg)
+    # one pass
+    w, m, v = w0.clone(), m0.clone(), v0.clone()
+    dxp = torch.empty((G, 9, rows, C), device=DEV)
+    assert int(lib.mft_conv2d_wgrad_adam_dgrad_ws_floats(n, H, H, C)) == dxp.numel()
+    assert ops.conv2d_wgrad_adam_dgrad(r1, dc2, w, m, v, dxp, 7, ipg)
+    dx, dg, db = torch.empty_like(dx_r), torch.empty_like(dg_r), torch.empty_like(db_r)
+    assert lib.mft_col2im_bn_backward_small(ops._p(dxp), ops._p(c1), ops._p(r1), ops._p(dx), n, H, H, C, ipg, ops._p(mean),
+                                            ops._p(rstd), ops._p(g1), C, ops._p(dg), ops._p(db), ops._stream()) == 0
+    # same reduction order -> identical gradient, hence identical first moments; v and w agree to the last ulp or two (the
+    # compiler contracts b2*v + (1-b2)*g*g into fused multiply-adds differently in the two kernels)
+    assert torch.equal(m, m_r)
+    assert float(((v - v_r).abs() / v_r.abs().clamp_min(1e-12)).max()) < 1e-6 and float((w - w_r).abs().max()) < 1e-7
+    assert float((dx - dx_r).abs().max()) <= 2e-5 * max(float(dx_r.abs().max()), 1e-6)
+    assert float((dg - dg_r).abs().max()) <= 2e-5 * max(float(dg_r.abs().max()), 1e-3)
+    assert float((db - db_r).abs().max()) <= 2e-5 * max(float(db_r.abs().max()), 1e-3)
+    # rows > 64 are outside the kernel's domain
+    big = torch.empty((1, 9, 9 * 9, C), device=DEV)
+    x9 = torch.zeros((9, H, H, C), device=DEV)
+    assert not ops.conv2d_wgrad_adam_dgrad(x9, x9, w[:1], m[:1], v[:1], big, 1, 9)
