@@ -84,6 +84,16 @@ int mft_ce_pool_bn_backward2(const float* feat, const int* labels, int imgs_per_
                              const float* gamma_b, long long gb_group_stride, float* dgamma_a, float* dbeta_a, float* dgamma_b,
                              float* dbeta_b, float* loss, void* stream);
 
+/* Stem cache as per-window extrema (backbone.py:295-297: BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) behind the frozen stem
+ * convolution).  mft_pool_window_minmax: x [n_img, H, W, C] -> ymax, ymin [n_img, OH, OW, C], the maximum / minimum of every
+ * 3x3/stride 2/pad 1 window of the RAW convolution output.  mft_bn_relu_pooled_gather: y[n] = ReLU(BN(pmax or pmin of image
+ * src_idx[n])) with the statistics of the group of n (channels with gamma >= 0 take the maximum, the others the minimum):
+ * bit-identical to mft_bn_relu_maxpool_gather on the full-resolution cache because the BatchNorm affine is monotone per channel. */
+int mft_pool_window_minmax(const float* x, float* ymax, float* ymin, long long n_img, int H, int W, int C, void* stream);
+int mft_bn_relu_pooled_gather(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH, int OW, int C,
+                              int imgs_per_group, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              void* stream);
+
 /* Pre-split activation planes for the bf16x3 convolutions: the frozen trunk convolutions consume every activation 9-36 times
  * (taps x output-channel tiles); the producers below split each fp32 value once into its three bf16 pieces
  * ([3][rows][C] unsigned short, plane_stride elements between planes) so the convolution's operand path is a plain copy.

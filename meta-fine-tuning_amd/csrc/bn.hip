@@ -441,6 +441,99 @@ extern "C" int mft_bn_apply_planes(const float* x, int ldx, float* y, int ldy, u
     return mft_launch_status();
 }
 
+// ------------------------------------------------------------------- stem cache as per-window (max, min) pairs
+// BN -> ReLU -> MaxPool(3,2,1) of a cached raw stem output depends on the mini-batch only through the per-channel affine
+// f(v) = (v - mean) * rstd * gamma + beta, and every floating-point step of f is monotone in v: non-decreasing for gamma >= 0,
+// non-increasing for gamma < 0.  Hence max_window relu(f(v)) = relu(f(max_window v)) (gamma >= 0) or relu(f(min_window v))
+// (gamma < 0) EXACTLY, bit for bit -- the cache keeps the window maxima and minima of the raw convolution output
+// (2 x 21 x 21 x 64 instead of 42 x 42 x 64 floats per image) and the per-step gather reads a quarter to a half of the bytes.
+namespace {
+__global__ __launch_bounds__(256) void pool_window_minmax_kernel(const float* __restrict__ x, float* __restrict__ ymax,
+                                                                 float* __restrict__ ymin, long long n_img, int H, int W, int C,
+                                                                 int OH, int OW) {
+    const int cq = C >> 2;
+    const long long total = n_img * OH * OW * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const long long n = t / OH;
+        f32x4 hi = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f}, lo = {3.4e38f, 3.4e38f, 3.4e38f, 3.4e38f};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int ih = oh * 2 - 1 + dh;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int iw = ow * 2 - 1 + dw;
+                if (iw < 0 || iw >= W) continue;
+                const f32x4 v = *(const f32x4*)(x + ((n * H + ih) * W + iw) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = fmaxf(hi[e], v[e]); lo[e] = fminf(lo[e], v[e]); }
+            }
+        }
+        *(f32x4*)(ymax + i * 4) = hi;
+        *(f32x4*)(ymin + i * 4) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_pooled_gather_kernel(const float* __restrict__ pmax, const float* __restrict__ pmin,
+                                                                    const int* __restrict__ src_idx, float* __restrict__ y,
+                                                                    int n_img, int HW, int C, int imgs_per_group,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta) {
+    const int cq = C >> 2;
+    const long long total = (long long)n_img * HW * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        const long long t = i / cq;
+        const int pix = (int)(t % HW);
+        const int n = (int)(t / HW);
+        const int g = n / imgs_per_group;
+        const long long src = ((long long)src_idx[n] * HW + pix) * C + c;
+        const f32x4 mu = *(const f32x4*)(mean + (long long)g * C + c);
+        const f32x4 rs = *(const f32x4*)(rstd + (long long)g * C + c);
+        const f32x4 ga = *(const f32x4*)(gamma + c);
+        const f32x4 be = *(const f32x4*)(beta + c);
+        const bool all_pos = ga[0] >= 0.f && ga[1] >= 0.f && ga[2] >= 0.f && ga[3] >= 0.f;
+        const bool all_neg = ga[0] < 0.f && ga[1] < 0.f && ga[2] < 0.f && ga[3] < 0.f;
+        f32x4 v;
+        if (all_pos) v = *(const f32x4*)(pmax + src);
+        else if (all_neg) v = *(const f32x4*)(pmin + src);
+        else {
+            const f32x4 a = *(const f32x4*)(pmax + src), b = *(const f32x4*)(pmin + src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ga[e] >= 0.f ? a[e] : b[e];
+        }
+        f32x4 o = (v - mu) * rs * ga + be;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        *(f32x4*)(y + i * 4) = o;
+    }
+}
+}  // namespace
+
+extern "C" int mft_pool_window_minmax(const float* x, float* ymax, float* ymin, long long n_img, int H, int W, int C, void* stream) {
+    if (C % 4 != 0 || n_img <= 0) return MFT_EINVAL;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = n_img * OH * OW * (C / 4);
+    hipLaunchKernelGGL(pool_window_minmax_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, ymax,
+                       ymin, n_img, H, W, C, OH, OW);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_pooled_gather(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH,
+                                         int OW, int C, int imgs_per_group, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, void* stream) {
+    if (C % 4 != 0 || !src_idx) return MFT_EINVAL;
+    if (imgs_per_group <= 0) imgs_per_group = n_img;
+    const long long total = (long long)n_img * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_pooled_gather_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, pmax,
+                       pmin, src_idx, y, n_img, OH * OW, C, imgs_per_group, mean, rstd, gamma, beta);
+    return mft_launch_status();
+}
+
 extern "C" int mft_bn_relu_maxpool_gather_planes(const float* x, const int* src_idx, float* y, unsigned short* planes,
                                                  long long plane_stride, int n_img, int H, int W, int C, int imgs_per_group,
                                                  const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -119,7 +119,9 @@ class FinetuneEngine:
             need = self.E * self.n_total * oh * oh * 64 * 4
             total = torch.cuda.get_device_properties(self.dev).total_memory
             stem_cache = need <= 0.35 * total
-        self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev) if stem_cache else None
+        # (the opt-in pre-split-planes trunk reads the full-resolution cache; the default is the pooled (max, min) form)
+        self._stem_pooled = False if Fn.X3_PLANES else None
+        self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev, pooled=self._stem_pooled) if stem_cache else None
 
     # ------------------------------------------------------------------ ingest
     def load_episode(self, slot, liz_x, Xs=None, Xall=None):
@@ -374,12 +376,12 @@ class FinetuneEngine:
         """Ingest + stem cache of the next batch on their own stream, into the alternate support store / stem cache / final-pass
         store, while this batch's inner loop runs: the stem convolution is matrix-bound, the inner loop HBM-bound."""
         if self._pre_bufs is None:
-            need = self.Xs.numel() * 4 + (self.stem.c0.numel() + 2 * self.stem.mean.numel()) * 4
+            need = self.Xs.numel() * 4 + self.stem.nbytes()
             free, total = torch.cuda.mem_get_info(self.dev)
             if need > 0.8 * free:
                 return                                           # not enough room for a second support store + stem cache
             self._pre_bufs = {"Xs": torch.empty_like(self.Xs),
-                              "stem": Fn.StemCache(self.W, self.E * self.n_total, self.size, self.dev),
+                              "stem": Fn.StemCache(self.W, self.E * self.n_total, self.size, self.dev, pooled=self._stem_pooled),
                               "stream": torch.cuda.Stream(device=self.dev)}
         b = self._pre_bufs
         sp = b["stream"]

@@ -170,14 +170,30 @@ class StemCache:
     mini-batch independent) stem convolution once per epoch.  The cache computes it once per image; trunk.1's
     mini-batch statistics are recombined exactly from per-image moments (csrc/bn.hip)."""
 
-    def __init__(self, W, n_slots, H, device, chunk=8192):
+    def __init__(self, W, n_slots, H, device, chunk=8192, pooled=None):
+        """``pooled`` (default: env MFT_STEM_POOLED, on): keep only the per-window maxima / minima of the raw stem output
+        (csrc/bn.hip, exact: the BatchNorm affine is monotone per channel) -- half the memory of the full-resolution cache and a
+        quarter to a half of the bytes per gather; the full-resolution form (``c0``) exists for the planes / test paths."""
         self.W = W
         self.n_slots = n_slots
         self.OH = (H + 6 - 7) // 2 + 1
-        self.c0 = torch.empty((n_slots, self.OH, self.OH, 64), device=device)
+        self.PH = (self.OH + 2 - 3) // 2 + 1
+        self.pooled = (os.environ.get("MFT_STEM_POOLED", "1") == "1") if pooled is None else bool(pooled)
+        chunk = int(os.environ.get("MFT_STEM_CHUNK", chunk))
+        self.chunk = min(chunk, n_slots)
         self.mean = torch.empty((n_slots, 64), device=device)
         self.m2 = torch.empty((n_slots, 64), device=device)
-        self.chunk = chunk
+        if self.pooled:
+            self.c0 = None
+            self._buf = torch.empty((self.chunk, self.OH, self.OH, 64), device=device)      # one chunk of raw stem output
+            self.pmax = torch.empty((n_slots, self.PH, self.PH, 64), device=device)
+            self.pmin = torch.empty((n_slots, self.PH, self.PH, 64), device=device)
+        else:
+            self.c0 = torch.empty((n_slots, self.OH, self.OH, 64), device=device)
+
+    def nbytes(self):
+        ts = [self.mean, self.m2] + ([self._buf, self.pmax, self.pmin] if self.pooled else [self.c0])
+        return sum(t.numel() * 4 for t in ts)
 
     def fill(self, x_nhwc):
         """x_nhwc [n_slots,H,H,3] -> conv outputs + moments (chunked launches; M = chunk*OH*OW rows each)."""
@@ -186,10 +202,24 @@ class StemCache:
         assert n == self.n_slots
         for i in range(0, n, self.chunk):
             j = min(i + self.chunk, n)
-            ops.conv2d(x_nhwc[i:j], self.W.conv["trunk.0"], 64, 7, 7, 2, 3, out=self.c0[i:j])
-            ops._lib.check(lib.mft_bn_image_moments(ops._p(self.c0[i:j]), 64, 64, self.OH * self.OH, j - i,
+            c0 = self._buf[:j - i] if self.pooled else self.c0[i:j]
+            ops.conv2d(x_nhwc[i:j], self.W.conv["trunk.0"], 64, 7, 7, 2, 3, out=c0)
+            ops._lib.check(lib.mft_bn_image_moments(ops._p(c0), 64, 64, self.OH * self.OH, j - i,
                                                     ops._p(self.mean[i:j]), ops._p(self.m2[i:j]), ops._stream()),
                            "mft_bn_image_moments")
+            if self.pooled:
+                ops._lib.check(lib.mft_pool_window_minmax(ops._p(c0), ops._p(self.pmax[i:j]), ops._p(self.pmin[i:j]), j - i,
+                                                          self.OH, self.OH, 64, ops._stream()), "mft_pool_window_minmax")
+
+    def gather(self, idx, n, m, s, g, b, ipg, out, planes=None):
+        """BN + ReLU + MaxPool of images idx with the mini-batch statistics (m, s) -> out [n, PH, PH, 64]."""
+        if self.pooled and planes is None:
+            ops._lib.check(ops._lib.lib().mft_bn_relu_pooled_gather(ops._p(self.pmax), ops._p(self.pmin), ops._p(idx), ops._p(out), n,
+                                                                    self.PH, self.PH, 64, ipg, ops._p(m), ops._p(s), ops._p(g),
+                                                                    ops._p(b), ops._stream()), "mft_bn_relu_pooled_gather")
+            return out
+        assert self.c0 is not None, "this path needs the full-resolution stem cache (StemCache(pooled=False))"
+        return ops.bn_relu_maxpool_gather(self.c0, idx, n, m, s, g, b, ipg, out=out, planes=planes)
 
 
 def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, fixed=None):
@@ -212,13 +242,12 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
         s = arena.get(tag + ".bn0.rstd", (groups, 64))
         ops.bn_combine_moments(cache.mean, cache.m2, idx, cache.OH * cache.OH, ipg, groups, mean=m, rstd=s)
         PH = (cache.OH + 2 - 3) // 2 + 1
-        if (X3_PLANES and X3_FUSED_STATS and upto == 7 and running is None and fixed is None and ipg * ((PH + 3) // 4) ** 2 >= 128
+        if (X3_PLANES and cache.c0 is not None and X3_FUSED_STATS and upto == 7 and running is None and fixed is None and ipg * ((PH + 3) // 4) ** 2 >= 128
                 and all(("trunk.%d.C1" % i) in W.conv3 for i in (4, 5, 6))):
             # frozen trunk on pre-split activations: each tensor between two bf16x3 convolutions is written once as three
             # bf16 planes by its producer (pool / BatchNorm-apply) instead of being re-split by every consumer tile
             ap = arena.get(tag + ".p0p", (3, n * PH * PH, 64), torch.int16)
-            a = ops.bn_relu_maxpool_gather(cache.c0, idx, n, m, s, g, b, ipg, out=arena.get(tag + ".p0", (n, PH, PH, 64)),
-                                           planes=ap)
+            a = cache.gather(idx, n, m, s, g, b, ipg, arena.get(tag + ".p0", (n, PH, PH, 64)), planes=ap)
             shape = (n, PH, PH, 64)
             for bi in (4, 5, 6):
                 cin, cout, stride = STAGES[bi]
@@ -231,7 +260,7 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
                 _, ap = r
                 OHb = (shape[1] + 2 - 3) // stride + 1
                 shape = (n, OHb, OHb, cout)
-        a = ops.bn_relu_maxpool_gather(cache.c0, idx, n, m, s, g, b, ipg, out=arena.get(tag + ".p0", (n, PH, PH, 64)))
+        a = cache.gather(idx, n, m, s, g, b, ipg, arena.get(tag + ".p0", (n, PH, PH, 64)))
     else:
         n = x.shape[0]
         groups = n // ipg

@@ -229,7 +229,7 @@ def test_presplit_activation_planes_are_bit_identical():
     W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=31), DEV, x3=True)
     rs = np.random.RandomState(9)
     x = torch.from_numpy(rs.standard_normal((60, 84, 84, 3)).astype(np.float32)).to(DEV)
-    cache = Fn.StemCache(W, 60, 84, DEV, chunk=32)
+    cache = Fn.StemCache(W, 60, 84, DEV, chunk=32, pooled=False)      # the planes chain reads the full-resolution cache
     cache.fill(x)
     idx = torch.from_numpy(rs.permutation(60)[:35].astype(np.int32)).to(DEV)
     outs = []
@@ -252,8 +252,22 @@ def test_stem_cache_matches_recomputed_stem():
     W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=27), DEV)
     rs = np.random.RandomState(8)
     x = torch.from_numpy(rs.standard_normal((40, 84, 84, 3)).astype(np.float32)).to(DEV)
-    cache = Fn.StemCache(W, 40, 84, DEV, chunk=16)          # ragged last chunk
+    cache = Fn.StemCache(W, 40, 84, DEV, chunk=16, pooled=False)          # ragged last chunk
     cache.fill(x)
+    # pooled form (default in the engine): per-window (max, min) of the raw stem output; the BatchNorm affine is monotone per
+    # channel, so the gather must reproduce the full-resolution BN -> ReLU -> MaxPool bit for bit -- also for negative gammas
+    pc = Fn.StemCache(W, 40, 84, DEV, chunk=16, pooled=True)
+    pc.fill(x)
+    assert pc.c0 is None and pc.nbytes() < 0.6 * cache.nbytes() + 16 * 42 * 42 * 64 * 4
+    idx_p = torch.from_numpy(rs.permutation(40)[:20].astype(np.int32)).to(DEV)
+    m_p = torch.empty((4, 64), device=DEV)
+    s_p = torch.empty((4, 64), device=DEV)
+    ops.bn_combine_moments(pc.mean, pc.m2, idx_p, 42 * 42, 5, 4, mean=m_p, rstd=s_p)
+    g_p, b_p = W.bn["trunk.1"]
+    for gam in (g_p, -g_p, g_p * torch.from_numpy(np.where(rs.rand(64) < 0.5, -1.0, 1.0).astype(np.float32)).to(DEV)):
+        full = cache.gather(idx_p, 20, m_p, s_p, gam.contiguous(), b_p, 5, torch.empty((20, 21, 21, 64), device=DEV))
+        pooled = pc.gather(idx_p, 20, m_p, s_p, gam.contiguous(), b_p, 5, torch.empty((20, 21, 21, 64), device=DEV))
+        assert torch.equal(full, pooled)
     idx = torch.from_numpy(rs.permutation(40)[:15].astype(np.int32)).to(DEV)
     a_cached = Fn.resnet10_trunk(W, None, Fn.Arena(DEV), 5, upto=4, tag="a", stem=(cache, idx))
     a_direct = Fn.resnet10_trunk(W, x[idx.long()].contiguous(), Fn.Arena(DEV), 5, upto=4, tag="b")
