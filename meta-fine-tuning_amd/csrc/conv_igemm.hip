@@ -49,6 +49,7 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
+int g_wgrad_pol = 3;          // w/m/v cache policy: bit 0 nontemporal loads, bit 1 nontemporal stores (mft_debug_set_conv_tile(9000 + pol))
 int g_wgrad_early = 1;        // 1: issue the tile's w/m/v loads before the reduction (mft_debug_set_conv_tile(5000/5001))
 int g_wgrad_min_lds_kb = 0;   // experiment: pad the fused wgrad+Adam workgroup's LDS to cap its occupancy (4000 + KB)
 int g_skinny = 1;      // 0: per-episode-weight launches use the generic tiles (mft_debug_set_conv_tile(3000/3001))
@@ -320,8 +321,11 @@ struct WgradArgs {
 // in LDS ([BM][BN+4]) and the w/m/v update streams with 16 B per lane and 4*BN contiguous bytes per row:
 // 3 reads + 3 writes per parameter instead of a gradient write plus Adam's 4 reads + 3 writes.
 // STEMW: the 7x7x3 stem (Cin == 3): the "ci" axis of the tile is the flattened k = (kh*KW+kw)*3+ci (147 -> 160).
-template <int BM, int BN, bool ADAM, bool STEMW, bool EARLYT = false>
+// POL: cache policy of the w/m/v stream (bit 0: nontemporal loads, bit 1: nontemporal stores); 3 is the default
+template <int BM, int BN, bool ADAM, bool STEMW, bool EARLYT = false, int POL = 3>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
+    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
     constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
     constexpr int QA = BM / 4;                  // float4 per A row
     constexpr int QB = BN / 4;
@@ -373,9 +377,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             e_gi[u] = gbase + (long long)(co0 + rr + u * 16) * p.Kpad;
-            e_m[u] = __builtin_nontemporal_load((const f32x4*)(p.m + e_gi[u]));
-            e_v[u] = __builtin_nontemporal_load((const f32x4*)(p.v + e_gi[u]));
-            e_w[u] = __builtin_nontemporal_load((const f32x4*)(p.w + e_gi[u]));
+            e_m[u] = ldp((const f32x4*)(p.m + e_gi[u]));
+            e_v[u] = ldp((const f32x4*)(p.v + e_gi[u]));
+            e_w[u] = ldp((const f32x4*)(p.w + e_gi[u]));
         }
     }
     const int m_begin = blockIdx.z * p.chunk_rows;
@@ -491,9 +495,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                     gi[u] = e_gi[u]; mm[u] = e_m[u]; vv[u] = e_v[u]; ww[u] = e_w[u];
                 } else {
                     gi[u] = gbase + (long long)(co0 + row) * p.Kpad;
-                    mm[u] = __builtin_nontemporal_load((const f32x4*)(p.m + gi[u]));
-                    vv[u] = __builtin_nontemporal_load((const f32x4*)(p.v + gi[u]));
-                    ww[u] = __builtin_nontemporal_load((const f32x4*)(p.w + gi[u]));
+                    mm[u] = ldp((const f32x4*)(p.m + gi[u]));
+                    vv[u] = ldp((const f32x4*)(p.v + gi[u]));
+                    ww[u] = ldp((const f32x4*)(p.w + gi[u]));
                 }
             }
 #pragma unroll
@@ -506,9 +510,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                     vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
                     ww[u][e] -= step_size * (mm[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps));
                 }
-                __builtin_nontemporal_store(mm[u], (f32x4*)(p.m + gi[u]));
-                __builtin_nontemporal_store(vv[u], (f32x4*)(p.v + gi[u]));
-                __builtin_nontemporal_store(ww[u], (f32x4*)(p.w + gi[u]));
+                stp(mm[u], (f32x4*)(p.m + gi[u]));
+                stp(vv[u], (f32x4*)(p.v + gi[u]));
+                stp(ww[u], (f32x4*)(p.w + gi[u]));
                 if (p.dw) *(f32x4*)(p.dw + gi[u]) = ge;
             }
         }
@@ -525,14 +529,14 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool ADAM, bool STEMW = false, bool EARLYT = false>
+template <int BM, int BN, bool ADAM, bool STEMW = false, bool EARLYT = false, int POL = 3>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
     constexpr int lds_ad = BM * (BN + 4) * 4;
     constexpr int lds0 = ADAM ? (lds_ad > lds_mm ? lds_ad : lds_mm) : lds_mm;
     int lds = lds0;
     if (ADAM && g_wgrad_min_lds_kb * 1024 > lds) lds = g_wgrad_min_lds_kb * 1024;
-    auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW, EARLYT>;
+    auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW, EARLYT, POL>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -581,6 +585,9 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     if (adam) {
         if (a.Cin % 64 != 0 || a.Cout % 64 != 0) return MFT_EINVAL;
         if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64) return launch_wgrad<128, 128, true>(a, taps, groups, s);
+        if (g_wgrad_early && g_wgrad_pol == 0) return launch_wgrad<64, 64, true, false, true, 0>(a, taps, groups, s);
+        if (g_wgrad_early && g_wgrad_pol == 1) return launch_wgrad<64, 64, true, false, true, 1>(a, taps, groups, s);
+        if (g_wgrad_early && g_wgrad_pol == 2) return launch_wgrad<64, 64, true, false, true, 2>(a, taps, groups, s);
         if (g_wgrad_early) return launch_wgrad<64, 64, true, false, true>(a, taps, groups, s);
         return launch_wgrad<64, 64, true>(a, taps, groups, s);
     }
@@ -643,7 +650,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
+    if (tile >= 9000) g_wgrad_pol = tile - 9000;
+    else if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
     else if (tile >= 7000) mft_skinny_set_tap(tile - 7000);
     else if (tile >= 6000) mft_skinny_set_dgrad_slices(tile - 6000);
     else if (tile >= 5000) g_wgrad_early = tile - 5000;
