@@ -23,6 +23,7 @@ int mft_skinny_fwd_dispatch(const float* in, int ldi, const float* w, float* out
 void mft_skinny_set_dgrad_slices(int n);
 void mft_skinny_set_tap(int v);
 void mft_skinny_set_x3(int v);
+void mft_skinny_set_nw(int v);
 int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
                               long long w_group_stride, hipStream_t s);
@@ -650,7 +651,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 9000) g_wgrad_pol = tile - 9000;
+    if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
+    else if (tile >= 9000) g_wgrad_pol = tile - 9000;
     else if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
     else if (tile >= 7000) mft_skinny_set_tap(tile - 7000);
     else if (tile >= 6000) mft_skinny_set_dgrad_slices(tile - 6000);

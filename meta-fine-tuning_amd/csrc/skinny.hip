@@ -246,14 +246,15 @@ struct SkinnyExitArgs {
 };
 
 // forward, whole activation in LDS (trunk.7.C2: 45 input pixels x 512 channels = 3 x 46 KB of bf16 planes)
-template <bool EXIT>
-__global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p, SkinnyExitArgs x) {
+// NW = waves per workgroup (16 output channels each): 16 at E >= 128; fewer, so that a small episode batch still fills the CUs
+template <bool EXIT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_conv_fwd_x3_kernel(SkinnyArgs p, SkinnyExitArgs x) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int g = blockIdx.y;
-    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int co0 = blockIdx.x * (16 * NW) + wave * 16;
     const int RS = p.Cin + SK_PADH;
     const int PL = p.rows_in * RS;
     const int ohw = p.OH * p.OW;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_x3_kernel(SkinnyArgs p, 
     for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
     {
         const int q4 = p.Cin / 4;
-        for (int i = tid; i < p.rows_in * q4; i += 1024) {
+        for (int i = tid; i < p.rows_in * q4; i += 64 * NW) {
             const int r = i / q4, c = (i - r * q4) * 4;
             sk_store3(ldh, r * RS + sk_perm(c), PL, *(const f32x4v*)(actg + (long long)r * p.lda + c));
         }
@@ -717,35 +718,36 @@ struct SkinnyEntryArgs {
     float eps;
 };
 
-__global__ __launch_bounds__(1024) void skinny_block_entry_x3_kernel(SkinnyEntryArgs q) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_block_entry_x3_kernel(SkinnyEntryArgs q) {
     const SkinnyArgs& p = q.c;
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int g = blockIdx.y;
-    const int co0 = blockIdx.x * 256 + wave * 16;
+    const int co0 = blockIdx.x * (16 * NW) + wave * 16;
     const int RS = p.Cin + SK_PADH;
     const int PL = 48 * RS;
     const int ohw = p.OH * p.OW;
     const int taps = p.KH * p.KW;
     const int gpt = p.Cin / 16;
     const int q4 = p.Cin / 4;
-    constexpr int NST = 3;
+    constexpr int NST = 48 / NW;                   // float4 staging slots per thread: 48 rows x (Cin <= 256)/4 = 3072 slots
     const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
     const float* wsrow = q.w_sc + (long long)g * q.wscs + (long long)(co0 + m) * p.Cin + 4 * kq;
     const float* actg = p.act + (long long)g * p.rows_in * p.lda;
 
     const int centre = (p.KH / 2) * p.KW + p.KW / 2;
     f32x4v st[NST];
-    // staging slot k of this thread: row (tid + 1024 k) / q4 of the 48-row im2col tile, 4 channels; the descriptors are
+    // staging slot k of this thread: row (tid + 64 NW k) / q4 of the 48-row im2col tile, 4 channels; the descriptors are
     // recomputed per pass (10 times per kernel) instead of living in registers through the MFMA loop
     auto gather = [&](int pass) {
         const int tap = pass < taps ? pass : centre;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * 64 * NW;
             const int r = i / q4;
             const int c = (i - r * q4) * 4;
             f32x4v v = {0.f, 0.f, 0.f, 0.f};
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(1024) void skinny_block_entry_x3_kernel(SkinnyEntry
         unsigned short* L = ldh + buf * 3 * PL;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int i = tid + k * 1024;
+            const int i = tid + k * 64 * NW;
             const int r = i / q4;
             if (r < 48) sk_store3(L, r * RS + sk_perm((i - r * q4) * 4), PL, st[k]);
         }
@@ -864,15 +866,15 @@ struct SkinnyBnArgs {
     float* dgamma; float* dbeta;                   // [groups][C]
 };
 
-template <bool BNB>
-__global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p, SkinnyBnArgs bn) {
+template <bool BNB, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p, SkinnyBnArgs bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int g = blockIdx.y;
-    const int ci0 = blockIdx.x * 256 + wave * 32;
+    const int ci0 = blockIdx.x * (32 * NW) + wave * 32;
     const int Cdy = p.Cin, Cdx = p.Cout;
     const int RS = Cdy + SK_PADH;
     const int PL = p.rows_in * RS;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_x3_kernel(SkinnyArgs p,
     for (int u = 0; u < U; ++u) load_group(u, a_cur[u]);
     {
         const int q4 = Cdy / 4;
-        for (int i = tid; i < p.rows_in * q4; i += 512) {
+        for (int i = tid; i < p.rows_in * q4; i += 64 * NW) {
             const int r = i / q4, c = (i - r * q4) * 4;
             sk_store3(ldh, r * RS + sk_perm(c), PL, *(const f32x4v*)(actg + (long long)r * p.lda + c));
         }
@@ -1032,6 +1034,38 @@ int g_skinny_x3 = 1;             // bf16x3 forms of the weight-streaming kernels
 int g_skinny_tap = 1;            // per-tap staged forward for shapes whose activation exceeds LDS (mft_debug_set_conv_tile(7000/7001))
 int g_skinny_dgrad_slices = 1;   // reduction-channel slices of the data-gradient kernel (mft_debug_set_conv_tile(6000 + n))
 
+int g_skinny_nw = 0;            // waves per workgroup of the per-episode bf16x3 kernels: 0 = widest (mft_debug_set_conv_tile(9100 + nw); 9199 = by episode count)
+
+// Workgroups of W waves each own 16*W (forward) or 32*W (data gradient) channels of one episode.  Narrower workgroups fill the
+// CUs at small episode batches and are 1.3-2x faster STANDALONE there (E = 32: block entry 122 -> 70 us, exit 204 -> 143 us,
+// data gradient 201 -> 156 us; tools/small_e_skinny.py), but every one of them holds ~140 KB of LDS, so a launch that covers all
+// 256 CUs leaves no CU on which the trunk stream's convolutions fit: in the two-stream engine that choice is SLOWER
+// (50-shot, E = 48: 5.4 vs 6.0 episodes/s; 20-shot, E = 64: 16.3 vs 16.5).  Default: the widest workgroups.
+inline int pick_nw(int groups, int wgs_per_group_at_max, int nw_max) {
+    if (g_skinny_nw == 0) return nw_max;
+    if (g_skinny_nw != 99) return g_skinny_nw <= nw_max ? (g_skinny_nw >= nw_max / 4 ? g_skinny_nw : nw_max / 4) : nw_max;
+    int nw = nw_max;
+    while (nw > nw_max / 4 && (long long)groups * wgs_per_group_at_max * (nw_max / nw) < 256) nw >>= 1;
+    return nw;
+}
+
+template <typename K, typename... A>
+int launch_big_lds(K kern, size_t max_lds, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+    // the dynamic-LDS limit is raised once per kernel instantiation (instantiations of one template share the pointer TYPE, so
+    // the "done" set is keyed by the function address)
+    static const void* done[64];
+    static int n_done = 0;
+    bool seen = false;
+    for (int i = 0; i < n_done; ++i) seen = seen || done[i] == (const void*)kern;
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+        if (e != hipSuccess) return (int)e;
+        if (n_done < 64) done[n_done++] = (const void*)kern;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+    return mft_launch_status();
+}
+
 int pick_slice(int rows_in, int Cin) {
     for (int cs = Cin; cs >= 128; cs /= 2) {
         if (cs % 128 != 0 || Cin % cs != 0) continue;
@@ -1045,6 +1079,7 @@ int pick_slice(int rows_in, int Cin) {
 void mft_skinny_set_dgrad_slices(int n) { g_skinny_dgrad_slices = n; }
 void mft_skinny_set_tap(int v) { g_skinny_tap = v; }
 void mft_skinny_set_x3(int v) { g_skinny_x3 = v; }
+void mft_skinny_set_nw(int v) { g_skinny_nw = v; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
 static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
@@ -1091,21 +1126,14 @@ static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out,
     if (g_skinny_x3 && (size_t)3 * rows_in * (Cin + SK_PADH) * 2 <= 150 * 1024 && Cin % (16 * SK_U) == 0) {
         size_t lds3 = (size_t)3 * rows_in * (Cin + SK_PADH) * 2;
         if (ex != nullptr && lds3 < (size_t)16 * 48 * 16 * 4) lds3 = (size_t)16 * 48 * 16 * 4;    // the pool's per-wave output tiles
-        static bool attr_x3 = false;
-        if (!attr_x3) {
-            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)skinny_conv_fwd_x3_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_x3 = true;
-        }
-        if (ex != nullptr)
-            hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel<true>, grid, dim3(1024), lds3, s, p, *ex);
-        else
-            hipLaunchKernelGGL(skinny_conv_fwd_x3_kernel<false>, grid, dim3(1024), lds3, s, p, SkinnyExitArgs{});
-        return mft_launch_status();
+        const int groups = n_img / imgs_per_group;
+        const int nw = pick_nw(groups, Cout / 256, 16);
+        const dim3 g2(Cout / (16 * nw), groups, 1);
+        const SkinnyExitArgs e0 = ex ? *ex : SkinnyExitArgs{};
+#define SK_FWD(EX, NW) launch_big_lds(skinny_conv_fwd_x3_kernel<EX, NW>, 150 * 1024, g2, dim3(64 * NW), lds3, s, p, e0)
+        if (ex != nullptr) return nw == 16 ? SK_FWD(true, 16) : nw == 8 ? SK_FWD(true, 8) : SK_FWD(true, 4);
+        return nw == 16 ? SK_FWD(false, 16) : nw == 8 ? SK_FWD(false, 8) : SK_FWD(false, 4);
+#undef SK_FWD
     }
     if (ex != nullptr) return MFT_EINVAL;          // the fused block exit exists in the bf16x3 form only
     const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
@@ -1139,21 +1167,15 @@ static int skinny_dgrad_impl(const float* dy, int ldy, const float* w, float* dx
     dim3 grid(Cin / 256, n_img / imgs_per_group, 1);
     if (g_skinny_x3 && g_skinny_dgrad_slices <= 1 && (size_t)3 * rows * (Cout + SK_PADH) * 2 <= 150 * 1024 && Cout % 64 == 0) {
         const size_t lds3 = (size_t)3 * rows * (Cout + SK_PADH) * 2;
-        static bool attr_x3 = false;
-        if (!attr_x3) {
-            hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_x3_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_x3 = true;
-        }
-        if (bn != nullptr)
-            hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel<true>, grid, dim3(512), lds3, s, p, *bn);
-        else
-            hipLaunchKernelGGL(skinny_conv_dgrad_x3_kernel<false>, grid, dim3(512), lds3, s, p, SkinnyBnArgs{});
-        return mft_launch_status();
+        const int groups = n_img / imgs_per_group;
+        int nw = pick_nw(groups, Cin / 256, 8);
+        if (nw > 8) nw = 8;
+        const dim3 g2(Cin / (32 * nw), groups, 1);
+        const SkinnyBnArgs b0 = bn ? *bn : SkinnyBnArgs{};
+#define SK_DG(BB, NW) launch_big_lds(skinny_conv_dgrad_x3_kernel<BB, NW>, 150 * 1024, g2, dim3(64 * NW), lds3, s, p, b0)
+        if (bn != nullptr) return nw == 8 ? SK_DG(true, 8) : nw == 4 ? SK_DG(true, 4) : SK_DG(true, 2);
+        return nw == 8 ? SK_DG(false, 8) : nw == 4 ? SK_DG(false, 4) : SK_DG(false, 2);
+#undef SK_DG
     }
     if (bn != nullptr) return MFT_EINVAL;          // the fused BatchNorm epilogue exists in the bf16x3 form only
     const size_t lds = (size_t)rows * (cs + SK_PADF) * sizeof(float);
@@ -1225,14 +1247,10 @@ extern "C" int mft_block_entry_small_forward(const float* x, int ldx, const floa
     q.w_sc = w_sc; q.wscs = wsc_group_stride; q.sc = sc; q.r1 = r1; q.gamma = gamma1; q.beta = beta1; q.gbs = gb_group_stride;
     q.mean = mean1; q.rstd = rstd1; q.eps = eps;
     const size_t lds_h = (size_t)2 * 3 * 48 * (Cin + SK_PADH) * 2;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skinny_block_entry_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           156 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-    hipLaunchKernelGGL(skinny_block_entry_x3_kernel, dim3(Cout / 256, n_img / imgs_per_group, 1), dim3(1024), lds_h,
-                       (hipStream_t)stream, q);
-    return mft_launch_status();
+    const int groups = n_img / imgs_per_group;
+    const int nw = pick_nw(groups, Cout / 256, 16);
+    const dim3 g2(Cout / (16 * nw), groups, 1);
+#define SK_EN(NW) launch_big_lds(skinny_block_entry_x3_kernel<NW>, 156 * 1024, g2, dim3(64 * NW), lds_h, (hipStream_t)stream, q)
+    return nw == 16 ? SK_EN(16) : nw == 8 ? SK_EN(8) : SK_EN(4);
+#undef SK_EN
 }
