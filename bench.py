@@ -191,7 +191,7 @@ def bench_metatrain(args, rank, world, dev, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "128")))
     ap.add_argument("--epochs", type=int, default=5)
