@@ -309,6 +309,13 @@ int mft_linear_head_sgd_run(const float* z_support, const int* y_support, const 
                             int D, int n_way, int n_steps, int batch_size, float* W, float* b, float lr, float momentum,
                             float dampening, float weight_decay, void* stream);
 
+/* Same single-launch run with torch.optim.Adam(lr, (beta1, beta2), eps, L2 weight_decay) on the head: finetune.finetune_linear
+ * with freeze_backbone=True (finetune.py:45-174, frozen branch of :123-135, :144, :163) trains only Classifier(512, n_way) on
+ * constant eval-mode features for 20 epochs of mini-batches of 5.                                                          */
+int mft_linear_head_adam_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups, int n_support_rows,
+                             int D, int n_way, int n_steps, int batch_size, float* W, float* b, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, void* stream);
+
 /* torch.optim.Adam.step over many tensors in one launch (train.py:28, meta_template.py:87): chunk_table is a DEVICE array of
  * n_chunks records {float* p; const float* g; float* m; float* v; long long n;} (40 bytes each, n <= 65536 elements; 16-byte aligned chunks take the float4 path).        */
 int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mft_conv2d_dgrad_bn_backward_small": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P, _L,
                                            _P, _P, _P],
     "mft_linear_head_sgd_run": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _P],
+    "mft_linear_head_adam_run": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P],
     "mft_adam_multi": [_P, _I, _I, _F, _F, _F, _F, _F, _P],
     "mft_adam_hyper_advance": [_P, _P, _F, _F, _F, _P],
     "mft_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],

@@ -457,21 +457,31 @@ extern "C" int mft_adam_multi(const void* chunk_table, int n_chunks, int step, f
 // a fresh Linear(D, n_way) trained on the frozen support features with SGD(lr .01, momentum .9, dampening .9,
 // weight_decay .001) for 100 epochs of mini-batches of 4 -- 700 dependent steps of ~10 kFLOP each.  One workgroup per
 // episode keeps the support features, W, b and the momentum buffers in LDS / registers and runs ALL steps in one launch.
+// ADAM = true: torch.optim.Adam(lr, betas (b1, b2), eps, L2 weight_decay) instead (finetune.finetune_linear with
+// freeze_backbone=True, finetune.py:110,140-160: the classifier on constant eval-mode features); `mom` / `damp` then carry
+// beta1 / beta2 and the bias corrections are advanced in double precision inside the loop.
 namespace {
+template <bool ADAM>
 __global__ __launch_bounds__(256) void linear_head_sgd_kernel(const float* __restrict__ z, const int* __restrict__ y,
                                                               const int* __restrict__ idx, int S, int D, int n_way, int T,
                                                               int bs, float* __restrict__ W, float* __restrict__ b, float lr,
-                                                              float mom, float damp, float wd) {
+                                                              float mom, float damp, float wd, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* zs = sm;                              // [S][D]
     float* Ws = zs + S * D;                      // [n_way][D]
     float* Bw = Ws + n_way * D;                  // momentum buffer of W
-    float* sl = Bw + n_way * D;                  // logits / dlogits [bs][16]
-    __shared__ float bsm[16], bbuf[16];
+    float* Vw = Bw + n_way * D;                  // ADAM: second moment of W
+    float* sl = Vw + (ADAM ? n_way * D : 0);     // logits / dlogits [bs][16]
+    __shared__ float bsm[16], bbuf[16], bv[16];
+    double p1 = 1.0, p2 = 1.0;                   // beta1^t, beta2^t
     for (int i = tid; i < S * D; i += 256) zs[i] = z[(long long)g * S * D + i];
-    for (int i = tid; i < n_way * D; i += 256) { Ws[i] = W[(long long)g * n_way * D + i]; Bw[i] = 0.f; }
-    if (tid < n_way) { bsm[tid] = b[(long long)g * n_way + tid]; bbuf[tid] = 0.f; }
+    for (int i = tid; i < n_way * D; i += 256) {
+        Ws[i] = W[(long long)g * n_way * D + i];
+        Bw[i] = 0.f;
+        if (ADAM) Vw[i] = 0.f;
+    }
+    if (tid < n_way) { bsm[tid] = b[(long long)g * n_way + tid]; bbuf[tid] = 0.f; bv[tid] = 0.f; }
     __syncthreads();
     const int* yg = y + (long long)g * S;
     const int* ig = idx + (long long)g * T * bs;
@@ -499,24 +509,47 @@ __global__ __launch_bounds__(256) void linear_head_sgd_kernel(const float* __res
             for (int c = 0; c < n_way; ++c) sl[r * 16 + c] = (__expf(sl[r * 16 + c] - lse) - (c == yy ? 1.f : 0.f)) * inv;
         }
         __syncthreads();
+        float step_size = lr, inv_sqrt_bc2 = 1.f;
+        if (ADAM) {
+            p1 *= (double)mom;
+            p2 *= (double)damp;
+            step_size = (float)((double)lr / (1.0 - p1));
+            inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - p2));
+        }
         for (int i = tid; i < n_way * D; i += 256) {
             const int c = i / D, d = i - c * D;
             float gr = 0.f;
             for (int r = 0; r < k; ++r) gr += sl[r * 16 + c] * zs[ig[t * bs + r] * D + d];
             const float w = Ws[i];
             gr += wd * w;
-            const float bu = (t == 0) ? gr : mom * Bw[i] + (1.f - damp) * gr;
-            Bw[i] = bu;
-            Ws[i] = w - lr * bu;
+            if (ADAM) {
+                const float m1 = mom * Bw[i] + (1.f - mom) * gr;
+                const float v1 = damp * Vw[i] + (1.f - damp) * gr * gr;
+                Bw[i] = m1;
+                Vw[i] = v1;
+                Ws[i] = w - step_size * (m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps));
+            } else {
+                const float bu = (t == 0) ? gr : mom * Bw[i] + (1.f - damp) * gr;
+                Bw[i] = bu;
+                Ws[i] = w - lr * bu;
+            }
         }
         if (tid < n_way) {
             float gr = 0.f;
             for (int r = 0; r < k; ++r) gr += sl[r * 16 + tid];
             const float w = bsm[tid];
             gr += wd * w;
-            const float bu = (t == 0) ? gr : mom * bbuf[tid] + (1.f - damp) * gr;
-            bbuf[tid] = bu;
-            bsm[tid] = w - lr * bu;
+            if (ADAM) {
+                const float m1 = mom * bbuf[tid] + (1.f - mom) * gr;
+                const float v1 = damp * bv[tid] + (1.f - damp) * gr * gr;
+                bbuf[tid] = m1;
+                bv[tid] = v1;
+                bsm[tid] = w - step_size * (m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps));
+            } else {
+                const float bu = (t == 0) ? gr : mom * bbuf[tid] + (1.f - damp) * gr;
+                bbuf[tid] = bu;
+                bsm[tid] = w - lr * bu;
+            }
         }
         __syncthreads();
     }
@@ -525,20 +558,35 @@ __global__ __launch_bounds__(256) void linear_head_sgd_kernel(const float* __res
 }
 }  // namespace
 
-extern "C" int mft_linear_head_sgd_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups,
-                                       int n_support_rows, int D, int n_way, int n_steps, int batch_size, float* W, float* b,
-                                       float lr, float momentum, float dampening, float weight_decay, void* stream) {
+template <bool ADAM>
+static int linear_head_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups, int n_support_rows,
+                           int D, int n_way, int n_steps, int batch_size, float* W, float* b, float lr, float a, float c, float wd,
+                           float eps, void* stream) {
     if (n_way < 1 || n_way > 16 || batch_size < 1 || batch_size > 16 || n_steps < 1) return MFT_EINVAL;
-    const size_t lds = ((size_t)n_support_rows * D + 2 * (size_t)n_way * D + 16 * 16) * sizeof(float);
+    const size_t lds = ((size_t)n_support_rows * D + (ADAM ? 3 : 2) * (size_t)n_way * D + 16 * 16) * sizeof(float);
     if (lds > 150 * 1024) return MFT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            150 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(linear_head_sgd_kernel, dim3(n_groups), dim3(256), lds, (hipStream_t)stream, z_support, y_support,
-                       idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, momentum, dampening, weight_decay);
+    hipLaunchKernelGGL(linear_head_sgd_kernel<ADAM>, dim3(n_groups), dim3(256), lds, (hipStream_t)stream, z_support, y_support,
+                       idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, a, c, wd, eps);
     return mft_launch_status();
+}
+
+extern "C" int mft_linear_head_sgd_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups,
+                                       int n_support_rows, int D, int n_way, int n_steps, int batch_size, float* W, float* b,
+                                       float lr, float momentum, float dampening, float weight_decay, void* stream) {
+    return linear_head_run<false>(z_support, y_support, idx_table, n_groups, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr,
+                                  momentum, dampening, weight_decay, 0.f, stream);
+}
+
+extern "C" int mft_linear_head_adam_run(const float* z_support, const int* y_support, const int* idx_table, int n_groups,
+                                        int n_support_rows, int D, int n_way, int n_steps, int batch_size, float* W, float* b,
+                                        float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    return linear_head_run<true>(z_support, y_support, idx_table, n_groups, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr,
+                                 beta1, beta2, weight_decay, eps, stream);
 }

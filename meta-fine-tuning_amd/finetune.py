@@ -92,14 +92,48 @@ def _linear_engine(state_in, n_way, n_support, n_query, size, n_views, E):
     return e
 
 
+def _finetune_linear_frozen(x0, state_in, n_way, n_support, n_query, classifier):
+    """finetune_linear(freeze_backbone=True) (finetune.py:45-174, frozen branch): eval-mode features are constants, only the
+    Linear(512, n_way) classifier is trained -- 20 epochs x 5 mini-batches of 5 with Adam(lr .01, weight_decay .001), all 100
+    steps in one launch (mft_linear_head_adam_run) -- and the scores are softmax(classifier(features of the queries))."""
+    from . import ops
+    feat = model_dict[params.model if params is not None else 'ResNet10'](flatten=True)
+    feat.load_state_dict({k.replace("feature.", "", 1): v for k, v in state_in.items()
+                          if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))})
+    feat = feat.cuda().eval()
+    support_size, batch_size, epochs = n_way * n_support, 5, 20
+    with torch.no_grad():
+        x = x0.cuda()
+        za = feat(x[:, :n_support].reshape(support_size, *x.shape[2:])).float().contiguous()
+        zb = feat(x[:, n_support:].reshape(n_way * n_query, *x.shape[2:])).float().contiguous()
+    w0, b0 = classifier_init(n_way) if classifier is None else (torch.as_tensor(classifier[0]), torch.as_tensor(classifier[1]))
+    W = w0.detach().clone().float().cuda().contiguous().view(1, n_way, -1)
+    b = b0.detach().clone().float().cuda().contiguous().view(1, n_way)
+    steps = []
+    for _ in range(epochs):                                          # finetune.py:139-141: one permutation per epoch
+        rand_id = np.random.permutation(support_size)
+        for j in range(0, support_size, batch_size):
+            ids = rand_id[j:min(j + batch_size, support_size)]
+            steps.append(np.concatenate([ids, -np.ones(batch_size - len(ids), dtype=ids.dtype)]))
+    table = torch.from_numpy(np.stack(steps).astype(np.int32)).cuda()
+    y_dev = torch.from_numpy(np.repeat(np.arange(n_way), n_support).astype(np.int32)).cuda()
+    D = za.shape[1]
+    rc = ops._lib.lib().mft_linear_head_adam_run(ops._p(za), ops._p(y_dev), ops._p(table), 1, support_size, D, n_way, table.shape[0],
+                                                 batch_size, ops._p(W), ops._p(b), 0.01, 0.9, 0.999, 1e-8, 0.001, ops._stream())
+    ops._lib.check(rc, "mft_linear_head_adam_run")
+    return torch.nn.functional.softmax(zb @ W[0].t() + b[0], dim=1)
+
+
 def finetune_linear(liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
                     pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
     """finetune.finetune_linear (finetune.py:45-174): the "baseline" branch of the README ensemble.  ``classifier`` =
     (w0 [n_way,512], b0 [n_way]) pins the initial Linear weights (default: torch's nn.Linear draw, as the reference)."""
-    if not flatten or freeze_backbone:
-        raise NotImplementedError("finetune_linear(): flatten=False / freeze_backbone are outside the HIP hot path")
+    if not flatten:
+        raise NotImplementedError("finetune_linear(): flatten=False is outside the HIP hot path")
     x0 = liz_x[0]
     n_query = x0.size(1) - n_support
+    if freeze_backbone:
+        return _finetune_linear_frozen(x0, state_in, n_way, n_support, n_query, classifier)
     e = _linear_engine(state_in, n_way, n_support, n_query, x0.size(-1), len(liz_x), 1)
     w0, b0 = classifier_init(n_way) if classifier is None else (torch.as_tensor(classifier[0]).view(1, n_way, -1),
                                                                  torch.as_tensor(classifier[1]).view(1, n_way))

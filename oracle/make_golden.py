@@ -371,6 +371,38 @@ def main():
         np.savez(os.path.join(GOLD, "g11_finetune_frozen.npz"), **out)
         print("g11 done")
 
+    # ---------------------------------------------------------------- G12 finetune_linear(freeze_backbone=True)
+    if want("g12"):
+        out = {}
+        size = 84
+        sd = synthetic.gnnnet_state_dict_with_running_stats(seed=57)
+        finetune.model_dict["ResNet10"] = make_factory(backbone, size)
+        finetune.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=1)
+        rs = np.random.RandomState(83)
+        w0 = (rs.uniform(-1, 1, size=(5, 512)) / np.sqrt(512)).astype(np.float32)
+        b0 = (rs.uniform(-1, 1, size=(5,)) / np.sqrt(512)).astype(np.float32)
+        RefLinear = nn.Linear
+
+        class SeededLinear12(RefLinear):
+            def __init__(self, i, o, *a, **k):
+                super().__init__(i, o, *a, **k)
+                if (o, i) == w0.shape:
+                    with torch.no_grad():
+                        self.weight.copy_(torch.from_numpy(w0))
+                        self.bias.copy_(torch.from_numpy(b0))
+
+        nn.Linear = SeededLinear12
+        liz = synthetic.test_episode(97, 5, 5, 15, size, gen_examples=1)
+        np.random.seed(10)
+        sc = finetune.finetune_linear(liz, None, state_in=copy.deepcopy(sd), linear=True, save_it=None, n_query=15,
+                                      freeze_backbone=True, n_way=5, n_support=5)
+        nn.Linear = RefLinear
+        out["w0"], out["b0"] = w0, b0
+        out["scores"] = sc.numpy()
+        out["next_perm"] = np.random.permutation(7)          # position of the numpy stream after the call
+        np.savez(os.path.join(GOLD, "g12_finetune_linear_frozen.npz"), **out)
+        print("g12 done")
+
 
 if __name__ == "__main__":
     main()

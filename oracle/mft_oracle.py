@@ -429,6 +429,43 @@ def finetune_linear_episode(state, liz_x, n_way=5, n_support=5, w0=None, b0=None
         return F.softmax(F.linear(out, w, b), dim=1)
 
 
+def finetune_linear_frozen_episode(state, liz_x, n_way=5, n_support=5, w0=None, b0=None, perms=None, epochs=20, batch_size=5,
+                                   dtype=torch.float32):
+    """finetune.finetune_linear(..., freeze_backbone=True) (finetune.py:45-174 with :123-135,:144,:163 taking the frozen
+    branch): the backbone is in eval mode and has no optimiser, so its features are constants; only the Linear(512, n_way)
+    classifier is trained -- Adam(lr .01, weight_decay .001), 20 epochs over the n_way*n_support original support images in
+    mini-batches of 5 -- and the scores are softmax(classifier(backbone_eval(query)))."""
+    sd_all = clone_state(state, dtype)
+    fsd = feature_state(sd_all)
+    x0 = liz_x[0].to(dtype)
+    n_query = x0.shape[1] - n_support
+    xa = x0[:, :n_support].contiguous().view(n_way * n_support, *x0.shape[2:])
+    xb = x0[:, n_support:].contiguous().view(n_way * n_query, *x0.shape[2:])
+    ya = torch.from_numpy(np.repeat(np.arange(n_way), n_support))
+    support_size = n_way * n_support
+    if perms is None:
+        perms = [np.random.permutation(support_size) for _ in range(epochs)]
+    w = w0.detach().clone().to(dtype)
+    b = b0.detach().clone().to(dtype)
+    adam_cls = adam_init([w, b])
+    with torch.no_grad():
+        za = resnet10_forward(fsd, xa, "", train=False)
+        zb = resnet10_forward(fsd, xb, "", train=False)
+    for ep in range(epochs):
+        rand_id = perms[ep]
+        for j in range(0, support_size, batch_size):
+            sel = torch.from_numpy(np.asarray(rand_id[j:min(j + batch_size, support_size)]))
+            for t in (w, b):
+                t.requires_grad_(True)
+            loss = F.cross_entropy(F.linear(za[sel], w, b), ya[sel])
+            grads = torch.autograd.grad(loss, [w, b])
+            for t in (w, b):
+                t.requires_grad_(False)
+            adam_step([w, b], list(grads), adam_cls, lr=0.01, weight_decay=0.001)
+    with torch.no_grad():
+        return F.softmax(F.linear(zb, w, b), dim=1)
+
+
 # --------------------------------------------------------------------------- meta-train / meta-fine-tune
 
 def meta_train_loss(sd, x, n_way, n_support, track=True):

@@ -414,3 +414,21 @@ def test_prefetched_next_batch_is_bit_identical():
     assert e1._pre_bufs is not None                           # the alternate buffers exist, i.e. the prefetch path ran
     for b in range(4):
         assert torch.equal(got[b], ref[b]), b
+
+
+def test_finetune_linear_frozen_backbone_vs_reference_golden(golden_dir):
+    """finetune_linear(freeze_backbone=True) (finetune.py:45-174, frozen branch): eval-mode features + 100 Adam steps on the
+    Linear head in one launch (mft_linear_head_adam_run) against the scores the REFERENCE produced for the same episode,
+    weights, classifier initialisation and numpy seed (G12); the numpy stream must end at the same position."""
+    from meta_fine_tuning_amd import finetune as ft
+    import argparse
+    g = _g(golden_dir, "g12_finetune_linear_frozen.npz")
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=57)
+    liz = synthetic.test_episode(97, 5, 5, 15, 84, gen_examples=1)
+    ft.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=1)
+    np.random.seed(10)
+    sc = ft.finetune_linear([v.to(DEV) for v in liz], None, sd, None, linear=True, freeze_backbone=True,
+                            classifier=(g["w0"], g["b0"])).cpu().numpy()
+    assert sc.shape == (75, 5)
+    assert np.abs(sc - g["scores"]).max() < 1e-3 and (sc.argmax(1) == g["scores"].argmax(1)).mean() >= 0.98, np.abs(sc - g["scores"]).max()
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])

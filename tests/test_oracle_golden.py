@@ -225,3 +225,14 @@ def test_g11_finetune_frozen_backbone(golden_dir):
     sc = O.finetune_frozen_episode(sd, liz, 5, 5, total_epoch=2).numpy()
     assert np.abs(sc - g["scores"]).max() < 1e-5
     assert np.array_equal(np.random.permutation(7), g["next_perm"])
+
+
+def test_g12_finetune_linear_frozen_backbone(golden_dir):
+    """finetune_linear(freeze_backbone=True): classifier-only Adam on eval-mode features (reference output; stream position)."""
+    g = np.load(os.path.join(golden_dir, "g12_finetune_linear_frozen.npz"))
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=57)
+    liz = synthetic.test_episode(97, 5, 5, 15, 84, gen_examples=1)
+    np.random.seed(10)
+    sc = O.finetune_linear_frozen_episode(sd, liz, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"])).numpy()
+    assert np.abs(sc - g["scores"]).max() < 1e-5
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])
