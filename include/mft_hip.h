@@ -158,6 +158,8 @@ int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 
 
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
 int mft_debug_set_conv_tile(int tile);
+/* All tuning knobs (mft_debug_set_conv_tile / mft_debug_set_x3_tile) back to their defaults. */
+int mft_debug_reset(void);
 
 /* conv data gradient (autograd of nn.Conv2d / nn.Linear inputs in loss.backward(), finetune.py:293; meta_template.py:86):
  * dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] * w[g][co][kh][kw][ci] (divisible offsets only), reading
@@ -351,6 +353,30 @@ int mft_pair_absdiff(const float* x, int ldx, float* d, int ldd, int n_graphs, i
 /* Wcompute tail (gnn.py:103-115): s[b,i,j] (ld = lds_, column 0 of the conv2d_last GEMM) -> A[b,i,:] =
  * softmax_j(s - 1e8*[i==j])                                                                    */
 int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, void* stream);
+/* Fused per-pair MLP of Wcompute (gnn.py:78-115; csrc/pair_mlp.hip).  The pair tensor |x_i - x_j| is never materialised and
+ * only the N(N+1)/2 pairs i <= j exist ("upper-triangle rows", row p(i,j) = i*N - i(i-1)/2 + (j-i); `ij[p]` = (i << 16) | j).
+ * A "group" is one episode: `graphs_per_group` graphs whose pair positions share BatchNorm statistics.
+ *   mft_pair_mlp_layer: one 1x1-conv layer over all groups.  mode 0: the A operand is |x_i - x_j| generated from the node
+ *     features `in` [n_groups*graphs_per_group*N, ld_in] (columns >= K masked); mode 1: `in` is the previous layer's RAW
+ *     output [rows, ld_in = K] and BatchNorm + leaky_relu(slope) is applied while loading, y = in*scale_in + shift_in per
+ *     group.  Writes the raw output `out` [n_groups*graphs_per_group*P, Cout] (bias added) and, per (group, 128-row tile),
+ *     the weighted per-channel (mean, M2) and weight sum (off-diagonal rows count twice) into ws_mean / ws_m2 [n_groups *
+ *     tiles_m, Cout] and ws_n [n_groups * tiles_m]; tiles_m = mft_pair_mlp_tiles_m(graphs_per_group, N).
+ *   mft_pair_mlp_stats_finalize: merges a group's tiles (Chan, tile order) into the next layer's affine scale = gamma *
+ *     rstd, shift = beta - mean * scale (biased variance over graphs_per_group*N*N positions; mean_out / rstd_out optional).
+ *   mft_pair_mlp_score: conv2d_last (C -> 1) on BatchNorm + leaky_relu of the last raw layer -> compact symmetric scores
+ *     s_ut [n_groups*graphs_per_group*P].
+ *   mft_masked_softmax_ut: A[b,i,:] = softmax_j(s[b,i,j] - 1e8*[i==j]) (gnn.py:105-115) reading s through p(i,j).      */
+int mft_pair_mlp_tiles_m(int graphs_per_group, int N);
+int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
+                       const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
+                       int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n, void* stream);
+int mft_pair_mlp_stats_finalize(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m, int C,
+                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                float* mean_out, float* rstd_out, void* stream);
+int mft_pair_mlp_score(const float* h, int C, const float* scale, const float* shift, const float* w5, const float* b5,
+                       float slope, float* s_ut, int n_groups, int graphs_per_group, int N, void* stream);
+int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, int N, void* stream);
 /* gmul (gnn.py:16-28) with J=2: y[b,i,:] = cat(x[b,i,:F], (A[b] @ x[b])[i,:F]) zero padded to ldy */
 int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy,
                         int n_graphs, int N, int F, void* stream);

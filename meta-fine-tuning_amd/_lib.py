@@ -28,6 +28,7 @@ SIGNATURES = {
     "mft_pack_dgrad": [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P],
     "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_debug_set_conv_tile": [_I],
+    "mft_debug_reset": [],
     "mft_split_bf16x3": [_P, _P, _L, _P],
     "mft_conv2d_nhwc_x3": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mft_debug_set_x3_tile": [_I],
@@ -83,6 +84,11 @@ SIGNATURES = {
     "mft_linear_head_scores": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "mft_pair_absdiff": [_P, _I, _P, _I, _I, _I, _I, _P],
     "mft_masked_softmax": [_P, _I, _P, _I, _I, _P],
+    "mft_pair_mlp_tiles_m": [_I, _I],
+    "mft_pair_mlp_layer": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "mft_pair_mlp_stats_finalize": [_P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P],
+    "mft_pair_mlp_score": [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P],
+    "mft_masked_softmax_ut": [_P, _P, _I, _I, _P],
     "mft_graph_aggregate": [_P, _P, _I, _P, _I, _I, _I, _I, _P],
     "mft_copy_cols": [_P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "mft_build_graph_nodes": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -24,15 +24,34 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, jobs=None):
+    """One object per .hip source (recompiled only when it or a header is newer), compiled ``jobs`` at a time, then linked."""
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")] + sources() + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    objdir = os.path.join(PKG, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(ROOT, "include", "mft_hip.h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+             "-I" + os.path.join(PKG, "csrc")]
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append([hipcc] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or int(os.environ.get("MFT_BUILD_JOBS", "4"))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 

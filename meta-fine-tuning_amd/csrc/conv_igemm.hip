@@ -665,6 +665,18 @@ extern "C" int mft_debug_set_conv_tile(int tile) {
     return 0;
 }
 
+extern "C" int mft_debug_set_x3_tile(int t);
+
+// Every tuning knob back to its default (tests call this from an always-run fixture: a failed assert between a set and its
+// hand-written restore must not leave later tests on a different kernel variant).
+extern "C" int mft_debug_reset(void) {
+    g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 3; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
+    mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
+    mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
+    mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(100);
+    return 0;
+}
+
 extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
                                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                      int imgs_per_group, long long w_group_stride, void* stream) {

@@ -460,22 +460,26 @@ extern "C" int mft_adam_multi(const void* chunk_table, int n_chunks, int step, f
 // ADAM = true: torch.optim.Adam(lr, betas (b1, b2), eps, L2 weight_decay) instead (finetune.finetune_linear with
 // freeze_backbone=True, finetune.py:110,140-160: the classifier on constant eval-mode features); `mom` / `damp` then carry
 // beta1 / beta2 and the bias corrections are advanced in double precision inside the loop.
+// ZLDS = false: the support features do not fit LDS beside W and its moments (20-shot: 100 rows, 50-shot: 250 rows of 512
+// floats = 512 KB); they stay in HBM / L2 -- a step touches only its <= bs rows (8 KB), twice.
 namespace {
-template <bool ADAM>
+template <bool ADAM, bool ZLDS>
 __global__ __launch_bounds__(256) void linear_head_sgd_kernel(const float* __restrict__ z, const int* __restrict__ y,
                                                               const int* __restrict__ idx, int S, int D, int n_way, int T,
                                                               int bs, float* __restrict__ W, float* __restrict__ b, float lr,
                                                               float mom, float damp, float wd, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* zs = sm;                              // [S][D]
-    float* Ws = zs + S * D;                      // [n_way][D]
+    float* zl = sm;                              // [S][D] (ZLDS only)
+    float* Ws = zl + (ZLDS ? S * D : 0);         // [n_way][D]
     float* Bw = Ws + n_way * D;                  // momentum buffer of W
     float* Vw = Bw + n_way * D;                  // ADAM: second moment of W
     float* sl = Vw + (ADAM ? n_way * D : 0);     // logits / dlogits [bs][16]
     __shared__ float bsm[16], bbuf[16], bv[16];
     double p1 = 1.0, p2 = 1.0;                   // beta1^t, beta2^t
-    for (int i = tid; i < S * D; i += 256) zs[i] = z[(long long)g * S * D + i];
+    if (ZLDS)
+        for (int i = tid; i < S * D; i += 256) zl[i] = z[(long long)g * S * D + i];
+    const float* zs = ZLDS ? (const float*)zl : z + (long long)g * S * D;
     for (int i = tid; i < n_way * D; i += 256) {
         Ws[i] = W[(long long)g * n_way * D + i];
         Bw[i] = 0.f;
@@ -563,17 +567,25 @@ static int linear_head_run(const float* z_support, const int* y_support, const i
                            int D, int n_way, int n_steps, int batch_size, float* W, float* b, float lr, float a, float c, float wd,
                            float eps, void* stream) {
     if (n_way < 1 || n_way > 16 || batch_size < 1 || batch_size > 16 || n_steps < 1) return MFT_EINVAL;
-    const size_t lds = ((size_t)n_support_rows * D + (ADAM ? 3 : 2) * (size_t)n_way * D + 16 * 16) * sizeof(float);
-    if (lds > 150 * 1024) return MFT_EINVAL;
+    const size_t head = ((ADAM ? 3 : 2) * (size_t)n_way * D + 16 * 16) * sizeof(float);
+    const size_t lds_z = (size_t)n_support_rows * D * sizeof(float) + head;
+    if (head > 150 * 1024) return MFT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            150 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(linear_head_sgd_kernel<ADAM>, dim3(n_groups), dim3(256), lds, (hipStream_t)stream, z_support, y_support,
-                       idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, a, c, wd, eps);
+    if (lds_z <= 150 * 1024)
+        hipLaunchKernelGGL((linear_head_sgd_kernel<ADAM, true>), dim3(n_groups), dim3(256), lds_z, (hipStream_t)stream, z_support,
+                           y_support, idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, a, c, wd, eps);
+    else
+        hipLaunchKernelGGL((linear_head_sgd_kernel<ADAM, false>), dim3(n_groups), dim3(256), head, (hipStream_t)stream, z_support,
+                           y_support, idx_table, n_support_rows, D, n_way, n_steps, batch_size, W, b, lr, a, c, wd, eps);
     return mft_launch_status();
 }
 

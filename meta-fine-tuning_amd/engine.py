@@ -42,6 +42,17 @@ def draw_perms(n_total, total_epoch, rng=np.random):
     return [rng.permutation(n_total) for _ in range(total_epoch)]
 
 
+def _on_device(fn):
+    """Run an engine entry point with the engine's device current (launches, streams and events all belong to it)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.dev):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
@@ -66,6 +77,29 @@ class FinetuneEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("FinetuneEngine needs an MI355X (HIP) device; there is no CPU fallback")
         self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        self._raw_stream = None
+        with torch.cuda.device(self.dev):
+            self._build(state, n_way, n_support, n_query, image_size, n_views, fine_tune_epoch, episodes_per_batch, batch_size, lr,
+                        head_state, fold50, fused_adam, pipeline, stem_cache, mode, x3, trunk_chunk)
+
+    def close(self):
+        """Release what the caching allocator does not own: the raw HIP priority stream (mft_stream_create_priority)."""
+        if self._raw_stream is not None:
+            torch.cuda.synchronize(self.dev)
+            ops._lib.lib().mft_stream_destroy(ctypes.c_void_p(self._raw_stream))
+            self._raw_stream = None
+            self.s_trunk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _build(self, state, n_way, n_support, n_query, image_size, n_views, fine_tune_epoch, episodes_per_batch, batch_size, lr,
+               head_state, fold50, fused_adam, pipeline, stem_cache, mode, x3, trunk_chunk):
         self.n_way, self.n_support, self.n_query = n_way, n_support, n_query
         self.size, self.n_views, self.epochs = image_size, n_views, fine_tune_epoch
         self.E, self.bs, self.lr = episodes_per_batch, batch_size, lr
@@ -102,6 +136,7 @@ class FinetuneEngine:
             out = ctypes.c_void_p()
             with torch.cuda.device(self.dev):
                 ops._lib.check(ops._lib.lib().mft_stream_create_priority(prio, ctypes.byref(out), None), "mft_stream_create_priority")
+            self._raw_stream = out.value
             self.s_trunk = torch.cuda.ExternalStream(out.value, device=self.dev)
         elif pipeline:
             self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio)
@@ -124,6 +159,7 @@ class FinetuneEngine:
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev, pooled=self._stem_pooled) if stem_cache else None
 
     # ------------------------------------------------------------------ ingest
+    @_on_device
     def load_episode(self, slot, liz_x, Xs=None, Xall=None):
         """finetune.py:208-233: support images of view 0 twice, then of views 1.. (device NCHW -> NHWC store).
         ``Xs`` / ``Xall``: target stores (default: the engine's current ones; the prefetch path fills the alternate pair)."""
@@ -142,6 +178,7 @@ class FinetuneEngine:
                                                      ops._p(Xall[slot * self.n_all]), ops._stream())
         ops._lib.check(rc, "mft_ingest_episode_views")
 
+    @_on_device
     def load_episode_source(self, slot, src_u8, params, Xs=None, Xall=None):
         """Ingest straight from raw images: src_u8 [n_way, n_support+n_query, Hs, Ws, 3] uint8 on the
         device, params [n_views, n_way*(n_support+n_query), 10] from augment.sample_view_params.  One launch writes the
@@ -187,6 +224,7 @@ class FinetuneEngine:
         return tables
 
     # ------------------------------------------------------------------ inner loop
+    @_on_device
     def prepare_batch(self):
         """Once per batch of episodes, after ingest: fill the stem cache for all resident support images."""
         if self.stem is not None:
@@ -242,6 +280,7 @@ class FinetuneEngine:
     def inner_step(self, idx_dev, lab_dev, k):
         return self.last_step(self.trunk_step(idx_dev, k, 0), lab_dev, k)
 
+    @_on_device
     def inner_loop(self, tables):
         """All inner steps.  With ``pipeline`` the frozen trunk of step t+1 runs on its own HIP stream while the
         HBM-bound last-block backward + Adam of step t runs on another (x6 is double-buffered); the two halves of a
@@ -315,6 +354,7 @@ class FinetuneEngine:
         cur.wait_stream(self.s_trunk)
         cur.wait_stream(self.s_last)
 
+    @_on_device
     def final_scores(self, arena=None):
         """finetune.py:306-317: transductive feature pass over all n_way*(n_support+n_query) images, then
         GnnNet.set_forward(is_feature=True) and softmax.  (finetune.py:307's second pass is dead compute.)"""
@@ -397,6 +437,7 @@ class FinetuneEngine:
             ev.record(sp)
         self._pre = {"token": episodes, "sources": sources, "done": ev, "n": len(episodes)}
 
+    @_on_device
     def run_batch(self, episodes, perms=None, return_feats=False, classifier_init=None, sources=False, defer_final=False,
                   prefetch=None):
         """episodes: list (<= E) of liz_x -- or, with ``sources=True``, of (src_u8, view_params) pairs for device-side view

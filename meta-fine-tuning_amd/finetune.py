@@ -1,72 +1,184 @@
-"""Test-time fine-tuning driver (mirror of finetune.py:182-328,424-682 for --method gnnnet).
+"""Test-time fine-tuning driver (mirror of finetune.py:45-328,424-682).
 
-``finetune(liz_x, y, model, state_in, save_it, ...)`` keeps the reference's signature and semantics
-(module-global ``params`` supplies ``model`` and ``fine_tune_epoch``; permutations come from the global numpy
-RNG) and runs on FinetuneEngine with a batch of one.  ``finetune_batched`` is the throughput entry point:
-E independent episodes in lockstep.  Real datasets are out of scope: ``main`` evaluates
-on the in-repo synthetic episodes with the reference's printed accuracy line.
+``finetune(liz_x, y, model, state_in, save_it, ...)`` / ``finetune_linear(...)`` keep the reference's signatures and
+semantics (module-global ``params`` supplies ``model`` and ``fine_tune_epoch``; permutations come from the global numpy
+RNG).  Three ways in, same arithmetic and same permutation stream:
+
+* one call per episode, as the reference's loop does (finetune.py:599-666): an engine with a batch of one;
+* ``finetune_batched`` / ``finetune_all_batched``: E independent episodes in lockstep (the throughput path);
+* the reference-shaped loop UNCHANGED except that the loader is wrapped in ``LookaheadLoader``: the wrapper reads E
+  episodes ahead, runs them as one lockstep batch (drawing their permutations in the order the sequential calls would) and
+  the per-episode ``finetune()`` / ``finetune_linear()`` calls of the loop body return the finished scores.
+
+``main`` mirrors the reference's ``__main__``: ``--method gnnnet | baseline | all``, ``--freeze_backbone``,
+``--n_shot 50`` (gnnnet_copy, as finetune_50.py:20).  Launched under ``torchrun`` it shards the 600 episodes over the ranks
+(parallel.shard_indices, one all-gather of accuracies at the end -- SURVEY.md §8(e)).  Real datasets and checkpoints are
+out of scope: episodes and weights are the in-repo synthetic ones.
 """
-import argparse
+import hashlib
+import os
 
 import numpy as np
 import torch
 
 from . import engine as eng
+from . import parallel
 from . import synthetic
 from .io_utils import model_dict, parse_args  # noqa: F401  (re-exported like the reference)
 
 params = None          # set by main(); finetune() reads params.model / params.fine_tune_epoch (finetune.py:185,261)
 
-_ENGINES = {}
+LINEAR_EPOCHS = 20     # finetune.py:134 (total_epoch = 20 in finetune_linear)
+
+
+# ------------------------------------------------------------------------------------------------ engine cache
+
+def _feature_items(state_in):
+    return [(k, v) for k, v in state_in.items() if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))]
+
+
+def _state_ident(state_in):
+    """Cheap identity of a checkpoint's backbone tensors: (key, address, autograd version).  Valid only while the cache entry
+    keeps the tensors alive (it does), so an address cannot be recycled for different weights."""
+    return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in _feature_items(state_in))
+
+
+def _state_fingerprint(state_in):
+    """Content hash of the backbone tensors (19.6 MB: ~15 ms).  Two checkpoints with equal bytes share one engine -- the
+    reference deep-copies the state for every episode (finetune.py:187), callers may too."""
+    h = hashlib.blake2b(digest_size=16)
+    for k, v in _feature_items(state_in):
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+class _EngineCache:
+    """Engines keyed on WHAT the checkpoint contains, not on where the caller's dict lives.  An entry pins the state dict it
+    was built from; a miss on the cheap identity falls back to the content hash (and remembers the new identity)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.entries = []          # dicts: idents (set), fp, cfg, engine, pins (list of state dicts kept alive)
+
+    def get(self, state_in, cfg, build):
+        ident = _state_ident(state_in)
+        for ent in self.entries:
+            if ent["cfg"] == cfg and ident in ent["idents"]:
+                return ent["engine"]
+        fp = _state_fingerprint(state_in)
+        for ent in self.entries:
+            if ent["cfg"] == cfg and ent["fp"] == fp:
+                if len(ent["pins"]) < 4:                 # remember a few aliases; beyond that just re-hash
+                    ent["idents"].add(ident)
+                    ent["pins"].append(state_in)
+                return ent["engine"]
+        while len(self.entries) >= self.capacity:
+            old = self.entries.pop(0)
+            old["engine"].close()
+        e = build()
+        self.entries.append({"idents": {ident}, "fp": fp, "cfg": cfg, "engine": e, "pins": [state_in]})
+        return e
+
+    def clear(self):
+        for ent in self.entries:
+            ent["engine"].close()
+        self.entries = []
+
+
+_ENGINES = _EngineCache(3)
+_LIN_ENGINES = _EngineCache(2)
+
+
+def _head_key(model):
+    return tuple((p.data_ptr(), p._version) for p in list(model.fc.parameters()) + list(model.gnn.parameters()))
 
 
 def _engine_for(state_in, model, n_way, n_support, n_query, size, n_views, epochs, E, fold50=False):
-    head_key = tuple((p.data_ptr(), p._version) for p in list(model.fc.parameters()) + list(model.gnn.parameters()))
-    key = (id(state_in), head_key, n_way, n_support, n_query, size, n_views, epochs, E, fold50)
-    e = _ENGINES.get(key)
-    if e is None:
-        if len(_ENGINES) >= 4:
-            _ENGINES.clear()
+    cfg = ("gnn", _head_key(model), n_way, n_support, n_query, size, n_views, epochs, E, fold50)
+
+    def build():
         head = {"fc." + k: v for k, v in model.fc.state_dict().items()}
         head.update({"gnn." + k: v for k, v in model.gnn.state_dict().items()})
-        e = eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=epochs,
-                               episodes_per_batch=E, head_state=head, fold50=fold50)
-        _ENGINES[key] = e
-    return e
+        return eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=epochs,
+                                  episodes_per_batch=E, head_state=head, fold50=fold50)
+    return _ENGINES.get(state_in, cfg, build)
 
 
-def finetune(liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
-             pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5):
-    """One episode: liz_x = [x0, x0, aug_1, ...] each [n_way, n_support+n_query, 3, H, W]; returns softmax scores
-    [n_way*n_query, n_way] (finetune.py:182-328)."""
+def _linear_engine(state_in, n_way, n_support, n_query, size, n_views, E):
+    cfg = ("linear", n_way, n_support, n_query, size, n_views, E)
+
+    def build():
+        return eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=LINEAR_EPOCHS,
+                                  episodes_per_batch=E, mode="linear")
+    return _LIN_ENGINES.get(state_in, cfg, build)
+
+
+# ------------------------------------------------------------------------------------------------ lookahead registry
+
+_READY = {}            # id(first view tensor) -> {"pin": tensor, "gnn": scores | None, "linear": scores | None}
+
+
+def _take_ready(liz_x, kind):
+    ent = _READY.get(id(liz_x[0]))
+    if ent is None or ent["pin"] is not liz_x[0] or ent.get(kind) is None:
+        return None
+    sc = ent[kind]
+    ent[kind] = None
+    if ent.get("gnn") is None and ent.get("linear") is None:
+        del _READY[id(liz_x[0])]
+    return sc
+
+
+# ------------------------------------------------------------------------------------------------ per-episode entry points
+
+def _params_of(p):
+    if p is None or p.model != 'ResNet10':
+        raise RuntimeError("finetune.params must be set (Namespace(model='ResNet10', fine_tune_epoch=...))")
+    return p
+
+
+def _eval_backbone(state_in, model_name):
+    feat = model_dict[model_name](flatten=True)
+    feat.load_state_dict({k.replace("feature.", "", 1): v for k, v in _feature_items(state_in)})
+    return feat.cuda().eval()
+
+
+def _finetune(P, liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+              pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5):
     if linear or not flatten or ds:
         raise NotImplementedError("finetune(): only the GNN scoring branch with a flattened backbone is on the HIP hot path "
                                   "(the linear branch is finetune_linear(); ds = DampNet, out of scope)")
-    if params is None or params.model != 'ResNet10':
-        raise RuntimeError("finetune.params must be set (Namespace(model='ResNet10', fine_tune_epoch=...))")
+    P = _params_of(P)
+    ready = _take_ready(liz_x, "gnn")
+    if ready is not None:
+        model.n_query = liz_x[0].size(1) - n_support               # finetune.py:312
+        return ready
     model = model.cuda()
     x0 = liz_x[0]
     n_query = x0.size(1) - n_support
     if freeze_backbone:
         # finetune.py:253-266: eval-mode backbone, no backbone optimiser; the classifier gets no gradient either, so the
         # loop at :270-299 changes nothing -- it only consumes one permutation per epoch.  Scores = GNN on eval features.
-        for _ in range(params.fine_tune_epoch):
+        for _ in range(P.fine_tune_epoch):
             np.random.permutation(n_way * n_support * (len(liz_x) + 1))
-        feat = model_dict[params.model](flatten=True)
-        feat.load_state_dict({k.replace("feature.", "", 1): v for k, v in state_in.items()
-                              if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))})
-        feat = feat.cuda().eval()
+        feat = _eval_backbone(state_in, P.model)
         with torch.no_grad():
             out_all = feat(x0.cuda().reshape(-1, *x0.shape[2:])).view(n_way, n_support + n_query, -1)
             model.n_query = n_query
             return torch.nn.functional.softmax(model.set_forward(out_all, is_feature=True), dim=1)
-    e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(liz_x), params.fine_tune_epoch, 1,
+    e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(liz_x), P.fine_tune_epoch, 1,
                     fold50=getattr(model, "FOLD50", False))
     model.n_query = n_query                                          # finetune.py:312
     return e.run_batch([liz_x])[0].clone()
 
 
-_LIN_ENGINES = {}
+def finetune(liz_x, y, model, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+             pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5):
+    """One episode: liz_x = [x0, x0, aug_1, ...] each [n_way, n_support+n_query, 3, H, W]; returns softmax scores
+    [n_way*n_query, n_way] (finetune.py:182-328)."""
+    return _finetune(params, liz_x, y, model, state_in, save_it, linear, flatten, n_query, ds, pretrained_dataset,
+                     freeze_backbone, n_way, n_support)
 
 
 def classifier_init(n_way, dim=512, n=1):
@@ -80,28 +192,13 @@ def classifier_init(n_way, dim=512, n=1):
     return torch.stack(ws), torch.stack(bs)
 
 
-def _linear_engine(state_in, n_way, n_support, n_query, size, n_views, E):
-    key = (id(state_in), n_way, n_support, n_query, size, n_views, E)
-    e = _LIN_ENGINES.get(key)
-    if e is None:
-        if len(_LIN_ENGINES) >= 2:
-            _LIN_ENGINES.clear()
-        e = eng.FinetuneEngine(state_in, n_way, n_support, n_query, size, n_views=n_views, fine_tune_epoch=20,
-                               episodes_per_batch=E, mode="linear")
-        _LIN_ENGINES[key] = e
-    return e
-
-
-def _finetune_linear_frozen(x0, state_in, n_way, n_support, n_query, classifier):
+def _finetune_linear_frozen(P, x0, state_in, n_way, n_support, n_query, classifier):
     """finetune_linear(freeze_backbone=True) (finetune.py:45-174, frozen branch): eval-mode features are constants, only the
-    Linear(512, n_way) classifier is trained -- 20 epochs x 5 mini-batches of 5 with Adam(lr .01, weight_decay .001), all 100
+    Linear(512, n_way) classifier is trained -- 20 epochs of mini-batches of 5 with Adam(lr .01, weight_decay .001), all
     steps in one launch (mft_linear_head_adam_run) -- and the scores are softmax(classifier(features of the queries))."""
     from . import ops
-    feat = model_dict[params.model if params is not None else 'ResNet10'](flatten=True)
-    feat.load_state_dict({k.replace("feature.", "", 1): v for k, v in state_in.items()
-                          if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))})
-    feat = feat.cuda().eval()
-    support_size, batch_size, epochs = n_way * n_support, 5, 20
+    feat = _eval_backbone(state_in, P.model if P is not None else 'ResNet10')
+    support_size, batch_size, epochs = n_way * n_support, 5, LINEAR_EPOCHS
     with torch.no_grad():
         x = x0.cuda()
         za = feat(x[:, :n_support].reshape(support_size, *x.shape[2:])).float().contiguous()
@@ -124,29 +221,52 @@ def _finetune_linear_frozen(x0, state_in, n_way, n_support, n_query, classifier)
     return torch.nn.functional.softmax(zb @ W[0].t() + b[0], dim=1)
 
 
-def finetune_linear(liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
-                    pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
-    """finetune.finetune_linear (finetune.py:45-174): the "baseline" branch of the README ensemble.  ``classifier`` =
-    (w0 [n_way,512], b0 [n_way]) pins the initial Linear weights (default: torch's nn.Linear draw, as the reference)."""
+def _finetune_linear(P, liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+                     pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
     if not flatten:
         raise NotImplementedError("finetune_linear(): flatten=False is outside the HIP hot path")
+    ready = _take_ready(liz_x, "linear")
+    if ready is not None:
+        return ready
     x0 = liz_x[0]
     n_query = x0.size(1) - n_support
     if freeze_backbone:
-        return _finetune_linear_frozen(x0, state_in, n_way, n_support, n_query, classifier)
+        return _finetune_linear_frozen(P, x0, state_in, n_way, n_support, n_query, classifier)
     e = _linear_engine(state_in, n_way, n_support, n_query, x0.size(-1), len(liz_x), 1)
     w0, b0 = classifier_init(n_way) if classifier is None else (torch.as_tensor(classifier[0]).view(1, n_way, -1),
                                                                  torch.as_tensor(classifier[1]).view(1, n_way))
     return e.run_batch([liz_x], classifier_init=(w0, b0))[0].clone()
 
 
-def finetune_all(liz_x, y, model, state_baseline, state_gnn, n_way=5, n_support=5, classifier=None):
+def finetune_linear(liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
+                    pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
+    """finetune.finetune_linear (finetune.py:45-174): the "baseline" branch of the README ensemble.  ``classifier`` =
+    (w0 [n_way,512], b0 [n_way]) pins the initial Linear weights (default: torch's nn.Linear draw, as the reference)."""
+    return _finetune_linear(params, liz_x, y, state_in, save_it, linear, flatten, n_query, ds, pretrained_dataset,
+                            freeze_backbone, n_way, n_support, classifier)
+
+
+def finetune_all(liz_x, y, model, state_baseline, state_gnn, n_way=5, n_support=5, classifier=None, freeze_backbone=False):
     """``--method all`` (finetune.py:634-649): scores_out = finetune_linear(baseline state) + finetune(gnnnet state);
     the numpy permutation stream is consumed in that order."""
     out = finetune_linear(liz_x, y, state_baseline, None, linear=True, n_way=n_way, n_support=n_support,
-                          classifier=classifier)
-    out = out + finetune(liz_x, y, model, state_gnn, 600, n_way=n_way, n_support=n_support)
+                          classifier=classifier, freeze_backbone=freeze_backbone)
+    out = out + finetune(liz_x, y, model, state_gnn, 600, n_way=n_way, n_support=n_support, freeze_backbone=freeze_backbone)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ batched entry points
+
+def draw_episode_perms(method, n_way, n_support, n_views, fine_tune_epoch, rng=np.random):
+    """The permutations ONE episode consumes, in the reference's order: ``--method all`` / ``baseline`` first draw
+    finetune_linear's 20 permutations of the support set (finetune.py:139-141), then ``all`` / ``gnnnet`` draw finetune's
+    ``fine_tune_epoch`` permutations of n_way*n_support*(n_views+1) (finetune.py:269-272).  -> (linear perms | None, gnn perms | None)"""
+    lin = gnn = None
+    if method in ("all", "baseline"):
+        lin = [rng.permutation(n_way * n_support) for _ in range(LINEAR_EPOCHS)]
+    if method in ("all", "gnnnet"):
+        gnn = [rng.permutation(n_way * n_support * (n_views + 1)) for _ in range(fine_tune_epoch)]
+    return lin, gnn
 
 
 def finetune_batched(episodes, model, state_in, fine_tune_epoch, n_way=5, n_support=5, episodes_per_batch=32,
@@ -166,41 +286,232 @@ def finetune_batched(episodes, model, state_in, fine_tune_epoch, n_way=5, n_supp
     return torch.cat(out)
 
 
+def finetune_linear_batched(episodes, state_in, n_way=5, n_support=5, episodes_per_batch=32, perms=None, classifiers=None):
+    """finetune_linear over a list of episodes in lockstep.  ``classifiers`` = (w0 [n,n_way,512], b0 [n,n_way]); default: one
+    nn.Linear draw per episode from torch's global RNG, in episode order."""
+    x0 = episodes[0][0]
+    n_query = x0.size(1) - n_support
+    e = _linear_engine(state_in, n_way, n_support, n_query, x0.size(-1), len(episodes[0]), episodes_per_batch)
+    if classifiers is None:
+        classifiers = classifier_init(n_way, n=len(episodes))
+    out = []
+    for i in range(0, len(episodes), episodes_per_batch):
+        chunk = episodes[i:i + episodes_per_batch]
+        p = None if perms is None else perms[i:i + episodes_per_batch]
+        ci = (classifiers[0][i:i + len(chunk)], classifiers[1][i:i + len(chunk)])
+        out.append(e.run_batch(chunk, perms=p, classifier_init=ci).clone())
+    return torch.cat(out)
+
+
+def scores_batched(method, episodes, model, state_gnn, state_b, fine_tune_epoch, n_way=5, n_support=5, episodes_per_batch=32,
+                   rngs=None, classifiers=None, parts=False):
+    """What the reference's loop body computes for each episode of ``episodes`` (finetune.py:615-619,647-649), in lockstep:
+    ``gnnnet`` -> finetune(); ``baseline`` -> finetune_linear(); ``all`` -> their sum.  The permutations of all episodes are
+    drawn FIRST, episode by episode in the order the sequential calls would draw them (from the global numpy RNG, or from
+    ``rngs[i]`` -- one generator per episode, the rank-count-invariant stream of parallel.episode_rng).
+    ``parts``: return (linear scores | None, gnn scores | None) instead of the sum."""
+    n = len(episodes)
+    n_views = len(episodes[0])
+    lin_p, gnn_p = [], []
+    for i in range(n):
+        lp, gp = draw_episode_perms(method, n_way, n_support, n_views, fine_tune_epoch, np.random if rngs is None else rngs[i])
+        lin_p.append(lp)
+        gnn_p.append(gp)
+    s_lin = s_gnn = None
+    if method in ("all", "baseline"):
+        s_lin = finetune_linear_batched(episodes, state_b, n_way, n_support, episodes_per_batch, perms=lin_p, classifiers=classifiers)
+    if method in ("all", "gnnnet"):
+        s_gnn = finetune_batched(episodes, model, state_gnn, fine_tune_epoch, n_way, n_support, episodes_per_batch, perms=gnn_p)
+    if parts:
+        return s_lin, s_gnn
+    return s_gnn if s_lin is None else (s_lin if s_gnn is None else s_lin + s_gnn)
+
+
+class LookaheadLoader:
+    """Wrap the episode loader of the reference's loop (``for idx, elem in enumerate(novel_loader)``, finetune.py:599,634) so
+    that the loop body stays as it is and the engine still sees E episodes at a time.
+
+    ``elem`` is the reference's list of (x, y) view tuples.  The wrapper pulls up to ``episodes_per_batch`` elems from the
+    underlying loader, runs them as one lockstep batch (``scores_batched``: permutations drawn in the sequential order) and
+    parks the per-episode scores in a registry keyed by the identity of the episode's first view tensor; then it yields the
+    elems one by one.  ``finetune(liz_x, ...)`` / ``finetune_linear(liz_x, ...)`` called by the loop body with that episode
+    return the parked scores instead of running an engine of one -- bit-identical to ``finetune_batched`` because it IS the
+    batched run (tests/test_drivers_gpu.py)."""
+
+    def __init__(self, loader, method, model, state_gnn=None, state_b=None, fine_tune_epoch=None, n_way=5, n_support=5,
+                 episodes_per_batch=32, classifiers=None):
+        self.loader, self.method, self.model = loader, method, model
+        self.state_gnn, self.state_b = state_gnn, state_b
+        self.epochs = fine_tune_epoch if fine_tune_epoch is not None else _params_of(params).fine_tune_epoch
+        self.n_way, self.n_support, self.E = n_way, n_support, episodes_per_batch
+        self.classifiers = classifiers
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        done = False
+        k = 0
+        while not done:
+            batch = []
+            while len(batch) < self.E:
+                try:
+                    batch.append(next(it))
+                except StopIteration:
+                    done = True
+                    break
+            if not batch:
+                break
+            eps = [[x.cuda() for (x, _y) in elem] for elem in batch]
+            cls = None if self.classifiers is None else (self.classifiers[0][k:k + len(batch)], self.classifiers[1][k:k + len(batch)])
+            k += len(batch)
+            s_lin, s_gnn = scores_batched(self.method, eps, self.model, self.state_gnn, self.state_b, self.epochs, self.n_way,
+                                          self.n_support, self.E, classifiers=cls, parts=True)
+            for j, elem in enumerate(batch):
+                pin = elem[0][0]
+                _READY[id(pin)] = {"pin": pin, "gnn": None if s_gnn is None else s_gnn[j],
+                                   "linear": None if s_lin is None else s_lin[j]}
+            for elem in batch:
+                yield elem
+
+
+# ------------------------------------------------------------------------------------------------ the 600-episode driver
+
+class SyntheticNovelLoader:
+    """Stand-in for ``SetDataManager2(...).get_data_loader(num_aug=gen_examples)`` (datasets/EuroSAT_few_shot.py:329-351):
+    yields ``elem`` = list of 2+gen_examples (x, y) tuples, views 0 and 1 identical.  ``indices``: the episode ids this rank owns."""
+
+    def __init__(self, indices, n_way, n_shot, n_query, size, gen_examples, seed0=0):
+        self.indices, self.a, self.seed0 = list(indices), (n_way, n_shot, n_query, size, gen_examples), seed0
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __iter__(self):
+        n_way, n_shot, n_query, size, G = self.a
+        y = torch.from_numpy(np.repeat(np.arange(n_way), n_shot + n_query).reshape(n_way, n_shot + n_query))
+        for i in self.indices:
+            views = synthetic.test_episode(self.seed0 + i, n_way, n_shot, n_query, size, G)
+            yield [(v, y) for v in views]
+
+
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
-             episodes_per_batch=32, verbose=True):
-    """600-episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies."""
+             episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None):
+    """The episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies (all ranks' episodes, in
+    episode order, on every rank).
+
+    With torch.distributed initialised the episodes are sharded (episode i -> rank i mod W) and every episode draws its
+    permutations from ``parallel.episode_rng(rng_seed, i)`` -- and its classifier initialisation from a torch generator
+    seeded the same way -- so the result does not depend on the rank count; pass ``rng_seed`` to get that stream at W = 1 too.
+    Without either the global numpy stream is used sequentially, exactly as the reference does."""
+    rank, W = parallel.world()
+    if W > 1 and rng_seed is None:
+        rng_seed = 10
+    mine = parallel.shard_indices(n_episodes, rank, W)
     y_query = np.repeat(range(n_way), n_query)
     accs = []
-    for i in range(0, n_episodes, episodes_per_batch):
-        eps = [[v.cuda() for v in synthetic.test_episode(seed0 + j, n_way, n_shot, n_query, size, gen_examples)]
-               for j in range(i, min(i + episodes_per_batch, n_episodes))]
-        for j, ep in enumerate(eps):
+    for c in range(0, len(mine), episodes_per_batch):
+        ids = mine[c:c + episodes_per_batch]
+        eps = [[v.cuda() for v in synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples)] for i in ids]
+        for ep in eps:
             assert torch.all(torch.eq(ep[0], ep[1]))                 # finetune.py:606
-        sc = finetune_batched(eps, model, state, fine_tune_epoch, n_way, n_shot, episodes_per_batch)
+        rngs = cls = None
+        if rng_seed is not None:
+            rngs = [parallel.episode_rng(rng_seed, i) for i in ids]
+            if method in ("all", "baseline"):
+                ws, bs = [], []
+                for i in ids:
+                    with torch.random.fork_rng(devices=[]):
+                        torch.manual_seed(parallel.episode_torch_seed(rng_seed, i))
+                        w, b = classifier_init(n_way)
+                    ws.append(w[0]); bs.append(b[0])
+                cls = (torch.stack(ws), torch.stack(bs))
+        if freeze_backbone:
+            sc = []
+            for k, ep in enumerate(eps):
+                st = np.random.get_state()
+                if rngs is not None:                                  # the frozen branches draw from the global stream
+                    np.random.set_state(rngs[k].get_state())
+                sc.append(_score_one(method, ep, model, state, state_b, n_way, n_shot, fine_tune_epoch,
+                                     None if cls is None else (cls[0][k], cls[1][k]), True))
+                if rngs is not None:
+                    np.random.set_state(st)
+            sc = torch.stack(sc)
+        else:
+            sc = scores_batched(method, eps, model, state, state_b, fine_tune_epoch, n_way, n_shot, episodes_per_batch,
+                                rngs=rngs, classifiers=cls)
         pred = sc.argmax(2).cpu().numpy()
         for p in pred:
             accs.append(float(np.mean(p == y_query)) * 100)
-    accs = np.asarray(accs)
-    if verbose:
+    dev = "cuda" if (W > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
+    accs = parallel.gather_episode_values(accs, n_episodes, device=dev)
+    if verbose and rank == 0:
         print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))))
     return accs
 
 
-def main(argv=None):
+def _score_one(method, liz_x, model, state, state_b, n_way, n_shot, fine_tune_epoch, classifier, freeze_backbone):
+    """Loop body of finetune.py:615-619 / :647-649 for one episode (per-episode entry points)."""
+    global params
+    import argparse
+    if params is None:
+        params = argparse.Namespace(model='ResNet10', fine_tune_epoch=fine_tune_epoch)
+    if method == "baseline":
+        return finetune_linear(liz_x, None, state_b, None, linear=True, freeze_backbone=freeze_backbone, n_way=n_way,
+                               n_support=n_shot, classifier=classifier)
+    if method == "all":
+        return finetune_all(liz_x, None, model, state_b, state, n_way, n_shot, classifier=classifier, freeze_backbone=freeze_backbone)
+    return finetune(liz_x, None, model, state, None, freeze_backbone=freeze_backbone, n_way=n_way, n_support=n_shot)
+
+
+def _init_distributed():
+    """Under torchrun (WORLD_SIZE > 1): one process per GPU, RCCL.  Must run before anything touches the GPU."""
+    W = int(os.environ.get("WORLD_SIZE", "1"))
+    if W <= 1 or torch.distributed.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MFT_ONE_DEVICE", "0") == "1":            # test hook: W ranks share device 0, gloo for the gather
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+
+
+def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
+    """finetune.py:424-682.  ``--method gnnnet`` (and gnnnet at ``--n_shot 50`` through gnnnet_copy, finetune_50.py),
+    ``--method baseline`` (finetune_linear on the baseline checkpoint), ``--method all`` (their sum)."""
     global params
     np.random.seed(10)                                               # finetune.py:425
     params = parse_args('train', argv)
+    _init_distributed()
     from .methods.gnnnet import GnnNet
     from .methods import gnnnet_copy
-    if params.method not in ('gnnnet',):
-        raise NotImplementedError("--method %s: only 'gnnnet' is on the HIP hot path" % params.method)
-    size = int(__import__("os").environ.get("MFT_IMAGE_SIZE", "84"))
-    cls = gnnnet_copy.GnnNet if params.n_shot == 50 else GnnNet
-    model = cls(model_dict[params.model], n_way=params.test_n_way, n_support=params.n_shot).cuda()
-    state = synthetic.gnnnet_state_dict(seed=0, n_way=params.test_n_way)   # no checkpoints offline (BASELINE.md §1)
-    model.load_state_dict(state)
-    return evaluate(model, state, 600, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
-                    params.fine_tune_epoch)
+    if params.method not in ('gnnnet', 'baseline', 'all'):
+        raise NotImplementedError("--method %s: 'gnnnet', 'baseline' and 'all' are on the HIP hot path (protonet / relationnet / "
+                                  "dampnet are out of scope, SURVEY.md §2.1)" % params.method)
+    size = int(os.environ.get("MFT_IMAGE_SIZE", "84"))
+    n_episodes = int(os.environ.get("MFT_EPISODES", n_episodes))
+    if model_cls is None:
+        model_cls = gnnnet_copy.GnnNet if params.n_shot == 50 else GnnNet
+    if episodes_per_batch is None:
+        episodes_per_batch = int(os.environ.get("MFT_EPISODES_PER_BATCH", {5: 128, 20: 64}.get(params.n_shot, 32)))
+    model = state = state_b = None
+    # no checkpoints offline (BASELINE.md §1): seeded synthetic weights stand in for <save_dir>/checkpoints/.../{600,400}.tar
+    if params.method in ('gnnnet', 'all'):
+        model = model_cls(model_dict[params.model], n_way=params.test_n_way, n_support=params.n_shot).cuda()
+        state = synthetic.gnnnet_state_dict(seed=0, n_way=params.test_n_way)
+        model.load_state_dict(state)
+    if params.method in ('baseline', 'all'):
+        state_b = synthetic.gnnnet_state_dict(seed=400, n_way=params.test_n_way)
+    print(params.freeze_backbone)                                    # finetune.py:591
+    accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
+                    params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
+                    episodes_per_batch=episodes_per_batch)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    return accs
 
 
 if __name__ == '__main__':

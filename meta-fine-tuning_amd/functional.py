@@ -614,9 +614,80 @@ class GnnHeadWeights:
             self.gc[name] = (ops.pack_conv_weight(w), dev(sd["gnn.%s.fc.bias" % name]), g, b, w.shape[0])
 
 
+_PAIR_IJ = {}
+FUSED_PAIR_MLP = os.environ.get("MFT_FUSED_PAIR_MLP", "1") == "1"
+PAIR_MLP_BYTES = int(float(os.environ.get("MFT_PAIR_MLP_GB", "6")) * (1 << 30))     # raw-activation budget per chunk of episodes
+
+
+def pair_index_table(N, device):
+    """(i << 16) | j of the upper-triangle pair rows, i-major: p(i, j) = i*N - i(i-1)/2 + (j - i), i <= j."""
+    key = (N, str(device))
+    t = _PAIR_IJ.get(key)
+    if t is None:
+        import numpy as np
+        i, j = np.triu_indices(N)
+        t = torch.from_numpy(((i.astype(np.int64) << 16) | j).astype(np.int32)).to(device)
+        _PAIR_IJ[key] = t
+    return t
+
+
 def wcompute(G, name, x, F, n_graphs, N, n_groups, arena, tag="wc"):
     """gnn.Wcompute.forward (gnn.py:78-132): x [n_graphs*N, ld] -> A [n_graphs, N, N].  BatchNorm statistics are
-    per group of n_graphs/n_groups graphs (one episode), over all graphs*N*N pair positions."""
+    per group of n_graphs/n_groups graphs (one episode), over all graphs*N*N pair positions.
+
+    Fused form (csrc/pair_mlp.hip): five grid-wide phases (one per BatchNorm), each ONE launch over a chunk of episodes; the
+    pair tensor |x_i - x_j| is generated in the first layer's loader, only the N(N+1)/2 pairs i <= j are computed (the score
+    is symmetric), every layer writes its RAW output once and the next layer applies BatchNorm + leaky_relu while loading;
+    statistics come out of the GEMM epilogues.  Episodes are processed in chunks so that the raw activations of a chunk stay
+    within ``PAIR_MLP_BYTES`` whatever E is."""
+    if not FUSED_PAIR_MLP:
+        return wcompute_unfused(G, name, x, F, n_graphs, N, n_groups, arena, tag)
+    layers, (w5, b5) = G.wc[name]
+    lib = ops._lib.lib()
+    gpg = n_graphs // n_groups
+    P = N * (N + 1) // 2
+    ij = pair_index_table(N, x.device)
+    A = arena.get(tag + ".A", (n_graphs, N, N))
+    widths = [l[4] for l in layers]                                   # 192, 192, 96, 96
+    per_group = gpg * P * 4 * (widths[0] + widths[1] + widths[3])     # h1, h2 live together; h3 reuses h1's buffer
+    chunk = max(1, min(n_groups, PAIR_MLP_BYTES // max(per_group, 1)))
+    tiles_m = int(lib.mft_pair_mlp_tiles_m(gpg, N))
+    rows_c = chunk * gpg * P
+    # raw layer outputs of one chunk, shared by all Wcompute instances of the head (same tag-independent names)
+    hbuf = [arena.get("pm.h%d" % i, (rows_c * w,)) for i, w in ((0, widths[0]), (1, widths[1]), (3, widths[3]))]
+    ws_mean = arena.get("pm.wsm", (chunk * tiles_m * 192,))
+    ws_m2 = arena.get("pm.wsq", (chunk * tiles_m * 192,))
+    ws_n = arena.get("pm.wsn", (chunk * tiles_m,))
+    scale = [arena.get("pm.sc%d" % i, (chunk, w)) for i, w in enumerate(widths)]
+    shift = [arena.get("pm.sh%d" % i, (chunk, w)) for i, w in enumerate(widths)]
+    s_ut = arena.get("pm.s", (rows_c,))
+    Kp = ops.round_up(F, 32)
+    ld = x.shape[1]
+    st = ops._stream
+    for g0 in range(0, n_groups, chunk):
+        ng = min(chunk, n_groups - g0)
+        xin = x[g0 * gpg * N:]
+        outs = [hbuf[0], hbuf[1], hbuf[0], hbuf[2]]                   # h1 -> h2 -> h3 (over h1) -> h4
+        h_in, ld_in, K, Kpad = xin, ld, F, Kp
+        for li, (w, b, gam, beta, cout) in enumerate(layers):
+            ops._lib.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij),
+                                                  ops._p(scale[li - 1]) if li else None, ops._p(shift[li - 1]) if li else None,
+                                                  ops._p(w), K, Kpad, ops._p(b), ops._p(outs[li]), cout, ng, gpg, N,
+                                                  ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), st()),
+                           "mft_pair_mlp_layer")
+            ops._lib.check(lib.mft_pair_mlp_stats_finalize(ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), ng, tiles_m, cout,
+                                                           ops._p(gam), ops._p(beta), ops.BN_EPS, ops._p(scale[li]),
+                                                           ops._p(shift[li]), None, None, st()), "mft_pair_mlp_stats_finalize")
+            h_in, ld_in, K, Kpad = outs[li], cout, cout, cout
+        ops._lib.check(lib.mft_pair_mlp_score(ops._p(h_in), widths[3], ops._p(scale[3]), ops._p(shift[3]), ops._p(w5), ops._p(b5),
+                                              ops.LRELU_SLOPE, ops._p(s_ut), ng, gpg, N, st()), "mft_pair_mlp_score")
+        ops._lib.check(lib.mft_masked_softmax_ut(ops._p(s_ut), ops._p(A[g0 * gpg:]), ng * gpg, N, st()), "mft_masked_softmax_ut")
+    return A
+
+
+def wcompute_unfused(G, name, x, F, n_graphs, N, n_groups, arena, tag="wc"):
+    """Round-1 form of ``wcompute``: the materialised pair tensor through generic GEMM / BatchNorm launches (kept as the A/B and
+    test reference of the fused kernels; MFT_FUSED_PAIR_MLP=0)."""
     layers, (w5, b5) = G.wc[name]
     Kp = ops.round_up(F, 32)
     rows = n_graphs * N * N

@@ -16,15 +16,23 @@ BN_EPS = 1e-5
 LRELU_SLOPE = 0.01
 
 
+_last_dev = None          # device index of the most recent pointer argument (arguments are marshalled left to right)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream OF THE DEVICE THE LAUNCH'S TENSORS LIVE ON (not of whatever device happens to be current:
+    an engine built for cuda:1 must not enqueue on device 0's stream).  Callers on a non-current device must also make
+    it current for the launch itself (FinetuneEngine does, ``torch.cuda.device(self.dev)``)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(_last_dev).cuda_stream)
 
 
 def _p(t):
+    global _last_dev
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("meta_fine_tuning_amd ops need CUDA (HIP) tensors; got a CPU tensor (no CPU fallback)")
+    _last_dev = t.device.index
     return ctypes.c_void_p(t.data_ptr())
 
 

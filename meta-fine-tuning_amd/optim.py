@@ -56,7 +56,8 @@ class Adam(torch.optim.Optimizer):
                     st = self.state[p]
                     ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"], beta1=b1,
                                   beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"])
-            # parameters were updated through raw pointers: bump autograd's version counters (the weight-pack caches key
-            # on them) with one fused no-op write
-            torch._foreach_add_([p.data for p in ps], 0)
+            # parameters were updated through raw pointers: bump autograd's version counters (the weight-pack caches of
+            # autograd_ops key on ``p._version``) with one fused no-op write ON THE PARAMETERS THEMSELVES -- an in-place op on
+            # ``p.data`` does not touch the parameter's counter (step() runs under no_grad, so this is legal on leaves)
+            torch._foreach_add_(ps, 0)
         return loss

@@ -31,6 +31,11 @@ def episode_rng(seed, episode_index):
     return np.random.RandomState((int(seed) * 1000003 + int(episode_index) * 7919) % (2 ** 32 - 1))
 
 
+def episode_torch_seed(seed, episode_index):
+    """Seed of the torch generator that draws episode i's Classifier initialisation (finetune.py:65) in sharded runs."""
+    return (int(seed) * 1000003 + int(episode_index) * 7919 + 104729) % (2 ** 31 - 1)
+
+
 def gather_episode_values(local_values, n_items, device="cpu"):
     """All ranks' per-episode values (sharded with ``shard_indices``) -> full array in episode order on every rank."""
     rank, W = world()
@@ -76,7 +81,12 @@ class FlatGradBucket:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
         torch._foreach_copy_(self.views, grads)                 # fused multi-tensor copies (104 tensors -> a few launches)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self.flat.is_cuda and dist.get_backend() == "gloo":   # CPU-test / one-device hook: stage through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)     # "nccl" == RCCL over xGMI
         self.flat.div_(W)
         torch._foreach_copy_(grads, self.views)
 
@@ -88,4 +98,25 @@ def broadcast_buffers(module, src=0):
     if W == 1:
         return
     for b in module.buffers():
-        dist.broadcast(b, src=src)
+        if b.is_cuda and dist.get_backend() == "gloo":
+            host = b.cpu()
+            dist.broadcast(host, src=src)
+            b.copy_(host)
+        else:
+            dist.broadcast(b, src=src)
+
+
+def broadcast_parameters(module, src=0):
+    """Rank ``src``'s parameters to every rank (once, before the first step: all ranks then stay identical because they apply
+    the same averaged gradient)."""
+    _, W = world()
+    if W == 1:
+        return
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.is_cuda and dist.get_backend() == "gloo":
+                host = p.detach().cpu()
+                dist.broadcast(host, src=src)
+                p.copy_(host)
+            else:
+                dist.broadcast(p.data, src=src)

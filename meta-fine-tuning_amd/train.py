@@ -7,8 +7,9 @@ import os
 import numpy as np
 import torch
 
-from . import configs, optim, synthetic
+from . import configs, optim, parallel, synthetic
 from .io_utils import get_assigned_file, model_dict, parse_args
+from .methods import gnnnet_copy
 from .methods.gnnnet import GnnNet
 
 
@@ -16,17 +17,18 @@ class SyntheticEpisodeLoader:
     """Stand-in for miniImageNet_few_shot.SetDataManager(...).get_data_loader(): ``n_episode`` episodes of
     [n_way, n_support+n_query, 3, size, size] (datasets/miniImageNet_few_shot.py:105-183)."""
 
-    def __init__(self, n_way, n_support, n_query, size=84, n_episode=100, seed0=0):
+    def __init__(self, n_way, n_support, n_query, size=84, n_episode=100, seed0=0, rank=0, world=1):
         self.a = (n_way, n_support, n_query, size)
         self.n_episode, self.seed0, self.epoch = n_episode, seed0, 0
+        self.rank, self.world = rank, world
 
     def __len__(self):
-        return self.n_episode
+        return len(range(self.rank, self.n_episode, self.world))
 
     def __iter__(self):
         base = self.seed0 + self.epoch * self.n_episode
         self.epoch += 1
-        for i in range(self.n_episode):
+        for i in range(self.rank, self.n_episode, self.world):
             n_way, ns, nq, size = self.a
             yield synthetic.train_episode(base + i, n_way, ns, nq, size), None
 
@@ -54,30 +56,61 @@ class SyntheticBatchLoader:
             yield x, torch.from_numpy(y)
 
 
-def train(base_loader, model, optimization, start_epoch, stop_epoch, params):
+class AllReduceAdam:
+    """Episode-parallel meta-training (new functionality: the reference is one process): every rank has run
+    ONE episode's backward from the common parameters; ``step`` sums all ranks' gradients in a single flat fp32 bucket
+    all-reduce (RCCL over xGMI under torchrun; 21.2 MB for GnnNet), divides by the world size and applies the same fused
+    Adam step on every rank.  With one rank it is the plain optimiser.  MetaTemplate's loops call only zero_grad() / step()."""
+
+    def __init__(self, params_iter, **kw):
+        ps = list(params_iter)
+        self.opt = optim.Adam(ps, **kw)          # torch.optim.Adam semantics, fused HIP update (train.py:28)
+        self.bucket = parallel.FlatGradBucket(ps) if parallel.world()[1] > 1 else None
+        self.param_groups, self.state = self.opt.param_groups, self.opt.state
+
+    def zero_grad(self, *a, **k):
+        return self.opt.zero_grad(*a, **k)
+
+    def step(self, closure=None):
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        return self.opt.step(closure)
+
+
+def train(base_loader, model, optimization, start_epoch, stop_epoch, params, variant50=False):
+    """train.py:26-61 (``variant50``: train_50.py:34-71 -- the 50-shot loops and a checkpoint every 10 epochs)."""
     if optimization != 'Adam':
         raise ValueError('Unknown optimization, please define by yourself')
-    optimizer = optim.Adam(model.parameters())          # torch.optim.Adam semantics, fused HIP update
+    optimizer = AllReduceAdam(model.parameters())
+    rank, W = parallel.world()
+    fifty = variant50 and params.n_shot == 50
     for epoch in range(start_epoch, stop_epoch):
         model.train()
         if params.method == 'baseline':
             model.train_loop(epoch, base_loader, optimizer)              # train.py:41-42: every other method -> train_loop
         elif not params.fine_tune:
-            model.train_loop2(epoch, base_loader, optimizer)
+            (model.train_loop50 if fifty else model.train_loop2)(epoch, base_loader, optimizer)
         else:
-            model.train_loop_finetune(epoch, base_loader, optimizer)
+            (model.train_loop_finetune50 if fifty else model.train_loop_finetune)(epoch, base_loader, optimizer)
             if epoch == (stop_epoch - 1):
                 model.MAML_update()
         if not os.path.isdir(params.checkpoint_dir):
-            os.makedirs(params.checkpoint_dir)
-        if (epoch % params.save_freq == 0) or (epoch == stop_epoch - 1):
-            outfile = os.path.join(params.checkpoint_dir, '{:d}.tar'.format(epoch))
-            torch.save({'epoch': epoch, 'state': model.state_dict()}, outfile)
+            os.makedirs(params.checkpoint_dir, exist_ok=True)
+        save_freq = 10 if variant50 else params.save_freq                # train_50.py:53,66
+        if (epoch % save_freq == 0) or (epoch == stop_epoch - 1):
+            # BatchNorm running statistics diverge per rank (never read on the hot path): the checkpoint takes rank 0's
+            parallel.broadcast_buffers(model, src=0)
+            if rank == 0:
+                outfile = os.path.join(params.checkpoint_dir, '{:d}.tar'.format(epoch))
+                torch.save({'epoch': epoch, 'state': model.state_dict()}, outfile)
     return model
 
 
-def main(argv=None, n_episode=100, size=84):
+def main(argv=None, n_episode=100, size=84, variant50=False):
     params = parse_args('train', argv)
+    from .finetune import _init_distributed
+    _init_distributed()                                                  # under torchrun: one process per GPU, RCCL
+    rank, W = parallel.world()
     if not params.start_epoch > 0:
         np.random.seed(10)
     if params.method not in ('gnnnet', 'baseline'):
@@ -91,15 +124,20 @@ def main(argv=None, n_episode=100, size=84):
         model = BaselineTrain(model_dict[params.model], params.num_classes).cuda()
     else:
         n_query = max(1, int(16 * params.test_n_way / params.train_n_way))
-        base_loader = SyntheticEpisodeLoader(params.train_n_way, params.n_shot, n_query, size, n_episode)
-        model = GnnNet(model_dict[params.model], n_way=params.train_n_way, n_support=params.n_shot).cuda()
+        # every rank draws its own episodes (rank r takes episode r, r+W, ... of the epoch's stream); same model init on all
+        base_loader = SyntheticEpisodeLoader(params.train_n_way, params.n_shot, n_query, size, n_episode, rank=rank, world=W)
+        cls = gnnnet_copy.GnnNet if (variant50 and params.n_shot == 50) else GnnNet          # train_50.py:154-157
+        torch.manual_seed(0) if W > 1 else None
+        model = cls(model_dict[params.model], n_way=params.train_n_way, n_support=params.n_shot).cuda()
         params.checkpoint_dir += '_%dway_%dshot' % (params.train_n_way, params.n_shot)
     os.makedirs(params.checkpoint_dir, exist_ok=True)
     if params.start_epoch > 0:
         tmp = torch.load(get_assigned_file(params.checkpoint_dir, params.start_epoch - 1))
         state = {k: v for k, v in tmp['state'].items() if "feature2." not in k and "feature3." not in k}
         model.load_state_dict(state)
-    return train(base_loader, model, 'Adam', params.start_epoch, params.stop_epoch, params)
+    if W > 1:
+        parallel.broadcast_parameters(model, src=0)                      # identical initial parameters on every rank
+    return train(base_loader, model, 'Adam', params.start_epoch, params.stop_epoch, params, variant50=variant50)
 
 
 if __name__ == '__main__':

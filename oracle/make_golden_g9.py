@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--nA", type=int, default=600)
     ap.add_argument("--nB", type=int, default=40)
     ap.add_argument("--only", default="AB", help="which configs to (re)compute; the other one is kept from the existing file")
+    ap.add_argument("--resume", action="store_true",
+                    help="continue a config from the episodes already in g9_accuracy.npz: the global numpy stream is fast-forwarded "
+                         "by the permutations those episodes drew (finetune.py:272: fine_tune_epoch draws of permutation(n_way*n_support*(G+3)) "
+                         "each) and the last stored episode is recomputed as a check of the stream position")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     mods = MG.import_reference()
@@ -84,7 +88,15 @@ def main():
         accs, chk = [], []
         np.random.seed(10)                     # finetune.py:425
         t0 = time.time()
-        for i in range(n):
+        start = 0
+        if args.resume and ("acc_" + tag) in res and len(res["acc_" + tag]) > 1:
+            accs, chk = list(res["acc_" + tag]), list(res["chk_" + tag])
+            start = len(accs) - 1                # recompute the last stored episode: must reproduce its checksum
+            for _ in range(start * E):
+                np.random.permutation(25 * (G + 3))
+            last_chk = chk[-1]
+            accs, chk = accs[:-1], chk[:-1]
+        for i in range(start, n):
             model = gnnnet.GnnNet(fac, n_way=5, n_support=5)
             model.load_state_dict(sd)
             model.train()
@@ -93,8 +105,14 @@ def main():
             sc = sc.detach().numpy()
             accs.append(float((sc.argmax(1) == y).mean() * 100.0))
             chk.append(sc[:, 0].astype(np.float64).sum())
-            if i % 20 == 0:
+            if args.resume and i == start and start > 0:
+                assert abs(chk[-1] - last_chk) < 1e-4, ("resume: stream position check failed", chk[-1], last_chk)
+                print("resume check ok at episode %d (chk %.9f)" % (i, chk[-1]), flush=True)
+            if i % 20 == 0 or i == n - 1:
                 print("config %s episode %d acc %.2f mean %.2f (%.0fs)" % (tag, i, accs[-1], np.mean(accs), time.time() - t0), flush=True)
+                part = dict(res)
+                part["acc_" + tag], part["chk_" + tag], part["cfg_" + tag] = np.array(accs), np.array(chk), np.array([E, G, len(accs)])
+                np.savez(acc_path, noise=np.array(NOISE), seed_sd=np.array(SEED_SD), ep_seed0=np.array(EP_SEED0), **part)
         res["acc_" + tag] = np.array(accs)
         res["chk_" + tag] = np.array(chk)
         res["cfg_" + tag] = np.array([E, G, n])

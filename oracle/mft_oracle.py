@@ -305,15 +305,23 @@ def gnnnet_set_forward(sd, x, n_way, n_support, n_query, is_feature=False, track
     return gnnnet_scores_from_z(sd, z, n_way, n_support, n_query)
 
 
-def gnnnet50_set_forward(sd, x, n_way, n_query, is_feature=True):
+def fold50_z(z, n_way, ns):
+    """gnnnet_copy.py:67-72,232-236: supports k and k+ns averaged -> ns graph nodes per class, queries appended."""
+    z3 = z[:, :2 * ns].reshape(n_way, 2, ns, z.shape[-1]).mean(dim=1)
+    return torch.cat([z3, z[:, 2 * ns:]], dim=1)
+
+
+def gnnnet50_set_forward(sd, x, n_way, n_query, is_feature=True, track=True):
     """gnnnet_copy.GnnNet.set_forward (gnnnet_copy.py:52-77): 50 supports folded to 25 by
     averaging support k with support k+25, then the 5-way 25-shot graph (N=130)."""
     ns = 25
-    assert is_feature and x.shape[1] == 2 * ns + 15         # gnnnet_copy.py:56
-    z = fc_project(sd, x.reshape(-1, x.shape[-1])).view(n_way, -1, 128)
-    z3 = z[:, :2 * ns].reshape(n_way, 2, ns, 128).mean(dim=1)
-    zz = torch.cat([z3, z[:, 2 * ns:]], dim=1)
-    return gnnnet_scores_from_z(sd, zz, n_way, ns, n_query)
+    if is_feature:
+        assert x.shape[1] == 2 * ns + 15                    # gnnnet_copy.py:56
+        feats = x.reshape(-1, x.shape[-1])
+    else:
+        feats = resnet10_forward(sd, x.reshape(-1, *x.shape[2:]), "feature.", train=True, track=track)
+    z = fc_project(sd, feats).view(n_way, -1, 128)
+    return gnnnet_scores_from_z(sd, fold50_z(z, n_way, ns), n_way, ns, n_query)
 
 
 # --------------------------------------------------------------------------- test-time finetune
@@ -336,8 +344,10 @@ def finetune_perms(n_total, total_epoch, rng=np.random):
 
 
 def finetune_episode(state, liz_x, n_way=5, n_support=5, total_epoch=5, perms=None, batch_size=5,
-                     dtype=torch.float32, return_feats=False, dead_query_pass=False):
+                     dtype=torch.float32, return_feats=False, dead_query_pass=False, fold50=False):
     """finetune.finetune (finetune.py:182-328), method gnnnet, flatten=True, freeze_backbone=False.
+    ``fold50``: finetune_50.finetune (finetune_50.py:182-330) -- the same loop, scored by gnnnet_copy.GnnNet.set_forward
+    (gnnnet_copy.py:52-77; ``n_support`` is then the TRUE support count, 50).
 
     state: full GnnNet state dict (feature.*, fc.*, gnn.*).  Returns softmax scores
     [n_way*n_query, n_way].  ``perms`` defaults to draws from the global numpy RNG
@@ -365,7 +375,10 @@ def finetune_episode(state, liz_x, n_way=5, n_support=5, total_epoch=5, perms=No
         if dead_query_pass:
             xb = x0[:, n_support:].contiguous().view(n_way * n_query, *x0.shape[2:])
             resnet10_forward(fsd, xb, "", train=True)
-        scores = gnnnet_set_forward(sd_all, feats, n_way, n_support, n_query, is_feature=True)
+        if fold50:
+            scores = gnnnet50_set_forward(sd_all, feats, n_way, n_query, is_feature=True)
+        else:
+            scores = gnnnet_set_forward(sd_all, feats, n_way, n_support, n_query, is_feature=True)
         out = F.softmax(scores, dim=1)
     if return_feats:
         return out, feats, fsd
@@ -468,10 +481,14 @@ def finetune_linear_frozen_episode(state, liz_x, n_way=5, n_support=5, w0=None, 
 
 # --------------------------------------------------------------------------- meta-train / meta-fine-tune
 
-def meta_train_loss(sd, x, n_way, n_support, track=True):
-    """GnnNet.set_forward_loss (gnnnet.py:219-224): CE(scores, repeat(range(n_way), n_query))."""
+def meta_train_loss(sd, x, n_way, n_support, track=True, fold50=False):
+    """GnnNet.set_forward_loss (gnnnet.py:219-224): CE(scores, repeat(range(n_way), n_query)).
+    ``fold50``: gnnnet_copy.GnnNet.set_forward_loss (gnnnet_copy.py:258-263; n_support = the true 50)."""
     n_query = x.shape[1] - n_support
-    scores = gnnnet_set_forward(sd, x, n_way, n_support, n_query, is_feature=False, track=track)
+    if fold50:
+        scores = gnnnet50_set_forward(sd, x, n_way, n_query, is_feature=False, track=track)
+    else:
+        scores = gnnnet_set_forward(sd, x, n_way, n_support, n_query, is_feature=False, track=track)
     y = torch.from_numpy(np.repeat(np.arange(n_way), n_query))
     return F.cross_entropy(scores, y), scores
 
@@ -483,9 +500,11 @@ def maml_update(feature, feature2, feature3, prefix="feature."):
             feature[prefix + k].sub_(feature3[k] - feature2[k])
 
 
-def set_forward_finetune(sd, x, n_way, n_support, mem, perms=None, total_epoch=15, batch_size=4):
+def set_forward_finetune(sd, x, n_way, n_support, mem, perms=None, total_epoch=15, batch_size=4, fold50=False):
     """GnnNet.set_forward_finetune (gnnnet.py:106-208).  ``mem`` carries first/feature2/feature3
-    between calls.  Returns scores [n_way*16, n_way] with autograd attached to ``sd`` tensors."""
+    between calls.  Returns scores [n_way*16, n_way] with autograd attached to ``sd`` tensors.
+    ``fold50``: gnnnet_copy.GnnNet.set_forward_finetune (gnnnet_copy.py:135-246): ``n_support`` = the true support count
+    (50), the caller passes total_epoch=5 (:177), and the supports are pair-averaged before the graph (:232-236)."""
     n_query = x.shape[1] - n_support
     if not mem.get("first", True):
         maml_update(sd, mem["feature2"], mem["feature3"])               # gnnnet.py:122
@@ -513,6 +532,8 @@ def set_forward_finetune(sd, x, n_way, n_support, mem, perms=None, total_epoch=1
     final = torch.cat([fs, fq], dim=1)
     assert final.shape[1] == n_support + 16                                           # :198
     z = fc_project(sd, final.view(-1, final.shape[-1])).view(n_way, -1, 128)
+    if fold50:
+        return gnnnet_scores_from_z(sd, fold50_z(z, n_way, n_support // 2), n_way, n_support // 2, n_query)
     return gnnnet_scores_from_z(sd, z, n_way, n_support, n_query)
 
 

@@ -24,3 +24,14 @@ def pytest_collection_modifyitems(config, items):
     """GPU tests fail loudly (not skip) when selected on a box without a GPU; on a CPU
     box they are deselected by `-m "not gpu"`."""
     return
+
+
+@pytest.fixture(autouse=True)
+def _restore_debug_knobs(request):
+    """The library's tuning knobs are process-global: put every one back to its default after each GPU test, whether it passed
+    or not (mft_debug_reset), so a failed assert cannot leave later tests on a different kernel variant."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import meta_fine_tuning_amd  # noqa: F401
+        from meta_fine_tuning_amd import _lib
+        _lib.lib().mft_debug_reset()

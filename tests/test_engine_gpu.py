@@ -118,6 +118,63 @@ def test_gnn_forward_vs_reference_golden(golden_dir, B, N):
     np.testing.assert_allclose(out.cpu().numpy().reshape(B, N, 5), g["out_%d_%d" % (B, N)], atol=2e-4)
 
 
+@pytest.mark.parametrize("B,N", [(15, 105), (15, 130)])
+def test_gnn_forward_full_graph_batches_vs_reference_golden(golden_dir, B, N):
+    """The 20-/50-shot graph sizes with the full 15-graph batch (BatchNorm over 15*N*N pair positions) through the fused
+    pair-MLP kernels, against the reference's own GNN_nl output (G2b)."""
+    g = _g(golden_dir, "g2b_gnn_full.npz")
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    G = Fn.GnnHeadWeights(sd, DEV, 5)
+    rs = np.random.RandomState(100 + N + B)
+    nodes = torch.from_numpy(rs.standard_normal((B, N, 133)).astype(np.float32))
+    x = torch.zeros(B * N, 256)
+    x[:, :133] = nodes.view(B * N, 133)
+    arena = Fn.Arena(DEV)
+    xd = x.to(DEV)
+    A0 = Fn.wcompute(G, "layer_w0", xd, 133, B, N, 1, arena).clone()
+    np.testing.assert_allclose(A0[0].cpu().numpy(), g["A0first_%d_%d" % (B, N)], atol=1e-5)
+    np.testing.assert_allclose((A0.double() ** 2).sum(2).cpu().numpy(), g["A0diag2_%d_%d" % (B, N)], atol=1e-5)
+    out = Fn.gnn_forward(G, xd, B, N, 1, arena)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, N, 5), g["out_%d_%d" % (B, N)], atol=3e-4)
+    # nothing of size [B*N*N, F] lives in the arena: the largest buffer is a raw layer output over the upper-triangle rows
+    biggest = max(t.numel() for t in arena.bufs.values())
+    assert biggest <= B * (N * (N + 1) // 2) * 192, biggest
+
+
+@pytest.mark.parametrize("N,F", [(30, 133), (30, 181), (105, 229), (7, 133)])
+def test_fused_pair_mlp_equals_materialised_wcompute(N, F, monkeypatch):
+    """csrc/pair_mlp.hip (upper-triangle rows, |x_i - x_j| in the loader, BatchNorm from the epilogue statistics, BatchNorm +
+    leaky_relu in the next loader) against the materialised sequence it replaces and against float64, two episodes of 3
+    graphs with DIFFERENT statistics; also with the episodes processed in two chunks."""
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    G = Fn.GnnHeadWeights(sd, DEV, 5)
+    name = {133: "layer_w0", 181: "layer_w1", 229: "w_comp_last"}[F]
+    rs = np.random.RandomState(N + F)
+    B, groups = 6, 2
+    nodes = rs.standard_normal((B, N, F)).astype(np.float32)
+    nodes[3:] *= 1.7                                                  # second episode: different scale
+    x = torch.zeros(B * N, 256)
+    x[:, :F] = torch.from_numpy(nodes).view(B * N, F)
+    x[:, F:] = 1e30                                                   # columns beyond F must be ignored
+    xd = x.to(DEV)
+    a_f = Fn.wcompute(G, name, xd, F, B, N, groups, Fn.Arena(DEV)).clone()
+    a_u = Fn.wcompute_unfused(G, name, xd, F, B, N, groups, Fn.Arena(DEV)).clone()
+    monkeypatch.setattr(Fn, "PAIR_MLP_BYTES", 1)                      # one episode per chunk
+    a_c = Fn.wcompute(G, name, xd, F, B, N, groups, Fn.Arena(DEV)).clone()
+    assert torch.equal(a_c, a_f)
+    # float64 statement of gnn.py:78-115 per episode
+    ref = []
+    for e in range(groups):
+        with torch.no_grad():
+            ref.append(O.wcompute(O.clone_state(sd, torch.float64), "gnn." + name, torch.from_numpy(nodes[3 * e:3 * e + 3]).double()))
+    ref = torch.cat(ref).numpy()
+    e_f = np.abs(a_f.cpu().numpy() - ref).max()
+    e_u = np.abs(a_u.cpu().numpy() - ref).max()
+    assert e_f < 2e-5 and e_f <= 3.0 * e_u + 2e-6, (e_f, e_u)
+    np.testing.assert_allclose(a_f.sum(2).cpu().numpy(), 1.0, atol=1e-5)
+    assert float(a_f.diagonal(dim1=1, dim2=2).abs().max()) == 0.0    # masked diagonal (gnn.py:105-107)
+
+
 def test_gnnnet_scores_50shot_fold(golden_dir):
     g = _g(golden_dir, "g7_gnnnet50.npz")
     sd = synthetic.gnn_head_state_dict(seed=19)

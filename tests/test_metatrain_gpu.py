@@ -190,3 +190,130 @@ def test_train_driver_baseline_method(tmp_path, monkeypatch):
     keys = list(ck["state"].keys())
     assert "feature.trunk.0.weight" in keys and "classifier.weight" in keys and ck["state"]["classifier.weight"].shape == (10, 512)
     assert m.top1.count == 2 * 3 * 16
+
+
+def _three_steps(make_opt, loop, seed_sd=27):
+    sd = synthetic.gnnnet_state_dict(seed=seed_sd)
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.train()
+    opt = make_opt(model.parameters())
+    losses = []
+    for it in range(3):
+        x = synthetic.train_episode(61 + it, 5, 5, 16, 84)
+        model.n_query = 16
+        opt.zero_grad()
+        loss = getattr(model, loop)(x)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return losses, {k: v.detach().clone() for k, v in model.named_parameters()}
+
+
+def test_fused_outer_adam_trains_on_fresh_weights():
+    """Three consecutive train.py steps with the fused optimiser (meta_fine_tuning_amd.optim.Adam writes parameters through raw
+    pointers) against the same three steps with torch.optim.Adam: the forward of step t+1 must see step t's update -- the
+    packed conv / GNN weight caches key on the parameters' autograd version counters, which the fused step has to bump
+    (round-1 bug: it bumped ``p.data``'s counter, so every step after the first ran on the initial weights)."""
+    from meta_fine_tuning_amd import optim
+    la, pa = _three_steps(lambda ps: optim.Adam(ps), "set_forward_loss")
+    lb, pb = _three_steps(lambda ps: torch.optim.Adam(ps), "set_forward_loss")
+    assert abs(la[0] - lb[0]) < 1e-6
+    # a model evaluated on stale weights repeats the loss of the initial weights; with fresh weights both optimisers agree
+    for a, b in zip(la[1:], lb[1:]):
+        assert abs(a - b) < 5e-3 * max(1.0, abs(b)), (la, lb)
+    for k in ("fc.0.weight", "gnn.layer_last.fc.weight", "feature.trunk.7.C2.weight", "feature.trunk.4.C1.weight", "gnn.layer_w0.conv2d_1.weight"):
+        # 3 steps of <= lr each: identical up to the entries whose gradient sign is at rounding level
+        d = (pa[k] - pb[k]).abs()
+        assert float((d < 2e-4).float().mean()) > 0.98, (k, float(d.max()), float((d < 2e-4).float().mean()))
+        assert float(d.max()) <= 6.1e-3
+
+
+def test_fused_outer_adam_baselinetrain_loss_falls():
+    """BaselineTrain.train_loop-style steps with the fused optimiser: the loss on a FIXED mini-batch must fall step after step
+    (it stays constant when the forward runs on stale packed weights)."""
+    from meta_fine_tuning_amd import optim, backbone
+    from meta_fine_tuning_amd.methods.baselinetrain import BaselineTrain
+    torch.manual_seed(3)
+    m = BaselineTrain(backbone.ResNet10, num_class=10).cuda()
+    m.train()
+    opt = optim.Adam(m.parameters())
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.standard_normal((16, 3, 84, 84)).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, 10, size=16))
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = m.forward_loss(x, y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[3] < losses[0] - 0.05 and len({round(v, 6) for v in losses}) == 4, losses
+
+
+def test_gnnnet50_set_forward_loss_backward(golden_dir):
+    """train_loop50's step (gnnnet_copy.py:80-97,258-263): loss and all gradient norms of the 50-shot compressed-GNN model
+    against the reference's own (G16)."""
+    from meta_fine_tuning_amd.methods import gnnnet_copy
+    g = _g(golden_dir, "g16_gnnnet50_loss.npz")
+    sd = synthetic.gnnnet_state_dict(seed=219)
+    model = gnnnet_copy.GnnNet(model_dict['ResNet10'], n_way=5, n_support=50)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.train()
+    x = synthetic.train_episode(261, 5, 50, 16, 84)
+    model.n_query = 16
+    loss = model.set_forward_loss(x)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 3e-4
+    gn = {k: float(p.grad.norm()) for k, p in model.named_parameters()}
+    for name, refn in zip(g["gradnames"], g["gradnorms"]):
+        assert abs(gn[str(name)] - refn) <= 1e-2 * refn + 1e-6, (name, gn[str(name)], refn)
+    named = dict(model.named_parameters())
+    np.testing.assert_allclose(named["fc.0.weight"].grad[:4, :8].cpu().numpy(), g["grad_fc0w_slice"], atol=5e-5)
+    np.testing.assert_allclose(named["feature.trunk.7.C2.weight"].grad[:2, :4, 1, 1].cpu().numpy(), g["grad_c7c2_slice"], atol=5e-5)
+
+
+def test_meta_finetune_50shot_two_episodes(golden_dir):
+    """train_50.py --fine_tune: two gnnnet_copy.GnnNet.set_forward_loss_finetune + Adam steps through train_loop_finetune50,
+    then MAML_update (gnnnet_copy.py:99-246) against the reference's fp32 run (G15)."""
+    from meta_fine_tuning_amd.methods import gnnnet_copy
+    g = _g(golden_dir, "g15_maml_50shot.npz")
+    sd = synthetic.gnnnet_state_dict(seed=217)
+    model = gnnnet_copy.GnnNet(model_dict['ResNet10'], n_way=5, n_support=50)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.train()
+    opt = torch.optim.Adam(model.parameters())
+    np.random.seed(10)
+    losses = []
+
+    class Two:
+        def __len__(self):
+            return 2
+
+        def __iter__(self):
+            for it in range(2):
+                yield synthetic.train_episode(251 + it, 5, 50, 16, 84), None
+
+    real_step = opt.step
+
+    def step_and_check(*a, **k):
+        r = real_step(*a, **k)
+        it = len(losses)
+        s = "_%d_f32" % it
+        losses.append(1)
+        # 5 x 63 Adam steps of +-lr dominate these norms: fp32 implementations agree to a fraction of a percent
+        assert abs(float(model.feature.trunk[7].C2.weight.detach().norm()) - float(g["c2n" + s])) < 0.6
+        assert abs(float(model.feature3.trunk[7].C2.weight.detach().norm()) - float(g["f3_c2n" + s])) < 0.6
+        assert abs(float(model.feature2.trunk[7].C2.weight.detach().norm()) - float(g["f2_c2n" + s])) < 0.6
+        assert abs(float(model.feature.trunk[0].weight.detach().norm()) - float(g["stemn" + s])) < 5e-3
+        return r
+    opt.step = step_and_check
+    model.train_loop_finetune50(0, Two(), opt)
+    assert len(losses) == 2 and model.n_query == 16 and not model.first
+    model.MAML_update()
+    np.testing.assert_allclose(model.feature.trunk[7].C2.weight.detach()[:2, :4, 1, 1].cpu().numpy(),
+                               g["c2_slice_final_f32"], atol=4.1e-3)
+    assert np.array_equal(np.random.permutation(7), g["next_perm_f32"])      # same number of permutations consumed

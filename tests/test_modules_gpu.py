@@ -182,3 +182,35 @@ def test_finetune_frozen_backbone_vs_reference_golden(golden_dir):
     sc = ft.finetune([v.cuda() for v in liz], None, model, sd, None, n_query=15, freeze_backbone=True).cpu().numpy()
     assert np.abs(sc - g["scores"]).max() < 1e-4          # forward-only: bar is 1e-3
     assert np.array_equal(np.random.permutation(7), g["next_perm"])
+
+
+@pytest.mark.parametrize("ns", [20, 50])
+def test_baselinefinetune_20_and_50_shot(golden_dir, ns):
+    """BaselineFinetune.set_forward / MetaTemplate.set_forward_adaptation at the 20- and 50-shot configurations: 100 / 250 support
+    rows do not fit LDS beside W and its momentum, the one-launch SGD run then reads its mini-batch rows from HBM / L2
+    (round-1 limit: ~64 rows).  Against the reference's own output (G17)."""
+    g = _g(golden_dir, "g17_baselinefinetune_20_50.npz")
+    b = BaselineFinetune(model_dict['ResNet10'], n_way=5, n_support=ns)
+    b.n_query = 15
+    f = torch.from_numpy(np.random.RandomState(171 + ns).standard_normal((5, ns + 15, 512)).astype(np.float32))
+    torch.manual_seed(123)
+    np.random.seed(10)
+    sc = b.set_forward(f, is_feature=True)
+    ref = g["scores_%d" % ns]
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), ref, atol=5e-3)
+    assert (sc.detach().cpu().numpy().argmax(1) == ref.argmax(1)).mean() >= 0.98
+
+
+def test_finetune_linear_frozen_backbone_20shot(golden_dir):
+    """finetune_linear(freeze_backbone=True) at 20 shots (100 support rows: the HBM-resident form of mft_linear_head_adam_run)."""
+    import argparse
+    from meta_fine_tuning_amd import finetune as ft
+    g = _g(golden_dir, "g18_finetune_linear_frozen_20shot.npz")
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=157)
+    liz = synthetic.test_episode(197, 5, 20, 15, 84, gen_examples=1)
+    ft.params = argparse.Namespace(model="ResNet10", fine_tune_epoch=1)
+    np.random.seed(10)
+    sc = ft.finetune_linear([v.cuda() for v in liz], None, sd, None, linear=True, freeze_backbone=True, n_support=20,
+                            classifier=(g["w0"], g["b0"])).cpu().numpy()
+    assert np.abs(sc - g["scores"]).max() < 1e-3 and (sc.argmax(1) == g["scores"].argmax(1)).mean() >= 0.98
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])

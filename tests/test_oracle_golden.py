@@ -236,3 +236,165 @@ def test_g12_finetune_linear_frozen_backbone(golden_dir):
     sc = O.finetune_linear_frozen_episode(sd, liz, 5, 5, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"])).numpy()
     assert np.abs(sc - g["scores"]).max() < 1e-5
     assert np.array_equal(np.random.permutation(7), g["next_perm"])
+
+
+# ------------------------------------------------------------------ round 2 fixtures (oracle/make_golden_r2.py)
+
+@pytest.mark.parametrize("B,N", [(15, 105), (15, 130)])
+def test_g2b_gnn_full_graph_batches(golden_dir, B, N):
+    """GNN_nl at the 20-/50-shot graph sizes with the full 15-graph batch (BatchNorm statistics over 15*N*N pairs)."""
+    g = _g(golden_dir, "g2b_gnn_full.npz")
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    rs = np.random.RandomState(100 + N + B)
+    nodes = torch.from_numpy(rs.standard_normal((B, N, 133)).astype(np.float32))
+    with torch.no_grad():
+        out = O.gnn_forward(sd, nodes)
+        A0 = O.wcompute(sd, "gnn.layer_w0", nodes)
+    np.testing.assert_allclose(A0[0].numpy(), g["A0first_%d_%d" % (B, N)], atol=2e-6)
+    np.testing.assert_allclose((A0.double() ** 2).sum(2).numpy(), g["A0diag2_%d_%d" % (B, N)], atol=1e-6)
+    np.testing.assert_allclose(out.numpy(), g["out_%d_%d" % (B, N)], atol=5e-5)
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f64", torch.float64)])
+def test_g4b_inner_loop_105_and_500_steps(golden_dir, tag, dt):
+    """The README setting's whole inner loop (500 Adam steps, 19 views) teacher-forced on a fixed index order: fp64 pins the
+    restatement tightly; fp32 against the reference's fp32 is held to the Adam sign-flip envelope."""
+    g = _g(golden_dir, "g4b_inner_loop_long.npz")
+    sd = O.clone_state(synthetic.resnet10_state_dict(seed=9), dt)
+    size = 84
+    views = synthetic.test_episode(31, 5, 5, 15, size, gen_examples=17)
+    xa = torch.cat([v[:, :5].contiguous().view(25, 3, size, size) for v in [views[0]] + views], 0).to(dt)
+    ya = torch.from_numpy(np.tile(np.repeat(np.arange(5), 5), len(views) + 1))
+    rs = np.random.RandomState(77)
+    order = np.concatenate([rs.permutation(500) for _ in range(5)])
+    assert np.array_equal(order, g["order"])
+    adam = O.adam_init([sd[k] for k in O.ADAPT_KEYS])
+    f64 = dt == torch.float64
+    n_steps = 500 if f64 else 105            # fp32 beyond 105 steps adds nothing the fp64 run does not pin (and costs CPU time)
+    for step in range(n_steps):
+        sel = torch.from_numpy(order[step * 5:(step + 1) * 5])
+        O.inner_step(sd, xa[sel], ya[sel], adam)
+        if step + 1 in (105, 500):
+            s = "_s%d_%s" % (step + 1, tag)
+            tol = 1e-6 if f64 else 0.15
+            assert abs(float(sd["trunk.7.C1.weight"].norm()) - float(g["wn_c1" + s])) < tol
+            assert abs(float(sd["trunk.7.C2.weight"].norm()) - float(g["wn_c2" + s])) < tol
+            assert abs(float(sd["trunk.7.shortcut.weight"].norm()) - float(g["wn_sc" + s])) < tol
+            with torch.no_grad():
+                probe = O.resnet10_forward(O.clone_state(sd), xa[:5], "", train=True).numpy()
+            ref = g["probe" + s]
+            if f64:
+                np.testing.assert_allclose(sd["trunk.7.BN2.weight"].numpy(), g["bn2_w" + s], atol=1e-7)
+                np.testing.assert_allclose(probe, ref, atol=1e-5)
+            else:
+                err = np.abs(probe - ref)
+                assert (err < 2e-2).mean() > 0.97 and err.max() < 0.3, (err.max(), (err < 2e-2).mean())
+
+
+def test_g5b_finetune_full_config(golden_dir):
+    """finetune() at BASELINE configs[1] (fine_tune_epoch=5, gen_examples=17: 500 inner steps)."""
+    g = _g(golden_dir, "g5b_finetune_full.npz")
+    sd = synthetic.gnnnet_state_dict(seed=13)
+    liz = synthetic.test_episode(41 + 17, 5, 5, 15, 84, gen_examples=17)
+    np.random.seed(10)
+    sc = O.finetune_episode(sd, liz, 5, 5, total_epoch=5).numpy()
+    ref = g["scores_E5_G17"]
+    assert np.abs(sc - ref).max() < 2e-2 and (sc.argmax(1) == ref.argmax(1)).mean() >= 0.97
+
+
+@pytest.mark.parametrize("E,G", [(0, 0), (1, 0), (1, 1)])
+def test_g13_finetune_20shot(golden_dir, E, G):
+    """finetune() at n_support=20 (BASELINE configs[2]: N=105 graph, 60-80 inner steps here)."""
+    g = _g(golden_dir, "g13_finetune_20shot.npz")
+    sd = synthetic.gnnnet_state_dict(seed=113)
+    liz = synthetic.test_episode(141 + G, 5, 20, 15, 84, gen_examples=G)
+    np.random.seed(10)
+    sc = O.finetune_episode(sd, liz, 5, 20, total_epoch=E).numpy()
+    ref = g["scores_E%d_G%d" % (E, G)]
+    np.testing.assert_allclose(sc, ref, atol=1e-5 if E == 0 else 5e-3)
+    assert (sc.argmax(1) == ref.argmax(1)).mean() >= 0.97
+
+
+@pytest.mark.parametrize("E,G", [(0, 0), (1, 0)])
+def test_g14_finetune_50shot(golden_dir, E, G):
+    """finetune_50.finetune() + gnnnet_copy.GnnNet at n_support=50 (BASELINE configs[4]: folded N=130 graph)."""
+    g = _g(golden_dir, "g14_finetune_50shot.npz")
+    sd = synthetic.gnnnet_state_dict(seed=213)
+    liz = synthetic.test_episode(241 + G, 5, 50, 15, 84, gen_examples=G)
+    np.random.seed(10)
+    sc = O.finetune_episode(sd, liz, 5, 50, total_epoch=E, fold50=True).numpy()
+    ref = g["scores_E%d_G%d" % (E, G)]
+    np.testing.assert_allclose(sc, ref, atol=1e-5 if E == 0 else 5e-3)
+    assert (sc.argmax(1) == ref.argmax(1)).mean() >= 0.97
+
+
+def test_g15_first_order_maml_50shot(golden_dir):
+    """train_50.py --fine_tune: gnnnet_copy.GnnNet.set_forward_loss_finetune (5 inner epochs over 250 supports in batches of 4,
+    pair-averaged supports in the graph) + outer Adam, twice, then MAML_update -- fp64 against the reference's fp64 run."""
+    g = _g(golden_dir, "g15_maml_50shot.npz")
+    dt, tag = torch.float64, "f64"
+    sd = O.clone_state(synthetic.gnnnet_state_dict(seed=217), dt)
+    pkeys = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    params = [sd[k] for k in pkeys]
+    outer = O.adam_init(params)
+    mem = {"first": True}
+    np.random.seed(10)
+    for it in range(2):
+        x = synthetic.train_episode(251 + it, 5, 50, 16, 84).to(dt)
+        for p in params:
+            p.requires_grad_(True)
+        scores = O.set_forward_finetune(sd, x, 5, 50, mem, total_epoch=5, fold50=True)
+        y = torch.from_numpy(np.repeat(np.arange(5), 16))
+        loss = torch.nn.functional.cross_entropy(scores, y)
+        grads = torch.autograd.grad(loss, params)
+        for p in params:
+            p.requires_grad_(False)
+        O.adam_step(params, grads, outer, lr=1e-3)
+        s = "_%d_%s" % (it, tag)
+        assert abs(float(loss.detach()) - float(g["loss" + s])) < 1e-6
+        assert abs(float(sd["feature.trunk.7.C2.weight"].norm()) - float(g["c2n" + s])) < 1e-6
+        assert abs(float(sd["feature.trunk.0.weight"].norm()) - float(g["stemn" + s])) < 1e-7
+        assert abs(float(mem["feature3"]["trunk.7.C2.weight"].norm()) - float(g["f3_c2n" + s])) < 1e-6
+    O.maml_update(sd, mem["feature2"], mem["feature3"])
+    np.testing.assert_allclose(sd["feature.trunk.7.C2.weight"][:2, :4, 1, 1].numpy(), g["c2_slice_final_" + tag], atol=1e-7)
+    assert np.array_equal(np.random.permutation(7), g["next_perm_" + tag])
+
+
+def test_g16_gnnnet50_loss_and_grads(golden_dir):
+    """gnnnet_copy.GnnNet.set_forward_loss + backward (train_loop50): oracle in fp64 vs the reference's fp32 outputs."""
+    g = _g(golden_dir, "g16_gnnnet50_loss.npz")
+    dt = torch.float64
+    sd = O.clone_state(synthetic.gnnnet_state_dict(seed=219), dt)
+    x = synthetic.train_episode(261, 5, 50, 16, 84).to(dt)
+    pkeys = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    loss, scores = O.meta_train_loss(sd, x, 5, 50, fold50=True)
+    np.testing.assert_allclose(scores.detach().numpy(), g["scores"], atol=5e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    grads = torch.autograd.grad(loss, [sd[k] for k in pkeys])
+    gn = {k: float(t.norm()) for k, t in zip(pkeys, grads)}
+    for name, ref in zip(g["gradnames"], g["gradnorms"]):
+        assert abs(gn[str(name)] - ref) <= 2e-3 * ref + 1e-7, name
+    gd = dict(zip(pkeys, grads))
+    np.testing.assert_allclose(gd["fc.0.weight"][:4, :8].numpy(), g["grad_fc0w_slice"], atol=1e-5)
+    np.testing.assert_allclose(gd["feature.trunk.7.C2.weight"][:2, :4, 1, 1].numpy(), g["grad_c7c2_slice"], atol=2e-6)
+
+
+@pytest.mark.parametrize("ns", [20, 50])
+def test_g17_baselinefinetune_20_50_shot(golden_dir, ns):
+    g = _g(golden_dir, "g17_baselinefinetune_20_50.npz")
+    feats = torch.from_numpy(np.random.RandomState(171 + ns).standard_normal((5, ns + 15, 512)).astype(np.float32))
+    np.random.seed(10)
+    sc = O.set_forward_adaptation(feats, 5, ns, torch.from_numpy(g["w0_%d" % ns]), torch.from_numpy(g["b0_%d" % ns]))
+    np.testing.assert_allclose(sc.numpy(), g["scores_%d" % ns], atol=5e-4)
+
+
+def test_g18_finetune_linear_frozen_20shot(golden_dir):
+    g = _g(golden_dir, "g18_finetune_linear_frozen_20shot.npz")
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=157)
+    liz = synthetic.test_episode(197, 5, 20, 15, 84, gen_examples=1)
+    np.random.seed(10)
+    sc = O.finetune_linear_frozen_episode(sd, liz, 5, 20, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"])).numpy()
+    assert np.abs(sc - g["scores"]).max() < 1e-5
+    assert np.array_equal(np.random.permutation(7), g["next_perm"])
