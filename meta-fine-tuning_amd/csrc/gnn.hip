@@ -75,6 +75,47 @@ __global__ __launch_bounds__(256) void graph_aggregate_kernel(const float* __res
     }
 }
 
+// Same contract, one workgroup per GRAPH: x[b] (N x F floats, <= 119 KB at N = 130, F = 229) is staged in LDS once and every
+// thread owns one feature column, so each x element is fetched from L2 once per graph instead of once per node row (the
+// row-per-workgroup form above re-reads x[b] N times: 21 GB of L2 traffic per launch at 128 episodes x 15 graphs x N = 105).
+// Four node rows share one pass over j: 1 LDS read + 4 FMAs with wave-uniform A values.
+__global__ __launch_bounds__(256) void graph_aggregate_lds_kernel(const float* __restrict__ A, const float* __restrict__ x, int ldx,
+                                                                  float* __restrict__ y, int ldy, int N, int F) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [N][F]
+    const int b = blockIdx.x;
+    const float* xb = x + (long long)b * N * ldx;
+    const float* Ab = A + (long long)b * N * N;
+    float* yb = y + (long long)b * N * ldy;
+    for (int i = threadIdx.x; i < N * F; i += 256) {
+        const int j = i / F, f = i - j * F;
+        xs[i] = xb[(long long)j * ldx + f];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 256) {
+        for (int i0 = 0; i0 < N; i0 += 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const float* r0 = Ab + (long long)i0 * N;
+            const float* r1 = Ab + (long long)min(i0 + 1, N - 1) * N;
+            const float* r2 = Ab + (long long)min(i0 + 2, N - 1) * N;
+            const float* r3 = Ab + (long long)min(i0 + 3, N - 1) * N;
+#pragma unroll 4
+            for (int j = 0; j < N; ++j) {
+                const float v = xs[j * F + f];
+                a0 += r0[j] * v; a1 += r1[j] * v; a2 += r2[j] * v; a3 += r3[j] * v;
+            }
+            yb[(long long)i0 * ldy + F + f] = a0;
+            if (i0 + 1 < N) yb[(long long)(i0 + 1) * ldy + F + f] = a1;
+            if (i0 + 2 < N) yb[(long long)(i0 + 2) * ldy + F + f] = a2;
+            if (i0 + 3 < N) yb[(long long)(i0 + 3) * ldy + F + f] = a3;
+        }
+    }
+    for (int i = threadIdx.x; i < N * ldy; i += 256) {
+        const int r = i / ldy, c = i - r * ldy;
+        if (c < F) yb[i] = xs[r * F + c];
+        else if (c >= 2 * F) yb[i] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                         int ldy, int col_off, int C, long long rows, int act,
                                                         float slope) {
@@ -170,6 +211,18 @@ extern "C" int mft_masked_softmax(const float* s, int lds_, float* A, int n_grap
 extern "C" int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy, int n_graphs, int N,
                                    int F, void* stream) {
     if (ldy < 2 * F) return MFT_EINVAL;
+    const size_t lds = (size_t)N * F * sizeof(float);
+    if (n_graphs >= 128 && lds <= 150 * 1024) {              // enough graphs to fill the chip with one workgroup each
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)graph_aggregate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               150 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(graph_aggregate_lds_kernel, dim3(n_graphs), dim3(256), lds, (hipStream_t)stream, A, x, ldx, y, ldy, N, F);
+        return mft_launch_status();
+    }
     hipLaunchKernelGGL(graph_aggregate_kernel, dim3(n_graphs * N), dim3(256), 0, (hipStream_t)stream, A, x, ldx, y,
                        ldy, n_graphs, N, F);
     return mft_launch_status();

@@ -22,6 +22,7 @@
 // HBM traffic per pair row: raw h1..h4 written once and read once (2 x 2304 B) against 13 KB for the unfused sequence,
 // on half the rows.  Arithmetic is fp32 MFMA (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate) as in csrc/conv_igemm.hip.
 #include "mft_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,8 +47,10 @@ struct PairArgs {
     float* ws_mean; float* ws_m2; float* ws_n;     // per (group, m-tile): [.., Cout], [.., Cout], [..]
 };
 
-// MODE 0: PAIR loader (layer 1), MODE 1: BNACT loader (layers 2-4)
-template <int MODE>
+// MODE 0: PAIR loader (layer 1), MODE 1: BNACT loader (layers 2-4).  DB: double-buffered LDS (one barrier per K-step, 64.5 KB:
+// two workgroups per CU) or single-buffered (two barriers per K-step, 32 KB: four workgroups per CU -- a tile is only 3-8
+// K-steps long, so its load / compute / store phases overlap across workgroups rather than inside one).
+template <int MODE, bool DB>
 __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     constexpr int BM = PM_BM, BN = PM_BN, BK = PM_BK, LD = PM_LD;
     constexpr int PA = BM / 32;        // 4 A passes of 32 rows
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float s_wrow[BM];
     __shared__ float s_red[4][BN];
-    __shared__ float s_mean[BN];
+    __shared__ float s_red2[4][BN];
     __shared__ float s_wsum[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
         for (int j = 0; j < PB; ++j) rb[j] = *(const f32x4*)(b_ptr[j] + k0);
     };
     auto store_tile = [&](int buf) {
-        float* As = smem + buf * (BM + BN) * LD;
+        float* As = smem + (DB ? buf : 0) * (BM + BN) * LD;
         float* Bs = As + BM * LD;
 #pragma unroll
         for (int j = 0; j < PA; ++j) *(f32x4*)(As + (lrow + 32 * j) * LD + c4) = ra[j];
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
-        const float* As = smem + buf * (BM + BN) * LD;
+        const float* As = smem + (DB ? buf : 0) * (BM + BN) * LD;
         const float* Bs = As + BM * LD;
         f32x4 av[4], bv[TN][4];
         {
@@ -190,11 +193,15 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t >> 2][t & 3], bv[j][t >> 2][t & 3], acc[j], 0, 0, 0);
+        if (!DB) __syncthreads();
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: bias, raw store, weighted tile statistics.  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h
+    // ---- epilogue: bias, raw store, weighted tile statistics.  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*h.
+    // Statistics in one pass around the bias as pivot: S1 = sum w*(v - bias), S2 = sum w*(v - bias)^2 are sums of the bare
+    // accumulators; tile mean = bias + S1/W, M2 = S2 - S1^2/W (cancellation only inside one 128-row tile; tiles are merged with
+    // Chan's formula by the finalize launch).
     const long long out_row0 = (long long)g * p.rows_per_group;
     float wr[16];
 #pragma unroll
@@ -208,60 +215,68 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + r;
         const float bias = p.bias[n];
-        float s = 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            acc[j][e] += bias;
+            const float a = acc[j][e];
             const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
             const int m = m0 + wave * 32 + row;
-            if (m < p.rows_per_group) p.out[(out_row0 + m) * p.Cout + n] = acc[j][e];
-            s += wr[e] * acc[j][e];
+            if (m < p.rows_per_group) p.out[(out_row0 + m) * p.Cout + n] = a + bias;
+            s1 += wr[e] * a;
+            s2 += wr[e] * a * a;
         }
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) s_red[wave][j * 32 + r] = s;
-    }
-    __syncthreads();
-    const float wtile = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    if (tid < BN) s_mean[tid] = (s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]) / wtile;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float mu = s_mean[j * 32 + r];
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float d = acc[j][e] - mu;
-            s += wr[e] * d * d;
-        }
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) s_red[wave][j * 32 + r] = s;
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) { s_red[wave][j * 32 + r] = s1; s_red2[wave][j * 32 + r] = s2; }
     }
     __syncthreads();
     const long long trow = (long long)g * p.tiles_m + mt;
     if (tid < BN) {
-        p.ws_mean[trow * p.Cout + n0 + tid] = s_mean[tid];
-        p.ws_m2[trow * p.Cout + n0 + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+        const float wtile = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        const float s1 = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+        const float s2 = s_red2[0][tid] + s_red2[1][tid] + s_red2[2][tid] + s_red2[3][tid];
+        p.ws_mean[trow * p.Cout + n0 + tid] = p.bias[n0 + tid] + s1 / wtile;
+        p.ws_m2[trow * p.Cout + n0 + tid] = fmaxf(s2 - s1 * (s1 / wtile), 0.f);
+        if (tid == 0 && nt == 0) p.ws_n[trow] = wtile;
     }
-    if (tid == 0 && nt == 0) p.ws_n[trow] = wtile;
 }
 
-// Chan merge of the m-tiles of one episode in tile order -> the next loader's affine: scale = gamma / sqrt(var + eps),
-// shift = beta - mean * scale (biased variance over all graphs*N*N pair positions, gnn.py:65-74 BatchNorm2d in train mode)
+// Chan merge of the m-tiles of one episode -> the next loader's affine: scale = gamma / sqrt(var + eps), shift = beta - mean *
+// scale (biased variance over all graphs*N*N pair positions, gnn.py:65-74 BatchNorm2d in train mode).  One workgroup per
+// (episode, 16 channels): 16 partitions each merge a contiguous range of tiles in tile order, then the 16 partials are merged
+// in partition order -- a fixed tree, bit-identical from run to run.
 __global__ __launch_bounds__(256) void pair_stats_finalize_kernel(const float* __restrict__ ws_mean, const float* __restrict__ ws_m2,
                                                                   const float* __restrict__ ws_n, int tiles_m, int C,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    const int g = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int t = 0; t < tiles_m; ++t) {
-            const long long row = (long long)g * tiles_m + t;
-            const float nb = ws_n[row], mb = ws_mean[row * C + c], qb = ws_m2[row * C + c];
-            const float nn = n + nb, d = mb - mean;
-            mean += d * (nb / nn);
-            m2 += qb + d * d * (n * nb / nn);
-            n = nn;
+    __shared__ float sn[16][16], sm[16][16], sq[16][16];
+    const int cb = C / 16;
+    const int g = blockIdx.x / cb, c = (blockIdx.x % cb) * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    const int per = (tiles_m + 15) / 16;
+    const int t0 = part * per, t1 = min(t0 + per, tiles_m);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const long long row = (long long)g * tiles_m + t;
+        const float nb = ws_n[row], mb = ws_mean[row * C + c], qb = ws_m2[row * C + c];
+        const float nn = n + nb, d = mb - mean;
+        mean += d * (nb / nn);
+        m2 += qb + d * d * (n * nb / nn);
+        n = nn;
+    }
+    sn[part][threadIdx.x & 15] = n; sm[part][threadIdx.x & 15] = mean; sq[part][threadIdx.x & 15] = m2;
+    __syncthreads();
+    if (part == 0) {
+        const int l = threadIdx.x & 15;
+        n = 0.f; mean = 0.f; m2 = 0.f;
+        for (int q = 0; q < 16; ++q) {
+            const float nb = sn[q][l];
+            if (nb > 0.f) {
+                const float nn = n + nb, d = sm[q][l] - mean;
+                mean += d * (nb / nn);
+                m2 += sq[q][l] + d * d * (n * nb / nn);
+                n = nn;
+            }
         }
         const float rstd = 1.f / sqrtf(m2 / n + eps);
         const float sc = rstd * gamma[c];
@@ -325,6 +340,12 @@ __global__ __launch_bounds__(256) void masked_softmax_ut_kernel(const float* __r
 
 }  // namespace
 
+static int g_pair_db = 0;     // 1: double-buffered LDS form (MFT_PAIR_DB=1 at load time; A/B measurements in DESIGN.md)
+__attribute__((constructor)) static void pair_env_init() {
+    const char* e = getenv("MFT_PAIR_DB");
+    if (e) g_pair_db = atoi(e);
+}
+
 extern "C" int mft_pair_mlp_tiles_m(int graphs_per_group, int N) {
     const long long P = (long long)N * (N + 1) / 2;
     return cdiv((long long)graphs_per_group * P, PM_BM);
@@ -348,27 +369,31 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
     p.slope = slope; p.ws_mean = ws_mean; p.ws_m2 = ws_m2; p.ws_n = ws_n;
     const long long nwg = (long long)p.tiles_m * p.tiles_n * n_groups;
     if (nwg > 0x7fffffffLL) return MFT_EINVAL;
-    const size_t lds = 2 * (PM_BM + PM_BN) * PM_LD * sizeof(float);        // 64.5 KB: two workgroups per CU
+    const size_t lds1 = (PM_BM + PM_BN) * PM_LD * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (mode == 0)
-        hipLaunchKernelGGL(pair_mlp_layer_kernel<0>, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(pair_mlp_layer_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_pair_db) {
+        if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 2 * lds1, st, p);
+        else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, true>), dim3((unsigned)nwg), dim3(256), 2 * lds1, st, p);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
+        else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
+    }
     return mft_launch_status();
 }
 
 extern "C" int mft_pair_mlp_stats_finalize(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m,
                                            int C, const float* gamma, const float* beta, float eps, float* scale, float* shift,
                                            float* mean_out, float* rstd_out, void* stream) {
-    if (n_groups < 1 || tiles_m < 1 || C < 1) return MFT_EINVAL;
-    hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, ws_mean, ws_m2, ws_n,
+    if (n_groups < 1 || tiles_m < 1 || C < 16 || C % 16 != 0) return MFT_EINVAL;
+    hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3(n_groups * (C / 16)), dim3(256), 0, (hipStream_t)stream, ws_mean, ws_m2, ws_n,
                        tiles_m, C, gamma, beta, eps, scale, shift, mean_out, rstd_out);
     return mft_launch_status();
 }

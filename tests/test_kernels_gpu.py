@@ -303,8 +303,9 @@ def test_adam_sgd_maml():
     assert torch.equal(ag.cpu(), a - (c - b))
 
 
-@pytest.mark.parametrize("B,N,Fd", [(15, 30, 133), (2, 105, 181), (2, 130, 229)])
+@pytest.mark.parametrize("B,N,Fd", [(15, 30, 133), (2, 105, 181), (2, 130, 229), (130, 30, 133), (128, 130, 229), (129, 7, 181)])
 def test_gnn_glue(B, N, Fd):
+    # B >= 128 graphs: mft_graph_aggregate's one-workgroup-per-graph form with x[b] staged in LDS
     ld = 256
     x = torch.zeros(B * N, ld)
     x[:, :Fd] = rnd((B * N, Fd), 35)
