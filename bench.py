@@ -49,18 +49,58 @@ def conv_flops(n_img, OH, Cout, K):
     return 2.0 * n_img * OH * OH * Cout * K
 
 
+def kernel_source_sha():
+    """Identity of the dominant kernel's source (csrc/conv_igemm.hip + csrc/mft_common.h): a PMC traffic figure is only quoted
+    for byte-identical kernel code."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("meta-fine-tuning_amd/csrc/conv_igemm.hip", "meta-fine-tuning_amd/csrc/mft_common.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(E):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate runs, gfx950 corrections applied; profiles/pmc_traffic.json).  None when no pass exists for this E."""
+    separate runs, gfx950 corrections applied; profiles/pmc_traffic.json, written by tools/pmc_traffic_json.py together with
+    the commit and the kernel-source hash it was measured on).  None unless a pass exists for this E AND for exactly this kernel
+    source -- a number measured on other code is not reported."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             j = json.load(f)
-        if int(j["episodes_per_step"]) == int(E):
+        if int(j["episodes_per_step"]) == int(E) and j.get("kernel_source_sha16") == kernel_source_sha():
             return {"mb_per_launch": j["traffic_mb_per_launch"], "algorithmic_mb_per_launch": j["algorithmic_mb_per_launch"],
-                    "source": "profiles/pmc_traffic.json (round %s)" % j["round"]}
+                    "source": "profiles/pmc_traffic.json (round %s, measured at commit %s, kernel source %s)"
+                              % (j["round"], j.get("head", "?"), j["kernel_source_sha16"])}
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+G9_NOISE, G9_SEED_SD, G9_EP_SEED0 = 2.0, 31, 90000          # oracle/make_golden_g9.py
+
+
+def g9_state():
+    """The weights of the accuracy golden G9 (seeded backbone + the head meta-trained with the REFERENCE's set_forward_loss,
+    tests/golden/g9_head.npz): with them the engine's accuracies are comparable with the reference's own finetune() run."""
+    from meta_fine_tuning_amd import synthetic
+    sd = synthetic.gnnnet_state_dict(seed=G9_SEED_SD)
+    hz = np.load(os.path.join(ROOT, "tests", "golden", "g9_head.npz"))
+    for k in hz.files:
+        sd[k] = torch.from_numpy(hz[k])
+    return sd
+
+
+def g9_episodes(n, dev, gen_examples=17, workers=None):
+    """The first ``n`` episodes of golden G9 config B (numpy-generated, exactly the tensors the reference ran on), moved to HBM."""
+    from concurrent.futures import ThreadPoolExecutor
+    from meta_fine_tuning_amd import synthetic
+
+    def make(i):
+        return synthetic.test_episode(G9_EP_SEED0 + i, 5, 5, 15, 84, gen_examples=gen_examples, noise=G9_NOISE)
+    with ThreadPoolExecutor(max_workers=workers or min(8, host_threads())) as ex:
+        eps = list(ex.map(make, range(n)))
+    return [[v.to(dev) for v in ep] for ep in eps]
 
 
 def host_threads():
@@ -215,6 +255,11 @@ def main():
                     "the current inner loop (A/B)")
     ap.add_argument("--no-defer-final", action="store_true", help="run each batch's final pass synchronously (A/B)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream inner loop (A/B against the 2-stream pipeline)")
+    ap.add_argument("--validate-episodes", type=int, default=24,
+                    help="self-validation: the first V slots of the resident pool are the first V episodes of the accuracy golden "
+                         "G9 (tests/golden/g9_accuracy.npz, the reference's own finetune() at this configuration); before the "
+                         "warm-up one batch is run on the golden's numpy permutation stream and its per-episode accuracies are "
+                         "compared with the reference's (0 = off)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -271,7 +316,11 @@ def main():
     if n_shot != 5 or size != 84:
         args.no_cpu_baseline = True
     views = 2 + args.gen_examples
-    state = synthetic.gnnnet_state_dict(seed=0)
+    # G9's weights (seeded backbone + head meta-trained with the reference): accuracies are then comparable with the golden
+    validate = (args.validate_episodes if (n_shot == 5 and size == 84 and args.epochs == 5 and args.gen_examples == 17
+                                            and not args.device_aug and rank == 0) else 0)
+    validate = min(validate, E)
+    state = g9_state() if (n_shot == 5) else synthetic.gnnnet_state_dict(seed=0)
     e = eng.FinetuneEngine(state, n_way, n_shot, n_query, size, n_views=views, fine_tune_epoch=args.epochs,
                            episodes_per_batch=E, device=dev, pipeline=not args.no_pipeline, fold50=(n_shot == 50))
     # resident synthetic episodes (class-structured so accuracy is meaningful); distinct per rank
@@ -284,8 +333,10 @@ def main():
         aug_rs = np.random.RandomState(1234 + rank)
         pool = None
     else:
-        pool = [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
-                                              gen_examples=args.gen_examples) for i in range(E)]
+        head = g9_episodes(validate, dev, args.gen_examples) if validate else []
+        pool = head + [synthetic.test_episode_device(1000 * 2 + rank * 100000 + i, dev, n_way, n_shot, n_query, size,
+                                                     gen_examples=args.gen_examples, noise=G9_NOISE if n_shot == 5 else 1.0)
+                       for i in range(len(head), E)]
 
     def one_batch():
         if args.device_aug:        # fresh random views every batch, parameters drawn on the host inside the timed region
@@ -297,6 +348,24 @@ def main():
         return e.run_batch(pool, defer_final=not args.no_defer_final, prefetch=None if args.no_prefetch else pool)
 
     y_query = np.repeat(np.arange(n_way), n_query)
+    validation = None
+    if validate:
+        # the golden's permutation stream: np.random.seed(10), five permutations of 500 per episode, episode by episode
+        # (finetune.py:425,272) -- slot i of this batch runs exactly what the reference ran for episode i
+        gz = np.load(os.path.join(ROOT, "tests", "golden", "g9_accuracy.npz"))
+        assert list(gz["cfg_B"][:2]) == [5, 17] and int(gz["cfg_B"][2]) >= validate
+        np.random.seed(10)
+        sc = e.run_batch(pool)
+        got = (sc[:validate].argmax(2).cpu().numpy() == y_query[None]).mean(1) * 100.0
+        ref = gz["acc_B"][:validate]
+        validation = {"episodes": int(validate), "mean_acc": round(float(got.mean()), 3), "golden_mean_acc": round(float(ref.mean()), 3),
+                      "abs_diff": round(abs(float(got.mean()) - float(ref.mean())), 3),
+                      "episodes_identical": int((np.abs(got - ref) < 1e-9).sum()),
+                      "episodes_within_2_queries": int((np.abs(got - ref) <= 2 * 100.0 / 75 + 1e-9).sum()),
+                      "ok": bool(abs(float(got.mean()) - float(ref.mean())) <= 1.0),
+                      "what": "first %d episodes of tests/golden/g9_accuracy.npz config B (the reference's finetune() on the same "
+                              "episodes, weights and numpy stream): fp32 implementations agree per episode up to Adam sign flips "
+                              "(DESIGN.md section 6)" % validate}
     np.random.seed(10 + rank)
 
     # ---- kernel timers: HIP events recorded on the stream each kernel is launched on (the engine runs the frozen
@@ -496,6 +565,9 @@ def main():
             "whole_path_tflops": round(value * fl / 1e12, 2),
             "whole_path_frac_of_f32_mfma_peak": round(value * fl / world / PEAK_F32_MFMA, 4),
             "mean_acc": round(float(acc_ep.mean()), 2),
+            "mean_acc_note": "all timed batches, resident pool re-run with fresh permutations each batch; weights = golden G9's "
+                             "(meta-trained head), so this is a real accuracy, not chance" if n_shot == 5 else "seed-0 random head",
+            "validation": validation,
             # whole path against the same HBM roof: the adaptable-state bytes an episode moves (per inner step: forward weights
             # 14.7 MB + data-gradient re-read 9.4 MB + Adam read/write of w, m, v 88.2 MB) over the wall time of
             # the timed region, everything else (trunk, final pass, ingest, host) counted as zero bytes
