@@ -50,7 +50,9 @@ constexpr int BK = 32;
 constexpr int LDS_LD = 36;
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
-int g_wgrad_pol = 3;          // w/m/v cache policy: bit 0 nontemporal loads, bit 1 nontemporal stores (mft_debug_set_conv_tile(9000 + pol))
+int g_wgrad_pol = 7;          // w/m/v cache policy: bit 0 nontemporal loads, bit 1 nontemporal stores; bit 2 (wgrad_adam_rows_kernel):
+                              // hardware v_rcp_f32 / v_sqrt_f32 + packed fp32 moment updates (mft_debug_set_conv_tile(9000 + pol))
+int g_wgrad_rows = 1;         // 1: <= 64 reduction rows use the 32 x 128 stream-shaped kernel (mft_debug_set_conv_tile(9500/9501))
 int g_wgrad_early = 1;        // 1: issue the tile's w/m/v loads before the reduction (mft_debug_set_conv_tile(5000/5001))
 int g_wgrad_min_lds_kb = 0;   // experiment: pad the fused wgrad+Adam workgroup's LDS to cap its occupancy (4000 + KB)
 int g_skinny = 1;      // 0: per-episode-weight launches use the generic tiles (mft_debug_set_conv_tile(3000/3001))
@@ -313,6 +315,7 @@ struct WgradArgs {
     // split-M: grid.z chunks of chunk_rows rows each write partial gradients to ws (reduced afterwards)
     int chunk_rows, chunks;
     float* ws;
+    int ws_inv_ow;       // wgrad_adam_rows_kernel: ceil(65536 / OW) (chunk_rows then holds ceil(65536 / (OH*OW)))
 };
 
 // dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
@@ -520,6 +523,160 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------- weight gradient + Adam, <= 64 reduction rows
+// The inner-loop regime (finetune.py:286-299): per episode the weight gradient is a reduction over 5 images x 3 x 3 = 45 pixel
+// rows, i.e. the launch is a pure w/m/v stream (6 x 4 B per parameter) with a sliver of matrix work.  Measured on this part
+// (tools/microbench/adam_tiles.hip): a 3-read/3-write stream walked in 64 x 64-float tiles (256-byte runs, the kernel above)
+// tops out at 5.9 TB/s, in 32 x 128-float tiles (512-byte runs) at 6.3 TB/s -- DRAM-page locality, not bytes in flight.  This
+// kernel is the 32 (co) x 128 (ci) form, shaped for the stream:
+//   * every operand row (<= 64 rows of dy and of the im2col slice) is requested FIRST, then the tile's w/m/v (12 x 16 B per
+//     lane, nontemporal): the in-order load counter lets the reduction start as soon as the operands are in while the 48 KB of
+//     w/m/v per workgroup stay in flight behind them;
+//   * one wave per 32 x 32 block (v_mfma_f32_32x32x2_f32, reduction order m = 2t + h exactly as conv_wgrad_kernel: the
+//     gradient and therefore Adam's result are bit-identical to it);
+//   * the gradient tile goes through LDS once ([32][132]) and Adam streams rows of 512 contiguous bytes.
+template <int POL>
+__global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
+    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4;
+    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
+    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [32][BM]   one half of the reduction rows at a time
+    float* Bs = smem + 32 * BM;       // [32][BLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    // tile order inside an episode: the whole K extent of 32 output-channel rows (ci-tile, then tap: 18 KB contiguous per row
+    // for trunk.7.C2) before the next 32 rows -- consecutive workgroups then walk whole DRAM pages of w, m and v
+    int bx = blockIdx.x;
+    int tci, tco, khkw;
+    if (p.chunks == 1) {                                     // (p.chunks doubles as the order switch: 1 = row-major walk)
+        tci = bx % p.tiles_ci; bx /= p.tiles_ci;
+        khkw = bx % (p.KH * p.KW);
+        tco = bx / (p.KH * p.KW);
+    } else {
+        tci = bx % p.tiles_ci; bx /= p.tiles_ci;
+        tco = bx % p.tiles_co;
+        khkw = bx / p.tiles_co;
+    }
+    const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+    const int co0 = tco * BM, ci0 = tci * BN;
+    const int ohw = p.OH * p.OW;
+    const int rows = p.rows_per_group;                       // <= 64
+    const long long row0 = (long long)g * rows;
+    const long long img0 = (long long)g * p.imgs_per_group;
+
+    // operand requests: A = dy[m][co0 .. co0+32) (8 float4 per row, 32 rows per pass), B = im2col[m][ci0 .. ci0+128) (8 rows per pass)
+    f32x4 va[2], vb[8];
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = arow + 32 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
+        va[j] = v;
+    }
+    // m -> (image, oh, ow) by multiplication with host-made reciprocals (exact for m < 64): the compiler's general 32-bit
+    // division is ~30 VALU instructions each, 16 of them per lane here -- more issue slots than the whole Adam epilogue
+    const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0 + bcol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = brow + 8 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < rows) {
+            const int img = (m * p.chunk_rows) >> 16, rem = m - img * ohw;          // chunk_rows / tiles_co carry the reciprocals
+            const int oh = (rem * p.ws_inv_ow) >> 16, ow = rem - oh * p.OW;
+            const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                v = *(const f32x4*)(in_g + ((img * p.H + ih) * p.W + iw) * p.ldi);
+        }
+        vb[j] = v;
+    }
+    // w/m/v requests: 32 float4 per row, 8 rows per pass, 4 passes
+    const int q = tid & 31, rr = tid >> 5;
+    f32x4 mm[4], vv[4], ww[4];
+    long long gi[4];
+    const long long gbase = (long long)g * p.dwgs + (long long)(co0 + rr) * p.Kpad + khkw * p.Cin + ci0 + 4 * q;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        gi[u] = gbase + (long long)(8 * u * p.Kpad);
+        mm[u] = ldp((const f32x4*)(p.m + gi[u]));
+        vv[u] = ldp((const f32x4*)(p.v + gi[u]));
+        ww[u] = ldp((const f32x4*)(p.w + gi[u]));
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half * 32 < rows) {                               // wave-uniform
+            if (half) __syncthreads();                        // fragment reads of the first half are done
+            *(f32x4*)(As + arow * BM + acol) = va[half];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[4 * half + j];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float a = As[(2 * t + h) * BM + r];
+                const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    float* Gs = smem;                 // [32][GLD], aliases As/Bs
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
+    __syncthreads();
+    const float step_size = p.hyper ? p.hyper[0] : p.step_size;
+    const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
+        if (POL & 4) {
+            // hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences, and the moment updates as
+            // packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32): the epilogue's VALU work competes with the co-running trunk
+            // convolutions for issue slots (A/B in DESIGN.md: +2 % end to end)
+            const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
+            mm[u] = p.b1 * mm[u] + c1 * ge;
+            vv[u] = p.b2 * vv[u] + c2 * (ge * ge);
+            f32x4 den;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps);
+            ww[u] -= step_size * (mm[u] * den);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mm[u][e] = p.b1 * mm[u][e] + (1.f - p.b1) * ge[e];
+                vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
+                ww[u][e] -= step_size * (mm[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps));
+            }
+        }
+        stp(mm[u], (f32x4*)(p.m + gi[u]));
+        stp(vv[u], (f32x4*)(p.v + gi[u]));
+        stp(ww[u], (f32x4*)(p.w + gi[u]));
+        if (p.dw) *(f32x4*)(p.dw + gi[u]) = ge;
+    }
+}
+
+int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t s) {
+    WgradArgs p = a;
+    p.tiles_ci = a.Cin / 128;
+    p.tiles_co = a.Cout / 32;
+    constexpr int lds = (32 * 32 + 32 * (128 + 32)) * 4;       // 24.6 KB (the gradient tile [32][132] aliases it)
+    p.chunks = g_wgrad_rows == 2 ? 2 : 1;
+    p.chunk_rows = (65536 + a.OH * a.OW - 1) / (a.OH * a.OW);
+    p.ws_inv_ow = (65536 + a.OW - 1) / a.OW;
+    dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
+    if (g_wgrad_pol == 7) hipLaunchKernelGGL(wgrad_adam_rows_kernel<7>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 3) hipLaunchKernelGGL(wgrad_adam_rows_kernel<3>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 2) hipLaunchKernelGGL(wgrad_adam_rows_kernel<2>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 1) hipLaunchKernelGGL(wgrad_adam_rows_kernel<1>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(wgrad_adam_rows_kernel<0>, grid, dim3(256), lds, s, p);
+    return mft_launch_status();
+}
+
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                             long long n, int chunks, long long dwgs) {
     const int g = blockIdx.y;
@@ -585,10 +742,12 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     if (stem) return adam ? MFT_EINVAL : launch_wgrad<64, 64, false, true>(a, 1, groups, s);
     if (adam) {
         if (a.Cin % 64 != 0 || a.Cout % 64 != 0) return MFT_EINVAL;
+        if (g_wgrad_rows && a.rows_per_group <= 64 && a.Cin % 128 == 0 && a.Cout % 32 == 0)
+            return launch_wgrad_adam_rows(a, taps, groups, s);
         if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && g_wgrad_tile != 64) return launch_wgrad<128, 128, true>(a, taps, groups, s);
-        if (g_wgrad_early && g_wgrad_pol == 0) return launch_wgrad<64, 64, true, false, true, 0>(a, taps, groups, s);
-        if (g_wgrad_early && g_wgrad_pol == 1) return launch_wgrad<64, 64, true, false, true, 1>(a, taps, groups, s);
-        if (g_wgrad_early && g_wgrad_pol == 2) return launch_wgrad<64, 64, true, false, true, 2>(a, taps, groups, s);
+        if (g_wgrad_early && (g_wgrad_pol & 3) == 0) return launch_wgrad<64, 64, true, false, true, 0>(a, taps, groups, s);
+        if (g_wgrad_early && (g_wgrad_pol & 3) == 1) return launch_wgrad<64, 64, true, false, true, 1>(a, taps, groups, s);
+        if (g_wgrad_early && (g_wgrad_pol & 3) == 2) return launch_wgrad<64, 64, true, false, true, 2>(a, taps, groups, s);
         if (g_wgrad_early) return launch_wgrad<64, 64, true, false, true>(a, taps, groups, s);
         return launch_wgrad<64, 64, true>(a, taps, groups, s);
     }
@@ -651,7 +810,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
+    if (tile >= 9500) g_wgrad_rows = tile - 9500;
+    else if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
     else if (tile >= 9000) g_wgrad_pol = tile - 9000;
     else if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
     else if (tile >= 7000) mft_skinny_set_tap(tile - 7000);
@@ -670,7 +830,7 @@ extern "C" int mft_debug_set_x3_tile(int t);
 // Every tuning knob back to its default (tests call this from an always-run fixture: a failed assert between a set and its
 // hand-written restore must not leave later tests on a different kernel variant).
 extern "C" int mft_debug_reset(void) {
-    g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 3; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
+    g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
     mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(100);

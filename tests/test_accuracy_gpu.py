@@ -35,13 +35,18 @@ def _run(golden_dir, tag, batch):
     y = np.repeat(np.arange(5), 15)
     accs, chk = [], []
     np.random.seed(10)                                   # finetune.py:425; permutations are then drawn episode by episode
-    for i in range(0, n, batch):
-        eps = [synthetic.test_episode(int(g["ep_seed0"]) + j, 5, 5, 15, 84, gen_examples=G, noise=float(g["noise"]))
-               for j in range(i, min(i + batch, n))]
-        sc = e.run_batch(eps).cpu().numpy()
-        for s in sc:
-            accs.append(float((s.argmax(1) == y).mean() * 100.0))
-            chk.append(float(s[:, 0].astype(np.float64).sum()))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def make(j):
+        return synthetic.test_episode(int(g["ep_seed0"]) + j, 5, 5, 15, 84, gen_examples=G, noise=float(g["noise"]))
+    with ThreadPoolExecutor(max_workers=8) as ex:         # the numpy episode generator is the slow part (~1 s per 19-view episode)
+        for i in range(0, n, batch):
+            eps = list(ex.map(make, range(i, min(i + batch, n))))
+            sc = e.run_batch(eps).cpu().numpy()
+            for s in sc:
+                accs.append(float((s.argmax(1) == y).mean() * 100.0))
+                chk.append(float(s[:, 0].astype(np.float64).sum()))
+    e.close()
     return np.array(accs), np.array(chk), ref, g["chk_" + tag]
 
 
@@ -61,7 +66,14 @@ def test_g9_accuracy_600_episodes_short_config(golden_dir):
 
 def test_g9_accuracy_full_config(golden_dir):
     """BASELINE configs[1]: fine_tune_epoch=5, gen_examples=17 (500 Adam steps per episode)."""
-    accs, chk, ref, ref_chk = _run(golden_dir, "B", 20)
-    assert abs(accs.mean() - ref.mean()) <= 0.7, (accs.mean(), ref.mean())      # +-0.2 % is a 600-episode statement
-    d = np.abs(accs - ref)                      # 500 chaotic Adam steps per episode: distributional bound (see the 600-episode test)
-    assert np.percentile(d, 90) <= 2.7 + 1e-6 and d.max() <= 10.7, (np.percentile(d, 90), d.max())
+    accs, chk, ref, ref_chk = _run(golden_dir, "B", 64)
+    n = len(ref)                                 # 600 once oracle/make_golden_g9.py --nB 600 has finished (it saves as it goes)
+    # the north_star bar, +-0.2 % on the 600-episode mean; proportionally wider while the fixture holds fewer episodes
+    tol = 0.2 if n >= 600 else 0.2 * (600.0 / n) ** 0.5 + 0.1
+    assert abs(accs.mean() - ref.mean()) <= tol, (n, accs.mean(), ref.mean())
+    # 500 chaotic Adam steps per episode: per-episode identity is not a meaningful bar (the result of ONE episode even depends on
+    # its slot in the batch through the summation order of the per-tile BatchNorm statistics); distributional bounds instead:
+    # 90 % of the episodes within two queries, 99 % within six, at most one episode in 200 further than eight queries
+    d = np.abs(accs - ref)
+    assert np.percentile(d, 90) <= 2.7 + 1e-6 and np.percentile(d, 99) <= 8.0 + 1e-6, (np.percentile(d, 90), np.percentile(d, 99))
+    assert np.mean(d > 10.7) <= 0.005, (np.mean(d > 10.7), d.max())

@@ -657,3 +657,52 @@ def test_wgrad_adam_with_fused_data_gradient(ipg):
     big = torch.empty((1, 9, 9 * 9, C), device=DEV)
     x9 = torch.zeros((9, H, H, C), device=DEV)
     assert not ops.conv2d_wgrad_adam_dgrad(x9, x9, w[:1], m[:1], v[:1], big, 1, 9)
+
+
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H", [("trunk.7.C2", 512, 512, 3, 1, 1, 3), ("trunk.7.C1", 256, 512, 3, 2, 1, 6),
+                                                          ("trunk.7.shortcut", 256, 512, 1, 2, 0, 6)])
+@pytest.mark.parametrize("ipg", [5, 4, 1])
+def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
+    """The stream-shaped 32 x 128 weight-gradient + Adam kernel of the inner loop (<= 64 reduction rows; csrc/conv_igemm.hip
+    wgrad_adam_rows_kernel): (i) with exact division / square root it is BIT-IDENTICAL to the 64 x 64 tile kernel (same
+    reduction order); (ii) its default epilogue (hardware v_rcp_f32 / v_sqrt_f32, packed moment updates) moves a weight by at
+    most a few 1e-9 relative to that; (iii) against torch.optim.Adam on the float64 gradient."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    G = 3
+    n = G * ipg
+    OH = (H + 2 * pad - k) // stride + 1
+    x = rnd((n, Cin, H, H), 201)
+    dy = rnd((n, Cout, OH, OH), 202) * 1e-2
+    w0 = rnd((G, Cout, Cin, k, k), 203, scale=0.02)
+    m0 = rnd((G, Cout, k * k * Cin), 204) * 1e-3
+    v0 = rnd((G, Cout, k * k * Cin), 205).abs() * 1e-6
+    xg, dyg = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+    wpk = torch.stack([ops.pack_conv_weight(w0[g].to(DEV)) for g in range(G)])
+    res = {}
+    for knobs, tag in (((9500, 9003), "tile"), ((9501, 9003), "rows_exact"), ((9501, 9007), "rows_fast")):
+        lib.mft_debug_reset()
+        for kn in knobs:
+            lib.mft_debug_set_conv_tile(kn)
+        w, m, v = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
+        ops.conv2d_wgrad_adam(xg, dyg, w, m, v, Cout, k, k, stride, pad, 7, imgs_per_group=ipg)
+        res[tag] = (w, m, v)
+    lib.mft_debug_reset()
+    for a, b in zip(res["tile"], res["rows_exact"]):
+        assert torch.equal(a, b), name
+    (wf, mf, vf), (we, me, ve) = res["rows_fast"], res["rows_exact"]
+    assert float(((mf - me).abs() / me.abs().clamp_min(1e-20)).max()) < 3e-7          # packed fma contraction: <= 1-2 ulp
+    assert float(((vf - ve).abs() / ve.abs().clamp_min(1e-20)).max()) < 3e-7
+    assert float((wf - we).abs().max()) < 1e-8, float((wf - we).abs().max())          # |update| <= ~1e-2, 1-ulp rcp / sqrt
+    # torch.optim.Adam on the float64 gradient of the same convolution
+    for g in range(G):
+        wt = w0[g].double().requires_grad_(True)
+        out = F.conv2d(x[g * ipg:(g + 1) * ipg].double(), wt, None, stride, pad)
+        out.backward(dy[g * ipg:(g + 1) * ipg].double())
+        grad = wt.grad.permute(0, 2, 3, 1).reshape(Cout, -1)                            # packed [Cout][kh][kw][ci]
+        b1, b2 = 0.9, 0.999
+        mr = b1 * m0[g].double() + (1 - b1) * grad
+        vr = b2 * v0[g].double() + (1 - b2) * grad * grad
+        wr = wpk[g].cpu().double() - (0.01 / (1 - b1 ** 7)) * mr / (vr.sqrt() / (1 - b2 ** 7) ** 0.5 + 1e-8)
+        assert float((wf[g].cpu().double() - wr).abs().max()) < 2e-6, name
+        assert float((mf[g].cpu().double() - mr).abs().max()) < 1e-7
