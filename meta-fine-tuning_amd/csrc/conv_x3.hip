@@ -74,7 +74,7 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // sits in the same basic block as the MFMAs of tile kt and the scheduler can issue it in their shadow (the single-buffer loop
 // has barrier - store - barrier between two MFMA blocks; PMC: waves 47 % issue-stalled / 24 % parked, matrix pipes 40 % busy).
 // Costs 92 KB of LDS per workgroup (one workgroup per CU instead of three).
-template <int BM, int BN, bool AP, bool DB>
+template <int BM, int BN, bool AP, bool DB, int HOIST = 0>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
@@ -213,30 +213,101 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     auto compute = [&](int buf) {
         const unsigned short* As = smem + buf * BUF;
         const unsigned short* Bs = As + 3 * A_PLANE;
+        // ALL fragment reads of the K-step (both 16-wide halves: 2 x 3 x (TM + TN) ds_read_b128) are issued before the first
+        // MFMA and pinned there (sched_barrier): left to itself the scheduler sinks each read to just before the MFMA that
+        // consumes it to save registers, which exposes one LDS round trip per MFMA (ISA of round 1: "ds_read, s_waitcnt, mfma"
+        // six times per half -- the matrix pipes measured 43 % busy).  In-order lgkmcnt lets the first MFMA start as soon as ITS
+        // two fragments are in while the remaining reads complete under the matrix work.
+        if constexpr (HOIST == 0) {
+            // round-1 form: fragments read per 16-wide half, scheduling left to the compiler
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
-            // six piece products per accumulator, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that no
-            // instruction waits on the result of the one issued just before it
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
+        bf16x8 a[2][TM][3], b[2][TN][3];
+        if constexpr (HOIST == 1) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+#pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[6] = {0, 0, 1, 1, 0, 2};
+            constexpr int TB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i][TA[t]], b[kk][j][TB[t]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // HOIST == 2: half 0's nine reads, then half 1's nine reads issued in the shadow of half 0's MFMAs
+            auto rd = [&](int kk) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                }
+            };
+            constexpr int TA[6] = {0, 0, 1, 1, 0, 2};
+            constexpr int TB[6] = {0, 1, 0, 1, 2, 0};
+            auto mm = [&](int kk) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i][TA[t]], b[kk][j][TB[t]], acc[i][j], 0, 0, 0);
+            };
+            rd(0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(1);
+            mm(0);
+            // one MFMA, then one or two reads, ... : the second half's reads ride under the first half's matrix work
+            for (int q = 0; q < 6 * TM * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (3 * (TM + TN) + 6 * TM * TN - 1) / (6 * TM * TN), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // Rejected variants of this loop (measured, removed again): two K-steps of operands in flight (second register stage):
@@ -371,6 +442,10 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 int g_x3_db = 0;           // double-buffered LDS form of the 128x64 kernel (mft_debug_set_x3_tile(60/61))
+int g_x3_hoist = 0;        // fragment-read schedule of the K-step: 0 compiler's (default), 1 all 18 reads pinned before the MFMAs, 2 second half's reads
+                           // under the first half's MFMAs (mft_debug_set_x3_tile(80 + v)).  Measured standalone over the five trunk shapes, one
+                           // process: 608 / 609 / 600 us -- with three waves per SIMD the exposed LDS round trips of one wave are covered by
+                           // the others; the schedule inside a wave is not what holds the matrix pipes at 43 %.
 int g_x3_row_swz = 1;      // conflict-free staging-row assignment (mft_debug_set_x3_tile(40/41))
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
@@ -383,14 +458,10 @@ int launch_x3(X3Args p, hipStream_t s) {
     p.row_swz = g_x3_row_swz;
     size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
-    auto kern = conv_x3_kernel<BM, BN, AP, DB>;
-    if (lds > 64 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_done = true;
-        }
+    auto kern = g_x3_hoist == 1 ? conv_x3_kernel<BM, BN, AP, DB, 1> : (g_x3_hoist == 2 ? conv_x3_kernel<BM, BN, AP, DB, 2> : conv_x3_kernel<BM, BN, AP, DB, 0>);
+    if (lds > 64 * 1024) {                  // opt-in double-buffered / throttled forms only
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
     return mft_launch_status();
@@ -588,6 +659,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 80) g_x3_hoist = t - 80;
     else if (t >= 60) g_x3_db = t - 60;
     else if (t >= 40) g_x3_row_swz = t - 40;
     else if (t >= 20) g_x3_xcd = t - 20;

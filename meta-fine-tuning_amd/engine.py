@@ -19,6 +19,9 @@ from . import functional as Fn
 from . import ops
 
 
+_DEBUG_SKIP_TRUNK = os.environ.get("MFT_DEBUG_SKIP_TRUNK", "0") == "1"     # results are then WRONG; timing experiments only
+
+
 class AdaptState:
     """Per-episode adaptable parameters + gradient + Adam moments (four tensor-major slabs)."""
 
@@ -71,6 +74,7 @@ class FinetuneEngine:
         if self.use_graph:
             pipeline = False
         self._graphs = {}
+        self._dbg_x6 = {}
         self._alt = None
         self._pre = None            # ingest + stem cache of the NEXT batch, enqueued on their own stream (run_batch(prefetch=))
         self._pre_bufs = None
@@ -91,6 +95,10 @@ class FinetuneEngine:
             ops._lib.lib().mft_stream_destroy(ctypes.c_void_p(self._raw_stream))
             self._raw_stream = None
             self.s_trunk = None
+            if getattr(self, "_raw_last", None) is not None:
+                ops._lib.lib().mft_stream_destroy(ctypes.c_void_p(self._raw_last))
+                self._raw_last = None
+                self.s_last = None
 
     def __del__(self):
         try:
@@ -132,7 +140,26 @@ class FinetuneEngine:
         # (trunk at the device's least priority, below torch's range: 68.2 / 68.1 / 67.7 vs 67.8 / 68.0 / 67.5 at normal)
         prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "1"))
         self.s_trunk = None
-        if pipeline and prio > 0:              # below torch's range: a HIP stream at the device's least priority
+        self._raw_last = None
+        # CU partition (opt-in, MFT_TRUNK_CUS_PER_XCD = n): the frozen-trunk stream may use n of the 32 CUs of every XCD, the
+        # last-block stream the other 32 - n (hipExtStreamCreateWithCUMask; mask bit i -> XCD i % 8, CU i // 8).  A 3-read /
+        # 3-write stream keeps 93 % of its rate on 160 of the 256 CUs (tools/microbench/adam_cus.hip) while the matrix-bound
+        # trunk scales with its CU count.
+        n_tr = int(os.environ.get("MFT_TRUNK_CUS_PER_XCD", "0"))
+        if pipeline and 0 < n_tr < 32:
+            def masked(bits):
+                words = (ctypes.c_uint * 8)()
+                for b in bits:
+                    words[b // 32] |= (1 << (b % 32))
+                out = ctypes.c_void_p()
+                ops._lib.check(ops._lib.lib().mft_stream_create_cumask(ctypes.cast(words, ctypes.c_void_p), 8, ctypes.byref(out)),
+                               "mft_stream_create_cumask")
+                return out.value
+            self._raw_stream = masked([i for i in range(256) if (i // 8) >= 32 - n_tr])
+            self._raw_last = masked([i for i in range(256) if (i // 8) < 32 - n_tr])
+            self.s_trunk = torch.cuda.ExternalStream(self._raw_stream, device=self.dev)
+            self.s_last = torch.cuda.ExternalStream(self._raw_last, device=self.dev)
+        elif pipeline and prio > 0:              # below torch's range: a HIP stream at the device's least priority
             out = ctypes.c_void_p()
             with torch.cuda.device(self.dev):
                 ops._lib.check(ops._lib.lib().mft_stream_create_priority(prio, ctypes.byref(out), None), "mft_stream_create_priority")
@@ -140,7 +167,8 @@ class FinetuneEngine:
             self.s_trunk = torch.cuda.ExternalStream(out.value, device=self.dev)
         elif pipeline:
             self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio)
-        self.s_last = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("MFT_LAST_PRIORITY", "-1"))) if pipeline else None
+        if self._raw_last is None:
+            self.s_last = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("MFT_LAST_PRIORITY", "-1"))) if pipeline else None
         px = image_size * image_size * 3
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
@@ -236,6 +264,11 @@ class FinetuneEngine:
         statistics).  Independent of the adapted weights, hence of the previous step."""
         E, H = self.E, self.size
         a = self.arena_trunk
+        if _DEBUG_SKIP_TRUNK and (k, parity) in self._dbg_x6:       # measurement aid only (tools): what the step costs without the trunk
+            return self._dbg_x6[(k, parity)]
+        if _DEBUG_SKIP_TRUNK:
+            self._dbg_x6[(k, parity)] = Fn.resnet10_trunk(self.W, None, a, k, upto=7, tag="tr%d.%d" % (k, parity), stem=(self.stem, idx_dev))
+            return self._dbg_x6[(k, parity)]
         if self.stem is not None:
             return Fn.resnet10_trunk(self.W, None, a, k, upto=7, tag="tr%d.%d" % (k, parity), stem=(self.stem, idx_dev))
         n = idx_dev.numel()                      # E*k images per step, times the number of steps in the chunk
