@@ -79,6 +79,51 @@ def sample_view_params(rs, n_img, Hs, Ws, size, num_aug):
     return P
 
 
+def sample_view_params_torch(n_img, Hs, Ws, size, num_aug):
+    """``sample_view_params`` on the REFERENCE's random stream: every draw comes from torch's global generator in the order
+    the reference's loader consumes it -- image by image (SubDataset2.__getitem__, datasets/EuroSAT_few_shot.py:156-170), per
+    augmented view RandomSizedCrop.get_params (torchvision 0.8.2: up to 10 x (uniform_ area, uniform_ log-aspect), then two
+    randint), ImageJitter's torch.rand(3) (data/additional_transforms.py:24), the two flips' torch.rand(1) -- so that after
+    torch.manual_seed(s) the views are the ones the reference's transforms would produce for the same images.
+    Sequential and therefore slow (~8 small torch calls per view); ``sample_view_params`` is the vectorised numpy-stream form."""
+    P = np.zeros((2 + num_aug, n_img, NPARAM), dtype=np.float32)
+    P[:2, :, 0:4] = noaug_box(Hs, Ws, size)
+    P[:2, :, 4:7] = 1.0
+    area = Hs * Ws
+    lo, hi = math.log(3.0 / 4.0), math.log(4.0 / 3.0)
+    for n in range(n_img):
+        for a in range(num_aug):
+            box = None
+            for _ in range(10):
+                target_area = area * torch.empty(1).uniform_(0.5, 0.9).item()
+                log_ratio = torch.log(torch.tensor((3.0 / 4.0, 4.0 / 3.0)))
+                aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+                w = int(round(math.sqrt(target_area * aspect)))
+                h = int(round(math.sqrt(target_area / aspect)))
+                if 0 < w <= Ws and 0 < h <= Hs:
+                    i = torch.randint(0, Hs - h + 1, size=(1,)).item()
+                    j = torch.randint(0, Ws - w + 1, size=(1,)).item()
+                    box = (i, j, h, w)
+                    break
+            if box is None:
+                in_ratio = float(Ws) / float(Hs)
+                if in_ratio < 3.0 / 4.0:
+                    w, h = Ws, int(round(Ws / (3.0 / 4.0)))
+                elif in_ratio > 4.0 / 3.0:
+                    h, w = Hs, int(round(Hs * (4.0 / 3.0)))
+                else:
+                    w, h = Ws, Hs
+                box = ((Hs - h) // 2, (Ws - w) // 2, h, w)
+            r = torch.rand(3)
+            P[2 + a, n, 0:4] = box
+            for k in range(3):
+                P[2 + a, n, 4 + k] = float(JITTER[k] * (r[k] * 2.0 - 1.0) + 1)
+            P[2 + a, n, 7] = float(bool(torch.rand(1) < 0.5))
+            P[2 + a, n, 8] = float(bool(torch.rand(1) < 0.5))
+            P[2 + a, n, 9] = 1.0
+    return P
+
+
 def augment_views(src_u8, params, size, out=None, view_stride=None, img_stride=None):
     """src_u8 [n_img, Hs, Ws, 3] uint8 device tensor, params [n_views, n_img, 10] (numpy or tensor) ->
     fp32 NHWC views [n_views, n_img, size, size, 3] (or written into ``out`` with the given strides, in floats)."""
