@@ -74,7 +74,9 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // sits in the same basic block as the MFMAs of tile kt and the scheduler can issue it in their shadow (the single-buffer loop
 // has barrier - store - barrier between two MFMA blocks; PMC: waves 47 % issue-stalled / 24 % parked, matrix pipes 40 % busy).
 // Costs 92 KB of LDS per workgroup (one workgroup per CU instead of three).
-template <int BM, int BN, bool AP, bool DB, int HOIST = 0>
+// DBG (timing experiments only, results are wrong): bit 0 no operand split (raw bits stored three times), bit 1 no MFMA,
+// bit 2 operands loaded once (no global loads in the K loop), bit 3 no LDS stores in the K loop, bit 4 no fragment reads
+template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
@@ -197,7 +199,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = S.ra3[j][pl];
             } else {
                 u32x2 p1, p2, p3;
-                split4(S.ra[j], p1, p2, p3);
+                if constexpr (DBG & 1) {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, S.ra[j]);
+                    p1[0] = raw[0]; p1[1] = raw[1]; p2[0] = raw[2]; p2[1] = raw[3]; p3 = p1;
+                } else {
+                    split4(S.ra[j], p1, p2, p3);
+                }
                 *(u32x2*)(As + off) = p1;
                 *(u32x2*)(As + A_PLANE + off) = p2;
                 *(u32x2*)(As + 2 * A_PLANE + off) = p3;
@@ -235,13 +242,23 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                         b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
                 constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
+                if constexpr (DBG & 2) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                acc[i][j][pl] += (float)a[i][pl][0] + (float)b[j][pl][1];      // keeps the reads alive
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+                }
             }
             return;
         }
@@ -330,10 +347,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         store_tile(st0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tile(kt + 1, st0);
-            compute(0);
+            if constexpr (!(DBG & 4)) { if (kt + 1 < nk) load_tile(kt + 1, st0); }
+            if constexpr (!(DBG & 16)) compute(0);
             __syncthreads();
-            if (kt + 1 < nk) store_tile(st0, 0);
+            if constexpr (!(DBG & 8)) { if (kt + 1 < nk) store_tile(st0, 0); }
             __syncthreads();
         }
     }
@@ -398,6 +415,226 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ ping-pong form
+// Ablation of conv_x3_kernel on the five trunk shapes (mft_debug_set_x3_tile(200 + bits), one process, sum of the launches):
+// full 600-670 us; without the operand split 535; without the MFMAs 412; without the K loop's global loads 445; without its
+// LDS stores 383; loads + split + stores alone (no fragment reads, no MFMAs) 316; nothing but the barriers 54.  The two
+// halves of a K-step -- stage (global load, bf16x3 split, LDS store: ~260 us) and multiply (fragment reads + MFMAs: ~330 us)
+// -- ADD UP: they never overlap, because the trunk's launches are only 2.8-8.6 workgroups per CU, all started at the same
+// moment, so the three resident workgroups of a CU march in step (all staging, then all multiplying).
+//
+// This kernel builds the overlap into the workgroup: 512 threads = two groups of four waves over the SAME 128 x 64 output
+// tile.  Group g owns the K-steps kt = g (mod 2), its own LDS buffer and its own accumulators.  In half-period h the group
+// h & 1 multiplies tile h (after issuing the global loads of its next tile h + 2) while the other group splits and stores
+// tile h + 1; one barrier per half-period.  Each SIMD holds one wave of either group, so the matrix pipe of a SIMD works for
+// one wave while the other wave does the VALU / LDS-store work next to it.  At the end group 1 hands its accumulators to
+// group 0 through LDS (the same fp32 sums, associated as (even K-steps) + (odd K-steps)) and group 0 runs the epilogue.
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PA = BM / 32, PB = BN / 64;
+    constexpr int A_PLANE = BM * X3_RS, B_PLANE = BN * X3_RS;
+    constexpr int BUF = 3 * (A_PLANE + B_PLANE);
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int grp = threadIdx.x >> 8;                 // wave-uniform
+    const int tid = threadIdx.x & 255;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    unsigned short* As = smem + grp * BUF;
+    unsigned short* Bs = As + 3 * A_PLANE;
+    int tile_id = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7;
+        const int xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = xcd * q + (xcd < rmd ? xcd : rmd) + slot;
+    }
+    const int nt = tile_id % p.tiles_n, mt = tile_id / p.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int g_id = tid >> 5, g_rr = (tid >> 3) & 3;
+    const int lrow = g_rr * 4 + (g_id & 3) + 16 * (g_id >> 2);        // conflict-free staging rows (see conv_x3_kernel)
+    const int c4 = (tid & 7) * 4;
+    const int ohw = p.OH * p.OW;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
+    int a_off[PA], a_ih0[PA], a_iw0[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int img = mm / ohw, rem = mm - img * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        a_ih0[j] = oh * p.stride - p.pad;
+        a_iw0[j] = ow * p.stride - p.pad;
+        a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * 4;
+    }
+    const int bseg = tid & 3;
+    const int brow = ((tid >> 2) & 3) * 4 + ((tid >> 4) & 3) + 16 * (tid >> 6);
+    int b_off[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
+    const int plane_bytes = (int)(p.plane * 2);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x4 ra[PA];
+    u32x4 rb[PB][3];
+    const int nk = p.Kpad / 32;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 32;
+        const int khkw = k0 / p.Cin;
+        const int ci0 = k0 - khkw * p.Cin;
+        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+        const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * 4;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const bool ok = a_ok[j] && (unsigned)(a_ih0[j] + kh) < (unsigned)p.H && (unsigned)(a_iw0[j] + kw) < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)(a_off[j] + tap_off) : 0x80000000u;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int off = (lrow + 32 * j) * X3_RS + c4;
+            u32x2 p1, p2, p3;
+            split4(ra[j], p1, p2, p3);
+            *(u32x2*)(As + off) = p1;
+            *(u32x2*)(As + A_PLANE + off) = p2;
+            *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = rb[j][pl];
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // prologue: group 0 stages tile 0; group 1 requests tile 1
+    if (grp == 0) { load_tile(0); store_tile(); }
+    else if (nk > 1) load_tile(1);
+    __syncthreads();
+    for (int hp = 0; hp < nk; ++hp) {
+        if ((hp & 1) == grp) {
+            if (hp + 2 < nk) load_tile(hp + 2);
+            compute();
+        } else if (hp + 1 < nk) {
+            store_tile();                       // tile hp + 1, requested one half-period (or the prologue) ago
+        }
+        __syncthreads();
+    }
+    // group 1 -> group 0: accumulators through LDS ([4 waves][TM*TN*16][64 lanes] floats, lane-contiguous)
+    float* red = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((wave * TM * TN + i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((wave * TM * TN + i * TN + j) * 16 + e) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int m = m0 + wm * (BM / 2) + i * 32 + row;
+                    if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
+                }
+            }
+    }
+    if (p.stats_ws != nullptr) {                 // fused BatchNorm statistics, as in conv_x3_kernel (group 0 holds the tile)
+        const int split = (m0 / p.rows_per_group + 1) * p.rows_per_group;
+        float* sred = reinterpret_cast<float*>(smem) + 4 * TM * TN * 16 * 64;      // behind the hand-over area
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = acc[i][j][e];
+                        if (m < p.M) {
+                            if (m < split) { a1 += v; a2 += v * v; }
+                            else { b1 += v; b2 += v * v; }
+                        }
+                    }
+                a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+                b1 += __shfl_xor(b1, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+                if (h == 0) {
+                    float* o = sred + ((((wm * 2 + wn) * TN + j) * 32 + r) << 2);
+                    o[0] = a1; o[1] = a2; o[2] = b1; o[3] = b2;
+                }
+            }
+        }
+        __syncthreads();
+        if (grp == 0 && wm == 0 && h == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* o0 = sred + ((((0 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const float* o1 = sred + ((((1 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const int n = n0 + wn * (BN / 2) + j * 32 + r;
+                float* w0 = p.stats_ws + (((long long)mt * 2 + 0) * p.Cout + n) * 2;
+                float* w1 = p.stats_ws + (((long long)mt * 2 + 1) * p.Cout + n) * 2;
+                w0[0] = o0[0] + o1[0]; w0[1] = o0[1] + o1[1];
+                w1[0] = o0[2] + o1[2]; w1[1] = o0[3] + o1[3];
+            }
+        }
+    }
+}
+
 // mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
 // (n_t, mean_t = s1/n_t, M2_t = s2 - s1^2/n_t) are merged in tile order with Chan's update.
 __global__ void x3_stats_finalize_kernel(const float* __restrict__ ws, int C, int M, int R, int BM, float eps,
@@ -442,6 +679,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 int g_x3_db = 0;           // double-buffered LDS form of the 128x64 kernel (mft_debug_set_x3_tile(60/61))
+int g_x3_dbg = 0;          // timing experiments (wrong results): mft_debug_set_x3_tile(200 + bits), see conv_x3_kernel
 int g_x3_hoist = 0;        // fragment-read schedule of the K-step: 0 compiler's (default), 1 all 18 reads pinned before the MFMAs, 2 second half's reads
                            // under the first half's MFMAs (mft_debug_set_x3_tile(80 + v)).  Measured standalone over the five trunk shapes, one
                            // process: 608 / 609 / 600 us -- with three waves per SIMD the exposed LDS round trips of one wave are covered by
@@ -459,11 +697,46 @@ int launch_x3(X3Args p, hipStream_t s) {
     size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     auto kern = g_x3_hoist == 1 ? conv_x3_kernel<BM, BN, AP, DB, 1> : (g_x3_hoist == 2 ? conv_x3_kernel<BM, BN, AP, DB, 2> : conv_x3_kernel<BM, BN, AP, DB, 0>);
+    if (g_x3_dbg && !AP && !DB) {
+        switch (g_x3_dbg) {
+            case 1: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 1>; break;
+            case 2: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 2>; break;
+            case 4: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 4>; break;
+            case 8: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 8>; break;
+            case 12: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 12>; break;
+            case 13: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 13>; break;
+            case 16: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 16>; break;
+            case 28: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 28>; break;
+            default: break;
+        }
+    }
     if (lds > 64 * 1024) {                  // opt-in double-buffered / throttled forms only
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    return mft_launch_status();
+}
+
+int g_x3_pp = 0;           // 512-thread ping-pong form of the 128x64 kernel (mft_debug_set_x3_tile(70/71)).  Measured, one process: 781 us
+                           // over the five trunk shapes against 618 us for conv_x3_kernel, and 64.5 vs 76-77 episodes/s in the bench: with one
+                           // 8-wave workgroup per CU the stage and multiply halves do overlap inside the workgroup, but the CU then runs 2
+                           // waves per SIMD instead of 3 and every barrier stalls all of them -- off.
+
+template <int BM, int BN>
+int launch_x3_pp(X3Args p, hipStream_t s) {
+    const int tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.Cout / BN;
+    p.xcd_swizzle = g_x3_xcd;
+    p.row_swz = 1;
+    const size_t lds = (size_t)2 * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);       // 92 KB: one workgroup (8 waves) per CU
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_x3_pp_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_x3_pp_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), lds, s, p);
     return mft_launch_status();
 }
 
@@ -658,8 +931,10 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 }
 
 extern "C" int mft_debug_set_x3_tile(int t) {
-    if (t >= 100) g_x3_min_lds_kb = t - 100;
+    if (t >= 200) g_x3_dbg = t - 200;
+    else if (t >= 100) g_x3_min_lds_kb = t - 100;
     else if (t >= 80) g_x3_hoist = t - 80;
+    else if (t >= 70) g_x3_pp = t - 70;
     else if (t >= 60) g_x3_db = t - 60;
     else if (t >= 40) g_x3_row_swz = t - 40;
     else if (t >= 20) g_x3_xcd = t - 20;
@@ -739,6 +1014,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.in_bytes = (unsigned)(ni * img_bytes);
         const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
                        : g_x3_db                      ? launch_x3<128, 64, false, true>(q, s)
+                       : (g_x3_pp && !g_x3_dbg)       ? launch_x3_pp<128, 64>(q, s)
                                                       : launch_x3<128, 64, false, false>(q, s);
         if (rc != 0) return rc;
     }

@@ -375,7 +375,8 @@ def test_g16_gnnnet50_loss_and_grads(golden_dir):
     grads = torch.autograd.grad(loss, [sd[k] for k in pkeys])
     gn = {k: float(t.norm()) for k, t in zip(pkeys, grads)}
     for name, ref in zip(g["gradnames"], g["gradnorms"]):
-        assert abs(gn[str(name)] - ref) <= 2e-3 * ref + 1e-7, name
+        # biases that feed a BatchNorm have an exactly-zero true gradient: the reference's fp32 run leaves ~2e-7 of rounding there
+        assert abs(gn[str(name)] - ref) <= 2e-3 * ref + 1e-6, name
     gd = dict(zip(pkeys, grads))
     np.testing.assert_allclose(gd["fc.0.weight"][:4, :8].numpy(), g["grad_fc0w_slice"], atol=1e-5)
     np.testing.assert_allclose(gd["feature.trunk.7.C2.weight"][:2, :4, 1, 1].numpy(), g["grad_c7c2_slice"], atol=2e-6)
