@@ -1004,7 +1004,8 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
     const long long max_imgs = 0x7fff0000LL / img_bytes;
     if (max_imgs < 1 || 3 * plane_elems * 2 >= 0x7fff0000LL) return MFT_EINVAL;
     if (stats_ws != nullptr && (max_imgs < n_img || rows_per_group < 128)) return MFT_EINVAL;   // tile numbering needs one launch
-    if (stats_ws != nullptr) tile = 1;
+    if (stats_ws != nullptr && tile != 3) tile = 1;
+    if (stats_ws != nullptr && tile == 3 && rows_per_group < 64) return MFT_EINVAL;
     for (long long i0 = 0; i0 < n_img; i0 += max_imgs) {
         const long long ni = (n_img - i0 < max_imgs) ? (n_img - i0) : max_imgs;
         X3Args q = p;
@@ -1013,6 +1014,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.M = (int)(ni * p.OH * p.OW);
         q.in_bytes = (unsigned)(ni * img_bytes);
         const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
+                       : (tile == 3)                  ? launch_x3<64, 64, false, false>(q, s)
                        : g_x3_db                      ? launch_x3<128, 64, false, true>(q, s)
                        : (g_x3_pp && !g_x3_dbg)       ? launch_x3_pp<128, 64>(q, s)
                                                       : launch_x3<128, 64, false, false>(q, s);
@@ -1029,7 +1031,7 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
 
 extern "C" long long mft_conv2d_x3_stats_ws_floats(int n_img, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
     const long long OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
-    return ((long long)n_img * OH * OW + 127) / 128 * 2 * Cout * 2;
+    return ((long long)n_img * OH * OW + 63) / 64 * 2 * Cout * 2;          // sized for the smallest tile (64 rows)
 }
 
 extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems,
@@ -1044,7 +1046,7 @@ extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsign
     if (rc != 0) return rc;
     const int groups = n_img / imgs_per_group;
     hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, groups), dim3(64), 0, (hipStream_t)stream,
-                       (const float*)stats_ws, Cout, n_img * OH * OW, R, 128, eps, mean, rstd);
+                       (const float*)stats_ws, Cout, n_img * OH * OW, R, g_x3_tile == 3 ? 64 : 128, eps, mean, rstd);
     return mft_launch_status();
 }
 
