@@ -649,7 +649,8 @@ def test_wgrad_adam_with_fused_data_gradient(ipg):
                                             ops._p(rstd), ops._p(g1), C, ops._p(dg), ops._p(db), ops._stream()) == 0
     # same reduction order -> identical gradient, hence identical first moments; v and w agree to the last ulp or two (the
     # compiler contracts b2*v + (1-b2)*g*g into fused multiply-adds differently in the two kernels)
-    assert torch.equal(m, m_r)
+    # the default weight-gradient launch now uses packed fp32 moment updates and hardware rcp / sqrt: a couple of ulps
+    assert float((m - m_r).abs().max()) <= 4e-7 * float(m_r.abs().max())
     assert float(((v - v_r).abs() / v_r.abs().clamp_min(1e-12)).max()) < 1e-6 and float((w - w_r).abs().max()) < 1e-7
     assert float((dx - dx_r).abs().max()) <= 2e-5 * max(float(dx_r.abs().max()), 1e-6)
     assert float((dg - dg_r).abs().max()) <= 2e-5 * max(float(dg_r.abs().max()), 1e-3)
@@ -692,9 +693,10 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
     for a, b in zip(res["tile"], res["rows_exact"]):
         assert torch.equal(a, b), name
     (wf, mf, vf), (we, me, ve) = res["rows_fast"], res["rows_exact"]
-    assert float(((mf - me).abs() / me.abs().clamp_min(1e-20)).max()) < 3e-7          # packed fma contraction: <= 1-2 ulp
-    assert float(((vf - ve).abs() / ve.abs().clamp_min(1e-20)).max()) < 3e-7
-    assert float((wf - we).abs().max()) < 1e-8, float((wf - we).abs().max())          # |update| <= ~1e-2, 1-ulp rcp / sqrt
+    # packed multiply-add contraction: a couple of ulps of the LARGER addend (relative error is unbounded where b1*m and (1-b1)*g cancel)
+    assert float((mf - me).abs().max()) <= 4e-7 * float(me.abs().max())
+    assert float((vf - ve).abs().max()) <= 4e-7 * float(ve.abs().max())
+    assert float((wf - we).abs().max()) < 4e-8, float((wf - we).abs().max())          # a couple of ulps of the weight itself (1.5e-8 at |w| ~ 0.2)
     # torch.optim.Adam on the float64 gradient of the same convolution
     for g in range(G):
         wt = w0[g].double().requires_grad_(True)
