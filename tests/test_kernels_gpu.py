@@ -696,7 +696,7 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
     # packed multiply-add contraction: a couple of ulps of the LARGER addend (relative error is unbounded where b1*m and (1-b1)*g cancel)
     assert float((mf - me).abs().max()) <= 4e-7 * float(me.abs().max())
     assert float((vf - ve).abs().max()) <= 4e-7 * float(ve.abs().max())
-    assert float((wf - we).abs().max()) < 4e-8, float((wf - we).abs().max())          # a couple of ulps of the weight itself (1.5e-8 at |w| ~ 0.2)
+    assert float((wf - we).abs().max()) < 1e-7, float((wf - we).abs().max())          # ulps of the weight plus ~3e-7 of the update (<= 0.02)
     # torch.optim.Adam on the float64 gradient of the same convolution
     for g in range(G):
         wt = w0[g].double().requires_grad_(True)
