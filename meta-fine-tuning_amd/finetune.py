@@ -413,7 +413,13 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
     accs = []
     for c in range(0, len(mine), episodes_per_batch):
         ids = mine[c:c + episodes_per_batch]
-        eps = [[v.cuda() for v in synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples)] for i in ids]
+        # the numpy generator of the synthetic episodes is the slow part of this loop (~1 s per 19-view episode): draw a batch's
+        # episodes on a few host threads (each episode is a pure function of its seed)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(ids))) as ex:
+            host = list(ex.map(lambda i: synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples), ids))
+        eps = [[v.cuda() for v in ep] for ep in host]
+        del host
         for ep in eps:
             assert torch.all(torch.eq(ep[0], ep[1]))                 # finetune.py:606
         rngs = cls = None

@@ -152,3 +152,87 @@ def test_checkpoints_interchange_with_the_reference(tmp_path):
     ours2 = gnnnet.GnnNet(backbone.ResNet10, n_way=5, n_support=5)
     ours2.load_state_dict(state, strict=True)
     assert list(ours2.state_dict().keys()) == list(ref.state_dict().keys())
+
+
+def test_engine_cache_is_content_keyed():
+    """finetune._EngineCache: same bytes -> same engine (deep copies, reloaded checkpoints), in-place updates of the same dict and
+    different checkpoints -> different engines; entries pin the dict they were built from; eviction closes engines."""
+    import copy
+    from meta_fine_tuning_amd import finetune as ft
+
+    class FakeEngine:
+        def __init__(self):
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    built = []
+
+    def build():
+        built.append(FakeEngine())
+        return built[-1]
+
+    cache = ft._EngineCache(2)
+    sd = {"feature.trunk.0.weight": torch.randn(4, 3), "feature.trunk.1.weight": torch.ones(4), "fc.0.weight": torch.randn(2, 2),
+          "feature2.trunk.0.weight": torch.zeros(4, 3)}
+    e0 = cache.get(sd, ("cfg",), build)
+    assert cache.get(sd, ("cfg",), build) is e0 and len(built) == 1                      # identity hit
+    assert cache.get(copy.deepcopy(sd), ("cfg",), build) is e0 and len(built) == 1       # content hit
+    other_head = dict(sd, **{"fc.0.weight": torch.randn(2, 2)})
+    assert cache.get(other_head, ("cfg",), build) is e0                                  # only the backbone tensors count
+    assert cache.get(sd, ("cfg2",), build) is not e0 and len(built) == 2                 # another configuration
+    with torch.no_grad():
+        sd["feature.trunk.0.weight"].mul_(2.0)                                           # same dict object, new weights
+    e2 = cache.get(sd, ("cfg",), build)
+    assert e2 is not e0 and len(built) == 3
+    assert len(cache.entries) == 2 and built[0].closed                                   # capacity 2: the oldest was evicted + closed
+    assert all(ent["pins"] for ent in cache.entries)
+    cache.clear()
+    assert all(b.closed for b in built) and not cache.entries
+
+
+def test_batched_permutation_draws_follow_the_sequential_order():
+    """scores_batched draws every episode's permutations up front, in the order the reference's sequential calls consume the
+    global numpy stream: per episode finetune_linear's 20 permutations of the support set (finetune.py:139-141), then
+    finetune's fine_tune_epoch permutations of n_way*n_support*(views+1) (finetune.py:269-272)."""
+    from meta_fine_tuning_amd import finetune as ft
+    np.random.seed(10)
+    got = [ft.draw_episode_perms("all", 5, 5, 4, 3) for _ in range(3)]
+    np.random.seed(10)
+    for lin, gnn in got:
+        for p in lin:
+            assert np.array_equal(p, np.random.permutation(25))
+        for p in gnn:
+            assert np.array_equal(p, np.random.permutation(25 * 5))
+    assert len(got[0][0]) == ft.LINEAR_EPOCHS and len(got[0][1]) == 3
+    np.random.seed(3)
+    lin, gnn = ft.draw_episode_perms("gnnnet", 5, 20, 19, 5)
+    assert lin is None and len(gnn) == 5 and gnn[0].shape == (2000,)
+    lin, gnn = ft.draw_episode_perms("baseline", 5, 50, 2, 1)
+    assert gnn is None and lin[0].shape == (250,)
+    # per-episode generators (sharded evaluation): a pure function of (seed, episode index)
+    from meta_fine_tuning_amd import parallel
+    a = ft.draw_episode_perms("gnnnet", 5, 5, 3, 2, parallel.episode_rng(10, 7))
+    b = ft.draw_episode_perms("gnnnet", 5, 5, 3, 2, parallel.episode_rng(10, 7))
+    c = ft.draw_episode_perms("gnnnet", 5, 5, 3, 2, parallel.episode_rng(10, 8))
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1])) and not np.array_equal(a[1][0], c[1][0])
+    assert parallel.episode_torch_seed(10, 7) != parallel.episode_torch_seed(10, 8)
+
+
+def test_finetune_50_and_train_50_mirror_surface():
+    """finetune_50 / train_50 export what the reference's 50-shot drivers define (finetune_50.py:20,48,182; train_50.py:30) and keep
+    their own module-global ``params``."""
+    import inspect
+    from meta_fine_tuning_amd import finetune as ft, finetune_50 as ft50, train_50
+    from meta_fine_tuning_amd.methods import gnnnet_copy
+    assert ft50.GnnNet is gnnnet_copy.GnnNet and ft50.params is None
+    ref_sig = ["liz_x", "y", "model", "state_in", "save_it", "linear", "flatten", "n_query", "ds", "pretrained_dataset",
+               "freeze_backbone", "n_way", "n_support"]
+    assert list(inspect.signature(ft50.finetune).parameters) == ref_sig == list(inspect.signature(ft.finetune).parameters)
+    assert list(inspect.signature(ft50.finetune_linear).parameters)[:13] == ["liz_x", "y", "state_in", "save_it", "linear", "flatten",
+                                                                              "n_query", "ds", "pretrained_dataset", "freeze_backbone",
+                                                                              "n_way", "n_support", "classifier"]
+    assert list(inspect.signature(train_50.train).parameters) == ["base_loader", "model", "optimization", "start_epoch", "stop_epoch", "params"]
+    m = gnnnet_copy.GnnNet(lambda: __import__("meta_fine_tuning_amd").backbone.ResNet10(), n_way=5, n_support=50)
+    assert m.n_support == 25 and m.support_label.shape == (1, 130, 5) and hasattr(m, "train_loop50") and hasattr(m, "train_loop_finetune50")
