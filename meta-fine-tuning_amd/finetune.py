@@ -353,7 +353,11 @@ class LookaheadLoader:
         it = iter(self.loader)
         done = False
         k = 0
+        issued = []
         while not done:
+            for key in issued:                  # scores the loop body never asked for (a skipped episode) must not stay pinned
+                _READY.pop(key, None)
+            issued = []
             batch = []
             while len(batch) < self.E:
                 try:
@@ -372,8 +376,11 @@ class LookaheadLoader:
                 pin = elem[0][0]
                 _READY[id(pin)] = {"pin": pin, "gnn": None if s_gnn is None else s_gnn[j],
                                    "linear": None if s_lin is None else s_lin[j]}
+                issued.append(id(pin))
             for elem in batch:
                 yield elem
+        for key in issued:
+            _READY.pop(key, None)
 
 
 # ------------------------------------------------------------------------------------------------ the 600-episode driver
