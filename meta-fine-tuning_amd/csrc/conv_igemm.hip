@@ -660,6 +660,118 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
     }
 }
 
+// EXPERIMENT (mft_debug_set_conv_tile(9504)): the same arithmetic as wgrad_adam_rows_kernel, but one workgroup WALKS all K tiles
+// of its 32 output-channel rows (tap-major, 128 input channels per tile) with the next tile's w/m/v requested one iteration ahead.
+// Purpose: does a walking workgroup keep the stream rate of the one-tile-per-workgroup form?  (It is the structure any fusion of
+// the next step's forward or of the data gradient into this launch needs.)
+template <int POL>
+__global__ __launch_bounds__(256) void wgrad_adam_walk_kernel(WgradArgs p) {
+    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4;
+    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
+    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [64][BM]   dY rows of this co-tile (resident)
+    float* Bs = smem + 64 * BM;           // [32][BLD]  half of the im2col rows of the current K tile
+    float* Gs = Bs + 32 * BLD;            // [32][GLD]  gradient tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y, tco = blockIdx.x;
+    const int co0 = tco * BM;
+    const int ohw = p.OH * p.OW;
+    const int rows = p.rows_per_group;
+    const long long row0 = (long long)g * rows;
+    const long long img0 = (long long)g * p.imgs_per_group;
+    const int n_kt = p.KH * p.KW * p.tiles_ci;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = arow + 32 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
+        *(f32x4*)(As + m * BM + acol) = v;
+    }
+    f32x4 vb[8];
+    auto load_b = [&](int kt) {
+        const int khkw = kt / p.tiles_ci, ci0 = (kt - khkw * p.tiles_ci) * BN;
+        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+        const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0 + bcol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = brow + 8 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < rows) {
+                const int img = (m * p.chunk_rows) >> 16, rem = m - img * ohw;
+                const int oh = (rem * p.ws_inv_ow) >> 16, ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) v = *(const f32x4*)(in_g + ((img * p.H + ih) * p.W + iw) * p.ldi);
+            }
+            vb[j] = v;
+        }
+    };
+    const int q = tid & 31, rr = tid >> 5;
+    const long long gbase = (long long)g * p.dwgs + (long long)(co0 + rr) * p.Kpad + 4 * q;
+    f32x4 cm[4], cv[4], cw[4], nm[4], nv[4], nw[4];
+    auto load_wmv = [&](int kt, f32x4* M_, f32x4* V_, f32x4* W_) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long gi = gbase + (long long)(8 * u * p.Kpad) + kt * BN;       // K index of tile kt = kt * 128 (tap-major)
+            M_[u] = ldp((const f32x4*)(p.m + gi));
+            V_[u] = ldp((const f32x4*)(p.v + gi));
+            W_[u] = ldp((const f32x4*)(p.w + gi));
+        }
+    };
+    load_b(0);
+    load_wmv(0, cm, cv, cw);
+    const float step_size = p.hyper ? p.hyper[0] : p.step_size;
+    const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int kn = kt + 1 < n_kt ? kt + 1 : kt;
+        load_wmv(kn, nm, nv, nw);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half * 32 < rows) {
+                if (half) __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[4 * half + j];
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float a = As[(32 * half + 2 * t + h) * BM + r];
+                    const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+        }
+        load_b(kn);                               // next tile's im2col rows (L2) under the epilogue
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long gi = gbase + (long long)(8 * u * p.Kpad) + kt * BN;
+            const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
+            const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
+            cm[u] = p.b1 * cm[u] + c1 * ge;
+            cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
+            f32x4 den;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
+            cw[u] -= step_size * (cm[u] * den);
+            stp(cm[u], (f32x4*)(p.m + gi));
+            stp(cv[u], (f32x4*)(p.v + gi));
+            stp(cw[u], (f32x4*)(p.w + gi));
+        }
+        __syncthreads();                          // Gs / Bs are rewritten by the next tile
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cm[u] = nm[u]; cv[u] = nv[u]; cw[u] = nw[u]; }
+    }
+}
+
 int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     WgradArgs p = a;
     p.tiles_ci = a.Cin / 128;
@@ -668,6 +780,11 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
     p.chunks = g_wgrad_rows == 2 ? 2 : 1;
     p.chunk_rows = (65536 + a.OH * a.OW - 1) / (a.OH * a.OW);
     p.ws_inv_ow = (65536 + a.OW - 1) / a.OW;
+    if (g_wgrad_rows == 4) {
+        constexpr int lds_walk = (64 * 32 + 32 * (128 + 32) + 32 * (128 + 4)) * 4;      // 45.6 KB
+        hipLaunchKernelGGL(wgrad_adam_walk_kernel<7>, dim3(p.tiles_co, groups, 1), dim3(256), lds_walk, s, p);
+        return mft_launch_status();
+    }
     dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
     if (g_wgrad_pol == 7) hipLaunchKernelGGL(wgrad_adam_rows_kernel<7>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 3) hipLaunchKernelGGL(wgrad_adam_rows_kernel<3>, grid, dim3(256), lds, s, p);
