@@ -489,3 +489,59 @@ def test_finetune_linear_frozen_backbone_vs_reference_golden(golden_dir):
     assert sc.shape == (75, 5)
     assert np.abs(sc - g["scores"]).max() < 1e-3 and (sc.argmax(1) == g["scores"].argmax(1)).mean() >= 0.98, np.abs(sc - g["scores"]).max()
     assert np.array_equal(np.random.permutation(7), g["next_perm"])
+
+
+def test_engine_full_config_vs_reference_golden(golden_dir):
+    """BASELINE configs[1] exactly (fine_tune_epoch 5, 17 augmented views = 500 Adam steps) on one episode: engine scores
+    against the scores the REFERENCE's finetune() produced (G5b) -- inside the Adam sign-flip envelope of SURVEY.md D7 -- and
+    against the float64 oracle no further than 4x the reference's own fp32-vs-fp64 distance."""
+    g = _g(golden_dir, "g5b_finetune_full.npz")
+    sd = synthetic.gnnnet_state_dict(seed=13)
+    liz = synthetic.test_episode(41 + 17, 5, 5, 15, 84, gen_examples=17)
+    e = eng.FinetuneEngine(sd, n_views=19, fine_tune_epoch=5, episodes_per_batch=2, device=DEV)
+    np.random.seed(10)
+    st = np.random.get_state()
+    sc = e.run_batch([liz])[0].cpu().numpy()
+    ref = g["scores_E5_G17"]
+    err = np.abs(sc - ref)
+    assert err.max() < 5e-2 and (sc.argmax(1) == ref.argmax(1)).mean() >= 0.96, (err.max(), (sc.argmax(1) == ref.argmax(1)).mean())
+    np.random.set_state(st)
+    o64 = O.finetune_episode(sd, liz, 5, 5, total_epoch=5, dtype=torch.float64).numpy()
+    assert np.abs(sc - o64).max() <= max(4.0 * np.abs(ref - o64).max(), 2e-3), (np.abs(sc - o64).max(), np.abs(ref - o64).max())
+    e.close()
+
+
+def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
+    """The whole inner loop of the README setting (500 Adam steps over 19 views) on the index order of golden G4b: last-block
+    weight norms after 105 and 500 steps against the reference's fp32 AND fp64 runs (the two differ by the Adam sign-flip
+    envelope; the engine must sit in the same envelope), probe features against fp64 within 4x the reference's own distance."""
+    g = _g(golden_dir, "g4b_inner_loop_long.npz")
+    size = 84
+    sd = synthetic.resnet10_state_dict(seed=9)
+    views = synthetic.test_episode(31, 5, 5, 15, size, gen_examples=17)
+    full = {"feature." + k: v for k, v in sd.items()}
+    full.update(synthetic.gnn_head_state_dict(seed=1))
+    order = g["order"]
+    for n_epochs, tag in ((None, 105), (5, 500)):
+        # epochs of 100 steps each: 105 steps = one epoch + 5 steps -> run 2 epochs' permutations but stop the tables at 105
+        e = eng.FinetuneEngine(full, n_views=19, fine_tune_epoch=5, episodes_per_batch=1, device=DEV)
+        e._ingest([views], False)
+        e.adapt.reset(e.W)
+        e.prepare_batch()
+        perms = [[order[ep * 500:(ep + 1) * 500] for ep in range(5)]]
+        tables = e.step_tables(perms, 1)[:tag]
+        e.inner_loop(tables)
+        torch.cuda.synchronize()
+        w = e.adapt.w.export(0)
+        for key, gk in (("trunk.7.C1.weight", "wn_c1"), ("trunk.7.C2.weight", "wn_c2"), ("trunk.7.shortcut.weight", "wn_sc")):
+            n_hip = float(w[key].norm())
+            n32, n64 = float(g["%s_s%d_f32" % (gk, tag)]), float(g["%s_s%d_f64" % (gk, tag)])
+            assert abs(n_hip - n64) <= max(4.0 * abs(n32 - n64), 0.02), (key, tag, n_hip, n32, n64)
+        # probe: the first five support images through the adapted network (train-mode BatchNorm, one group of 5)
+        xa = torch.cat([v[:, :5].contiguous().view(25, 3, size, size) for v in [views[0]] + views], 0)
+        feat = Fn.resnet10_forward(e.W, ops.nchw_to_nhwc(xa[:5].to(DEV)), Fn.Arena(DEV), ipg=5, slab=e.adapt.w).cpu().numpy()
+        p32, p64 = g["probe_s%d_f32" % tag], g["probe_s%d_f64" % tag]
+        d_ref = np.abs(p32 - p64)
+        d_hip = np.abs(feat - p64)
+        assert np.percentile(d_hip, 99) <= max(4.0 * np.percentile(d_ref, 99), 5e-3), (tag, np.percentile(d_hip, 99), np.percentile(d_ref, 99))
+        e.close()
