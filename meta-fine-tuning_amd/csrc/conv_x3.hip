@@ -164,11 +164,18 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     Stage st0;
     const int nk = p.Kpad / 32;
 
+    // tap bookkeeping of the K walk, carried incrementally (the tiles are requested in order): k0 = kt*32 -> (kh, kw, ci0).
+    // The divisions k0 / Cin and khkw / KW cost ~40 dependent scalar instructions at the top of every K-step (PMC: 2.5 SALU
+    // instructions per MFMA) in front of the operand requests.
+    int t_kt = 0, t_ci0 = 0, t_kh = 0, t_kw = 0;
     auto load_tile = [&](int kt, Stage& S) {
         const int k0 = kt * 32;
-        const int khkw = k0 / p.Cin;                       // uniform (scalar) tap bookkeeping
-        const int ci0 = k0 - khkw * p.Cin;
-        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+        while (t_kt < kt) {                                // uniform; one iteration per call in the K loop
+            ++t_kt;
+            t_ci0 += 32;
+            if (t_ci0 == p.Cin) { t_ci0 = 0; if (++t_kw == p.KW) { t_kw = 0; ++t_kh; } }
+        }
+        const int ci0 = t_ci0, kh = t_kh, kw = t_kw;
         const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * ESZ;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
