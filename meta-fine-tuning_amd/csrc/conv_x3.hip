@@ -76,14 +76,22 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // Costs 92 KB of LDS per workgroup (one workgroup per CU instead of three).
 // DBG (timing experiments only, results are wrong): bit 0 no operand split (raw bits stored three times), bit 1 no MFMA,
 // bit 2 operands loaded once (no global loads in the K loop), bit 3 no LDS stores in the K loop, bit 4 no fragment reads
-template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0>
+// XS: 64-byte LDS rows (no padding) with an XOR swizzle of the four 16-byte chunks of a row, chunk' = chunk ^ ((row >> 2) & 3):
+// fragment reads (16 lanes = 16 consecutive rows, one chunk) and staging writes (consecutive rows, whole rows) stay
+// conflict-free, and the tile takes 36 KB instead of 46 KB of LDS -> FOUR workgroups per CU instead of three.
+template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0, bool XS = false>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
     constexpr int PA = AP ? BM / 64 : BM / 32;   // A passes: fp32: 32 rows x 8 threads x float4; planes: 64 rows x 4 threads x 16 B
     constexpr int PB = BN / 64;           // B passes: 64 rows per pass, 4 threads x 16 B per row and plane
-    constexpr int A_PLANE = BM * X3_RS;   // bf16 elements
-    constexpr int B_PLANE = BN * X3_RS;
+    constexpr int RS = XS ? 32 : X3_RS;
+    constexpr int A_PLANE = BM * RS;      // bf16 elements
+    constexpr int B_PLANE = BN * RS;
+    auto lo = [](int row, int c) -> int {          // element offset of bf16 column c (multiple of 4) of a row inside a plane
+        if constexpr (XS) return row * 32 + ((((c >> 3) ^ (row >> 2)) & 3) << 3) + (c & 7);
+        else return row * X3_RS + c;
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* As = smem;                    // [3][BM][RS]
     unsigned short* Bs = smem + 3 * A_PLANE;      // [3][BN][RS]
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const bool g_swz = p.row_swz != 0;
+    const bool g_swz = !XS && p.row_swz != 0;
     // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  With the
     // natural order the n-tiles of one m-tile (which read the SAME im2col rows) and neighbouring m-tiles (which share
     // halo rows) land on different XCDs and every L2 fetches the activation separately -- PMC showed ~6x the input size
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         unsigned short* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const int off = (lrow + RPP * j) * X3_RS + c4;
+            const int off = lo(lrow + RPP * j, c4);
             if constexpr (AP) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = S.ra3[j][pl];
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         for (int j = 0; j < PB; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = S.rb[j][pl];
+                *(u32x4*)(Bs + pl * B_PLANE + lo(brow + 64 * j, bseg * 8)) = S.rb[j][pl];
     };
 
     auto compute = [&](int buf) {
@@ -241,12 +249,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + lo(wm * (BM / 2) + i * 32 + r, kk * 16 + h * 8));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + lo(wn * (BN / 2) + j * 32 + r, kk * 16 + h * 8));
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
                 constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
                 if constexpr (DBG & 2) {
@@ -277,10 +285,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + lo(wm * (BM / 2) + i * 32 + r, kk * 16 + h * 8));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + lo(wn * (BN / 2) + j * 32 + r, kk * 16 + h * 8));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -303,10 +311,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
                 for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        a[kk][i][pl] = *(const bf16x8*)(As + pl * A_PLANE + lo(wm * (BM / 2) + i * 32 + r, kk * 16 + h * 8));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
+                        b[kk][j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + lo(wn * (BN / 2) + j * 32 + r, kk * 16 + h * 8));
                 }
             };
             constexpr int TA[6] = {0, 0, 1, 1, 0, 2};
@@ -691,7 +699,10 @@ int g_x3_hoist = 0;        // fragment-read schedule of the K-step: 0 compiler's
                            // under the first half's MFMAs (mft_debug_set_x3_tile(80 + v)).  Measured standalone over the five trunk shapes, one
                            // process: 608 / 609 / 600 us -- with three waves per SIMD the exposed LDS round trips of one wave are covered by
                            // the others; the schedule inside a wave is not what holds the matrix pipes at 43 %.
-int g_x3_row_swz = 1;      // conflict-free staging-row assignment (mft_debug_set_x3_tile(40/41))
+int g_x3_row_swz = 1;      // LDS layout (mft_debug_set_x3_tile(40 + v)): 0 80-byte rows, natural staging rows; 1 80-byte rows, conflict-free
+                           // staging-row assignment (default); 2 64-byte rows with an XOR chunk swizzle: 36 KB per tile, 4 workgroups per CU
+                           // instead of 3 (bit-identical; measured 643 vs 634 us over the five trunk shapes and 72.8 vs 73.4 episodes/s:
+                           // occupancy is not the limiter either)
 int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21))
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
@@ -701,8 +712,16 @@ int launch_x3(X3Args p, hipStream_t s) {
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz;
-    size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);
+    const bool xs = g_x3_row_swz == 2 && !AP && !DB && g_x3_hoist == 0 && g_x3_dbg == 0;
+    size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * (xs ? 32 : X3_RS) * sizeof(unsigned short);
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
+    if (xs) {
+        if constexpr (!AP && !DB) {
+            hipLaunchKernelGGL((conv_x3_kernel<BM, BN, false, false, 0, 0, true>), dim3((unsigned)(tiles_m * (p.Cout / BN))), dim3(256), lds, s,
+                               ([&] { X3Args q = p; q.tiles_n = p.Cout / BN; q.xcd_swizzle = g_x3_xcd; q.row_swz = 0; return q; })());
+            return mft_launch_status();
+        }
+    }
     auto kern = g_x3_hoist == 1 ? conv_x3_kernel<BM, BN, AP, DB, 1> : (g_x3_hoist == 2 ? conv_x3_kernel<BM, BN, AP, DB, 2> : conv_x3_kernel<BM, BN, AP, DB, 0>);
     if (g_x3_dbg && !AP && !DB) {
         switch (g_x3_dbg) {

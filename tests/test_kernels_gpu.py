@@ -344,8 +344,8 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
     scale = max(float(ref.abs().max()), 1.0)
     e32 = float((y32 - ref).abs().max())
     w3 = ops.split_weight_x3(wpk)
-    for patch_mode in (10, 12, 71, 81, 82):          # implicit-GEMM form, the opt-in LDS-patch form where it applies, the opt-in
-        _lib.lib().mft_debug_reset()                 # 512-thread ping-pong form, the two pinned fragment-read schedules
+    for patch_mode in (10, 12, 71, 81, 82, 42, 3):   # implicit-GEMM form, the opt-in LDS-patch form where it applies, the opt-in 512-thread
+        _lib.lib().mft_debug_reset()                 # ping-pong form, the two pinned fragment-read schedules, the XOR-swizzled 36 KB LDS layout, 64x64 tiles
         _lib.lib().mft_debug_set_x3_tile(patch_mode)
         y3 = nchw(ops.conv2d_x3(xg, w3, Cout, k, k, stride, pad).cpu()).double()
         e3 = float((y3 - ref).abs().max())
