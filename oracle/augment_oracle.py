@@ -5,7 +5,13 @@ plus its own ImageJitter (data/additional_transforms.py:16-31).  torchvision is 
 transforms is a thin wrapper over a PIL call, restated below with PIL itself (Pillow is what the reference runs on):
 Scale/Resize -> Image.resize(BILINEAR); CenterCrop -> Image.crop; RandomSizedCrop -> crop + resize(BILINEAR);
 ImageEnhance.{Brightness,Contrast,Color}; flips -> Image.transpose; ToTensor -> /255 CHW; Normalize.
-Given the SAME random parameters as the kernel, this is the image the reference's pipeline would produce."""
+Given the SAME random parameters as the kernel, this is the image the reference's pipeline would produce.
+
+Parity pin: the IMAGE arithmetic is pinned by running the real third-party code (Pillow -- present in this image and on the GPU
+box -- is what executes below; torch's own float32 ops do ToTensor / Normalize).  The RANDOM DRAW SEQUENCE of the transforms lives in
+torchvision (requirements.txt:20 pins torchvision==0.8.2), which is neither vendored in the reference tree nor installed here: it is
+restated below from the published algorithm and anchored only on the reference's call sites -- **parity unpinned** for that half
+(``tv_get_params`` / ``tv_image_view_params``)."""
 import math
 
 import numpy as np

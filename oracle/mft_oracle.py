@@ -13,9 +13,12 @@ does and fails loudly when its HIP library is missing.
 
 Parity pin: the reference has no tests or golden vectors, so the
 oracle is pinned against outputs of the reference itself, imported on CPU in
-the build container by ``oracle/make_golden.py``; the resulting vectors live in
-``tests/golden/*.npz`` and ``tests/test_oracle_golden.py`` checks this file
-against them everywhere (no /root/reference needed at test time).
+the build container by ``oracle/make_golden.py``, ``make_golden_r2.py`` and
+``make_golden_g9.py`` (20 fixtures: every §8(a) function incl. the 20-shot and
+50-shot configurations, fp32 and fp64 trajectories, 600 + 600 per-episode
+accuracies); the resulting vectors live in ``tests/golden/*.npz`` and
+``tests/test_oracle_golden.py`` checks this file against them everywhere (no
+/root/reference needed at test time).
 """
 import math
 from collections import OrderedDict
