@@ -520,6 +520,29 @@ def main():
             del xs, dys, ws, ms_, vs_
         except RuntimeError as ex:          # e.g. not enough free memory next to a large engine
             roof["standalone"] = {"error": str(ex)[:120]}
+        # what a pure w/m/v stream gets on THIS lease (the same binary measures 5.2-6.3 TB/s on different leases): an Adam-shaped
+        # 3-read / 3-write pass over scratch arrays of the size of one parameter slab, no gradient operand, no matrix work
+        try:
+            from meta_fine_tuning_amd import _lib as _L
+            n_el = (E * 3673088) // 1024 * 1024
+            sw, sm, sv = (torch.zeros(n_el, device=dev) for _ in range(3))
+            st_ = ops._stream
+            _L.check(_L.lib().mft_stream_probe(ops._p(sw), ops._p(sm), ops._p(sv), n_el, st_()), "mft_stream_probe")
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                _L.lib().mft_stream_probe(ops._p(sw), ops._p(sm), ops._p(sv), n_el, st_())
+            e1.record()
+            torch.cuda.synchronize()
+            ceil_gbs = 24.0 * n_el * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roof["stream_reference"] = {"what": "pure 3-read/3-write Adam-shaped stream over %.1f GB of scratch on this lease, no co-running work, "
+                                              "no gradient operand (mft_stream_probe; a reference point, not a bound: rates of this probe vary 5.1-6.3 TB/s from lease to lease)" % (12.0 * n_el / 1e9), "achieved": round(ceil_gbs, 1), "unit": "GB/s",
+                                      "frac_of_peak": round(ceil_gbs / PEAK_HBM_GBS, 4),
+                                      "dominant_kernel_in_situ_vs_this": round(ach / ceil_gbs, 4)}
+            del sw, sm, sv
+        except RuntimeError as ex:
+            roof["stream_reference"] = {"error": str(ex)[:120]}
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
         tot_fl = sum(f for _, _, f in conv_events)
         n_launch = len(conv_events)

@@ -40,6 +40,10 @@ int mft_stream_create_cumask(const unsigned* mask_words, int n_words, void** str
  * greatest priority.                                                                                                          */
 int mft_stream_create_priority(int priority, void** stream_out, int* range_out);
 int mft_stream_destroy(void* stream);
+/* Measurement aid (no reference counterpart): one Adam-shaped 3-read / 3-write pass over three scratch arrays of n floats
+ * (n a multiple of 1024) with no gradient operand -- the pure-stream rate of the memory system bench.py quotes beside the fused
+ * weight-gradient + Adam kernel's.                                                                                          */
+int mft_stream_probe(float* w, float* m, float* v, long long n, void* stream);
 int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream);
 
 /* Device-side test-time views (datasets/EuroSAT_few_shot.py:145-170,240-276; data/additional_transforms.py:16-31): for every

@@ -20,6 +20,7 @@ SIGNATURES = {
     "mft_device_info": [_P, _P],
     "mft_stream_create_cumask": [_P, _I, _P],
     "mft_stream_destroy": [_P],
+    "mft_stream_probe": [_P, _P, _P, _L, _P],
     "mft_probe_placement": [_P, _I, _I, _P],
     "mft_augment_views": [_P, _I, _I, _I, _P, _I, _P, _L, _L, _I, _P, _P, _P],
     "mft_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _P],

@@ -49,6 +49,44 @@ extern "C" int mft_stream_create_priority(int priority, void** stream_out, int* 
     return 0;
 }
 
+// Adam-shaped 3-read / 3-write stream over three scratch arrays (no gradient operand, no matrix work): the rate this lease's
+// memory system gives a pure w/m/v stream -- bench.py reports the fused weight-gradient + Adam kernel against it, because the same
+// binary measures 5.2-6.3 TB/s on different leases (tools/microbench/adam_cus.hip).
+namespace {
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_probe_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, long long n4) {
+    constexpr int U = 4;
+    const long long chunk4 = 256LL * U;
+    for (long long c = blockIdx.x; (c + 1) * chunk4 <= n4; c += gridDim.x) {
+        pf32x4 ww[U], mm[U], vv[U];
+        const long long base = c * chunk4 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mm[u] = __builtin_nontemporal_load((const pf32x4*)m + base + u * 256);
+            vv[u] = __builtin_nontemporal_load((const pf32x4*)v + base + u * 256);
+            ww[u] = __builtin_nontemporal_load((const pf32x4*)w + base + u * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const pf32x4 ge = ww[u] * 1e-3f;
+            mm[u] = 0.9f * mm[u] + 0.1f * ge;
+            vv[u] = 0.999f * vv[u] + 0.001f * (ge * ge);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ww[u][e] -= 0.01f * (mm[u][e] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[u][e]) + 1e-8f));
+            __builtin_nontemporal_store(mm[u], (pf32x4*)m + base + u * 256);
+            __builtin_nontemporal_store(vv[u], (pf32x4*)v + base + u * 256);
+            __builtin_nontemporal_store(ww[u], (pf32x4*)w + base + u * 256);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mft_stream_probe(float* w, float* m, float* v, long long n, void* stream) {
+    if (n < 4096 || (n & 1023) != 0) return MFT_EINVAL;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w, m, v, n / 4);
+    return mft_launch_status();
+}
+
 extern "C" int mft_stream_destroy(void* stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
 
 extern "C" int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream) {
