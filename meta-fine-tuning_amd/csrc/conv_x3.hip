@@ -75,7 +75,8 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // has barrier - store - barrier between two MFMA blocks; PMC: waves 47 % issue-stalled / 24 % parked, matrix pipes 40 % busy).
 // Costs 92 KB of LDS per workgroup (one workgroup per CU instead of three).
 // DBG (timing experiments only, results are wrong): bit 0 no operand split (raw bits stored three times), bit 1 no MFMA,
-// bit 2 operands loaded once (no global loads in the K loop), bit 3 no LDS stores in the K loop, bit 4 no fragment reads
+// bit 2 operands loaded once (no global loads in the K loop), bit 3 no LDS stores in the K loop, bit 4 no fragment reads,
+// bit 5 no barriers in the K loop
 // XS: 64-byte LDS rows (no padding) with an XOR swizzle of the four 16-byte chunks of a row, chunk' = chunk ^ ((row >> 2) & 3):
 // fragment reads (16 lanes = 16 consecutive rows, one chunk) and staging writes (consecutive rows, whole rows) stay
 // conflict-free, and the tile takes 36 KB instead of 46 KB of LDS -> FOUR workgroups per CU instead of three.
@@ -364,9 +365,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         for (int kt = 0; kt < nk; ++kt) {
             if constexpr (!(DBG & 4)) { if (kt + 1 < nk) load_tile(kt + 1, st0); }
             if constexpr (!(DBG & 16)) compute(0);
-            __syncthreads();
+            if constexpr (!(DBG & 32)) __syncthreads();
             if constexpr (!(DBG & 8)) { if (kt + 1 < nk) store_tile(st0, 0); }
-            __syncthreads();
+            if constexpr (!(DBG & 32)) __syncthreads();
         }
     }
 
@@ -733,6 +734,10 @@ int launch_x3(X3Args p, hipStream_t s) {
             case 13: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 13>; break;
             case 16: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 16>; break;
             case 28: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 28>; break;
+            case 32: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 32>; break;
+            case 34: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 34>; break;
+            case 36: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 36>; break;
+            case 33: kern = conv_x3_kernel<BM, BN, AP, DB, 0, 33>; break;
             default: break;
         }
     }
