@@ -339,7 +339,10 @@ def test_g15_first_order_maml_50shot(golden_dir):
     outer = O.adam_init(params)
     mem = {"first": True}
     np.random.seed(10)
-    for it in range(2):
+    # the second episode (MAML_update undo + final bookkeeping) doubles the 2 minutes this fp64 test takes on 8 CPU threads: it runs
+    # with MFT_SLOW_TESTS=1; the default CPU run pins the first episode + outer step, the GPU suite runs both episodes (fp32 golden)
+    n_it = 2 if os.environ.get("MFT_SLOW_TESTS", "0") == "1" else 1
+    for it in range(n_it):
         x = synthetic.train_episode(251 + it, 5, 50, 16, 84).to(dt)
         for p in params:
             p.requires_grad_(True)
@@ -355,9 +358,10 @@ def test_g15_first_order_maml_50shot(golden_dir):
         assert abs(float(sd["feature.trunk.7.C2.weight"].norm()) - float(g["c2n" + s])) < 1e-6
         assert abs(float(sd["feature.trunk.0.weight"].norm()) - float(g["stemn" + s])) < 1e-7
         assert abs(float(mem["feature3"]["trunk.7.C2.weight"].norm()) - float(g["f3_c2n" + s])) < 1e-6
-    O.maml_update(sd, mem["feature2"], mem["feature3"])
-    np.testing.assert_allclose(sd["feature.trunk.7.C2.weight"][:2, :4, 1, 1].numpy(), g["c2_slice_final_" + tag], atol=1e-7)
-    assert np.array_equal(np.random.permutation(7), g["next_perm_" + tag])
+    if n_it == 2:
+        O.maml_update(sd, mem["feature2"], mem["feature3"])
+        np.testing.assert_allclose(sd["feature.trunk.7.C2.weight"][:2, :4, 1, 1].numpy(), g["c2_slice_final_" + tag], atol=1e-7)
+        assert np.array_equal(np.random.permutation(7), g["next_perm_" + tag])
 
 
 def test_g16_gnnnet50_loss_and_grads(golden_dir):
