@@ -236,3 +236,26 @@ def test_finetune_50_and_train_50_mirror_surface():
     assert list(inspect.signature(train_50.train).parameters) == ["base_loader", "model", "optimization", "start_epoch", "stop_epoch", "params"]
     m = gnnnet_copy.GnnNet(lambda: __import__("meta_fine_tuning_amd").backbone.ResNet10(), n_way=5, n_support=50)
     assert m.n_support == 25 and m.support_label.shape == (1, 130, 5) and hasattr(m, "train_loop50") and hasattr(m, "train_loop_finetune50")
+
+
+def test_bench_helpers_and_pmc_provenance(tmp_path, monkeypatch):
+    """bench.py's host-side helpers: the algorithmic FLOP count of SURVEY.md §8(d), and the rule that `roofline.traffic` is only
+    quoted from a PMC pass measured on byte-identical kernel source (profiles/pmc_traffic.json carries commit + source hash)."""
+    import json
+    import bench
+    # C2: P = 2500 image passes, 100-image final pass, GNN (15, 30): 1.0228 TFLOP per episode at 84x84 (SURVEY.md §8d: "1.02")
+    fl = bench.episode_flops(5, 5, 15, 19, 5)
+    assert abs(fl / 1e12 - 1.0228) < 2e-3
+    assert bench.episode_flops(5, 20, 15, 19, 5) > 3.9e12 and bench.episode_flops(5, 50, 15, 19, 5) > 9.9e12
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16
+    # the committed PMC record must belong to the committed kernel source (else bench reports traffic = null)
+    with open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")) as f:
+        rec = json.load(f)
+    assert rec["kernel_source_sha16"] == sha, "profiles/pmc_traffic.json was measured on different kernel source: re-run tools/final_profiles.sh"
+    t = bench.pmc_traffic(rec["episodes_per_step"])
+    assert t is not None and 1.0 <= t["mb_per_launch"] / t["algorithmic_mb_per_launch"] < 1.1
+    assert bench.pmc_traffic(rec["episodes_per_step"] + 1) is None
+    # a record with a foreign hash is refused
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
+    assert bench.pmc_traffic(rec["episodes_per_step"]) is None
