@@ -52,6 +52,7 @@ int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the oth
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
 int g_wgrad_pol = 7;          // w/m/v cache policy: bit 0 nontemporal loads, bit 1 nontemporal stores; bit 2 (wgrad_adam_rows_kernel):
                               // hardware v_rcp_f32 / v_sqrt_f32 + packed fp32 moment updates (mft_debug_set_conv_tile(9000 + pol))
+int g_wgrad_trim = 1;         // 1: no matrix instructions for the zero rows beyond rows_per_group (mft_debug_set_conv_tile(9600/9601))
 int g_wgrad_rows = 1;         // 1: <= 64 reduction rows use the 32 x 128 stream-shaped kernel (mft_debug_set_conv_tile(9500/9501))
 int g_wgrad_early = 1;        // 1: issue the tile's w/m/v loads before the reduction (mft_debug_set_conv_tile(5000/5001))
 int g_wgrad_min_lds_kb = 0;   // experiment: pad the fused wgrad+Adam workgroup's LDS to cap its occupancy (4000 + KB)
@@ -316,6 +317,7 @@ struct WgradArgs {
     int chunk_rows, chunks;
     float* ws;
     int ws_inv_ow;       // wgrad_adam_rows_kernel: ceil(65536 / OW) (chunk_rows then holds ceil(65536 / (OH*OW)))
+    int mma_rows;        // wgrad_adam_rows_kernel: reduction rows that get matrix instructions (rows_per_group, or 64 = the padded form)
 };
 
 // dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
@@ -618,9 +620,14 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float a = As[(2 * t + h) * BM + r];
-                const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                // rows beyond the group's (45 of 64 in the inner loop) are zeros: skipping their MFMAs changes no bit of the sum
+                // and saves 9 of 32 matrix instructions -- the launch is power-limited together with the trunk stream
+                if (32 * half + 2 * t < p.mma_rows) {            // wave-uniform
+                    const float a = As[(2 * t + h) * BM + r];
+                    const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
+                    if constexpr (POL & 8) acc[t] += a + b;      // measurement aid (power / time without the matrix work)
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -634,7 +641,9 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
-        if (POL & 4) {
+        if constexpr ((POL & 16) != 0) {                         // measurement aid: no Adam arithmetic, the stream only
+            mm[u] += ge; vv[u] += ge; ww[u] += ge;
+        } else if (POL & 4) {
             // hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences, and the moment updates as
             // packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32): the epilogue's VALU work competes with the co-running trunk
             // convolutions for issue slots (A/B in DESIGN.md: +2 % end to end)
@@ -772,6 +781,133 @@ __global__ __launch_bounds__(256) void wgrad_adam_walk_kernel(WgradArgs p) {
     }
 }
 
+
+// Output-channel walk (mft_debug_set_conv_tile(9505)): one workgroup owns one K tile (tap, 128 input channels) of an episode and
+// walks the Cout / 32 output-channel tiles.  The tile's im2col rows -- 80 % of the operand bytes a tile of wgrad_adam_rows_kernel
+// requests from L2, re-read there by every one of the 16 output-channel tiles -- are fetched and parked in LDS ONCE per walk; only
+// the dY slice (<= 64 x 32 floats) changes from tile to tile and is requested one tile ahead together with the next w/m/v.  Per
+// tile the reduction order, the gradient and Adam's arithmetic are those of wgrad_adam_rows_kernel (bit-identical results); the
+// DRAM access pattern is the same as well (the 36 workgroups of an episode step through the output channels side by side, so
+// together they still cover whole 18 KB weight rows).  Why: the launch runs at the package power limit beside the trunk stream
+//  -- operand traffic and LDS staging it does not issue are joules the stream gets back as clock.
+template <int POL>
+__global__ __launch_bounds__(256) void wgrad_adam_cowalk_kernel(WgradArgs p) {
+    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4;
+    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
+    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RP = p.chunks;              // reduction rows held in LDS: 48 or 64 (>= rows_per_group)
+    float* Bs = smem;                     // [RP][BLD] im2col rows of this K tile, resident for the whole walk
+    float* As = smem + RP * BLD;          // [RP][BM]  dY rows of the current output-channel tile
+    float* Gs = As;                       // [32][GLD] gradient tile (aliases As: separated by barriers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    const int tci = blockIdx.x % p.tiles_ci, khkw = blockIdx.x / p.tiles_ci;
+    const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+    const int ci0 = tci * BN;
+    const int ohw = p.OH * p.OW;
+    const int rows = p.rows_per_group;
+    const long long row0 = (long long)g * rows;
+    const long long img0 = (long long)g * p.imgs_per_group;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+    {
+        const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0 + bcol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = brow + 8 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < rows) {
+                const int img = (m * p.chunk_rows) >> 16, rem = m - img * ohw;
+                const int oh = (rem * p.ws_inv_ow) >> 16, ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) v = *(const f32x4*)(in_g + ((img * p.H + ih) * p.W + iw) * p.ldi);
+            }
+            if (m < RP) *(f32x4*)(Bs + m * BLD + bcol) = v;
+        }
+    }
+    auto load_a = [&](int tco, f32x4* A_) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = arow + 32 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + tco * BM + acol);
+            A_[j] = v;
+        }
+    };
+    const int q = tid & 31, rr = tid >> 5;
+    const long long gbase = (long long)g * p.dwgs + (long long)rr * p.Kpad + khkw * p.Cin + ci0 + 4 * q;
+    auto load_wmv = [&](int tco, f32x4* M_, f32x4* V_, f32x4* W_) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long gi = gbase + (long long)(tco * BM + 8 * u) * p.Kpad;
+            M_[u] = ldp((const f32x4*)(p.m + gi));
+            V_[u] = ldp((const f32x4*)(p.v + gi));
+            W_[u] = ldp((const f32x4*)(p.w + gi));
+        }
+    };
+    f32x4 va[2], na[2], cm[4], cv[4], cw[4], nm[4], nv[4], nw[4];
+    load_a(0, va);
+    load_wmv(0, cm, cv, cw);
+    const float step_size = p.hyper ? p.hyper[0] : p.step_size;
+    const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
+    for (int tco = 0; tco < p.tiles_co; ++tco) {
+        const int tn = tco + 1 < p.tiles_co ? tco + 1 : tco;
+        load_a(tn, na);                                   // the next tile's requests go out first; this tile's are a walk-step old
+        load_wmv(tn, nm, nv, nw);
+        if (tco) __syncthreads();                         // the previous tile's gradient reads are done (Gs aliases As)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (arow + 32 * j < RP) *(f32x4*)(As + (arow + 32 * j) * BM + acol) = va[j];
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (32 * half + 2 * t < p.mma_rows) {         // wave-uniform; rows beyond the group's are zeros
+                    const float a = As[(32 * half + 2 * t + h) * BM + r];
+                    const float b = Bs[(32 * half + 2 * t + h) * BLD + wave * 32 + r];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+        __syncthreads();                                  // every wave has read its dY fragments
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long gi = gbase + (long long)(tco * BM + 8 * u) * p.Kpad;
+            const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
+            if (POL & 4) {
+                const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
+                cm[u] = p.b1 * cm[u] + c1 * ge;
+                cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
+                f32x4 den;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
+                cw[u] -= step_size * (cm[u] * den);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cm[u][e] = p.b1 * cm[u][e] + (1.f - p.b1) * ge[e];
+                    cv[u][e] = p.b2 * cv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
+                    cw[u][e] -= step_size * (cm[u][e] / (sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps));
+                }
+            }
+            stp(cm[u], (f32x4*)(p.m + gi));
+            stp(cv[u], (f32x4*)(p.v + gi));
+            stp(cw[u], (f32x4*)(p.w + gi));
+            if (p.dw) *(f32x4*)(p.dw + gi) = ge;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cm[u] = nm[u]; cv[u] = nv[u]; cw[u] = nw[u]; }
+        va[0] = na[0]; va[1] = na[1];
+    }
+}
+
 int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     WgradArgs p = a;
     p.tiles_ci = a.Cin / 128;
@@ -780,6 +916,17 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
     p.chunks = g_wgrad_rows == 2 ? 2 : 1;
     p.chunk_rows = (65536 + a.OH * a.OW - 1) / (a.OH * a.OW);
     p.ws_inv_ow = (65536 + a.OW - 1) / a.OW;
+    p.mma_rows = g_wgrad_trim ? a.rows_per_group : 64;
+    if (g_wgrad_rows == 5 && p.tiles_ci * taps >= 16) {      // (a 1x1 layer has too few K tiles to fill the CUs with walkers)
+        // rows resident in LDS: 48 when the group has <= 48 reduction rows (the inner loop's 45): 47.6 KB = three workgroups per CU
+        const int RP = a.rows_per_group <= 48 ? 48 : 64;
+        const int lds_co = (RP * (128 + 32) + (RP * 32 > 32 * (128 + 4) ? RP * 32 : 32 * (128 + 4))) * 4;
+        p.chunks = RP;
+        dim3 grid_co(p.tiles_ci * taps, groups, 1);
+        if (g_wgrad_pol == 3) hipLaunchKernelGGL(wgrad_adam_cowalk_kernel<3>, grid_co, dim3(256), lds_co, s, p);
+        else hipLaunchKernelGGL(wgrad_adam_cowalk_kernel<7>, grid_co, dim3(256), lds_co, s, p);
+        return mft_launch_status();
+    }
     if (g_wgrad_rows == 4) {
         constexpr int lds_walk = (64 * 32 + 32 * (128 + 32) + 32 * (128 + 4)) * 4;      // 45.6 KB
         hipLaunchKernelGGL(wgrad_adam_walk_kernel<7>, dim3(p.tiles_co, groups, 1), dim3(256), lds_walk, s, p);
@@ -787,6 +934,12 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
     }
     dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
     if (g_wgrad_pol == 7) hipLaunchKernelGGL(wgrad_adam_rows_kernel<7>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 15) hipLaunchKernelGGL(wgrad_adam_rows_kernel<15>, grid, dim3(256), lds, s, p);     // timing / power aids
+    else if (g_wgrad_pol == 23) hipLaunchKernelGGL(wgrad_adam_rows_kernel<23>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 31) hipLaunchKernelGGL(wgrad_adam_rows_kernel<31>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 6) hipLaunchKernelGGL(wgrad_adam_rows_kernel<6>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 5) hipLaunchKernelGGL(wgrad_adam_rows_kernel<5>, grid, dim3(256), lds, s, p);
+    else if (g_wgrad_pol == 4) hipLaunchKernelGGL(wgrad_adam_rows_kernel<4>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 3) hipLaunchKernelGGL(wgrad_adam_rows_kernel<3>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 2) hipLaunchKernelGGL(wgrad_adam_rows_kernel<2>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 1) hipLaunchKernelGGL(wgrad_adam_rows_kernel<1>, grid, dim3(256), lds, s, p);
@@ -927,7 +1080,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 9500) g_wgrad_rows = tile - 9500;
+    if (tile >= 9600) g_wgrad_trim = tile - 9600;
+    else if (tile >= 9500) g_wgrad_rows = tile - 9500;
     else if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
     else if (tile >= 9000) g_wgrad_pol = tile - 9000;
     else if (tile >= 8000) mft_skinny_set_x3(tile - 8000);
@@ -947,7 +1101,7 @@ extern "C" int mft_debug_set_x3_tile(int t);
 // Every tuning knob back to its default (tests call this from an always-run fixture: a failed assert between a set and its
 // hand-written restore must not leave later tests on a different kernel variant).
 extern "C" int mft_debug_reset(void) {
-    g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
+    g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
     mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(70); mft_debug_set_x3_tile(80); mft_debug_set_x3_tile(100); mft_debug_set_x3_tile(200);

@@ -259,3 +259,22 @@ def test_bench_helpers_and_pmc_provenance(tmp_path, monkeypatch):
     # a record with a foreign hash is refused
     monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
     assert bench.pmc_traffic(rec["episodes_per_step"]) is None
+    # the power sampler reads hwmon files: fake one GPU under load and one idle
+    import time
+    ps = bench.PowerSampler()
+    for i, (uw, hz) in enumerate(((1378e6, 2140e6), (95e6, 132e6))):
+        d = tmp_path / ("hw%d" % i)
+        d.mkdir()
+        (d / "power1_input").write_text("%d\n" % uw)
+        (d / "freq1_input").write_text("%d\n" % hz)
+        (d / "power1_cap").write_text("1400000000\n")
+    ps.cards = [(str(tmp_path / "hw1" / "power1_input"), str(tmp_path / "hw1" / "freq1_input"), str(tmp_path / "hw1" / "power1_cap")),
+                (str(tmp_path / "hw0" / "power1_input"), str(tmp_path / "hw0" / "freq1_input"), str(tmp_path / "hw0" / "power1_cap"))]
+    ps.start()
+    time.sleep(0.2)
+    r = ps.stop()
+    assert r["socket_w_median"] == 1378 and r["shader_mhz_median"] == 2140 and r["power_cap_w"] == 1400 and r["samples"] >= 2
+    empty = bench.PowerSampler()
+    empty.cards = []
+    empty.start()
+    assert empty.stop() is None

@@ -682,7 +682,8 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
     xg, dyg = nhwc(x).to(DEV), nhwc(dy).to(DEV)
     wpk = torch.stack([ops.pack_conv_weight(w0[g].to(DEV)) for g in range(G)])
     res = {}
-    for knobs, tag in (((9500, 9003), "tile"), ((9501, 9003), "rows_exact"), ((9501, 9007), "rows_fast")):
+    for knobs, tag in (((9500, 9003), "tile"), ((9501, 9003), "rows_exact"), ((9501, 9007), "rows_fast"), ((9505, 9003), "cowalk_exact"),
+                       ((9505, 9007), "cowalk_fast"), ((9501, 9007, 9600), "rows_fast_padded")):
         lib.mft_debug_reset()
         for kn in knobs:
             lib.mft_debug_set_conv_tile(kn)
@@ -692,6 +693,10 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
     lib.mft_debug_reset()
     for a, b in zip(res["tile"], res["rows_exact"]):
         assert torch.equal(a, b), name
+    # the output-channel walk (one workgroup per K tile, im2col rows resident in LDS) and the padded matrix loop change no bit
+    for other, base in (("cowalk_exact", "rows_exact"), ("cowalk_fast", "rows_fast"), ("rows_fast_padded", "rows_fast")):
+        for a, b in zip(res[other], res[base]):
+            assert torch.equal(a, b), (name, other)
     (wf, mf, vf), (we, me, ve) = res["rows_fast"], res["rows_exact"]
     # packed multiply-add contraction: a couple of ulps of the LARGER addend (relative error is unbounded where b1*m and (1-b1)*g cancel)
     assert float((mf - me).abs().max()) <= 4e-7 * float(me.abs().max())

@@ -36,4 +36,8 @@ for NS in 20 50; do
   python3 tools/pmc_mfma_util.py $O/pmc_gnn$NS 8 > $O/${TAG}_gnn_pmc_mfma_util_${NS}shot.txt
 done
 find $O -name "*.csv" -size +1M -delete
+# power / clock: the step runs at the package power limit (hwmon sampling; no privileges needed)
+python3 tools/power_probe.py 128 5 2>&1 | grep -v amdgpu.ids > $O/${TAG}_power_probe.txt
+python3 tools/power_breakdown.py 128 3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_power_breakdown.txt
+tail -7 $O/${TAG}_power_probe.txt
 ls $O

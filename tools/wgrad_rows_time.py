@@ -20,7 +20,7 @@ for name, Cin, Cout, k, stride, pad, H in shapes:
     K = k * k * Cin
     w0 = torch.randn(E, Cout, K, device=dev, generator=g) * 0.02
     res = {}
-    for knob, tag in ((9501, "rows 32x128"), (9504, "rows walking"), (9500, "tile 64x64")):
+    for knob, tag in ((9501, "rows 32x128"), (9504, "rows walking"), (9505, "rows co-walk"), (9500, "tile 64x64")):
         lib.mft_debug_set_conv_tile(knob)
         w, m, v = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
         ops.conv2d_wgrad_adam(x, dy, w, m, v, Cout, k, k, stride, pad, 1, 5)
@@ -34,5 +34,6 @@ for name, Cin, Cout, k, stride, pad, H in shapes:
         us = a.elapsed_time(b) * 100
         print("%-18s %-12s %8.1f us  %.2f TB/s" % (name, tag, us, 24.0 * w.numel() / us / 1e6))
     same = all(torch.equal(p, q) for p, q in zip(res["rows 32x128"], res["rows walking"]))
-    print("%-18s bit-identical w/m/v after step 1: %s" % (name, same))
+    same2 = all(torch.equal(p, q) for p, q in zip(res["rows 32x128"], res["rows co-walk"]))
+    print("%-18s bit-identical w/m/v after step 1: walking %s, co-walk %s" % (name, same, same2))
 lib.mft_debug_reset()
