@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a wedged rendezvous or child process must fail its test, not hang the run (pytest-timeout, when installed; the slowest test,
+    # an fp64 oracle pass over a 50-shot meta-training episode, takes 2-3 minutes on 8 CPU threads)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = float(os.environ.get("MFT_TEST_TIMEOUT", "1200"))
 
 
 @pytest.fixture(scope="session")
