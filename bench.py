@@ -264,7 +264,7 @@ def bench_metatrain(args, rank, world, dev, dist):
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -518,15 +518,16 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     power = power.stop() if power is not None else None
+    cdev = "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev        # gloo (test hook) gathers host tensors
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     acc = torch.cat(accs).argmax(2).cpu().numpy() == y_query[None]
     acc_ep = acc.mean(1) * 100.0
     if dist is not None:
-        gathered = [torch.zeros(len(acc_ep), device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor(acc_ep, device=dev, dtype=torch.float64))
+        gathered = [torch.zeros(len(acc_ep), device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(acc_ep, device=cdev, dtype=torch.float64))
         acc_ep = torch.cat(gathered).cpu().numpy()
 
     # ---- rooflines: one more identical batch (same two-stream pipeline) with an event pair around every launch of the

@@ -277,3 +277,30 @@ def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
         d = np.abs(named[k].detach().cpu().numpy() - p0[k])
         # two Adam steps of <= lr = 1e-3 each; identical up to summation-order rounding on near-zero gradients
         assert (d < 2e-5).mean() > 0.995 and d.max() <= 2.1e-3, (k, d.max(), (d < 2e-5).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["finetune", "metatrain"])
+def test_bench_two_ranks_one_json_line(workload):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU; here both ranks on one device over
+    gloo, the MFT_BENCH_ONE_DEVICE hook): barrier + device synchronisation around the timed steps, MAX over ranks, rank 0 prints
+    ONE JSON line whose value is the whole-job rate over both ranks."""
+    import json
+    env = dict(os.environ, MFT_BENCH_ONE_DEVICE="1", MFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", workload]
+    if workload == "finetune":
+        cmd += ["--episodes-per-batch", "8", "--epochs", "1", "--gen-examples", "2", "--no-standalone", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "episodes/s" and d["value"] > 0 and d["vs_baseline"] is None
+    per_step = 2 * (8 if workload == "finetune" else 1)                  # episodes of BOTH ranks per step
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]
+    if workload == "finetune":
+        assert d["config"]["episodes_total"] == 2 * 8 * 2 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+        assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
