@@ -39,6 +39,7 @@ struct X3Args {
     unsigned in_plane_bytes;
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
     int rows_per_group;            // >= BM when stats_ws is set
+    int s1_rows;                   // conv_x3_s1_kernel: rows of the staged A image (BM + halo + one zero row per image-row boundary)
 };
 
 constexpr int X3_RS = 40;          // bf16 per LDS row: 32 data + 8 pad (80 B)
@@ -651,6 +652,248 @@ __global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: shared taps
+// The implicit-GEMM kernel above fetches, splits and stores the A tile of every tap separately, although the three kw taps of one
+// kernel row read the SAME pixels shifted by one: with OW == W the flat output index m is also the flat input pixel index, and tap
+// (kh, kw) of output m needs pixel m + (kh-1) W + (kw-1) -- or zero where ow + kw - 1 leaves the image row.  This form stages, per
+// (kh, 32-channel slice), ONE image of the BM pixels m0 .. m0+BM-1 shifted by (kh-1) rows, plus one halo pixel at each end and one
+// all-zero row at every image-row boundary inside the tile (LDS row of pixel m: (m - m0) + 1 + number of boundaries before it), and
+// the three kw taps read their fragments from it at row offsets -1 / 0 / +1: the zero rows ARE the horizontal padding, so no
+// per-lane masking is needed.  Global loads, bf16x3 splits and LDS stores of the A operand drop to a third; the weights (B) are
+// staged per tap as before.  K is walked (kh, ci, kw) instead of (kh, kw, ci): the same products, summed in another order.
+// The launch is power-limited: the saving is in joules first, in issue slots second.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PA = BM / 32, PB = BN / 64;
+    constexpr int RS = X3_RS;
+    constexpr int B_PLANE = BN * RS;
+    const int A_PLANE = p.s1_rows * RS;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* As = smem;                       // [3][s1_rows][RS]
+    unsigned short* Bs = smem + 3 * A_PLANE;         // [3][BN][RS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int tile_id = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7;
+        const int xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = xcd * q + (xcd < rmd ? xcd : rmd) + slot;
+    }
+    const int nt = tile_id % p.tiles_n;
+    const int mt = tile_id / p.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int W = p.W, H = p.H;
+    const int fr0 = m0 / W;                          // flat image-row index (img * H + oh) of the tile's first pixel
+
+    const int g_id = tid >> 5, g_rr = (tid >> 3) & 3;
+    const int lrow = p.row_swz ? g_rr * 4 + (g_id & 3) + 16 * (g_id >> 2) : tid >> 3;
+    const int c4 = (tid & 7) * 4;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
+    int a_off[PA], a_oh[PA], a_lds[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int t = lrow + 32 * j, m = m0 + t;
+        const int fr = m / W;
+        a_ok[j] = m < p.M;
+        a_oh[j] = fr - (fr / H) * H;
+        a_off[j] = (m * p.ldi + c4) * 4;
+        a_lds[j] = (t + 1 + fr - fr0) * RS + c4;
+    }
+    // halo pixels m0 - 1 and m0 + BM (threads 0-7 / 8-15): real only when they lie in the same image row as their neighbour
+    const int hside = (tid >> 3) & 1;
+    const int mh = hside ? m0 + BM : m0 - 1;
+    const int frh = (mh > 0 ? mh : 0) / W;
+    const bool h_ok = tid < 16 && (hside ? (mh < p.M && mh - frh * W != 0) : (m0 > 0 && m0 - fr0 * W != 0));
+    const int h_oh = frh - (frh / H) * H;
+    const int h_off = (mh * p.ldi + c4) * 4;
+    const int h_lds = (hside ? BM + 1 + (m0 + BM - 1) / W - fr0 : 0) * RS + c4;
+
+    const int bseg = tid & 3;
+    const int brow = p.row_swz ? ((tid >> 2) & 3) * 4 + ((tid >> 4) & 3) + 16 * (tid >> 6) : tid >> 2;
+    int b_off[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
+    const int plane_bytes = (int)(p.plane * 2);
+
+    // fragment rows of this lane inside the staged image
+    int fa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int t = wm * (BM / 2) + i * 32 + r;
+        fa[i] = (t + 1 + (m0 + t) / W - fr0) * RS;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    struct Stage {
+        f32x4 ra[PA];
+        f32x4 rh;
+        u32x4 rb[PB][3];
+    };
+    Stage st;
+    const int n_ci = p.Cin / 32;
+    const int n_ms = 3 * n_ci;                       // macro steps: (kh, 32-channel slice), three kw taps each
+    auto load_a = [&](int ms, Stage& S) {
+        const int kh = ms / n_ci, ci0 = (ms - kh * n_ci) * 32;
+        const int shift = ((kh - 1) * W * p.ldi + ci0) * 4;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const bool ok = a_ok[j] && (unsigned)(a_oh[j] + kh - 1) < (unsigned)H;
+            S.ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, ok ? (unsigned)(a_off[j] + shift) : 0x80000000u, 0, 0));
+        }
+        const bool okh = h_ok && (unsigned)(h_oh + kh - 1) < (unsigned)H;
+        S.rh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, okh ? (unsigned)(h_off + shift) : 0x80000000u, 0, 0));
+    };
+    auto load_b = [&](int ms, int kw, Stage& S) {
+        const int kh = ms / n_ci, ci0 = (ms - kh * n_ci) * 32;
+        const int k0 = (kh * 3 + kw) * p.Cin + ci0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                S.rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
+    };
+    auto put_a = [&](const f32x4 v, int off) {
+        u32x2 p1, p2, p3;
+        split4(v, p1, p2, p3);
+        *(u32x2*)(As + off) = p1;
+        *(u32x2*)(As + A_PLANE + off) = p2;
+        *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+    };
+    auto store_a = [&](const Stage& S) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) put_a(S.ra[j], a_lds[j]);
+        if (tid < 16) put_a(S.rh, h_lds);
+    };
+    auto store_b = [&](const Stage& S) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * RS + bseg * 8) = S.rb[j][pl];
+    };
+    auto compute = [&](int kw) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // the zero rows (image-row boundaries, halo rows that fall outside their image row) are written once and never touched again
+    for (int i = tid; i < 3 * A_PLANE / 8; i += 256) ((u32x4*)As)[i] = (u32x4){0u, 0u, 0u, 0u};
+    load_a(0, st);
+    load_b(0, 0, st);
+    __syncthreads();
+    store_a(st);
+    store_b(st);
+    __syncthreads();
+    for (int ms = 0; ms < n_ms; ++ms) {
+        const int msn = ms + 1 < n_ms ? ms + 1 : ms;      // branch-free body: the last image is simply requested twice
+        load_b(ms, 1, st);
+        compute(0);
+        __syncthreads();
+        store_b(st);
+        __syncthreads();
+        load_b(ms, 2, st);
+        compute(1);
+        __syncthreads();
+        store_b(st);
+        __syncthreads();
+        load_a(msn, st);
+        load_b(msn, 0, st);
+        compute(2);
+        __syncthreads();
+        store_a(st);
+        store_b(st);
+        __syncthreads();
+    }
+
+    // epilogue (as conv_x3_kernel): C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + wm * (BM / 2) + i * 32 + row;
+                if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
+            }
+        }
+    if (p.stats_ws != nullptr) {
+        static_assert(TN == 1 || TN == 2, "stats epilogue");
+        const int split = (m0 / p.rows_per_group + 1) * p.rows_per_group;
+        float* sred = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[i][j][e];
+                    if (m < p.M) {
+                        if (m < split) { a1 += v; a2 += v * v; }
+                        else { b1 += v; b2 += v * v; }
+                    }
+                }
+            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+            b1 += __shfl_xor(b1, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+            if (h == 0) {
+                float* o = sred + ((((wm * 2 + wn) * TN + j) * 32 + r) << 2);
+                o[0] = a1; o[1] = a2; o[2] = b1; o[3] = b2;
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && h == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* o0 = sred + ((((0 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const float* o1 = sred + ((((1 * 2 + wn) * TN + j) * 32 + r) << 2);
+                const int n = n0 + wn * (BN / 2) + j * 32 + r;
+                float* w0 = p.stats_ws + (((long long)mt * 2 + 0) * p.Cout + n) * 2;
+                float* w1 = p.stats_ws + (((long long)mt * 2 + 1) * p.Cout + n) * 2;
+                w0[0] = o0[0] + o1[0]; w0[1] = o0[1] + o1[1];
+                w1[0] = o0[2] + o1[2]; w1[1] = o0[3] + o1[3];
+            }
+        }
+    }
+}
+
 // mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
 // (n_t, mean_t = s1/n_t, M2_t = s2 - s1^2/n_t) are merged in tile order with Chan's update.
 __global__ void x3_stats_finalize_kernel(const float* __restrict__ ws, int C, int M, int R, int BM, float eps,
@@ -746,6 +989,21 @@ int launch_x3(X3Args p, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    return mft_launch_status();
+}
+
+int g_x3_s1 = 1;           // 3x3 / stride 1 / pad 1 layers: A image staged once per (kh, channel slice) for its three kw taps
+                           // (conv_x3_s1_kernel; mft_debug_set_x3_tile(90/91))
+
+template <int BM, int BN>
+int launch_x3_s1(X3Args p, hipStream_t s) {
+    const int tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.Cout / BN;
+    p.xcd_swizzle = g_x3_xcd;
+    p.row_swz = g_x3_row_swz != 0;
+    p.s1_rows = BM + 2 + (BM - 1) / p.W + 1;
+    const size_t lds = (size_t)3 * (p.s1_rows + BN) * X3_RS * sizeof(unsigned short);
+    hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
     return mft_launch_status();
 }
 
@@ -964,6 +1222,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 extern "C" int mft_debug_set_x3_tile(int t) {
     if (t >= 200) g_x3_dbg = t - 200;
     else if (t >= 100) g_x3_min_lds_kb = t - 100;
+    else if (t >= 90) g_x3_s1 = t - 90;
     else if (t >= 80) g_x3_hoist = t - 80;
     else if (t >= 70) g_x3_pp = t - 70;
     else if (t >= 60) g_x3_db = t - 60;
@@ -1044,7 +1303,11 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.out = out + i0 * p.OH * p.OW * ldo;
         q.M = (int)(ni * p.OH * p.OW);
         q.in_bytes = (unsigned)(ni * img_bytes);
-        const int rc = (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
+        const bool s1 = g_x3_s1 && tile == 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !g_x3_db && !g_x3_pp && !g_x3_dbg &&
+                        g_x3_hoist == 0 && g_x3_row_swz != 2 && g_x3_min_lds_kb == 0 &&
+                        (size_t)3 * (128 + 2 + 127 / W + 1 + 64) * X3_RS * sizeof(unsigned short) <= 64 * 1024;
+        const int rc = s1 ? launch_x3_s1<128, 64>(q, s)
+                       : (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
                        : (tile == 3)                  ? launch_x3<64, 64, false, false>(q, s)
                        : g_x3_db                      ? launch_x3<128, 64, false, true>(q, s)
                        : (g_x3_pp && !g_x3_dbg)       ? launch_x3_pp<128, 64>(q, s)

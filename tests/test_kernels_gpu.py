@@ -344,7 +344,7 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
     scale = max(float(ref.abs().max()), 1.0)
     e32 = float((y32 - ref).abs().max())
     w3 = ops.split_weight_x3(wpk)
-    for patch_mode in (10, 12, 71, 81, 82, 42, 3):   # implicit-GEMM form, the opt-in LDS-patch form where it applies, the opt-in 512-thread
+    for patch_mode in (10, 90, 12, 71, 81, 82, 42, 3):   # default (shared-tap form on 3x3 / stride-1 layers), per-tap implicit-GEMM form, the opt-in LDS-patch form where it applies, the opt-in 512-thread
         _lib.lib().mft_debug_reset()                 # ping-pong form, the two pinned fragment-read schedules, the XOR-swizzled 36 KB LDS layout, 64x64 tiles
         _lib.lib().mft_debug_set_x3_tile(patch_mode)
         y3 = nchw(ops.conv2d_x3(xg, w3, Cout, k, k, stride, pad).cpu()).double()
@@ -352,6 +352,47 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
         assert e3 <= 2e-5 * scale, (name, patch_mode, e3)
         assert e3 <= 2.0 * e32 + 1e-7 * scale, (name, patch_mode, e3, e32)
     _lib.lib().mft_debug_reset()
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(7, 5, 5, 32, 64), (3, 13, 13, 64, 128), (1, 21, 21, 64, 64), (9, 7, 9, 96, 64), (2, 9, 4, 32, 64),
+                                            (130, 1, 1, 32, 64), (5, 3, 40, 64, 64), (4, 130, 2, 32, 64)])
+def test_conv2d_bf16x3_shared_tap_geometries(n, H, W, Cin, Cout):
+    """conv_x3_s1_kernel (3x3, stride 1, pad 1: one staged image per (kh, channel slice) serves the three kw taps; zero rows at the
+    image-row boundaries are the horizontal padding) on geometries that stress its row bookkeeping -- rows shorter and longer than a
+    128-pixel tile, non-square maps, many images per tile, a ragged last tile, 1x1 maps -- against float64 and against the per-tap
+    kernel (same products, other summation order), with and without the BatchNorm statistics epilogue."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    x = rnd((n, Cin, H, W), 61)
+    w = rnd((Cout, Cin, 3, 3), 62, scale=(2.0 / (9 * Cout)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xg = nhwc(x).to(DEV)
+    w3 = ops.split_weight_x3(ops.pack_conv_weight(w.to(DEV)))
+    scale = max(float(ref.abs().max()), 1.0)
+    outs = {}
+    for knob in (91, 90):
+        lib.mft_debug_reset()
+        lib.mft_debug_set_x3_tile(knob)
+        outs[knob] = nchw(ops.conv2d_x3(xg, w3, Cout, 3, 3, 1, 1).cpu()).double()
+        assert float((outs[knob] - ref).abs().max()) <= 2e-5 * scale, knob
+    lib.mft_debug_reset()
+    assert float((outs[91] - outs[90]).abs().max()) <= 4e-6 * scale
+    if Cin > 32 and H * W > 1:                      # with one channel slice both kernels walk K in the same order
+        assert not torch.equal(outs[91], outs[90])  # the shared-tap kernel really ran
+    # statistics epilogue: groups of ipg images with >= 128 rows each
+    ipg = max(1, -(-128 // (H * W)))
+    if n % ipg == 0:
+        groups = n // ipg
+        out = torch.empty(n, H, W, Cout, device=DEV)
+        nws = int(lib.mft_conv2d_x3_stats_ws_floats(n, H, W, Cout, 3, 3, 1, 1))
+        ws = torch.empty(max(nws, 1), device=DEV)
+        mean, rstd = torch.empty(groups, Cout, device=DEV), torch.empty(groups, Cout, device=DEV)
+        r = ops.conv2d_x3_bnstats(xg, w3, Cout, 3, 3, 1, 1, ipg, out, ws, mean, rstd)
+        if r is not None:
+            yr = ref.permute(0, 2, 3, 1).reshape(groups, -1, Cout)
+            assert float((mean.cpu().double() - yr.mean(1)).abs().max()) <= 1e-5 * scale
+            assert float((rstd.cpu().double() - 1.0 / (yr.var(1, unbiased=False) + 1e-5).sqrt()).abs().max()) <= 2e-4 * float(rstd.abs().max())
+            assert float((nchw(out.cpu()).double() - ref).abs().max()) <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("ipg", [5, 4, 1])
