@@ -95,6 +95,10 @@ phases.append(("idle", time.time(), time.time() + 1.5, 0))
 time.sleep(1.5)
 no_trunk()
 phase("last-block stream alone (20 steps)", lambda: e.inner_loop(tables[:20]))
+orig_wgrad = ops.conv2d_wgrad_adam
+ops.conv2d_wgrad_adam = lambda *a, **kw: None
+phase("  ... without weight-gradient + Adam", lambda: e.inner_loop(tables[:20]))
+ops.conv2d_wgrad_adam = orig_wgrad
 restore()
 phase("trunk alone (20 steps)", lambda: [e.trunk_step(i, k, 0) for i in idx_dev])
 phase("both: the inner loop (20 steps)", lambda: e.inner_loop(tables[:20]))
