@@ -8,8 +8,6 @@ HEAD=${3:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
 mkdir -p $O
-python3 bench.py > $O/${TAG}_bench_E128.json 2> $O/bench.err
-tail -1 $O/${TAG}_bench_E128.json | cut -c1-400
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-standalone --validate-episodes 0 > $O/kt_bench.log 2>&1
 tail -1 $O/kt_bench.log | cut -c1-300
 python3 tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/${TAG}_kernel_stats_E128_pipelined.txt
@@ -36,6 +34,9 @@ for NS in 20 50; do
   python3 tools/pmc_mfma_util.py $O/pmc_gnn$NS 8 > $O/${TAG}_gnn_pmc_mfma_util_${NS}shot.txt
 done
 find $O -name "*.csv" -size +1M -delete
+# the default bench line LAST: profiles/pmc_traffic.json now belongs to this kernel source, so roofline.traffic is filled in
+python3 bench.py > $O/${TAG}_bench_E128.json 2> $O/bench.err
+tail -1 $O/${TAG}_bench_E128.json | cut -c1-400
 # power / clock: the step runs at the package power limit (hwmon sampling; no privileges needed)
 python3 tools/power_probe.py 128 5 2>&1 | grep -v amdgpu.ids > $O/${TAG}_power_probe.txt
 python3 tools/power_breakdown.py 128 3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_power_breakdown.txt
