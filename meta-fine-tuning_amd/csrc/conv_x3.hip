@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
         const int fr = m / W;
         a_ok[j] = m < p.M;
         a_oh[j] = fr - (fr / H) * H;
-        a_off[j] = (m * p.ldi + c4) * 4;
+        a_off[j] = ((a_ok[j] ? m : 0) * p.ldi + c4) * 4;           // (rows beyond M are never requested; keep the product in range)
         a_lds[j] = (t + 1 + fr - fr0) * RS + c4;
     }
     // halo pixels m0 - 1 and m0 + BM (threads 0-7 / 8-15): real only when they lie in the same image row as their neighbour
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     const int frh = (mh > 0 ? mh : 0) / W;
     const bool h_ok = tid < 16 && (hside ? (mh < p.M && mh - frh * W != 0) : (m0 > 0 && m0 - fr0 * W != 0));
     const int h_oh = frh - (frh / H) * H;
-    const int h_off = (mh * p.ldi + c4) * 4;
+    const int h_off = ((h_ok ? mh : 0) * p.ldi + c4) * 4;
     const int h_lds = (hside ? BM + 1 + (m0 + BM - 1) / W - fr0 : 0) * RS + c4;
 
     const int bseg = tid & 3;
