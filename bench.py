@@ -553,9 +553,11 @@ def main():
                 "largest_shape": {"what": "trunk.7.C2 (512x512x3x3) x %d episodes" % E,
                                   "avg_launch_us": round(sum(t for t, _ in big) * 1e3 / len(big), 2),
                                   "achieved": round(big[0][1] * len(big) / (sum(t for t, _ in big) * 1e-3) / 1e9, 1)},
-                "practical_ceiling_note": "a pure 3-read/3-write Adam stream reaches 5.2-6.3 TB/s on this part depending on the "
-                                          "lease (stream_reference below is this lease's); in situ the step runs at the package "
-                                          "power limit with the shader clock throttled (see power)"}
+                "practical_ceiling_note": "a pure 3-read/3-write Adam stream reaches 4.9-6.4 TB/s on this part depending on WHERE "
+                                          "its three arrays live (tools/placement_scan.py); the engine picks the slabs' buffers by "
+                                          "measured rate (slab_placement), stream_reference.on_engine_slabs is that stream over the "
+                                          "engine's own slabs; in situ the step runs at the package power limit with the shader "
+                                          "clock throttled (see power)"}
         # the same kernel with the GPU to itself (no trunk stream beside it): what the overlap costs the HBM-bound launch
         try:
             if args.no_standalone:
@@ -601,6 +603,19 @@ def main():
                                       "frac_of_peak": round(ceil_gbs / PEAK_HBM_GBS, 4),
                                       "dominant_kernel_in_situ_vs_this": round(ach / ceil_gbs, 4)}
             del sw, sm, sv
+            # the same probe over the engine's OWN w / m / v slabs (their placement is chosen by measured stream rate,
+            # engine.AdaptState._place; the batch results are already on the host, so the slabs may be overwritten now)
+            ad = e.adapt
+            n_sl = ad.w.flat.numel() // 1024 * 1024
+            _L.lib().mft_stream_probe(ops._p(ad.w.flat), ops._p(ad.m.flat), ops._p(ad.v.flat), n_sl, st_())
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                _L.lib().mft_stream_probe(ops._p(ad.w.flat), ops._p(ad.m.flat), ops._p(ad.v.flat), n_sl, st_())
+            e1.record()
+            torch.cuda.synchronize()
+            slab_gbs = 24.0 * n_sl * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roof["stream_reference"]["on_engine_slabs"] = {"achieved": round(slab_gbs, 1), "dominant_kernel_in_situ_vs_this": round(ach / slab_gbs, 4)}
         except RuntimeError as ex:
             roof["stream_reference"] = {"error": str(ex)[:120]}
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
@@ -658,6 +673,7 @@ def main():
                                "achieved": round(value / world * 0.1122 * n_steps_ep, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(value / world * 0.1122 * n_steps_ep / PEAK_HBM_GBS, 4)},
             "power": power,
+            "slab_placement": e.adapt.placement,
             "roofline": roof,
             "roofline_mfma": roof_mfma,
             "roofline_mfma_x3": roof_x3,

@@ -27,11 +27,82 @@ class AdaptState:
 
     def __init__(self, E, device):
         self.E = E
-        self.w = Fn.LastBlockSlab(E, device)
-        self.g = Fn.LastBlockSlab(E, device)
-        self.m = Fn.LastBlockSlab(E, device)
-        self.v = Fn.LastBlockSlab(E, device)
+        self.placement = None
+        flats = self._place(E, device)
+        self.w = Fn.LastBlockSlab(E, device, flat=flats[0])
+        self.g = Fn.LastBlockSlab(E, device, flat=flats[3])
+        self.m = Fn.LastBlockSlab(E, device, flat=flats[1])
+        self.v = Fn.LastBlockSlab(E, device, flat=flats[2])
+        self.w_alt_flat = flats[4]          # second weight slab of the deferred final pass (FinetuneEngine._flip_buffers), placed as well
         self.step = 0
+
+    def _place(self, E, device):
+        """WHERE the w / m / v slabs live decides how fast they stream: the same 3-read / 3-write pass measures 4.9-6.3 TB/s over
+        different triples of separately allocated 1.9 GB buffers of ONE process, reproducibly per triple (tools/placement_scan.py:
+        typically the first ~10 GB a process allocates are the slow ones among themselves) -- and these slabs are 3/4 of the bytes
+        the inner loop moves.  So K candidate buffers are allocated, every triple is timed with the Adam-shaped probe
+        (mft_stream_probe, a few hundred milliseconds in all) and the fastest triple becomes (w, m, v); the gradient slab takes a
+        fourth, the rest go back to the allocator.  Placement does not touch any result.  MFT_SLAB_CANDIDATES=0 turns it off."""
+        total = E * Fn.ADAPT_NUMEL
+        K = int(os.environ.get("MFT_SLAB_CANDIDATES", "12"))
+        ballast_gb = min(float(os.environ.get("MFT_SLAB_BALLAST_GB", "12")), 6.4 * total * 4 / (1 << 30))
+        dev = torch.device(device)
+        if K >= 5 and dev.type == "cuda" and total * 4 >= (64 << 20):
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            budget = int(free_b * 0.4)
+            K = min(K, budget // (total * 4))
+            ballast_gb = min(ballast_gb, max(0.0, (budget - K * total * 4) / 2.0 / (1 << 30)))
+        if K < 5 or dev.type != "cuda" or total * 4 < (64 << 20):
+            return [None, None, None, None, None]
+        import itertools
+        with torch.cuda.device(dev):
+            # candidates in groups of four with throw-away ballast between the groups: consecutive allocations share a region of
+            # the address space, and regions of tens of GB differ (36 consecutive 1.9 GB buffers: triples of neighbours stream at
+            # 4.9-5.4 TB/s over the first ~32 GB, 5.7-6.4 over the next ~20 GB, 5.3 after that)
+            cands, ballast = [], []
+            for i in range(K):
+                if i and i % 4 == 0 and ballast_gb > 0:
+                    ballast.append(torch.empty(int(ballast_gb * (1 << 28)), device=dev))
+                cands.append(torch.empty(total, device=dev))
+            for c in cands:
+                c.zero_()
+            del ballast
+            n = total // 1024 * 1024
+            lib = ops._lib.lib()
+
+            def rate(t, reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    ops._lib.check(lib.mft_stream_probe(ops._p(cands[t[0]]), ops._p(cands[t[1]]), ops._p(cands[t[2]]), n,
+                                                        ops._stream()), "mft_stream_probe")
+                b.record()
+                b.synchronize()
+                return 24.0 * n * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+            triples = list(itertools.combinations(range(K), 3))
+            rate(triples[0], 2)                                        # clocks up
+            rates = {t: rate(t, 2) for t in triples}
+            # (w, m, v) and a second weight slab w' for the deferred final pass: the best pair of triples sharing (m, v)
+            def key(t):
+                return tuple(sorted(t))
+
+            best, best_score = None, -1.0
+            for m_, v_ in itertools.combinations(range(K), 2):
+                ws = sorted((rates[key((w_, m_, v_))], w_) for w_ in range(K) if w_ not in (m_, v_))
+                score = min(ws[-1][0], ws[-2][0])
+                if score > best_score:
+                    best, best_score = (ws[-1][1], m_, v_, ws[-2][1]), score
+            w_, m_, v_, w2_ = best
+            rest = [i for i in range(K) if i not in best]
+            self.placement = {"candidates": K, "chosen_gbs": round(rates[key((w_, m_, v_))], 1),
+                              "chosen_alt_gbs": round(rates[key((w2_, m_, v_))], 1), "best_gbs": round(max(rates.values()), 1),
+                              "worst_gbs": round(min(rates.values()), 1), "median_gbs": round(float(np.median(list(rates.values()))), 1),
+                              "first_three_allocations_gbs": round(rates[(0, 1, 2)], 1), "chosen": [w_, m_, v_, w2_]}
+            keep = [cands[w_], cands[m_], cands[v_], cands[rest[0]], cands[w2_]]
+            del cands
+            torch.cuda.empty_cache()          # the unused candidates and the ballast go back to the driver, not into torch's cache
+            return keep
 
     def reset(self, W):
         self.w.load_shared(W)
@@ -426,7 +497,7 @@ class FinetuneEngine:
         and adapted, so both live in two alternating buffers (m, v, g are only used inside the inner loop and stay single)."""
         if self._alt is None:
             self._alt = [(self.adapt.w, self.Xall),
-                         (Fn.LastBlockSlab(self.E, self.dev, zero=False), torch.empty_like(self.Xall))]
+                         (Fn.LastBlockSlab(self.E, self.dev, zero=False, flat=self.adapt.w_alt_flat), torch.empty_like(self.Xall))]
             self._final_done = [None, None]
             self._bi = 0
             self.arena_final = Fn.Arena(self.dev)

@@ -104,10 +104,14 @@ class LastBlockSlab:
            "bn1g": "trunk.7.BN1.weight", "bn1b": "trunk.7.BN1.bias", "bn2g": "trunk.7.BN2.weight",
            "bn2b": "trunk.7.BN2.bias", "bnsg": "trunk.7.BNshortcut.weight", "bnsb": "trunk.7.BNshortcut.bias"}
 
-    def __init__(self, E, device, zero=True):
+    def __init__(self, E, device, zero=True, flat=None):
         self.E = E
         total = E * ADAPT_NUMEL
-        self.flat = torch.zeros(total, device=device) if zero else torch.empty(total, device=device)
+        if flat is not None:                      # a buffer chosen by the caller (engine.AdaptState: placement by measured stream rate)
+            assert flat.numel() == total and flat.dtype == torch.float32 and flat.is_contiguous()
+            self.flat = flat.zero_() if zero else flat
+        else:
+            self.flat = torch.zeros(total, device=device) if zero else torch.empty(total, device=device)
         off = 0
         for name, n in self.ORDER:
             v = self.flat[off:off + E * n]

@@ -556,3 +556,26 @@ def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
         d_hip = np.abs(feat - p64)
         assert np.percentile(d_hip, 99) <= max(4.0 * np.percentile(d_ref, 99), 5e-3), (tag, np.percentile(d_hip, 99), np.percentile(d_ref, 99))
         e.close()
+
+
+def test_adam_slab_placement_changes_no_result(monkeypatch):
+    """engine.AdaptState._place picks the w / m / v (and second w) buffers among separately allocated candidates by the measured rate
+    of the Adam-shaped stream over them (where the slabs live decides how fast they stream; it cannot change a result): the scores
+    of a batch are bit-identical with the selection on and off, the report names four distinct candidates and its chosen triple is
+    not slower than the first three allocations."""
+    sd = synthetic.gnnnet_state_dict(seed=3)
+    eps = [synthetic.test_episode(70 + i, 5, 5, 15, 84, gen_examples=1) for i in range(6)]
+    perms = [[np.random.RandomState(40 + i).permutation(100)] for i in range(6)]
+    outs = {}
+    for k in ("12", "0"):
+        monkeypatch.setenv("MFT_SLAB_CANDIDATES", k)
+        e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=1, episodes_per_batch=6, device=DEV)
+        outs[k] = e.run_batch(eps, perms=perms).clone()
+        rep = e.adapt.placement
+        if k == "0":
+            assert rep is None
+        else:
+            assert rep["candidates"] >= 5 and len(set(rep["chosen"])) == 4
+            assert rep["chosen_gbs"] >= 0.98 * rep["first_three_allocations_gbs"] and rep["worst_gbs"] <= rep["chosen_gbs"] <= rep["best_gbs"]
+        e.close()
+    assert torch.equal(outs["12"], outs["0"])
