@@ -404,7 +404,8 @@ class SyntheticNovelLoader:
 
 
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
-             episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None):
+             episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None,
+             device_episodes=False):
     """The episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies (all ranks' episodes, in
     episode order, on every rank).
 
@@ -422,11 +423,16 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         ids = mine[c:c + episodes_per_batch]
         # the numpy generator of the synthetic episodes is the slow part of this loop (~1 s per 19-view episode): draw a batch's
         # episodes on a few host threads (each episode is a pure function of its seed)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(8, len(ids))) as ex:
-            host = list(ex.map(lambda i: synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples), ids))
-        eps = [[v.cuda() for v in ep] for ep in host]
-        del host
+        if device_episodes:
+            # the same synthetic distribution drawn with the device generator straight into HBM (a pure function of the seed as
+            # well; not the numpy episodes): 600 19-view episodes are 96 GB of views -- minutes of host time, seconds on the GPU
+            eps = [synthetic.test_episode_device(seed0 + i, "cuda", n_way, n_shot, n_query, size, gen_examples) for i in ids]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, len(ids))) as ex:
+                host = list(ex.map(lambda i: synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples), ids))
+            eps = [[v.cuda() for v in ep] for ep in host]
+            del host
         for ep in eps:
             assert torch.all(torch.eq(ep[0], ep[1]))                 # finetune.py:606
         rngs = cls = None
@@ -521,7 +527,7 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     print(params.freeze_backbone)                                    # finetune.py:591
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
-                    episodes_per_batch=episodes_per_batch)
+                    episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     return accs
