@@ -674,7 +674,7 @@ def main():
             "whole_path_hbm": {"algorithmic_gb_per_episode": round(0.1122 * n_steps_ep, 2),
                                "achieved": round(value / world * 0.1122 * n_steps_ep, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(value / world * 0.1122 * n_steps_ep / PEAK_HBM_GBS, 4)},
-            "power": power,
+            "power": power if power is None else dict(power, joules_per_episode=round(power["socket_w_median"] * dt / (E * args.steps), 2)),
             "slab_placement": e.adapt.placement,
             "roofline": roof,
             "roofline_mfma": roof_mfma,
