@@ -24,6 +24,7 @@ void mft_skinny_set_dgrad_slices(int n);
 void mft_skinny_set_tap(int v);
 void mft_skinny_set_x3(int v);
 void mft_skinny_set_nw(int v);
+void mft_skinny_set_lines(int v);
 int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
                               long long w_group_stride, hipStream_t s);
@@ -1080,7 +1081,8 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 }
 
 extern "C" int mft_debug_set_conv_tile(int tile) {
-    if (tile >= 9600) g_wgrad_trim = tile - 9600;
+    if (tile >= 9700) mft_skinny_set_lines(tile - 9700);
+    else if (tile >= 9600) g_wgrad_trim = tile - 9600;
     else if (tile >= 9500) g_wgrad_rows = tile - 9500;
     else if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
     else if (tile >= 9000) g_wgrad_pol = tile - 9000;
@@ -1102,7 +1104,7 @@ extern "C" int mft_debug_set_x3_tile(int t);
 // hand-written restore must not leave later tests on a different kernel variant).
 extern "C" int mft_debug_reset(void) {
     g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
-    mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
+    mft_skinny_set_lines(1); mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(70); mft_debug_set_x3_tile(80); mft_debug_set_x3_tile(91); mft_debug_set_x3_tile(100); mft_debug_set_x3_tile(200);
     return 0;

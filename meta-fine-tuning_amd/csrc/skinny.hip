@@ -195,6 +195,41 @@ __device__ __forceinline__ void sk_split_a(const f32x4v w0, const f32x4v w1, bf1
     }
 }
 
+// Full-line weight loads.  In MFMA fragment order lane (m, kq) reads 16 B of row m, so one wave-instruction touches 16 rows x 64 B:
+// HALF cache lines, whose other halves follow in the next instruction.  A read-only stream of that shape tops out at 5.5 TB/s where
+// whole 128-B lines per instruction reach 6.95 (tools/microbench/read_pattern.hip; the 64-B run is what costs, not the lane order).
+// With LN the two loads of a k32 group are re-dealt: the first reads rows 0-7 of the wave's 16 (lanes m < 8: floats 4 kq of the
+// group, lanes m >= 8: floats 16 + 4 kq of row m - 8), the second rows 8-15 the same way -- 8 rows x 128 B each -- and two DPP
+// row rotations by 8 lanes hand every lane the pieces the fragment order wants (8 v_mov_dpp per 32 B of weights per lane).
+// Same registers, same values, same arithmetic as the fragment-order loads: results are bit-identical.
+template <bool LN>
+__device__ __forceinline__ const float* sk_wbase(const float* w_co0, int m, int kq, int K) {
+    if constexpr (LN) return w_co0 + (long long)(m & 7) * K + 4 * kq + 16 * (m >> 3);
+    else return w_co0 + (long long)m * K + 4 * kq;
+}
+// pointer of load number qq (units of 16 floats; pairs (even, odd) belong to one k32 group) relative to a lane base from sk_wbase
+template <bool LN>
+__device__ __forceinline__ const float* sk_wptr(const float* base, int qq, int K) {
+    if constexpr (LN) return base + (long long)(qq & ~1) * 16 + ((qq & 1) ? (long long)8 * K : 0);
+    else return base + (long long)qq * 16;
+}
+template <bool LN>
+__device__ __forceinline__ void sk_wfix(f32x4v& w0, f32x4v& w1) {
+    if constexpr (LN) {
+        f32x4v f0, f1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // (element copies first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this compiler)
+            const float ta = w0[e], tb = w1[e];
+            const int a = __builtin_bit_cast(int, ta), b = __builtin_bit_cast(int, tb);
+            // row_ror:8 = 0x128; bank_mask 0xc: lanes 8-15 of every row of 16 take the rotated source, 0x3: lanes 0-7
+            f0[e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false));
+            f1[e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false));
+        }
+        w0 = f0; w1 = f1;
+    }
+}
+
 // six piece products, smallest first (same order as conv_x3_kernel); weights are the A side
 #define SK_X3_MFMA(ACC, A, B)                                                              \
     {                                                                                      \
@@ -247,7 +282,7 @@ struct SkinnyExitArgs {
 
 // forward, whole activation in LDS (trunk.7.C2: 45 input pixels x 512 channels = 3 x 46 KB of bf16 planes)
 // NW = waves per workgroup (16 output channels each): 16 at E >= 128; fewer, so that a small episode batch still fills the CUs
-template <bool EXIT, int NW>
+template <bool EXIT, int NW, bool LN>
 __global__ __launch_bounds__(64 * NW) void skinny_conv_fwd_x3_kernel(SkinnyArgs p, SkinnyExitArgs x) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     const int tid = threadIdx.x;
@@ -275,14 +310,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_conv_fwd_x3_kernel(SkinnyArgs 
         n_ih0[nb] = oh * p.stride - p.pad;
         n_iw0[nb] = ow * p.stride - p.pad;
     }
-    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* wrow = sk_wbase<LN>(p.w + (long long)g * p.wgs + (long long)co0 * p.K, m, kq, p.K);
     const float* actg = p.act + (long long)g * p.rows_in * p.lda;
 
     // weights of one output channel are contiguous over (tap, ci); SK_U float4 per lane stay in flight: a register pair is
     // re-issued for the next chunk as soon as its pieces have been split off
     f32x4v a_cur[SK_U];
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, u, p.K));
     {
         const int q4 = p.Cin / 4;
         for (int i = tid; i < p.rows_in * q4; i += 64 * NW) {
@@ -311,10 +346,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_conv_fwd_x3_kernel(SkinnyArgs 
 #pragma unroll
         for (int u = 0; u < SK_U; u += 2) {
             bf16x8 a[3], b[3][3];
+            sk_wfix<LN>(a_cur[u], a_cur[u + 1]);
             sk_split_a(a_cur[u], a_cur[u + 1], a);
             if (more) {
-                a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u) * 16));
-                a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u + 1) * 16));
+                a_cur[u] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, q0 + SK_U + u, p.K));
+                a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, q0 + SK_U + u + 1, p.K));
             }
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb)
@@ -605,6 +641,7 @@ __global__ __launch_bounds__(512) void skinny_conv_dgrad_kernel(SkinnyArgs p) {
 
 // forward, per-tap staging, bf16x3 (trunk.7.C1 / shortcut): the gathered [48][Cin] im2col rows of one tap are split while
 // they are scattered into the three bf16 planes (double buffered: 2 x 3 x 48 x (Cin + 16) x 2 B = 153 KB at Cin = 256)
+template <bool LN>
 __global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
     const int tid = threadIdx.x;
@@ -619,7 +656,7 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs
     const int gpt = p.Cin / 16;
     const int q4 = p.Cin / 4;
     constexpr int NST = 3;
-    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
+    const float* wrow = sk_wbase<LN>(p.w + (long long)g * p.wgs + (long long)co0 * p.K, m, kq, p.K);
     const float* actg = p.act + (long long)g * p.rows_in * p.lda;
 
     int s_off[NST], s_c[NST], s_img[NST], s_ih0[NST], s_iw0[NST];
@@ -664,7 +701,7 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs
     for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
     f32x4v a_cur[SK_U];
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, u, p.K));
     const int n_groups = taps * gpt;
     gather(0);
     scatter(0);
@@ -678,10 +715,11 @@ __global__ __launch_bounds__(1024) void skinny_conv_fwd_tap_x3_kernel(SkinnyArgs
 #pragma unroll
             for (int u = 0; u < SK_U; u += 2) {
                 bf16x8 a[3], b[3][3];
+                sk_wfix<LN>(a_cur[u], a_cur[u + 1]);
                 sk_split_a(a_cur[u], a_cur[u + 1], a);
                 if (more) {
-                    a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u) * 16));
-                    a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)(q0 + SK_U + u + 1) * 16));
+                    a_cur[u] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, q0 + SK_U + u, p.K));
+                    a_cur[u + 1] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, q0 + SK_U + u + 1, p.K));
                 }
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
@@ -718,7 +756,7 @@ struct SkinnyEntryArgs {
     float eps;
 };
 
-template <int NW>
+template <int NW, bool LN>
 __global__ __launch_bounds__(64 * NW) void skinny_block_entry_x3_kernel(SkinnyEntryArgs q) {
     const SkinnyArgs& p = q.c;
     extern __shared__ __attribute__((aligned(16))) unsigned short ldh[];
@@ -734,8 +772,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_block_entry_x3_kernel(SkinnyEn
     const int gpt = p.Cin / 16;
     const int q4 = p.Cin / 4;
     constexpr int NST = 48 / NW;                   // float4 staging slots per thread: 48 rows x (Cin <= 256)/4 = 3072 slots
-    const float* wrow = p.w + (long long)g * p.wgs + (long long)(co0 + m) * p.K + 4 * kq;
-    const float* wsrow = q.w_sc + (long long)g * q.wscs + (long long)(co0 + m) * p.Cin + 4 * kq;
+    const float* wrow = sk_wbase<LN>(p.w + (long long)g * p.wgs + (long long)co0 * p.K, m, kq, p.K);
+    const float* wsrow = sk_wbase<LN>(q.w_sc + (long long)g * q.wscs + (long long)co0 * p.Cin, m, kq, p.Cin);
     const float* actg = p.act + (long long)g * p.rows_in * p.lda;
 
     const int centre = (p.KH / 2) * p.KW + p.KW / 2;
@@ -776,10 +814,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_block_entry_x3_kernel(SkinnyEn
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) acc[nb] = acs[nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
     const int n_groups = taps * gpt;               // C1's k16 groups; the shortcut's gpt groups follow as pass `taps`
-    auto wptr = [&](int qq) { return qq < n_groups ? wrow + (long long)qq * 16 : wsrow + (long long)(qq - n_groups) * 16; };
+    auto wptr = [&](int qq) { return qq < n_groups ? sk_wptr<LN>(wrow, qq, p.K) : sk_wptr<LN>(wsrow, qq - n_groups, p.Cin); };
     f32x4v a_cur[SK_U];
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)(wrow + (long long)u * 16));
+    for (int u = 0; u < SK_U; ++u) a_cur[u] = __builtin_nontemporal_load((const f32x4v*)sk_wptr<LN>(wrow, u, p.K));
     gather(0);
     scatter(0);
     __syncthreads();
@@ -791,6 +829,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_block_entry_x3_kernel(SkinnyEn
 #pragma unroll
             for (int u = 0; u < SK_U; u += 2) {
                 bf16x8 a[3], b[3][3];
+                sk_wfix<LN>(a_cur[u], a_cur[u + 1]);
                 sk_split_a(a_cur[u], a_cur[u + 1], a);
                 if (more) {
                     a_cur[u] = __builtin_nontemporal_load((const f32x4v*)wptr(q0 + SK_U + u));
@@ -1034,6 +1073,7 @@ int g_skinny_x3 = 1;             // bf16x3 forms of the weight-streaming kernels
 int g_skinny_tap = 1;            // per-tap staged forward for shapes whose activation exceeds LDS (mft_debug_set_conv_tile(7000/7001))
 int g_skinny_dgrad_slices = 1;   // reduction-channel slices of the data-gradient kernel (mft_debug_set_conv_tile(6000 + n))
 
+int g_skinny_lines = 1;         // full-line weight loads + DPP fix-up in the bf16x3 forward kernels (mft_debug_set_conv_tile(9700/9701))
 int g_skinny_nw = 0;            // waves per workgroup of the per-episode bf16x3 kernels: 0 = widest (mft_debug_set_conv_tile(9100 + nw); 9199 = by episode count)
 
 // Workgroups of W waves each own 16*W (forward) or 32*W (data gradient) channels of one episode.  Narrower workgroups fill the
@@ -1080,6 +1120,7 @@ void mft_skinny_set_dgrad_slices(int n) { g_skinny_dgrad_slices = n; }
 void mft_skinny_set_tap(int v) { g_skinny_tap = v; }
 void mft_skinny_set_x3(int v) { g_skinny_x3 = v; }
 void mft_skinny_set_nw(int v) { g_skinny_nw = v; }
+void mft_skinny_set_lines(int v) { g_skinny_lines = v; }
 
 // Returns MFT_EINVAL when the shape is outside the skinny kernel's domain (callers fall back to the generic kernel).
 static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
@@ -1104,12 +1145,16 @@ static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out,
             const size_t lds_h = (size_t)2 * 3 * 48 * (Cin + SK_PADH) * 2;
             static bool attr_tx = false;
             if (!attr_tx) {
-                hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_tap_x3_kernel,
+                hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_tap_x3_kernel<true>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void*)skinny_conv_fwd_tap_x3_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                 if (e != hipSuccess) return (int)e;
                 attr_tx = true;
             }
-            hipLaunchKernelGGL(skinny_conv_fwd_tap_x3_kernel, grid, dim3(1024), lds_h, s, p);
+            if (g_skinny_lines) hipLaunchKernelGGL(skinny_conv_fwd_tap_x3_kernel<true>, grid, dim3(1024), lds_h, s, p);
+            else hipLaunchKernelGGL(skinny_conv_fwd_tap_x3_kernel<false>, grid, dim3(1024), lds_h, s, p);
             return mft_launch_status();
         }
         const size_t lds_t = (size_t)2 * 48 * (Cin + SK_PADF) * sizeof(float);
@@ -1130,7 +1175,8 @@ static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out,
         const int nw = pick_nw(groups, Cout / 256, 16);
         const dim3 g2(Cout / (16 * nw), groups, 1);
         const SkinnyExitArgs e0 = ex ? *ex : SkinnyExitArgs{};
-#define SK_FWD(EX, NW) launch_big_lds(skinny_conv_fwd_x3_kernel<EX, NW>, 150 * 1024, g2, dim3(64 * NW), lds3, s, p, e0)
+#define SK_FWD(EX, NW) (g_skinny_lines ? launch_big_lds(skinny_conv_fwd_x3_kernel<EX, NW, true>, 150 * 1024, g2, dim3(64 * NW), lds3, s, p, e0) \
+                                       : launch_big_lds(skinny_conv_fwd_x3_kernel<EX, NW, false>, 150 * 1024, g2, dim3(64 * NW), lds3, s, p, e0))
         if (ex != nullptr) return nw == 16 ? SK_FWD(true, 16) : nw == 8 ? SK_FWD(true, 8) : SK_FWD(true, 4);
         return nw == 16 ? SK_FWD(false, 16) : nw == 8 ? SK_FWD(false, 8) : SK_FWD(false, 4);
 #undef SK_FWD
@@ -1250,7 +1296,8 @@ extern "C" int mft_block_entry_small_forward(const float* x, int ldx, const floa
     const int groups = n_img / imgs_per_group;
     const int nw = pick_nw(groups, Cout / 256, 16);
     const dim3 g2(Cout / (16 * nw), groups, 1);
-#define SK_EN(NW) launch_big_lds(skinny_block_entry_x3_kernel<NW>, 156 * 1024, g2, dim3(64 * NW), lds_h, (hipStream_t)stream, q)
+#define SK_EN(NW) (g_skinny_lines ? launch_big_lds(skinny_block_entry_x3_kernel<NW, true>, 156 * 1024, g2, dim3(64 * NW), lds_h, (hipStream_t)stream, q) \
+                                  : launch_big_lds(skinny_block_entry_x3_kernel<NW, false>, 156 * 1024, g2, dim3(64 * NW), lds_h, (hipStream_t)stream, q))
     return nw == 16 ? SK_EN(16) : nw == 8 ? SK_EN(8) : SK_EN(4);
 #undef SK_EN
 }

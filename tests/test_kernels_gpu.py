@@ -415,6 +415,12 @@ def test_skinny_per_episode_conv_and_dgrad(name, Cin, Cout, k, stride, pad, H, i
         outs.append(nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad, imgs_per_group=ipg).cpu()).double())
     _lib.lib().mft_debug_set_conv_tile(3001)
     _lib.lib().mft_debug_set_conv_tile(8001)
+    # full-line weight loads + DPP re-deal (default) against the MFMA-fragment-order loads: the same registers end up with the same
+    # values, so not a bit may change
+    _lib.lib().mft_debug_set_conv_tile(9700)
+    frag = nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad, imgs_per_group=ipg).cpu()).double()
+    _lib.lib().mft_debug_set_conv_tile(9701)
+    assert torch.equal(frag, outs[1]), name
     scale = max(float(ref.abs().max()), 1.0)
     e32 = float((outs[2] - ref).abs().max())
     for o in outs:
