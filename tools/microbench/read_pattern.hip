@@ -46,6 +46,28 @@ __global__ __launch_bounds__(1024) void quad_kernel(const float* __restrict__ w,
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[threadIdx.x] = acc[0];
 }
 
+// (e) the data-gradient kernel's shape: 8 B per lane, lanes m = 0..15 of a quarter-wave read 128 B of one row, four rows (kq) per
+//     wave-instruction (full lines, but half the bytes per instruction); 512-thread workgroups, 32 loads in flight per lane pair
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void dgrad_shape_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 8 waves x 32 input channels = 256 of the 512 columns... rows streamed
+    const int m = lane & 15, kq = lane >> 4;
+    const int e = blockIdx.x >> 1, half = blockIdx.x & 1;
+    // wave owns 32 columns (ci) x all 512 rows (co) of one tap-slice: walk the rows 16 at a time (kq, t)
+    f32x2 acc = {0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* col = w + (long long)e * CO * K + tap * 512 + half * 256 + wave * 32 + 2 * m;
+        for (int co0 = 0; co0 < CO; co0 += 32) {
+            f32x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const f32x2*)(col + (long long)(co0 + 4 * u + kq) * K));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
+    if (acc[0] + acc[1] == 12345.678f) out[threadIdx.x] = acc[0];
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void line_kernel(const float* __restrict__ w, float* __restrict__ out) {
     constexpr int NW = NT / 64;
@@ -94,6 +116,8 @@ int main() {
         const float td = time_ms([&] { hipLaunchKernelGGL(quad_kernel<16>, dim3(E * 2), dim3(1024), 0, 0, w, out); });
         const float te = time_ms([&] { hipLaunchKernelGGL(quad_kernel<8>, dim3(E * 2), dim3(1024), 0, 0, w, out); });
         const float tf = time_ms([&] { hipLaunchKernelGGL(quad_kernel<4>, dim3(E * 2), dim3(1024), 0, 0, w, out); });
+        const float tg = time_ms([&] { hipLaunchKernelGGL(dgrad_shape_kernel, dim3(E * 2), dim3(512), 0, 0, w, out); });
+        printf("data-gradient shape (8 B per lane, 4 rows x 128 B per instruction) %.2f TB/s\n", n * 4 / tg / 1e9);
         printf("adjacent lanes, 16 rows x 64 B %.2f | 8 rows x 128 B %.2f | 4 rows x 256 B %.2f TB/s\n", n * 4 / td / 1e9, n * 4 / te / 1e9, n * 4 / tf / 1e9);
         printf("fragment-shaped (16 rows x 64 B per instruction) %.2f TB/s | 1 KB runs, 1024-thread WGs %.2f TB/s | 1 KB runs, 256-thread WGs %.2f TB/s\n",
                n * 4 / ta / 1e9, n * 4 / tb / 1e9, n * 4 / tc / 1e9);
