@@ -22,6 +22,20 @@ from . import ops
 _DEBUG_SKIP_TRUNK = os.environ.get("MFT_DEBUG_SKIP_TRUNK", "0") == "1"     # results are then WRONG; timing experiments only
 
 
+def pick_slab_buffers(rates, K):
+    """``rates``: {sorted triple of candidate indices: measured rate of the 3-read / 3-write stream over those three buffers}.
+    Returns (w, m, v, w2): the pair (m, v) and the two weight buffers w, w2 that maximise min(rate(w, m, v), rate(w2, m, v)) --
+    the deferred final pass alternates between two weight slabs that share the moment slabs."""
+    import itertools
+    best, best_score = None, -1.0
+    for m_, v_ in itertools.combinations(range(K), 2):
+        ws = sorted((rates[tuple(sorted((w_, m_, v_)))], w_) for w_ in range(K) if w_ not in (m_, v_))
+        score = min(ws[-1][0], ws[-2][0])
+        if score > best_score:
+            best, best_score = (ws[-1][1], m_, v_, ws[-2][1]), score
+    return best
+
+
 class AdaptState:
     """Per-episode adaptable parameters + gradient + Adam moments (four tensor-major slabs)."""
 
@@ -87,12 +101,7 @@ class AdaptState:
             def key(t):
                 return tuple(sorted(t))
 
-            best, best_score = None, -1.0
-            for m_, v_ in itertools.combinations(range(K), 2):
-                ws = sorted((rates[key((w_, m_, v_))], w_) for w_ in range(K) if w_ not in (m_, v_))
-                score = min(ws[-1][0], ws[-2][0])
-                if score > best_score:
-                    best, best_score = (ws[-1][1], m_, v_, ws[-2][1]), score
+            best = pick_slab_buffers(rates, K)
             w_, m_, v_, w2_ = best
             rest = [i for i in range(K) if i not in best]
             self.placement = {"candidates": K, "chosen_gbs": round(rates[key((w_, m_, v_))], 1),

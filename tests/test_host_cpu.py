@@ -278,3 +278,25 @@ def test_bench_helpers_and_pmc_provenance(tmp_path, monkeypatch):
     empty.cards = []
     empty.start()
     assert empty.stop() is None
+
+
+def test_slab_placement_choice():
+    """engine.pick_slab_buffers: from measured triple rates pick (w, m, v) and a second weight buffer sharing (m, v) -- synthetic rates
+    with two 'regions' (triples inside region {0, 1, 2, 3} are slow, as the first allocations of a process typically are)."""
+    import itertools
+    from meta_fine_tuning_amd import engine as eng
+    K = 8
+    rates = {}
+    for t in itertools.combinations(range(K), 3):
+        slow = sum(1 for i in t if i < 4)
+        rates[t] = {3: 5.0, 2: 5.6, 1: 6.1, 0: 6.2}[slow] + 0.001 * sum(t)
+    w, m, v, w2 = eng.pick_slab_buffers(rates, K)
+    assert len({w, m, v, w2}) == 4 and min(w, m, v, w2) >= 4                 # everything out of the slow region
+    assert rates[tuple(sorted((w, m, v)))] >= 6.2 and rates[tuple(sorted((w2, m, v)))] >= 6.2
+    # one dominant triple does not win if its (m, v) pair has no good second weight buffer
+    rates2 = {t: 5.0 for t in itertools.combinations(range(5), 3)}
+    rates2[(0, 1, 2)] = 6.4
+    rates2[(2, 3, 4)] = 6.0
+    rates2[(1, 3, 4)] = 6.0
+    w, m, v, w2 = eng.pick_slab_buffers(rates2, 5)
+    assert {m, v} == {3, 4} and {w, w2} == {1, 2}
