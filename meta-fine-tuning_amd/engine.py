@@ -54,9 +54,10 @@ class AdaptState:
         """WHERE the w / m / v slabs live decides how fast they stream: the same 3-read / 3-write pass measures 4.9-6.3 TB/s over
         different triples of separately allocated 1.9 GB buffers of ONE process, reproducibly per triple (tools/placement_scan.py:
         typically the first ~10 GB a process allocates are the slow ones among themselves) -- and these slabs are 3/4 of the bytes
-        the inner loop moves.  So K candidate buffers are allocated, every triple is timed with the Adam-shaped probe
-        (mft_stream_probe, a few hundred milliseconds in all) and the fastest triple becomes (w, m, v); the gradient slab takes a
-        fourth, the rest go back to the allocator.  Placement does not touch any result.  MFT_SLAB_CANDIDATES=0 turns it off."""
+        the inner loop moves.  So K candidate buffers are allocated (groups of four, ballast between the groups), every triple is
+        timed with the Adam-shaped probe (mft_stream_probe; ~1.5 s in all at E = 128) and pick_slab_buffers chooses (w, m, v) and the
+        second weight slab of the deferred final pass; the gradient slab takes any other candidate, the rest goes back to the
+        driver.  Placement does not touch any result.  MFT_SLAB_CANDIDATES=0 turns it off."""
         total = E * Fn.ADAPT_NUMEL
         K = int(os.environ.get("MFT_SLAB_CANDIDATES", "12"))
         ballast_gb = min(float(os.environ.get("MFT_SLAB_BALLAST_GB", "12")), 6.4 * total * 4 / (1 << 30))
@@ -97,15 +98,10 @@ class AdaptState:
             triples = list(itertools.combinations(range(K), 3))
             rate(triples[0], 2)                                        # clocks up
             rates = {t: rate(t, 2) for t in triples}
-            # (w, m, v) and a second weight slab w' for the deferred final pass: the best pair of triples sharing (m, v)
-            def key(t):
-                return tuple(sorted(t))
-
-            best = pick_slab_buffers(rates, K)
-            w_, m_, v_, w2_ = best
+            w_, m_, v_, w2_ = best = pick_slab_buffers(rates, K)
             rest = [i for i in range(K) if i not in best]
-            self.placement = {"candidates": K, "chosen_gbs": round(rates[key((w_, m_, v_))], 1),
-                              "chosen_alt_gbs": round(rates[key((w2_, m_, v_))], 1), "best_gbs": round(max(rates.values()), 1),
+            self.placement = {"candidates": K, "chosen_gbs": round(rates[tuple(sorted((w_, m_, v_)))], 1),
+                              "chosen_alt_gbs": round(rates[tuple(sorted((w2_, m_, v_)))], 1), "best_gbs": round(max(rates.values()), 1),
                               "worst_gbs": round(min(rates.values()), 1), "median_gbs": round(float(np.median(list(rates.values()))), 1),
                               "first_three_allocations_gbs": round(rates[(0, 1, 2)], 1), "chosen": [w_, m_, v_, w2_]}
             keep = [cands[w_], cands[m_], cands[v_], cands[rest[0]], cands[w2_]]
