@@ -286,11 +286,10 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, BT>;
     if (lds > 64 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static MftPerDeviceOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
         }
     }
     dim3 grid(tiles_m * p.tiles_n, groups, 1);
@@ -967,11 +966,10 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     if (ADAM && g_wgrad_min_lds_kb * 1024 > lds) lds = g_wgrad_min_lds_kb * 1024;
     auto kern = conv_wgrad_kernel<BM, BN, ADAM, STEMW, EARLYT, POL>;
     if (lds > 64 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static MftPerDeviceOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
         }
     }
     WgradArgs p = a;

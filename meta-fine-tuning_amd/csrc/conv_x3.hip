@@ -1019,11 +1019,10 @@ int launch_x3_pp(X3Args p, hipStream_t s) {
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = 1;
     const size_t lds = (size_t)2 * 3 * (BM + BN) * X3_RS * sizeof(unsigned short);       // 92 KB: one workgroup (8 waves) per CU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static MftPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_x3_pp_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((conv_x3_pp_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), lds, s, p);
     return mft_launch_status();
@@ -1274,12 +1273,11 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.tiles_n = Cout / 64;
         const int img_groups = (n_img + G - 1) / G;
         const size_t lds = (size_t)3 * G * (R + 2) * (W + 2) * X3_RS * sizeof(unsigned short);
-        static bool attr_done = false;
-        if (!attr_done) {
+        static MftPerDeviceOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                64 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
         }
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(conv3x3_patch_x3_kernel, dim3((unsigned)(img_groups * q.row_blocks * q.tiles_n)), dim3(256), lds, s, q);

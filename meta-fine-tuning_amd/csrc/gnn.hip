@@ -213,12 +213,11 @@ extern "C" int mft_graph_aggregate(const float* A, const float* x, int ldx, floa
     if (ldy < 2 * F) return MFT_EINVAL;
     const size_t lds = (size_t)N * F * sizeof(float);
     if (n_graphs >= 128 && lds <= 150 * 1024) {              // enough graphs to fill the chip with one workgroup each
-        static bool attr_done = false;
-        if (!attr_done) {
+        static MftPerDeviceOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)graph_aggregate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                150 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
         }
         hipLaunchKernelGGL(graph_aggregate_lds_kernel, dim3(n_graphs), dim3(256), lds, (hipStream_t)stream, A, x, ldx, y, ldy, N, F);
         return mft_launch_status();

@@ -570,15 +570,14 @@ static int linear_head_run(const float* z_support, const int* y_support, const i
     const size_t head = ((ADAM ? 3 : 2) * (size_t)n_way * D + 16 * 16) * sizeof(float);
     const size_t lds_z = (size_t)n_support_rows * D * sizeof(float) + head;
     if (head > 150 * 1024) return MFT_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static MftPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            150 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     if (lds_z <= 150 * 1024)
         hipLaunchKernelGGL((linear_head_sgd_kernel<ADAM, true>), dim3(n_groups), dim3(256), lds_z, (hipStream_t)stream, z_support,

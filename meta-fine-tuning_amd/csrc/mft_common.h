@@ -53,4 +53,17 @@ __device__ __forceinline__ void mft_split4_bf16(const f32x4 x, mft_u32x2& p1, mf
     p3[1] = mft_pk_bf16(r[2], r[3]);
 }
 
+// hipFuncSetAttribute applies to the CURRENT device only: a "done" flag per device (an engine may be built on cuda:1 after
+// another one ran on cuda:0 in the same process).  need() is true the first time it is asked on a device.
+struct MftPerDeviceOnce {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -370,13 +370,12 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
     const long long nwg = (long long)p.tiles_m * p.tiles_n * n_groups;
     if (nwg > 0x7fffffffLL) return MFT_EINVAL;
     const size_t lds1 = (PM_BM + PM_BN) * PM_LD * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static MftPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
     if (g_pair_db) {

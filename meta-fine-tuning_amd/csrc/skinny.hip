@@ -1093,14 +1093,18 @@ template <typename K, typename... A>
 int launch_big_lds(K kern, size_t max_lds, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
     // the dynamic-LDS limit is raised once per kernel instantiation (instantiations of one template share the pointer TYPE, so
     // the "done" set is keyed by the function address)
-    static const void* done[64];
+    // (per device: the attribute belongs to the current device's copy of the code object)
+    static const void* done[256];
+    static int done_dev[256];
     static int n_done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     bool seen = false;
-    for (int i = 0; i < n_done; ++i) seen = seen || done[i] == (const void*)kern;
+    for (int i = 0; i < n_done; ++i) seen = seen || (done[i] == (const void*)kern && done_dev[i] == dev);
     if (!seen) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return (int)e;
-        if (n_done < 64) done[n_done++] = (const void*)kern;
+        if (n_done < 256) { done[n_done] = (const void*)kern; done_dev[n_done++] = dev; }
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
     return mft_launch_status();
@@ -1183,12 +1187,11 @@ static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out,
     }
     if (ex != nullptr) return MFT_EINVAL;          // the fused block exit exists in the bf16x3 form only
     const size_t lds = (size_t)rows_in * (cs + SK_PADF) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static MftPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            110 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(skinny_conv_fwd_kernel, grid, dim3(1024), lds, s, p);
     return mft_launch_status();
@@ -1225,12 +1228,11 @@ static int skinny_dgrad_impl(const float* dy, int ldy, const float* w, float* dx
     }
     if (bn != nullptr) return MFT_EINVAL;          // the fused BatchNorm epilogue exists in the bf16x3 form only
     const size_t lds = (size_t)rows * (cs + SK_PADF) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static MftPerDeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            110 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(skinny_conv_dgrad_kernel, grid, dim3(512), lds, s, p);
     return mft_launch_status();

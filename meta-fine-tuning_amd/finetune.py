@@ -12,8 +12,9 @@ RNG).  Three ways in, same arithmetic and same permutation stream:
 
 ``main`` mirrors the reference's ``__main__``: ``--method gnnnet | baseline | all``, ``--freeze_backbone``,
 ``--n_shot 50`` (gnnnet_copy, as finetune_50.py:20).  Launched under ``torchrun`` it shards the 600 episodes over the ranks
-(parallel.shard_indices, one all-gather of accuracies at the end -- SURVEY.md §8(e)).  Real datasets and checkpoints are
-out of scope: episodes and weights are the in-repo synthetic ones.
+(parallel.shard_indices, one all-gather of accuracies at the end -- SURVEY.md §8(e)).  Checkpoints are looked up where the reference looks
+(``checkpoint_files``, finetune.py:448-527); real datasets are out of scope: episodes are the in-repo
+synthetic ones, and without a checkpoint on disk the weights are too (``standin_state``).
 """
 import hashlib
 import os
@@ -116,13 +117,24 @@ def _linear_engine(state_in, n_way, n_support, n_query, size, n_views, E):
 
 # ------------------------------------------------------------------------------------------------ lookahead registry
 
-_READY = {}            # id(first view tensor) -> {"pin": tensor, "gnn": scores | None, "linear": scores | None}
+_READY = {}            # id(first view tensor) -> {"pin": tensor, "gnn": scores | None, "linear": scores | None, "ctx": {...}}
 
 
-def _take_ready(liz_x, kind):
+def _take_ready(liz_x, kind, freeze_backbone=False, state_in=None, model=None):
+    """Scores a LookaheadLoader parked for this episode, or None.  An entry was computed for ONE (state dict, model,
+    freeze_backbone) combination: a call that asks for anything else raises instead of silently returning the parked result
+    (the lookahead has already consumed this episode's permutations, so recomputing here would not be the reference's stream
+    either)."""
     ent = _READY.get(id(liz_x[0]))
     if ent is None or ent["pin"] is not liz_x[0] or ent.get(kind) is None:
         return None
+    ctx = ent["ctx"]
+    want_state = ctx["state_gnn"] if kind == "gnn" else ctx["state_b"]
+    if bool(freeze_backbone) != ctx["freeze_backbone"] or (state_in is not None and state_in is not want_state) \
+            or (kind == "gnn" and model is not None and model is not ctx["model"]):
+        raise RuntimeError("LookaheadLoader parked %s scores for this episode with freeze_backbone=%s and its own state_in / "
+                           "model; this call asks for freeze_backbone=%s / another state_in or model -- construct the loader "
+                           "with the arguments the loop body passes" % (kind, ctx["freeze_backbone"], bool(freeze_backbone)))
     sc = ent[kind]
     ent[kind] = None
     if ent.get("gnn") is None and ent.get("linear") is None:
@@ -150,7 +162,7 @@ def _finetune(P, liz_x, y, model, state_in, save_it, linear=False, flatten=True,
         raise NotImplementedError("finetune(): only the GNN scoring branch with a flattened backbone is on the HIP hot path "
                                   "(the linear branch is finetune_linear(); ds = DampNet, out of scope)")
     P = _params_of(P)
-    ready = _take_ready(liz_x, "gnn")
+    ready = _take_ready(liz_x, "gnn", freeze_backbone, state_in, model)
     if ready is not None:
         model.n_query = liz_x[0].size(1) - n_support               # finetune.py:312
         return ready
@@ -225,7 +237,7 @@ def _finetune_linear(P, liz_x, y, state_in, save_it, linear=False, flatten=True,
                      pretrained_dataset='miniImageNet', freeze_backbone=False, n_way=5, n_support=5, classifier=None):
     if not flatten:
         raise NotImplementedError("finetune_linear(): flatten=False is outside the HIP hot path")
-    ready = _take_ready(liz_x, "linear")
+    ready = _take_ready(liz_x, "linear", freeze_backbone, state_in)
     if ready is not None:
         return ready
     x0 = liz_x[0]
@@ -336,11 +348,17 @@ class LookaheadLoader:
     parks the per-episode scores in a registry keyed by the identity of the episode's first view tensor; then it yields the
     elems one by one.  ``finetune(liz_x, ...)`` / ``finetune_linear(liz_x, ...)`` called by the loop body with that episode
     return the parked scores instead of running an engine of one -- bit-identical to ``finetune_batched`` because it IS the
-    batched run (tests/test_drivers_gpu.py)."""
+    batched run (tests/test_drivers_gpu.py).
+
+    ``freeze_backbone`` must be what the loop body passes (finetune.py:615-619,647-649 pass it on every call).  The frozen
+    branches train no backbone, so there is nothing to batch: the wrapper then yields the elems untouched and the per-episode
+    calls run their own frozen path (eval-mode features, finetune.py:253-266) -- and a parked result is only ever handed to a
+    call with the same freeze_backbone / state_in / model (``_take_ready`` raises otherwise)."""
 
     def __init__(self, loader, method, model, state_gnn=None, state_b=None, fine_tune_epoch=None, n_way=5, n_support=5,
-                 episodes_per_batch=32, classifiers=None):
+                 episodes_per_batch=32, classifiers=None, freeze_backbone=False):
         self.loader, self.method, self.model = loader, method, model
+        self.freeze_backbone = bool(freeze_backbone)
         self.state_gnn, self.state_b = state_gnn, state_b
         self.epochs = fine_tune_epoch if fine_tune_epoch is not None else _params_of(params).fine_tune_epoch
         self.n_way, self.n_support, self.E = n_way, n_support, episodes_per_batch
@@ -350,10 +368,14 @@ class LookaheadLoader:
         return len(self.loader)
 
     def __iter__(self):
+        if self.freeze_backbone:
+            yield from self.loader
+            return
         it = iter(self.loader)
         done = False
         k = 0
         issued = []
+        ctx = {"freeze_backbone": False, "state_gnn": self.state_gnn, "state_b": self.state_b, "model": self.model}
         while not done:
             for key in issued:                  # scores the loop body never asked for (a skipped episode) must not stay pinned
                 _READY.pop(key, None)
@@ -375,7 +397,7 @@ class LookaheadLoader:
             for j, elem in enumerate(batch):
                 pin = elem[0][0]
                 _READY[id(pin)] = {"pin": pin, "gnn": None if s_gnn is None else s_gnn[j],
-                                   "linear": None if s_lin is None else s_lin[j]}
+                                   "linear": None if s_lin is None else s_lin[j], "ctx": ctx}
                 issued.append(id(pin))
             for elem in batch:
                 yield elem
@@ -498,13 +520,97 @@ def _init_distributed():
         torch.distributed.init_process_group("nccl")
 
 
+PRETRAINED_DATASET = "miniImageNet"          # finetune.py:431,448,468,488: hard-coded, NOT params.dataset
+
+
+def checkpoint_files(p):
+    """The checkpoint files the reference's ``__main__`` opens (finetune.py:448-527), as (gnnnet file | None, baseline file | None):
+
+    * ``--method baseline`` / ``all``: <save_dir>/checkpoints/miniImageNet/<model>_baseline[_aug]/ -- ``400.tar`` when
+      ``--save_iter`` is given (the literal 400 of :455,472), else the newest epoch for ``baseline`` (get_resume_file) or
+      best_model.tar / newest for ``all`` (get_best_file);
+    * ``--method all``: the GNN checkpoint is ALWAYS <model>_gnnnet_aug_<n>way_<k>shot/600.tar (:469,510-514: ``_aug`` and 600
+      are literals there, whatever --train_aug / --save_iter say);
+    * any other method: <model>_<method>[_aug]_<n>way_<k>shot/<save_iter>.tar, or best_model.tar / newest with --save_iter -1."""
+    from . import configs
+    from .io_utils import get_assigned_file, get_best_file, get_resume_file
+    f_gnn = f_b = None
+    if p.method in ("baseline", "all"):
+        d = '%s/checkpoints/%s/%s_%s' % (configs.save_dir, PRETRAINED_DATASET, p.model, "baseline")
+        if p.train_aug:
+            d += '_aug'
+        if p.save_iter != -1:
+            f_b = get_assigned_file(d, 400)
+        elif p.method in ('baseline', 'baseline++'):
+            f_b = get_resume_file(d)
+        else:
+            f_b = get_best_file(d)
+    if p.method == "all":
+        d2 = '%s/checkpoints/%s/%s_%s' % (configs.save_dir, 'miniImageNet', p.model, "gnnnet") + '_aug'
+        d2 += '_%dway_%dshot' % (p.train_n_way, p.n_shot)
+        f_gnn = get_assigned_file(d2, 600)
+    elif p.method != "baseline":
+        d = '%s/checkpoints/%s/%s_%s' % (configs.save_dir, 'miniImageNet', p.model, p.method)
+        if p.train_aug:
+            d += '_aug'
+        d += '_%dway_%dshot' % (p.train_n_way, p.n_shot)
+        f_gnn = get_assigned_file(d, p.save_iter) if p.save_iter != -1 else get_best_file(d)
+    return f_gnn, f_b
+
+
+def load_checkpoint_state(modelfile):
+    """``torch.load(modelfile)['state']`` minus the ``feature2.`` / ``feature3.`` entries a --fine_tune run leaves behind
+    (finetune.py:498-512,531-540; train.py:197-202).  Tensors stay on the host: the engine packs its own device copies."""
+    tmp = torch.load(modelfile, map_location="cpu")
+    state = tmp['state']
+    for key in list(state.keys()):
+        if "feature2." in key or "feature3." in key:
+            state.pop(key)
+    return state
+
+
+def standin_state(kind, n_way):
+    """No checkpoint on this box (the reference's logs.zip cannot be fetched offline): deterministic stand-ins.  ``gnn``: the
+    seeded backbone + the GNN head that was meta-trained with the REFERENCE's set_forward_loss for accuracy golden G9
+    (tests/golden/g9_head.npz) -- the printed accuracy is then a real one (~90 % on the synthetic episodes at the README
+    settings), not the below-chance score of a random head.  ``baseline``: a seeded backbone (finetune_linear trains its own
+    classifier)."""
+    if kind == "baseline":
+        return synthetic.gnnnet_state_dict(seed=400, n_way=n_way)
+    head = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g9_head.npz")
+    if n_way == 5 and os.path.isfile(head):
+        sd = synthetic.gnnnet_state_dict(seed=31, n_way=n_way)
+        hz = np.load(head)
+        for k in hz.files:
+            sd[k] = torch.from_numpy(hz[k])
+        return sd
+    return synthetic.gnnnet_state_dict(seed=0, n_way=n_way)
+
+
+def _resolve_state(kind, modelfile, n_way, explicit, verbose):
+    """Load ``modelfile`` if it exists.  A missing file is an error when the user named an epoch AND its checkpoint directory
+    exists (the reference's torch.load raises there, finetune.py:498); otherwise the stand-in weights are used and said so."""
+    if modelfile is not None and os.path.isfile(modelfile):
+        if verbose:
+            print("loading %s checkpoint %s" % (kind, modelfile))
+        return load_checkpoint_state(modelfile), modelfile
+    if modelfile is not None and explicit and os.path.isdir(os.path.dirname(modelfile)):
+        raise FileNotFoundError(modelfile)
+    if verbose:
+        print("no %s checkpoint%s: synthetic stand-in weights" % (kind, "" if modelfile is None else " at " + modelfile))
+    return standin_state(kind, n_way), None
+
+
 def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     """finetune.py:424-682.  ``--method gnnnet`` (and gnnnet at ``--n_shot 50`` through gnnnet_copy, finetune_50.py),
-    ``--method baseline`` (finetune_linear on the baseline checkpoint), ``--method all`` (their sum)."""
+    ``--method baseline`` (finetune_linear on the baseline checkpoint), ``--method all`` (their sum).  Checkpoints are looked
+    up exactly where the reference looks (``checkpoint_files``): what ``train.main --dataset miniImageNet`` wrote under
+    ``configs.save_dir`` is what this evaluates."""
     global params
     np.random.seed(10)                                               # finetune.py:425
     params = parse_args('train', argv)
     _init_distributed()
+    rank, _W = parallel.world()
     from .methods.gnnnet import GnnNet
     from .methods import gnnnet_copy
     if params.method not in ('gnnnet', 'baseline', 'all'):
@@ -517,13 +623,16 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     if episodes_per_batch is None:
         episodes_per_batch = int(os.environ.get("MFT_EPISODES_PER_BATCH", {5: 128, 20: 64}.get(params.n_shot, 32)))
     model = state = state_b = None
-    # no checkpoints offline: seeded synthetic weights stand in for <save_dir>/checkpoints/.../{600,400}.tar
+    f_gnn, f_b = checkpoint_files(params)
+    main.loaded = {"gnnnet": None, "baseline": None}                 # what was actually read (tests, logs)
     if params.method in ('gnnnet', 'all'):
         model = model_cls(model_dict[params.model], n_way=params.test_n_way, n_support=params.n_shot).cuda()
-        state = synthetic.gnnnet_state_dict(seed=0, n_way=params.test_n_way)
-        model.load_state_dict(state)
+        # `all` names 600.tar by literal, gnnnet names <save_iter>.tar: both explicit unless --save_iter is -1 for gnnnet
+        state, main.loaded["gnnnet"] = _resolve_state("gnnnet", f_gnn, params.test_n_way,
+                                                      params.method == 'all' or params.save_iter != -1, rank == 0)
+        model.load_state_dict(state)                                 # finetune.py:512,540
     if params.method in ('baseline', 'all'):
-        state_b = synthetic.gnnnet_state_dict(seed=400, n_way=params.test_n_way)
+        state_b, main.loaded["baseline"] = _resolve_state("baseline", f_b, params.test_n_way, params.save_iter != -1, rank == 0)
     print(params.freeze_backbone)                                    # finetune.py:591
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,

@@ -16,23 +16,34 @@ BN_EPS = 1e-5
 LRELU_SLOPE = 0.01
 
 
-_last_dev = None          # device index of the most recent pointer argument (arguments are marshalled left to right)
+import threading
+
+_tls = threading.local()      # per host thread: the device of the pointer arguments marshalled for the launch being assembled
 
 
-def _stream():
-    """The current HIP stream OF THE DEVICE THE LAUNCH'S TENSORS LIVE ON (not of whatever device happens to be current:
-    an engine built for cuda:1 must not enqueue on device 0's stream).  Callers on a non-current device must also make
-    it current for the launch itself (FinetuneEngine does, ``torch.cuda.device(self.dev)``)."""
-    return ctypes.c_void_p(torch.cuda.current_stream(_last_dev).cuda_stream)
+def _stream(t=None):
+    """The current HIP stream of the device THIS launch's tensors live on.  ``t``: a tensor / torch.device / index names the
+    device explicitly; without it the device is the one the ``_p()`` calls of the same argument list saw (Python evaluates
+    arguments left to right and every launcher takes the stream last).  The record is per host thread and is consumed here, so
+    it can neither leak into a later launch nor be overwritten by another thread's engine on another device; a launch whose
+    pointer arguments sit on two devices raises."""
+    dev = getattr(_tls, "dev", None)
+    _tls.dev = None
+    if t is not None:
+        dev = t.device.index if torch.is_tensor(t) else (t.index if isinstance(t, torch.device) else int(t))
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _p(t):
-    global _last_dev
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("meta_fine_tuning_amd ops need CUDA (HIP) tensors; got a CPU tensor (no CPU fallback)")
-    _last_dev = t.device.index
+    prev = getattr(_tls, "dev", None)
+    if prev is not None and prev != t.device.index and getattr(_tls, "strict", True):
+        _tls.dev = None
+        raise RuntimeError("one launch got pointers on cuda:%d and cuda:%d" % (prev, t.device.index))
+    _tls.dev = t.device.index
     return ctypes.c_void_p(t.data_ptr())
 
 

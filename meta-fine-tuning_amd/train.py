@@ -22,13 +22,20 @@ class SyntheticEpisodeLoader:
         self.n_episode, self.seed0, self.epoch = n_episode, seed0, 0
         self.rank, self.world = rank, world
 
+    def steps_per_rank(self):
+        """Every rank MUST run the same number of steps: each step is one collective (AllReduceAdam.step), so a rank with one
+        episode more would wait in an all-reduce its peers never enter.  floor(n_episode / W) steps per rank; the n_episode % W
+        episodes left over at the end of the epoch's stream are not drawn (with W = 1 nothing is dropped)."""
+        return self.n_episode // self.world
+
     def __len__(self):
-        return len(range(self.rank, self.n_episode, self.world))
+        return self.steps_per_rank()
 
     def __iter__(self):
         base = self.seed0 + self.epoch * self.n_episode
         self.epoch += 1
-        for i in range(self.rank, self.n_episode, self.world):
+        for s in range(self.steps_per_rank()):
+            i = self.rank + s * self.world
             n_way, ns, nq, size = self.a
             yield synthetic.train_episode(base + i, n_way, ns, nq, size), None
 

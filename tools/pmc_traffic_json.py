@@ -31,7 +31,10 @@ def main():
     fdir, wdir, E, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     head = sys.argv[5] if len(sys.argv) > 5 else "unknown"
     import bench
-    if fdir.startswith("mean:"):            # pmc_traffic_json.py mean:<fetch KB>:<calls> mean:<write KB>:<calls> E round head  (from a committed summary)
+    typed = fdir.startswith("mean:")
+    if typed:            # pmc_traffic_json.py mean:<fetch KB>:<calls> mean:<write KB>:<calls> E round head  (from a committed summary)
+        # numbers typed on the command line carry NO provenance: the record gets no kernel-source hash, so bench.py never quotes
+        # it as `roofline.traffic` (it is a note for humans only)
         fetch, nf = float(fdir.split(":")[1]), int(fdir.split(":")[2])
         write, nw = float(wdir.split(":")[1]), int(wdir.split(":")[2])
     else:
@@ -42,7 +45,7 @@ def main():
                        "--pmc WRITE_SIZE runs of bench.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE x1, unit KB; calibration: "
                        "profiles/r01_c_pmc_calibration.txt).  bench.py copies `traffic` from here only when its episodes-per-step AND the "
                        "kernel-source hash match.",
-           "round": rnd, "head": head, "kernel_source_sha16": bench.kernel_source_sha(), "episodes_per_step": E,
+           "round": rnd, "head": head, "kernel_source_sha16": None if typed else bench.kernel_source_sha(), "episodes_per_step": E,
            "kernel": "wgrad_adam_rows_kernel (fused weight gradient + Adam; conv_wgrad_kernel<64,64,ADAM> in round 1)", "launches": nf, "fetch_kb_mean_raw": round(fetch, 1), "write_kb_mean_raw": round(write, 1),
            "traffic_mb_per_launch": round((2.0 * fetch + write) * 1024 / 1e6, 1), "algorithmic_mb_per_launch": round(alg, 1)}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
