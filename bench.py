@@ -174,39 +174,81 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(state, episode, budget_s=12.0, max_steps=60):
-    """Oracle (CPU restatement validated against the reference) timed on this box's host cores on a bounded sample:
-    as many inner steps as fit in ``budget_s`` (>= 3, <= max_steps) + the final 100-image pass + GNN, extrapolated
-    to the 500 steps of one episode."""
+def cpu_baseline(state, episode, leg_budget_s=12.0):
+    """the oracle (CPU restatement validated against the reference) timed on this box's host cores.
+    C2 = ONE WHOLE episode of finetune() -- all 500 inner Adam steps, the 100-image pass, the GNN head -- at all granted cores and
+    again at 8 threads (the core count of the container the reference's own numbers were taken in); C1 = one train_loop step
+    (set_forward_loss + backward + Adam over all 104 tensors, median of 3) at all granted cores.  A leg that would exceed
+    ``leg_budget_s`` stops after the steps it has done and says so (the rest is then extrapolated from its own step time), so a
+    slow host cannot stall the GPU measurement."""
     from oracle import mft_oracle as O
     cores = host_threads()
-    torch.set_num_threads(cores)
-    sd_all = O.clone_state(state)
-    fsd = O.feature_state(sd_all)
+    sd0 = O.clone_state(state)
     xa, ya = O.finetune_support_set(episode, 5, 5)
-    adam = O.adam_init([fsd[k] for k in O.ADAPT_KEYS])
-    perm = np.random.RandomState(0).permutation(xa.shape[0])
-    # warm
-    O.inner_step(fsd, xa[torch.from_numpy(perm[:5])], ya[torch.from_numpy(perm[:5])], adam)
-    t0 = time.perf_counter()
-    n_done = 0
-    while n_done < max_steps and (n_done < 3 or time.perf_counter() - t0 < budget_s):
-        s = n_done
-        sel = torch.from_numpy(perm[(s * 5) % 495:(s * 5) % 495 + 5])
-        O.inner_step(fsd, xa[sel], ya[sel], adam)
-        n_done += 1
-    t_step = (time.perf_counter() - t0) / n_done
+    n_total = xa.shape[0]
     x0 = episode[0]
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        feats = O.resnet10_forward(fsd, x0.reshape(100, *x0.shape[2:]), "", train=True).view(5, 20, -1)
-        O.gnnnet_set_forward(sd_all, feats, 5, 5, 15, is_feature=True)
-    t_final = time.perf_counter() - t0
-    t_episode = 500 * t_step + t_final
-    return {"value": round(1.0 / t_episode, 5), "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": "%d inner steps (%.1f ms each) + final 100-image pass + GNN (%.2f s), extrapolated to 500 steps; "
-                      "torch-CPU oracle, %d threads (os.cpu_count()=%s)" % (n_done, t_step * 1e3, t_final, cores,
-                                                                           os.cpu_count())}
+
+    def whole_episode(threads):
+        torch.set_num_threads(threads)
+        sd_all = O.clone_state(sd0)
+        fsd = O.feature_state(sd_all)
+        adam = O.adam_init([fsd[k] for k in O.ADAPT_KEYS])
+        rs = np.random.RandomState(0)
+        sel0 = torch.from_numpy(rs.permutation(n_total)[:5])
+        O.inner_step(O.feature_state(O.clone_state(sd0)), xa[sel0], ya[sel0], O.adam_init([fsd[k].clone() for k in O.ADAPT_KEYS]))   # warm
+        t0 = time.perf_counter()
+        done, n_steps = 0, 5 * ((n_total + 4) // 5)
+        for ep in range(5):
+            perm = rs.permutation(n_total)
+            for j in range(0, n_total, 5):
+                if time.perf_counter() - t0 > leg_budget_s and done >= 20:
+                    break
+                sel = torch.from_numpy(perm[j:j + 5])
+                O.inner_step(fsd, xa[sel], ya[sel], adam)
+                done += 1
+        t_steps = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            feats = O.resnet10_forward(fsd, x0.reshape(100, *x0.shape[2:]), "", train=True).view(5, 20, -1)
+            O.gnnnet_set_forward(sd_all, feats, 5, 5, 15, is_feature=True)
+        t_final = time.perf_counter() - t1
+        t_episode = t_steps * (n_steps / done) + t_final
+        return {"threads": threads, "episodes_per_s": round(1.0 / t_episode, 5), "seconds_per_episode": round(t_episode, 2),
+                "inner_steps_timed": done, "inner_steps_per_episode": n_steps, "ms_per_inner_step": round(t_steps / done * 1e3, 2),
+                "final_pass_and_gnn_s": round(t_final, 2), "extrapolated": done < n_steps}
+
+    legs = [whole_episode(cores)]
+    if cores != 8:
+        legs.append(whole_episode(min(8, cores) if cores < 8 else 8))
+    # C1: one meta-training step (train.py:28, meta_template.py:76-92) on a 5-way 5-shot 16-query 84x84 episode
+    torch.set_num_threads(cores)
+    from meta_fine_tuning_amd import synthetic
+    xe = synthetic.train_episode(5000, 5, 5, 16, 84)
+    sd_t = O.clone_state(sd0)
+    keys = [k for k, v in sd_t.items() if v.dtype.is_floating_point and "running_" not in k]
+    ps = [sd_t[k].requires_grad_(True) for k in keys]
+    ast = O.adam_init([p.detach() for p in ps])
+    t_c1 = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        loss, _ = O.meta_train_loss(sd_t, xe, 5, 5)
+        gs = torch.autograd.grad(loss, ps, allow_unused=True)
+        with torch.no_grad():
+            O.adam_step([p.detach() for p in ps], [g if g is not None else torch.zeros_like(p) for g, p in zip(gs, ps)], ast, lr=1e-3)
+        if it:
+            t_c1.append(time.perf_counter() - t0)
+    c1 = float(np.median(t_c1))
+    best = legs[0]
+    return {"value": best["episodes_per_s"], "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": "ONE whole episode of BASELINE configs[1] (%d of %d inner Adam steps timed at %.1f ms each%s + the 100-image "
+                      "pass + GNN head %.2f s = %.2f s per episode) on the torch-CPU oracle with %d threads (os.cpu_count()=%s)"
+                      % (best["inner_steps_timed"], best["inner_steps_per_episode"], best["ms_per_inner_step"],
+                         ", rest extrapolated" if best["extrapolated"] else "", best["final_pass_and_gnn_s"],
+                         best["seconds_per_episode"], cores, os.cpu_count()),
+            "legs": legs,
+            "c1_train_loop_step": {"seconds": round(c1, 3), "episodes_per_s": round(1.0 / c1, 3), "threads": cores,
+                                   "what": "one meta-training episode (105 images 84x84: set_forward_loss + backward + Adam over "
+                                           "104 tensors), median of 3 after one warm-up"}}
 
 
 def cpu_baseline_subprocess(gen_examples, timeout_s=240):
@@ -225,6 +267,59 @@ def cpu_baseline_subprocess(gen_examples, timeout_s=240):
     except subprocess.TimeoutExpired:
         note = "cpu baseline child exceeded %d s" % timeout_s
     return {"value": None, "unit": "episodes/s", "cores": host_threads(), "kind": "port", "sample": note}
+
+
+def self_launch(n_gpus):
+    """Start ``n_gpus`` ranks of this same command line under torch.distributed.run (127.0.0.1 rendezvous on a free port) from a
+    parent that has not initialised any GPU; stdout / stderr of the ranks pass through; returns their exit status."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n_gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def strong_scaling_leg(n_episodes, state, rank, world, dev, e_max=128):
+    """STRONG scaling next to the weak-scaling headline: a FIXED job -- the reference's 600-episode evaluation
+    (finetune.py:593-682: `--method gnnnet --n_shot 5 --fine_tune_epoch 5 --gen_examples 17`) -- split over the ranks
+    (episode i -> rank i mod W), timed from the call of finetune.evaluate to the gathered accuracies on every rank:
+    engine build (slab placement included), on-device episode generation, all inner loops, final passes, the one all-gather.
+    Episodes per lockstep batch = the rank's share split into equal batches of at most ``e_max``."""
+    import torch.distributed as dist
+    from meta_fine_tuning_amd import finetune as ft
+    from meta_fine_tuning_amd.io_utils import model_dict
+    from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+    model = GnnNet(model_dict["ResNet10"], n_way=5, n_support=5).cuda()
+    model.load_state_dict(state)
+    ft._ENGINES.clear()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    np.random.seed(10)
+    tm = {}
+    t0 = time.perf_counter()
+    accs = ft.evaluate(model, state, n_episodes, 5, 5, 15, 84, 17, 5, seed0=7000, episodes_per_batch=e_max, verbose=False,
+                       method="gnnnet", rng_seed=10, device_episodes=True, balance=True, timings=tm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ft._ENGINES.clear()
+    return {"what": "fixed job: %d episodes of BASELINE configs[1] over %d rank(s) through finetune.evaluate (engine build + slab "
+                    "placement + on-device episode generation + inner loops + final passes + accuracy gather), MAX over ranks"
+                    % (n_episodes, world),
+            "scaling": "strong", "episodes": n_episodes, "n_gpus": world, "wall_s": round(dt, 3),
+            "episodes_per_s": round(n_episodes / dt, 2), "episodes_per_batch": tm.get("episodes_per_batch"),
+            "batches_per_rank": tm.get("batches"), "engine_ready_after_s": None if "engine_ready_s" not in tm else round(tm["engine_ready_s"], 3),
+            "mean_acc": round(float(accs.mean()), 2)}
 
 
 def bench_metatrain(args, rank, world, dev, dist):
@@ -308,6 +403,9 @@ def main():
                     "the current inner loop (A/B)")
     ap.add_argument("--no-defer-final", action="store_true", help="run each batch's final pass synchronously (A/B)")
     ap.add_argument("--no-pipeline", action="store_true", help="single-stream inner loop (A/B against the 2-stream pipeline)")
+    ap.add_argument("--strong-episodes", type=int, default=600,
+                    help="after the timed (weak-scaling) region: the reference's fixed 600-episode evaluation split over the ranks, "
+                         "wall time end to end -> `strong_scaling` in the JSON line (0 = off; default config only)")
     ap.add_argument("--validate-episodes", type=int, default=24,
                     help="self-validation: the first V slots of the resident pool are the first V episodes of the accuracy golden "
                          "G9 (tests/golden/g9_accuracy.npz, the reference's own finetune() at this configuration); before the "
@@ -323,12 +421,16 @@ def main():
         print(json.dumps(cpu_baseline(state, ep)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process never touches a GPU; it starts the N ranks as fresh children
+        # (python -m torch.distributed.run, one rank per GPU over RCCL), relays their output -- rank 0 prints the ONE JSON
+        # line -- and exits with their status
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the product path")
     if world > 1:
@@ -641,6 +743,17 @@ def main():
                      "avg_launch_us": round(tot_ms * 1e3 / n_launch, 2),
                      "algorithmic_gflop_per_launch": round(tot_fl / n_launch / 1e9, 3)}
 
+    placement = e.adapt.placement
+    strong = None
+    if (args.strong_episodes > 0 and n_shot == 5 and size == 84 and args.epochs == 5 and args.gen_examples == 17
+            and not args.device_aug):
+        # the weak-scaling engine and its resident pool go first: the fixed job builds its own engine (that IS part of what it times)
+        e.close()
+        pool = srcs = head = None
+        del e
+        torch.cuda.empty_cache()
+        strong = strong_scaling_leg(args.strong_episodes, state, rank, world, dev, e_max=E)
+
     if rank == 0:
         total_eps = E * args.steps * world
         value = total_eps / dt
@@ -675,7 +788,8 @@ def main():
                                "achieved": round(value / world * 0.1122 * n_steps_ep, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(value / world * 0.1122 * n_steps_ep / PEAK_HBM_GBS, 4)},
             "power": power if power is None else dict(power, joules_per_episode=round(power["socket_w_median"] * dt / (E * args.steps), 2)),
-            "slab_placement": e.adapt.placement,
+            "slab_placement": placement,
+            "strong_scaling": strong,
             "roofline": roof,
             "roofline_mfma": roof_mfma,
             "roofline_mfma_x3": roof_x3,

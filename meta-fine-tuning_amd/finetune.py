@@ -425,38 +425,83 @@ class SyntheticNovelLoader:
             yield [(v, y) for v in views]
 
 
+def balanced_batch(n_mine, e_max):
+    """Episodes per lockstep batch for a rank that owns ``n_mine`` episodes: the engine always runs full batches (a short one is
+    padded with copies of its last episode), so 600 episodes at 128 per batch would pay for 640.  Same number of batches, equal
+    sizes: 600 -> 5 x 120."""
+    if n_mine <= 0:
+        return max(1, e_max)
+    nb = (n_mine + e_max - 1) // e_max
+    return (n_mine + nb - 1) // nb
+
+
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
              episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None,
-             device_episodes=False):
+             device_episodes=False, balance=False, timings=None):
     """The episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies (all ranks' episodes, in
     episode order, on every rank).
 
     With torch.distributed initialised the episodes are sharded (episode i -> rank i mod W) and every episode draws its
     permutations from ``parallel.episode_rng(rng_seed, i)`` -- and its classifier initialisation from a torch generator
     seeded the same way -- so the result does not depend on the rank count; pass ``rng_seed`` to get that stream at W = 1 too.
-    Without either the global numpy stream is used sequentially, exactly as the reference does."""
+    Without either the global numpy stream is used sequentially, exactly as the reference does.
+
+    The loop is software-pipelined (nothing of it changes a result): the episodes of batch b+2 are generated on a side stream
+    while batch b adapts; for ``--method gnnnet`` batch b+1's ingest + stem cache run beside batch b's inner loop and batch b's
+    final pass + GNN head beside batch b+1's first steps (FinetuneEngine.run_batch(defer_final=, prefetch=)); accuracies are
+    read from the device once, at the end.  ``balance``: equalise the batch sizes (``balanced_batch``)."""
+    import time
+    t_start = time.perf_counter()
     rank, W = parallel.world()
     if W > 1 and rng_seed is None:
         rng_seed = 10
     mine = parallel.shard_indices(n_episodes, rank, W)
+    if balance:
+        episodes_per_batch = balanced_batch(len(mine), episodes_per_batch)
     y_query = np.repeat(range(n_way), n_query)
-    accs = []
-    for c in range(0, len(mine), episodes_per_batch):
-        ids = mine[c:c + episodes_per_batch]
-        # the numpy generator of the synthetic episodes is the slow part of this loop (~1 s per 19-view episode): draw a batch's
-        # episodes on a few host threads (each episode is a pure function of its seed)
+    batches = [mine[c:c + episodes_per_batch] for c in range(0, len(mine), episodes_per_batch)]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cur = torch.cuda.current_stream(dev)
+    s_gen = torch.cuda.Stream(device=dev) if device_episodes else None
+    gens = {}
+
+    def ensure_gen(bi):
+        """Episodes of batch ``bi`` -> gens[bi] = (list of liz_x on the device, 'ready' event, views-0/1-differ flag)."""
+        if bi >= len(batches) or bi in gens:
+            return
+        ids = batches[bi]
         if device_episodes:
             # the same synthetic distribution drawn with the device generator straight into HBM (a pure function of the seed as
             # well; not the numpy episodes): 600 19-view episodes are 96 GB of views -- minutes of host time, seconds on the GPU
-            eps = [synthetic.test_episode_device(seed0 + i, "cuda", n_way, n_shot, n_query, size, gen_examples) for i in ids]
+            s_gen.wait_stream(cur)
+            with torch.cuda.stream(s_gen):
+                eps = [synthetic.test_episode_device(seed0 + i, dev, n_way, n_shot, n_query, size, gen_examples) for i in ids]
         else:
+            # the numpy generator is the slow part (~1 s per 19-view episode): a batch's episodes on a few host threads (each
+            # episode is a pure function of its seed)
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(8, len(ids))) as ex:
                 host = list(ex.map(lambda i: synthetic.test_episode(seed0 + i, n_way, n_shot, n_query, size, gen_examples), ids))
             eps = [[v.cuda() for v in ep] for ep in host]
             del host
-        for ep in eps:
-            assert torch.all(torch.eq(ep[0], ep[1]))                 # finetune.py:606
+        with torch.cuda.stream(s_gen if s_gen is not None else cur):
+            bad = torch.stack([(ep[0] != ep[1]).any() for ep in eps]).any()      # finetune.py:606, checked without a sync per episode
+            ev = torch.cuda.Event()
+            ev.record()
+        gens[bi] = (eps, ev, bad)
+
+    pipelined = (method == "gnnnet" and not freeze_backbone and model is not None)
+    engine = None
+    flags, score_chunks = [], []
+    ensure_gen(0)
+    ensure_gen(1)
+    for bi, ids in enumerate(batches):
+        eps, ev, bad = gens.pop(bi)
+        cur.wait_event(ev)
+        flags.append(bad)
+        if bi + 1 in gens:
+            cur.wait_event(gens[bi + 1][1])             # (generated during the previous batch; only batch 0 really waits)
+        ensure_gen(bi + 2)                              # runs on the side stream beside this batch's inner loop
         rngs = cls = None
         if rng_seed is not None:
             rngs = [parallel.episode_rng(rng_seed, i) for i in ids]
@@ -479,14 +524,35 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
                 if rngs is not None:
                     np.random.set_state(st)
             sc = torch.stack(sc)
+        elif pipelined:
+            if engine is None:
+                engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, len(eps[0]), fine_tune_epoch,
+                                     episodes_per_batch, fold50=getattr(model, "FOLD50", False))
+                if timings is not None:
+                    torch.cuda.synchronize(dev)
+                    timings["engine_ready_s"] = time.perf_counter() - t_start
+            perms = [draw_episode_perms(method, n_way, n_shot, len(ep), fine_tune_epoch, np.random if rngs is None else rngs[k])[1]
+                     for k, ep in enumerate(eps)]
+            nxt = gens.get(bi + 1)
+            sc = engine.run_batch(eps, perms=perms, defer_final=True, prefetch=None if nxt is None else nxt[0])
         else:
             sc = scores_batched(method, eps, model, state, state_b, fine_tune_epoch, n_way, n_shot, episodes_per_batch,
                                 rngs=rngs, classifiers=cls)
+        score_chunks.append(sc)
+        del eps
+    torch.cuda.synchronize(dev)                          # deferred final passes included
+    assert not bool(torch.stack(flags).any()) if flags else True                 # finetune.py:606
+    accs = []
+    for sc in score_chunks:
         pred = sc.argmax(2).cpu().numpy()
         for p in pred:
             accs.append(float(np.mean(p == y_query)) * 100)
-    dev = "cuda" if (W > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
-    accs = parallel.gather_episode_values(accs, n_episodes, device=dev)
+    gdev = "cuda" if (W > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
+    accs = parallel.gather_episode_values(accs, n_episodes, device=gdev)
+    if timings is not None:
+        timings["total_s"] = time.perf_counter() - t_start
+        timings["episodes_per_batch"] = episodes_per_batch
+        timings["batches"] = len(batches)
     if verbose and rank == 0:
         print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))))
     return accs
@@ -636,7 +702,8 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     print(params.freeze_backbone)                                    # finetune.py:591
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
-                    episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1")
+                    episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1",
+                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     return accs

@@ -36,7 +36,7 @@ def main():
         from meta_fine_tuning_amd import configs
         configs.save_dir = tempfile.mkdtemp()
         torch.manual_seed(0)
-        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=2 * W, size=84)
+        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=2 * W + (W - 1), size=84)          # n_episode % W != 0: every rank must still run 2 steps
         out = {k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k in
                ("fc.0.weight", "gnn.layer_last.fc.weight", "feature.trunk.7.C2.weight", "feature.trunk.0.weight")}
         np.savez(a.out + ".%d.npz" % rank, **out)

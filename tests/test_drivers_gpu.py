@@ -280,16 +280,22 @@ def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["finetune", "metatrain"])
-def test_bench_two_ranks_one_json_line(workload):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU; here both ranks on one device over
-    gloo, the MFT_BENCH_ONE_DEVICE hook): barrier + device synchronisation around the timed steps, MAX over ranks, rank 0 prints
-    ONE JSON line whose value is the whole-job rate over both ranks."""
+@pytest.mark.parametrize("workload,launcher", [("finetune", "self"), ("finetune", "torchrun"), ("metatrain", "self")])
+def test_bench_two_ranks_one_json_line(workload, launcher):
+    """bench.py for N > 1, both ways in: ``launcher == "torchrun"`` is how the driver starts it (torch.distributed.run, one rank
+    per GPU); ``"self"`` is the PLAIN command `python bench.py --gpus 2` -- a parent that never touches the GPU spawns the ranks,
+    relays their output and exits with their status.  Here both ranks share one device over gloo (MFT_BENCH_ONE_DEVICE hook).
+    Barrier + device synchronisation around the timed steps, MAX over ranks, rank 0 prints ONE JSON line whose value is the
+    whole-job rate over both ranks."""
     import json
     env = dict(os.environ, MFT_BENCH_ONE_DEVICE="1", MFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", workload]
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     if workload == "finetune":
         cmd += ["--episodes-per-batch", "8", "--epochs", "1", "--gen-examples", "2", "--no-standalone", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -304,3 +310,109 @@ def test_bench_two_ranks_one_json_line(workload):
     if workload == "finetune":
         assert d["config"]["episodes_total"] == 2 * 8 * 2 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
         assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
+
+
+def test_bench_self_launch_propagates_failure():
+    """The self-launching parent exits with the ranks' status: without the one-device hook rank 1 of `--gpus 2` asks for cuda:1,
+    which a one-GPU box does not have (on a multi-GPU node the command simply succeeds and the test has nothing to show)."""
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a box with exactly one GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "MFT_BENCH_ONE_DEVICE", "MFT_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload",
+                        "metatrain"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints, pipelined loop
+
+def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys):
+    """What train.main writes is what finetune.main evaluates (finetune.py:448-527 lookup): two epochs of meta-training, then
+    `finetune.main --save_iter 1` reads <save_dir>/checkpoints/miniImageNet/ResNet10_gnnnet_5way_5shot/1.tar and returns exactly
+    the accuracies of loading that .tar by hand."""
+    from meta_fine_tuning_amd import configs, train
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    train.main(["--dataset", "miniImageNet", "--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "2", "--save_freq", "1"],
+               n_episode=2, size=84)
+    f = tmp_path / "checkpoints" / "miniImageNet" / "ResNet10_gnnnet_5way_5shot" / "1.tar"
+    assert f.is_file() and (f.parent / "0.tar").is_file()
+    monkeypatch.setenv("MFT_EPISODES", "3")
+    monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
+    ft._ENGINES.clear()
+    accs = ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
+    out = capsys.readouterr().out
+    assert ft.main.loaded["gnnnet"] == str(f) and ("loading gnnnet checkpoint %s" % f) in out
+    state = torch.load(str(f), map_location="cpu")["state"]
+    state = {k: v for k, v in state.items() if "feature2." not in k and "feature3." not in k}
+    model = _model(state)
+    np.random.seed(10)
+    ft._ENGINES.clear()
+    ref = ft.evaluate(model, state, 3, 5, 5, 15, 84, 1, 1, episodes_per_batch=2, verbose=False, method="gnnnet",
+                      device_episodes=True, balance=True)
+    assert np.array_equal(accs, ref)
+    # the trained weights are not the stand-ins: the stand-in run differs
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path / "empty"))
+    accs2 = ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
+    assert ft.main.loaded["gnnnet"] is None and "synthetic stand-in weights" in capsys.readouterr().out
+    assert accs2.mean() > 40.0                                        # G9's meta-trained head, not a random one (chance = 20 %)
+    # an epoch that was never written, in a directory that exists: the reference's torch.load raises
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        ft.main(["--method", "gnnnet", "--save_iter", "5", "--fine_tune_epoch", "1", "--gen_examples", "1"])
+    ft._ENGINES.clear()
+
+
+def test_pipelined_evaluate_equals_batch_by_batch():
+    """finetune.evaluate's software pipeline (episodes generated two batches ahead on a side stream, next batch's ingest + stem
+    cache prefetched, final passes deferred, one read-back at the end) returns exactly what the plain per-batch
+    scores_batched calls return on the same episodes and permutation streams."""
+    sd = synthetic.gnnnet_state_dict(seed=13)
+    model = _model(sd)
+    ft._ENGINES.clear()
+    accs = ft.evaluate(model, sd, 7, 5, 5, 15, 84, 1, 1, seed0=900, episodes_per_batch=2, verbose=False, method="gnnnet",
+                       rng_seed=10, device_episodes=True)
+    from meta_fine_tuning_amd import parallel
+    y_query = np.repeat(range(5), 15)
+    ref = []
+    for c in range(0, 7, 2):
+        ids = list(range(c, min(c + 2, 7)))
+        eps = [synthetic.test_episode_device(900 + i, "cuda", 5, 5, 15, 84, 1) for i in ids]
+        sc = ft.scores_batched("gnnnet", eps, model, sd, None, 1, 5, 5, 2, rngs=[parallel.episode_rng(10, i) for i in ids])
+        ref += [float(np.mean(p == y_query)) * 100 for p in sc.argmax(2).cpu().numpy()]
+    assert np.array_equal(accs, np.asarray(ref))
+    ft._ENGINES.clear()
+
+
+def test_strong_scaling_leg_small():
+    """bench.strong_scaling_leg on a tiny fixed job (one rank): the record carries the wall time of the whole evaluation."""
+    import bench
+    ft._ENGINES.clear()
+    r = bench.strong_scaling_leg(4, bench.g9_state(), 0, 1, "cuda:0", e_max=2)
+    assert r["scaling"] == "strong" and r["episodes"] == 4 and r["batches_per_rank"] == 2 and r["episodes_per_batch"] == 2
+    assert r["wall_s"] > 0 and abs(r["episodes_per_s"] - 4 / r["wall_s"]) < 0.05 and r["mean_acc"] > 40.0
+
+
+def test_lookahead_loader_with_freeze_backbone_runs_the_frozen_path():
+    """The reference's loop body passes freeze_backbone on every call (finetune.py:615-619): a LookaheadLoader built with it
+    yields the loader untouched and the per-episode calls score with eval-mode features, exactly as without the wrapper."""
+    ft.params = argparse.Namespace(model='ResNet10', fine_tune_epoch=1, method="gnnnet")
+    sd = synthetic.gnnnet_state_dict_with_running_stats(seed=13)
+    model = _model(sd)
+    eps = [synthetic.test_episode(720 + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)]
+    np.random.seed(10)
+    ref = [ft.finetune(ep, None, model, sd, None, freeze_backbone=True) for ep in eps]
+    np.random.seed(10)
+    got = []
+    for elem in ft.LookaheadLoader(_Loader(eps), "gnnnet", model, sd, None, 1, 5, 5, episodes_per_batch=2, freeze_backbone=True):
+        liz_x = [x for (x, y) in elem]
+        got.append(ft.finetune(liz_x, None, model, sd, None, freeze_backbone=True))
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)) and not ft._READY
+    # and the non-frozen wrapper refuses a frozen call instead of handing out fine-tuned scores
+    it = iter(ft.LookaheadLoader(_Loader(eps), "gnnnet", model, sd, None, 1, 5, 5, episodes_per_batch=2))
+    elem = next(it)
+    with pytest.raises(RuntimeError):
+        ft.finetune([x for (x, y) in elem], None, model, sd, None, freeze_backbone=True)
+    it.close()
+    ft._READY.clear()
+    ft._ENGINES.clear()

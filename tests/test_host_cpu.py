@@ -307,3 +307,101 @@ def test_slab_placement_choice():
     rates2[(1, 3, 4)] = 6.0
     w, m, v, w2 = eng.pick_slab_buffers(rates2, 5)
     assert {m, v} == {3, 4} and {w, w2} == {1, 2}
+
+
+# ------------------------------------------------------------------------------------------------ round 3 host logic
+
+def test_meta_training_loader_gives_every_rank_the_same_number_of_steps(monkeypatch):
+    """Every step of episode-parallel meta-training is one collective (train.AllReduceAdam.step): with n_episode % W != 0 (the
+    CLI default 100 episodes on 8 GPUs) the ranks must still run the SAME number of steps, over disjoint episodes."""
+    from meta_fine_tuning_amd import train
+    drawn = []
+    monkeypatch.setattr(train.synthetic, "train_episode", lambda seed, *a, **k: drawn.append(seed) or seed)
+    for n_episode, W in ((100, 8), (7, 2), (5, 3), (4, 4), (100, 1)):
+        seen, lens = [], []
+        for r in range(W):
+            ld = train.SyntheticEpisodeLoader(5, 5, 16, 84, n_episode, rank=r, world=W)
+            got = [x for x, _ in ld]
+            assert len(got) == len(ld) == n_episode // W
+            lens.append(len(got))
+            seen += got
+            assert [x for x, _ in ld] == [g + n_episode for g in got]          # the next epoch continues the stream
+        assert len(set(lens)) == 1 and len(set(seen)) == len(seen) and max(seen) < n_episode
+        assert len(seen) == n_episode - n_episode % W
+
+
+def test_checkpoint_lookup_mirrors_the_reference(tmp_path, monkeypatch):
+    """finetune.checkpoint_files against the paths the reference's __main__ opens (finetune.py:448-527, io_utils.py:49-69)."""
+    from meta_fine_tuning_amd import configs, finetune as ft
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    base = str(tmp_path) + "/checkpoints/miniImageNet/"
+    P = lambda *a: io_utils.parse_args('train', list(a))
+    # gnnnet: <model>_gnnnet[_aug]_<n>way_<k>shot/<save_iter>.tar                                      (finetune.py:486-498)
+    assert ft.checkpoint_files(P("--method", "gnnnet", "--save_iter", "600")) == (base + "ResNet10_gnnnet_5way_5shot/600.tar", None)
+    assert ft.checkpoint_files(P("--method", "gnnnet", "--save_iter", "7", "--train_aug", "--n_shot", "20", "--train_n_way", "3")) == \
+        (base + "ResNet10_gnnnet_aug_3way_20shot/7.tar", None)
+    # --save_iter -1: best_model.tar if present, else the newest epoch, else None                     (io_utils.py:53-69)
+    d = tmp_path / "checkpoints" / "miniImageNet" / "ResNet10_gnnnet_5way_5shot"
+    assert ft.checkpoint_files(P("--method", "gnnnet")) == (None, None)
+    d.mkdir(parents=True)
+    for name in ("3.tar", "12.tar"):
+        (d / name).write_bytes(b"")
+    assert ft.checkpoint_files(P("--method", "gnnnet"))[0] == str(d / "12.tar")
+    (d / "best_model.tar").write_bytes(b"")
+    assert ft.checkpoint_files(P("--method", "gnnnet"))[0] == str(d / "best_model.tar")
+    # baseline: literal 400.tar when --save_iter is given, newest epoch otherwise                       (finetune.py:448-462)
+    assert ft.checkpoint_files(P("--method", "baseline", "--save_iter", "9")) == (None, base + "ResNet10_baseline/400.tar")
+    db = tmp_path / "checkpoints" / "miniImageNet" / "ResNet10_baseline_aug"
+    db.mkdir(parents=True)
+    for name in ("100.tar", "399.tar", "best_model.tar"):
+        (db / name).write_bytes(b"")
+    assert ft.checkpoint_files(P("--method", "baseline", "--train_aug")) == (None, str(db / "399.tar"))      # get_resume_file skips best_model
+    # all: the GNN file is ALWAYS ..._gnnnet_aug_<n>way_<k>shot/600.tar; the baseline file uses get_best_file   (:464-480,508-514)
+    assert ft.checkpoint_files(P("--method", "all", "--train_aug")) == (base + "ResNet10_gnnnet_aug_5way_5shot/600.tar", str(db / "best_model.tar"))
+    assert ft.checkpoint_files(P("--method", "all", "--save_iter", "5")) == (base + "ResNet10_gnnnet_aug_5way_5shot/600.tar",
+                                                                             base + "ResNet10_baseline/400.tar")
+    # loading strips what a --fine_tune run leaves in the state dict                                   (finetune.py:501-511)
+    f = tmp_path / "x.tar"
+    torch.save({"epoch": 1, "state": {"feature.a": torch.ones(2), "feature2.a": torch.zeros(2), "feature3.trunk.b": torch.zeros(1),
+                                      "fc.0.weight": torch.ones(1)}}, str(f))
+    assert sorted(ft.load_checkpoint_state(str(f))) == ["fc.0.weight", "feature.a"]
+    # an epoch the user named, in a directory that exists, must exist (the reference's torch.load raises)
+    with pytest.raises(FileNotFoundError):
+        ft._resolve_state("gnnnet", str(d / "77.tar"), 5, True, False)
+    sd, used = ft._resolve_state("gnnnet", str(tmp_path / "nowhere" / "1.tar"), 5, True, False)
+    assert used is None and len(sd) == 140
+    hz = np.load(os.path.join(ROOT, "tests", "golden", "g9_head.npz"))
+    assert all(torch.equal(sd[k], torch.from_numpy(hz[k])) for k in hz.files)          # not a random head
+
+
+def test_balanced_batches_and_lookahead_guard():
+    from meta_fine_tuning_amd import finetune as ft
+    assert [ft.balanced_batch(n, 128) for n in (600, 300, 150, 75, 128, 129, 1)] == [120, 100, 75, 75, 128, 65, 1]
+    for n in range(1, 700, 37):
+        e = ft.balanced_batch(n, 128)
+        nb = (n + 127) // 128
+        assert e <= 128 and e * nb >= n and (e - 1) * nb < n
+    # a parked score is handed out only to the call it was computed for
+    x = torch.zeros(1)
+    st, st2, model = {"a": 1}, {"a": 1}, object()
+    ctx = {"freeze_backbone": False, "state_gnn": st, "state_b": st2, "model": model}
+    ft._READY[id(x)] = {"pin": x, "gnn": "G", "linear": "L", "ctx": ctx}
+    with pytest.raises(RuntimeError):
+        ft._take_ready([x], "gnn", True, st, model)                  # --freeze_backbone call against non-frozen parked scores
+    with pytest.raises(RuntimeError):
+        ft._take_ready([x], "gnn", False, st2, model)                # another state dict
+    assert ft._take_ready([x], "linear", False, st2) == "L" and ft._take_ready([x], "gnn", False, st, model) == "G"
+    assert not ft._READY
+    # the frozen branches train nothing: the wrapper passes the loader through untouched
+    la = ft.LookaheadLoader([1, 2, 3], "gnnnet", None, fine_tune_epoch=1, freeze_backbone=True)
+    assert list(la) == [1, 2, 3] and not ft._READY
+
+
+def test_placement_hint_roundtrip(tmp_path, monkeypatch):
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    engine._PLACEMENT_HINTS.clear()
+    assert engine._placement_hint("k") is None
+    engine._placement_hint("k", {"chosen": [1, 2, 3, 4], "chosen_gbs": 6.1, "chosen_alt_gbs": 6.0})
+    engine._PLACEMENT_HINTS.clear()                                   # another process: the file answers
+    assert engine._placement_hint("k")["chosen"] == [1, 2, 3, 4] and engine._placement_hint("other") is None
