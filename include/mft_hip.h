@@ -193,6 +193,31 @@ int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ld
                                int stride, int pad, int imgs_per_group, long long group_stride,
                                int step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* loss.backward() + delta_opt.step() of inner step t AND the convolution of inner step t+1 in one pass over w, m, v
+ * (finetune.py:286-299: the first reader of what Adam wrote is `pretrained_model(z_batch)` of the NEXT iteration;
+ * backbone.py:251-261 for the block structure).  Per-episode ("group") weights, <= 48 output pixels per episode.
+ * Gradient + Adam exactly as mft_conv2d_wgrad_adam_nhwc (bit-identical w, m, v; dw_or_null also receives the gradient;
+ * `hyper` != NULL: step size / bias correction from device memory as in the *_dev launchers, `step`/`lr` ignored).
+ * x_next: the NEXT step's input activation (same geometry as x; NULL = no forward, the last inner step).  Every workgroup
+ * multiplies each weight tile it has just updated with x_next's im2col rows while the tile is still in LDS, so the updated
+ * weights are not read back from HBM by a forward launch.  `mode` selects the epilogue over the episode's pixels:
+ *   0  raw [n_img*OH*OW, Cout] only                                   (trunk.7.shortcut; its BatchNorm is applied by mode 2)
+ *   1  raw + mean / rstd [groups, Cout] + act = ReLU(BN(raw))          (trunk.7.C1 + BN1 + ReLU, backbone.py:252-254)
+ *   2  raw + both BatchNorms' statistics + act = ReLU(BN(raw) + BN_s(sc_raw)) + pooled [n_img, Cout] = global average pool of act
+ *                                                                      (trunk.7.C2 .. AvgPool2d, backbone.py:255-261,438)
+ * gamma / beta (and gamma_s / beta_s) are per-group with stride gb_group_stride.  MFT_EINVAL outside the domain
+ * (Cin % 128, Cout % 32, imgs_per_group * OH * OW <= 48, imgs_per_group <= 8).                                             */
+int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
+                                float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                int pad, int imgs_per_group, long long group_stride, int step, const float* hyper, float lr,
+                                float beta1, float beta2, float eps, const float* x_next, int mode, float* raw, float* act,
+                                const float* gamma, const float* beta, long long gb_group_stride, float* mean, float* rstd,
+                                const float* sc_raw, const float* gamma_s, const float* beta_s, float* mean_s, float* rstd_s,
+                                float* pooled, float bn_eps, void* stream);
+/* 1: correctly rounded division / square root in that launch's Adam epilogue (default 0: v_rcp_f32 / v_sqrt_f32, as
+ * mft_conv2d_wgrad_adam_nhwc's default).                                                                                   */
+void mft_wgrad_fwd_set_exact(int on);
+
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */
 /* F.batch_norm(training=True) statistics (backbone.py:224,227,240,409; gnn.py:65-74; gnnnet.py:30):
  * per (group, channel) mean and 1/sqrt(biased var + eps) over rows_per_group rows.

@@ -185,7 +185,8 @@ def _on_device(fn):
 class FinetuneEngine:
     def __init__(self, state, n_way=5, n_support=5, n_query=15, image_size=84, n_views=19, fine_tune_epoch=5,
                  episodes_per_batch=16, batch_size=5, lr=0.01, device="cuda:0", head_state=None, fold50=False,
-                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True, graph=False, trunk_chunk=None):
+                 fused_adam=True, pipeline=True, stem_cache=True, mode="gnn", x3=True, graph=False, trunk_chunk=None,
+                 fuse_next=None):
         """state: GnnNet state dict ('feature.*', 'fc.*', 'gnn.*'); n_views = 2 + gen_examples.
         ``head_state`` overrides the fc/gnn weights (the reference scores with the *loaded model*, finetune.py:316).
         ``mode`` "gnn": finetune.finetune (inner loss on the raw feature, GNN scoring);
@@ -213,6 +214,8 @@ class FinetuneEngine:
         with torch.cuda.device(self.dev):
             self._build(state, n_way, n_support, n_query, image_size, n_views, fine_tune_epoch, episodes_per_batch, batch_size, lr,
                         head_state, fold50, fused_adam, pipeline, stem_cache, mode, x3, trunk_chunk)
+            if fuse_next is not None:
+                self.fuse_next = bool(fuse_next)
 
     def close(self):
         """Release what the caching allocator does not own: the raw HIP priority stream (mft_stream_create_priority)."""
@@ -256,6 +259,9 @@ class FinetuneEngine:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)     # device-side Adam step counter / bias
         self.hyper = torch.zeros(2, device=self.dev)                           # corrections (graph replay)
         self.pipeline = pipeline
+        # the weight-gradient + Adam launches of step t also run step t+1's last-block forward (csrc/wgrad_fwd.hip): the updated
+        # weights are not read back by a forward launch.  MFT_FUSE_NEXT=0 restores the separate block-entry / block-exit launches.
+        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "1") == "1"
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
@@ -401,12 +407,18 @@ class FinetuneEngine:
         xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (n, H * H * 3)))
         return Fn.resnet10_trunk(self.W, xb.view(n, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
 
-    def last_step(self, x6, lab_dev, k):
+    def last_step(self, x6, lab_dev, k, nxt=None, tape=None):
         """Adapted part: trunk.7 forward with per-episode weights, CE on the 512-d feature, last-block backward,
-        Adam (finetune.py:286-299)."""
+        Adam (finetune.py:286-299).
+        ``nxt`` = (x6 of the NEXT step | None, its tape buffers | None): the weight-gradient + Adam launches also run the next
+        step's trunk.7 forward (Fn.last_block_backward(nxt=)); ``tape``: this step's forward as left by the PREVIOUS step's
+        launches (None: run the forward here -- the first step of a loop)."""
         E = self.E
-        tape = {}
-        feat = Fn.last_block_forward(self.W, x6, self.arena, k, slab=self.adapt.w, tape=tape, tag="s%d" % k)
+        if tape is None:
+            tape = {}
+            feat = Fn.last_block_forward(self.W, x6, self.arena, k, slab=self.adapt.w, tape=tape, tag="s%d" % k)
+        else:
+            feat = tape["feat"]
         self.adapt.step += 1
         if self.mode == "linear":
             # classifier step (logits, CE, d feature, Adam(lr .01, wd .001) on W, b) in one launch; finetune.py:147-158
@@ -429,12 +441,17 @@ class FinetuneEngine:
                                    adam=(self.adapt.m, self.adapt.v, self.hyper, self.lr), ce=ce)
         elif self.fused_adam:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
-                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr), ce=ce)
+                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr), ce=ce, nxt=nxt)
         else:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k, ce=ce)
             ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
                           lr=self.lr)
         return loss
+
+    def _next_tape(self, x6, k, parity):
+        n, H6 = x6.shape[0], x6.shape[1]
+        oh = (H6 + 2 - 3) // 2 + 1
+        return Fn.next_step_tape(self.arena, "nx%d.%d" % (k, parity), n, oh, oh, 512, n // k)
 
     def inner_step(self, idx_dev, lab_dev, k):
         return self.last_step(self.trunk_step(idx_dev, k, 0), lab_dev, k)
@@ -475,13 +492,66 @@ class FinetuneEngine:
                 slab.copy_(lab_all[t])
                 g.replay()
             return
+        uniform = len({t[0] for t in tables}) == 1
+        k0 = tables[0][0]
+        H6 = (((((self.size + 6 - 7) // 2 + 1) + 2 - 3) // 2 + 1 + 1) // 2 + 1) // 2        # 84 -> 42 -> 21 -> 11 -> 6; 224 -> 14
+        fuse = (self.fuse_next and uniform and self.fused_adam and not self.use_graph and Fn.next_forward_ok(k0, H6))
         if not self.pipeline:
+            if fuse:
+                # step t's weight-gradient launches also produce step t+1's last-block forward: x6 of t+1 must exist before them
+                n_steps = len(tables)
+                x6 = self.trunk_step(idx_all[0], k0, 0)
+                tape = None
+                for t in range(n_steps):
+                    x6n = self.trunk_step(idx_all[t + 1], k0, (t + 1) % 3) if t + 1 < n_steps else None
+                    tn = self._next_tape(x6, k0, (t + 1) & 1) if x6n is not None else None
+                    self.last_step(x6, lab_all[t], k0, nxt=(x6n, tn), tape=tape)
+                    x6, tape = x6n, tn
+                return
             for (k, _, _), idx, lab in zip(tables, idx_all, lab_all):
                 self.inner_step(idx, lab, k)
             return
         cur = torch.cuda.current_stream(dev)
         self.s_trunk.wait_stream(cur)
         self.s_last.wait_stream(cur)
+        if fuse and self.trunk_chunk == 1:
+            # The frozen trunk runs TWO steps ahead on its own stream (three x6 buffers): the last-block launches of step t read
+            # x6[t] (weight gradients) and x6[t+1] (the next step's forward they also compute).
+            n_steps = len(tables)
+            x6s, ready, done = [None] * n_steps, [None] * n_steps, [None, None, None]
+
+            def launch_trunk(t):
+                par = t % 3
+                with torch.cuda.stream(self.s_trunk):
+                    if done[par] is not None:
+                        self.s_trunk.wait_event(done[par])
+                    x6s[t] = self.trunk_step(idx_all[t], k0, par)
+                    ready[t] = torch.cuda.Event()
+                    ready[t].record(self.s_trunk)
+
+            launch_trunk(0)
+            if n_steps > 1:
+                launch_trunk(1)
+            tape = None
+            for t in range(n_steps):
+                if t + 2 < n_steps:
+                    launch_trunk(t + 2)               # its buffer was last read by step t-1, whose completion event it waits for
+                with torch.cuda.stream(self.s_last):
+                    self.s_last.wait_event(ready[t])
+                    x6n = tn = None
+                    if t + 1 < n_steps:
+                        self.s_last.wait_event(ready[t + 1])
+                        x6n = x6s[t + 1]
+                        tn = self._next_tape(x6n, k0, (t + 1) & 1)
+                    self.last_step(x6s[t], lab_all[t], k0, nxt=(x6n, tn), tape=tape)
+                    tape = tn
+                    ev = torch.cuda.Event()
+                    ev.record(self.s_last)
+                    done[t % 3] = ev
+                x6s[t] = None
+            cur.wait_stream(self.s_trunk)
+            cur.wait_stream(self.s_last)
+            return
         # The frozen trunk does not depend on the adaptation, so it runs AHEAD in chunks of ``trunk_chunk`` steps: one set
         # of trunk launches covers T steps (T*E*k images, BatchNorm groups of k images as before), then the last-block
         # stream consumes the T slices.  Bigger launches for the MFMA-bound half, T times fewer of them.

@@ -18,6 +18,7 @@ synthetic ones, and without a checkpoint on disk the weights are too (``standin_
 """
 import hashlib
 import os
+import sys
 
 import numpy as np
 import torch
@@ -658,12 +659,12 @@ def _resolve_state(kind, modelfile, n_way, explicit, verbose):
     exists (the reference's torch.load raises there, finetune.py:498); otherwise the stand-in weights are used and said so."""
     if modelfile is not None and os.path.isfile(modelfile):
         if verbose:
-            print("loading %s checkpoint %s" % (kind, modelfile))
+            print("loading %s checkpoint %s" % (kind, modelfile), file=sys.stderr)          # (stdout keeps the reference's lines only)
         return load_checkpoint_state(modelfile), modelfile
     if modelfile is not None and explicit and os.path.isdir(os.path.dirname(modelfile)):
         raise FileNotFoundError(modelfile)
     if verbose:
-        print("no %s checkpoint%s: synthetic stand-in weights" % (kind, "" if modelfile is None else " at " + modelfile))
+        print("no %s checkpoint%s: synthetic stand-in weights" % (kind, "" if modelfile is None else " at " + modelfile), file=sys.stderr)
     return standin_state(kind, n_way), None
 
 

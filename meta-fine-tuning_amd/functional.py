@@ -491,11 +491,29 @@ def _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, 
     return dc1
 
 
-def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None):
+def next_step_tape(arena, tag, n, oh, ow, C, groups):
+    """Buffers the fused weight-gradient + Adam + next-forward launches (csrc/wgrad_fwd.hip) fill for inner step t+1: the same
+    fields simple_block's tape carries for the adapted last block, plus the pooled feature."""
+    rows = n * oh * ow
+    t = {k: arena.get(tag + "." + k, (n, oh, ow, C)) for k in ("c1", "r1", "c2", "sc", "out")}
+    for k in ("m1", "s1", "m2", "s2", "ms", "ss"):
+        t[k] = arena.get(tag + "." + k, (groups, C))
+    t["feat"] = arena.get(tag + ".feat", (n, C))
+    t["pooled"] = True
+    assert t["c1"].numel() == rows * C
+    return t
+
+
+def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None, nxt=None):
     """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
     ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
     ``adam`` = (m_slab, v_slab, step, lr): fuse the Adam update of the three conv weights into the wgrad
-    epilogues (their gradients are then not materialised) and update the BatchNorm affine tail separately."""
+    epilogues (their gradients are then not materialised) and update the BatchNorm affine tail separately.
+    ``nxt`` = (x_next | None, tape_next | None) (needs ``adam``): the three weight-gradient + Adam launches also run the NEXT inner
+    step's trunk.7 forward on ``x_next`` from the weight tiles they have just updated and fill ``tape_next`` (next_step_tape) --
+    no forward launch reads the updated weights back (csrc/wgrad_fwd.hip).  The BatchNorm-affine Adam tail then runs BEFORE them
+    (their epilogues apply the updated gamma / beta), C1 and the shortcut before C2 (whose forward consumes r1 and sc of step
+    t+1).  x_next None: the last inner step (update only)."""
     x, c1, r1, c2, sc, out = tape["x"], tape["c1"], tape["r1"], tape["c2"], tape["sc"], tape["out"]
     n, oh, ow, C = out.shape
     groups = n // ipg
@@ -571,17 +589,55 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
                                                             ops._p(grads.bn1g), ops._p(grads.bn1b), ops._stream()),
                            "mft_col2im_bn_backward_small")
             done_c2 = True
+    def adam_tail():
+        m, v, step, lr = adam
+        nb = params.E * 6 * 512                       # BatchNorm affine tail of the tensor-major slab
+        hyper = step if torch.is_tensor(step) else None
+        ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], 1 if hyper is not None else step,
+                      lr=lr, hyper=hyper)
+
+    if nxt is not None:
+        assert adam is not None and not done_c2
+        x_next, tn = nxt
+        m_, v_, step, lr = adam
+        hyper = step if torch.is_tensor(step) else None
+        st = 1 if hyper is not None else step
+        dc1 = _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd)
+        adam_tail()
+        kw = dict(lr=lr, hyper=hyper)
+        fw = x_next is not None
+        ok = ops.wgrad_adam_next_forward(x, dsc, params.scw, m_.scw, v_.scw, 1, 1, 2, 0, st, ipg, x_next=x_next, mode=ops.WF_RAW,
+                                         raw=tn["sc"] if fw else None, **kw)
+        ok = ok and ops.wgrad_adam_next_forward(x, dc1, params.c1w, m_.c1w, v_.c1w, 3, 3, 2, 1, st, ipg, x_next=x_next,
+                                                mode=ops.WF_ENTRY, raw=tn["c1"] if fw else None, act=tn["r1"] if fw else None,
+                                                gamma=params.bn1g, beta=params.bn1b, gbs=C, mean=tn["m1"] if fw else None,
+                                                rstd=tn["s1"] if fw else None, **kw)
+        ok = ok and ops.wgrad_adam_next_forward(r1, dc2, params.c2w, m_.c2w, v_.c2w, 3, 3, 1, 1, st, ipg,
+                                                x_next=tn["r1"] if fw else None, mode=ops.WF_EXIT, raw=tn["c2"] if fw else None,
+                                                act=tn["out"] if fw else None, gamma=params.bn2g, beta=params.bn2b, gbs=C,
+                                                mean=tn["m2"] if fw else None, rstd=tn["s2"] if fw else None,
+                                                sc_raw=tn["sc"] if fw else None, gamma_s=params.bnsg, beta_s=params.bnsb,
+                                                mean_s=tn["ms"] if fw else None, rstd_s=tn["ss"] if fw else None,
+                                                pooled=tn["feat"] if fw else None, **kw)
+        if not ok:
+            raise RuntimeError("wgrad_adam_next_forward: shape outside the fused kernel's domain (the caller checks next_forward_ok)")
+        if fw:
+            tn["x"] = x_next
+        return
     if not done_c2:
         dc1 = _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd)
         wgrad(r1, dc2, "c2w", 3, 1, 1)
     wgrad(x, dc1, "c1w", 3, 2, 1)
     wgrad(x, dsc, "scw", 1, 2, 0)
     if adam is not None:
-        m, v, step, lr = adam
-        nb = params.E * 6 * 512                       # BatchNorm affine tail of the tensor-major slab
-        hyper = step if torch.is_tensor(step) else None
-        ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], 1 if hyper is not None else step,
-                      lr=lr, hyper=hyper)
+        adam_tail()
+
+
+def next_forward_ok(ipg, H6):
+    """Domain of the fused next-step forward for trunk.7 (3x3 / stride 2 on an H6 x H6 map): all of an episode's output pixels
+    must fit the kernel's 48-pixel tile (84x84 inputs: 5 images x 3 x 3 = 45)."""
+    oh = (H6 + 2 - 3) // 2 + 1
+    return FUSED_LAST_BLOCK and not FUSED_DGRAD and 0 < ipg <= 8 and ipg * oh * oh <= 48
 
 
 # ------------------------------------------------------------------------------------------ GNN head

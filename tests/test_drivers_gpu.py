@@ -341,8 +341,9 @@ def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys)
     monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
     ft._ENGINES.clear()
     accs = ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
-    out = capsys.readouterr().out
-    assert ft.main.loaded["gnnnet"] == str(f) and ("loading gnnnet checkpoint %s" % f) in out
+    cap = capsys.readouterr()
+    assert ft.main.loaded["gnnnet"] == str(f) and ("loading gnnnet checkpoint %s" % f) in cap.err
+    assert cap.out.splitlines()[0] == "False" and "3 Test Acc = " in cap.out            # stdout: the reference's lines only
     state = torch.load(str(f), map_location="cpu")["state"]
     state = {k: v for k, v in state.items() if "feature2." not in k and "feature3." not in k}
     model = _model(state)
@@ -354,7 +355,7 @@ def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys)
     # the trained weights are not the stand-ins: the stand-in run differs
     monkeypatch.setattr(configs, "save_dir", str(tmp_path / "empty"))
     accs2 = ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
-    assert ft.main.loaded["gnnnet"] is None and "synthetic stand-in weights" in capsys.readouterr().out
+    assert ft.main.loaded["gnnnet"] is None and "synthetic stand-in weights" in capsys.readouterr().err
     assert accs2.mean() > 40.0                                        # G9's meta-trained head, not a random one (chance = 20 %)
     # an epoch that was never written, in a directory that exists: the reference's torch.load raises
     monkeypatch.setattr(configs, "save_dir", str(tmp_path))

@@ -228,7 +228,7 @@ def test_fused_wgrad_adam_equals_unfused():
     perms = [[rs.permutation(75)] for _ in range(2)]
     outs = []
     for fused in (False, True):
-        e = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=1, episodes_per_batch=2, device=DEV, fused_adam=fused)
+        e = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=1, episodes_per_batch=2, device=DEV, fused_adam=fused, fuse_next=False)
         sc = e.run_batch(eps, perms=perms)
         outs.append((sc.clone(), e.adapt.w.flat.clone(), e.adapt.m.flat.clone(), e.adapt.v.flat.clone()))
     (s0, w0, m0, v0), (s1, w1, m1, v1) = outs
@@ -261,6 +261,38 @@ def test_fused_last_block_launches_match_separate_launches():
         (float(dm.max()), float((dm > 1e-5).float().mean()), float((v0 - v1).abs().max()))
     # Adam's first steps move every weight by ~lr * sign(g): elements whose gradient is at rounding level take a different
     # path under ANY reordering of the BatchNorm sums (1.5 % of the weights here), while m, v and the scores agree closely
+    frac_far = float(((w0 - w1).abs() > 1e-4).float().mean())
+    assert frac_far < 5e-2 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))
+
+
+def test_next_forward_fusion_matches_separate_forward_launches():
+    """The default inner loop -- step t's weight-gradient + Adam launches also compute step t+1's trunk.7 forward from the
+    weight tiles they have just updated (csrc/wgrad_fwd.hip; fp32 MFMA, K walked tile by tile) -- against the same engine with
+    the separate block-entry / block-exit launches (bf16x3, another summation order): the FIRST step's update is bit-identical
+    (its forward is the same launch in both), later steps agree to fp32 rounding amplified by Adam, like any two fp32 forms."""
+    sd = synthetic.gnnnet_state_dict(seed=33)
+    eps = [synthetic.test_episode(700 + i, 5, 5, 15, 84, gen_examples=0) for i in range(2)]
+    rs = np.random.RandomState(11)
+    perms = [[rs.permutation(75)] for _ in range(2)]
+    outs, first = [], []
+    for fuse in (False, True):
+        for pipe in (False, True):
+            e = eng.FinetuneEngine(sd, n_views=2, fine_tune_epoch=1, episodes_per_batch=2, device=DEV, fuse_next=fuse, pipeline=pipe)
+            e._ingest(eps, False)
+            e.adapt.reset(e.W)
+            e.prepare_batch()
+            e.inner_loop(e.step_tables(perms, 2)[:1])
+            torch.cuda.synchronize()
+            first.append(e.adapt.w.flat.clone())
+            sc = e.run_batch(eps, perms=perms)
+            outs.append((sc.clone(), e.adapt.w.flat.clone(), e.adapt.m.flat.clone(), e.adapt.v.flat.clone()))
+            e.close()
+    assert all(torch.equal(first[0], f) for f in first[1:])                       # one step: the same update, bit for bit
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and all(torch.equal(a, b) for a, b in zip(outs[2], outs[3]))
+    (s0, w0, m0, v0), (s1, w1, m1, v1) = outs[0], outs[2]
+    dm = (m0 - m1).abs()
+    assert float(dm.max()) < 3e-4 and float((dm > 1e-5).float().mean()) < 1e-3 and float((v0 - v1).abs().max()) < 1e-6, \
+        (float(dm.max()), float((dm > 1e-5).float().mean()), float((v0 - v1).abs().max()))
     frac_far = float(((w0 - w1).abs() > 1e-4).float().mean())
     assert frac_far < 5e-2 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))
 
@@ -417,7 +449,7 @@ def test_hipgraph_inner_step_is_bit_identical():
     eps = [synthetic.test_episode(800 + i, 5, 5, 15, 84, gen_examples=1) for i in range(2)]
     rs = np.random.RandomState(15)
     perms = [[rs.permutation(100), rs.permutation(100)] for _ in range(2)]
-    e0 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, pipeline=False)
+    e0 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, pipeline=False, fuse_next=False)
     ref = e0.run_batch(eps, perms=perms).clone()
     wref = e0.adapt.w.flat.clone()
     e1 = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=2, device=DEV, graph=True)

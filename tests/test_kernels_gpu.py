@@ -762,3 +762,95 @@ def test_wgrad_adam_rows_kernel(name, Cin, Cout, k, stride, pad, H, ipg):
         # (entries with v ~ 1e-9 amplify the fp32-vs-fp64 gradient difference by 1 / sqrt(v))
         assert float((wf[g].cpu().double() - wr).abs().max()) < 2e-5, name
         assert float((mf[g].cpu().double() - mr).abs().max()) < 1e-7
+
+
+# ---------------------------------------------------------------------- weight gradient + Adam + the next step's convolution
+
+@pytest.mark.parametrize("ipg", [5, 4, 1])
+def test_wgrad_adam_next_forward_kernel(ipg):
+    """csrc/wgrad_fwd.hip on the three trunk.7 layers (per-episode weights, 84x84 geometry): (i) the gradient and (w, m, v)
+    are BIT-IDENTICAL to mft_conv2d_wgrad_adam_nhwc (fast and exact epilogue); (ii) the convolution of the NEXT step's
+    activation with the updated weights, and each epilogue -- raw (shortcut), BatchNorm + ReLU (C1), both BatchNorms + add +
+    ReLU + average pool (C2) -- against float64 on the updated weights the launch itself produced."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    G = 3
+    n = G * ipg
+    eps = ops.BN_EPS
+    for exact in (0, 1):
+        lib.mft_debug_reset()
+        lib.mft_wgrad_fwd_set_exact(exact)
+        if exact:
+            lib.mft_debug_set_conv_tile(9003)
+        sc_raw = None
+        for name, Cin, Cout, k, stride, pad, H, mode in (("shortcut", 256, 512, 1, 2, 0, 6, ops.WF_RAW), ("C1", 256, 512, 3, 2, 1, 6, ops.WF_ENTRY),
+                                                         ("C2", 512, 512, 3, 1, 1, 3, ops.WF_EXIT)):
+            OH = (H + 2 * pad - k) // stride + 1
+            rows = ipg * OH * OH
+            x = rnd((n, Cin, H, H), 301)
+            xn = rnd((n, Cin, H, H), 302)
+            dy = rnd((n, Cout, OH, OH), 303) * 1e-2
+            w0 = rnd((G, Cout, Cin, k, k), 304, scale=0.02)
+            m0 = rnd((G, Cout, k * k * Cin), 305) * 1e-3
+            v0 = rnd((G, Cout, k * k * Cin), 306).abs() * 1e-6
+            gam, bet = 1.0 + 0.1 * rnd((G, Cout), 307), 0.1 * rnd((G, Cout), 308)
+            gas, bes = 1.0 + 0.1 * rnd((G, Cout), 309), 0.1 * rnd((G, Cout), 310)
+            xg, xng, dyg = nhwc(x).to(DEV), nhwc(xn).to(DEV), nhwc(dy).to(DEV)
+            wpk = torch.stack([ops.pack_conv_weight(w0[g].to(DEV)) for g in range(G)])
+            # reference launch: gradient + Adam only
+            wr, mr, vr = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
+            dwr = torch.zeros_like(wr)
+            ops.conv2d_wgrad_adam(xg, dyg, wr, mr, vr, Cout, k, k, stride, pad, 7, imgs_per_group=ipg, dw=dwr)
+            w, m, v = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
+            dw = torch.zeros_like(w)
+            raw = torch.full((n * OH * OH, Cout), float("nan"), device=DEV)
+            act = torch.full_like(raw, float("nan"))
+            mean, rstd, means, rstds = (torch.full((G, Cout), float("nan"), device=DEV) for _ in range(4))
+            pooled = torch.full((n, Cout), float("nan"), device=DEV)
+            kw = dict(x_next=xng, mode=mode, raw=raw, dw=dw)
+            if mode != ops.WF_RAW:
+                kw.update(act=act, gamma=gam.to(DEV), beta=bet.to(DEV), gbs=Cout, mean=mean, rstd=rstd)
+            if mode == ops.WF_EXIT:
+                kw.update(sc_raw=sc_raw, gamma_s=gas.to(DEV), beta_s=bes.to(DEV), mean_s=means, rstd_s=rstds, pooled=pooled)
+            assert ops.wgrad_adam_next_forward(xg, dyg, w, m, v, k, k, stride, pad, 7, ipg, **kw)
+            assert torch.equal(dw, dwr) and torch.equal(m, mr) and torch.equal(v, vr) and torch.equal(w, wr), (name, exact)
+            # without x_next: the same update, nothing else written
+            w2, m2, v2 = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
+            assert ops.wgrad_adam_next_forward(xg, dyg, w2, m2, v2, k, k, stride, pad, 7, ipg)
+            assert torch.equal(w2, wr) and torch.equal(m2, mr) and torch.equal(v2, vr)
+            # float64 statement of the next step on the UPDATED weights
+            raw_r = torch.empty((G, rows, Cout), dtype=torch.float64)
+            for g in range(G):
+                wg = ops.unpack_conv_weight(w[g].contiguous(), (Cout, Cin, k, k)).cpu().double()
+                o = F.conv2d(xn[g * ipg:(g + 1) * ipg].double(), wg, None, stride, pad)
+                raw_r[g] = o.permute(0, 2, 3, 1).reshape(rows, Cout)
+            got = raw.view(G, rows, Cout).cpu().double()
+            scale = float(raw_r.abs().max())
+            assert float((got - raw_r).abs().max()) <= 3e-6 * scale, (name, float((got - raw_r).abs().max()), scale)
+            if mode == ops.WF_RAW:
+                sc_raw = raw.clone()
+                sc_raw_r = raw_r
+                continue
+            mu = raw_r.mean(1, keepdim=True)
+            rs = 1.0 / (raw_r.var(1, unbiased=False, keepdim=True) + eps).sqrt()
+            assert float((mean.cpu().double() - mu[:, 0]).abs().max()) <= 3e-6 * scale
+            assert float((rstd.cpu().double() / rs[:, 0] - 1).abs().max()) <= 2e-5
+            y = (raw_r - mu) * rs * gam.double()[:, None] + bet.double()[:, None]
+            if mode == ops.WF_EXIT:
+                mus = sc_raw_r.mean(1, keepdim=True)
+                rss = 1.0 / (sc_raw_r.var(1, unbiased=False, keepdim=True) + eps).sqrt()
+                assert float((means.cpu().double() - mus[:, 0]).abs().max()) <= 3e-6 * float(sc_raw_r.abs().max())
+                assert float((rstds.cpu().double() / rss[:, 0] - 1).abs().max()) <= 2e-5
+                y = y + (sc_raw_r - mus) * rss * gas.double()[:, None] + bes.double()[:, None]
+            y = y.clamp_min(0)
+            assert float((act.view(G, rows, Cout).cpu().double() - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1.0), name
+            if mode == ops.WF_EXIT:
+                pr = y.view(G, ipg, OH * OH, Cout).mean(2).reshape(n, Cout)
+                assert float((pooled.cpu().double() - pr).abs().max()) <= 2e-5 * max(float(pr.abs().max()), 1.0)
+    lib.mft_wgrad_fwd_set_exact(0)
+    lib.mft_debug_reset()
+    # outside the domain: more than 48 output pixels per episode
+    xb = torch.zeros((6, 6, 6, 256), device=DEV)
+    dyb = torch.zeros((6, 3, 3, 512), device=DEV)
+    wb = torch.zeros((1, 512, 2304), device=DEV)
+    assert not ops.wgrad_adam_next_forward(xb, dyb, wb, wb.clone(), wb.clone(), 3, 3, 2, 1, 1, 6)
