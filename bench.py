@@ -50,11 +50,11 @@ def conv_flops(n_img, OH, Cout, K):
 
 
 def kernel_source_sha():
-    """Identity of the dominant kernel's source (csrc/conv_igemm.hip + csrc/mft_common.h): a PMC traffic figure is only quoted
+    """Identity of the dominant kernel's source (csrc/wgrad_fwd.hip + csrc/mft_common.h): a PMC traffic figure is only quoted
     for byte-identical kernel code."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("meta-fine-tuning_amd/csrc/conv_igemm.hip", "meta-fine-tuning_amd/csrc/mft_common.h"):
+    for rel in ("meta-fine-tuning_amd/csrc/wgrad_fwd.hip", "meta-fine-tuning_amd/csrc/mft_common.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -595,6 +595,23 @@ def main():
             adam_events.append((a, b, 6.0 * 4.0 * w.numel()))
         return ok
 
+    orig_wgrad_next = ops.wgrad_adam_next_forward
+
+    def timed_wgrad_next(x, dy, w, m, v, *a, **kw):
+        # the default form of the dominant launch (csrc/wgrad_fwd.hip): weight gradient + Adam that also computes the next inner
+        # step's convolution from the tiles it has just updated.  Algorithmic traffic as before: 6 x 4 B per parameter.
+        if not timing["on"]:
+            return orig_wgrad_next(x, dy, w, m, v, *a, **kw)
+        s = torch.cuda.current_stream()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record(s)
+        ok = orig_wgrad_next(x, dy, w, m, v, *a, **kw)
+        eb.record(s)
+        if ok:
+            adam_events.append((ea, eb, 6.0 * 4.0 * w.numel()))
+        return ok
+
+    ops.wgrad_adam_next_forward = timed_wgrad_next
     ops.conv2d_wgrad_adam_dgrad = timed_wgrad_adam_dgrad
     ops.conv2d = timed_conv2d
     ops.conv2d_wgrad_adam = timed_wgrad_adam
@@ -646,9 +663,12 @@ def main():
         n_a = len(adam_events)
         ach = a_by / (a_ms * 1e-3) / 1e9
         big = [(a.elapsed_time(b), f) for a, b, f in adam_events if f == max(x[2] for x in adam_events)]
-        roof = {"bound": "hbm", "kernel": "wgrad_adam_rows_kernel (trunk.7 weight gradient with torch.optim.Adam fused in the "
-                                          "epilogue; per-episode w,m,v streamed once per inner step; conv_wgrad_kernel<64,64,ADAM> "
-                                          "beyond 64 reduction rows)",
+        roof = {"bound": "hbm", "kernel": "wgrad_adam_fwd_kernel (trunk.7 weight gradient with torch.optim.Adam fused in the epilogue AND "
+                                          "the next inner step's convolution from the weight tiles just updated; per-episode w,m,v "
+                                          "streamed once per inner step and not read again by a forward launch; MFT_FUSE_NEXT=0: "
+                                          "wgrad_adam_rows_kernel + separate forward launches)" if e.fuse_next else
+                                          "wgrad_adam_rows_kernel (trunk.7 weight gradient with torch.optim.Adam fused in the "
+                                          "epilogue; per-episode w,m,v streamed once per inner step)",
                 "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
                 "traffic": pmc_traffic(E), "launches": n_a, "avg_launch_us": round(a_ms * 1e3 / n_a, 2),
                 "algorithmic_mb_per_launch": round(a_by / n_a / 1e6, 2),
@@ -681,8 +701,31 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             t_us = e0.elapsed_time(e1) * 1e3 / 5
-            roof["standalone"] = {"what": "trunk.7.C2 x %d episodes on the engine's own slabs, no co-running stream" % E, "avg_launch_us": round(t_us, 2),
+            roof["standalone"] = {"what": "trunk.7.C2 x %d episodes on the engine's own slabs, no co-running stream, gradient + Adam only "
+                                          "(wgrad_adam_rows_kernel)" % E, "avg_launch_us": round(t_us, 2),
                                   "achieved": round(24.0 * ws.numel() / (t_us * 1e-6) / 1e9, 1)}
+            if e.fuse_next:
+                # the fused form alone: same update + the next step's C2 forward, BatchNorms, add, ReLU, pool from the updated tiles
+                tn = {k_: torch.empty((E * 5, 3, 3, 512), device=dev) for k_ in ("c2", "out", "sc")}
+                st_ = {k_: torch.empty((E, 512), device=dev) for k_ in ("m2", "s2", "ms", "ss")}
+                tn["sc"].normal_(generator=gen)
+                ft_ = torch.empty((E * 5, 512), device=dev)
+                ad_ = e.adapt.w
+
+                def fused_once(step_):
+                    orig_wgrad_next(xs, dys, ws, ms_, vs_, 3, 3, 1, 1, step_, 5, x_next=xs, mode=ops.WF_EXIT, raw=tn["c2"], act=tn["out"],
+                                    gamma=ad_.bn2g, beta=ad_.bn2b, gbs=512, mean=st_["m2"], rstd=st_["s2"], sc_raw=tn["sc"],
+                                    gamma_s=ad_.bnsg, beta_s=ad_.bnsb, mean_s=st_["ms"], rstd_s=st_["ss"], pooled=ft_)
+                fused_once(1)
+                torch.cuda.synchronize()
+                e0.record()
+                for it in range(5):
+                    fused_once(2 + it)
+                e1.record()
+                torch.cuda.synchronize()
+                t_us = e0.elapsed_time(e1) * 1e3 / 5
+                roof["standalone_fused"] = {"what": "the same launch WITH the next step's C2 forward + block exit (wgrad_adam_fwd_kernel), alone",
+                                            "avg_launch_us": round(t_us, 2), "achieved": round(24.0 * ws.numel() / (t_us * 1e-6) / 1e9, 1)}
             del xs, dys
         except RuntimeError as ex:          # e.g. not enough free memory next to a large engine
             roof["standalone"] = {"error": str(ex)[:120]}

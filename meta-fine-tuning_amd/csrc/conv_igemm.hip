@@ -510,12 +510,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             for (int u = 0; u < 4; ++u) {
                 const int row = rr + (r0 + u) * RP;
                 const f32x4 ge = *(const f32x4*)(Gs + row * GLD + 4 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    mm[u][e] = p.b1 * mm[u][e] + (1.f - p.b1) * ge[e];
-                    vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
-                    ww[u][e] -= step_size * (mm[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps));
-                }
+                mft_adam4_exact(mm[u], vv[u], ww[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
                 stp(mm[u], (f32x4*)(p.m + gi[u]));
                 stp(vv[u], (f32x4*)(p.v + gi[u]));
                 stp(ww[u], (f32x4*)(p.w + gi[u]));
@@ -647,20 +642,9 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
             // hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences, and the moment updates as
             // packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32): the epilogue's VALU work competes with the co-running trunk
             // convolutions for issue slots (A/B in DESIGN.md: +2 % end to end)
-            const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
-            mm[u] = p.b1 * mm[u] + c1 * ge;
-            vv[u] = p.b2 * vv[u] + c2 * (ge * ge);
-            f32x4 den;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps);
-            ww[u] -= step_size * (mm[u] * den);
+            mft_adam4_fast(mm[u], vv[u], ww[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mm[u][e] = p.b1 * mm[u][e] + (1.f - p.b1) * ge[e];
-                vv[u][e] = p.b2 * vv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
-                ww[u][e] -= step_size * (mm[u][e] / (sqrtf(vv[u][e]) * inv_sqrt_bc2 + p.eps));
-            }
+            mft_adam4_exact(mm[u], vv[u], ww[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
         }
         stp(mm[u], (f32x4*)(p.m + gi[u]));
         stp(vv[u], (f32x4*)(p.v + gi[u]));
@@ -764,13 +748,7 @@ __global__ __launch_bounds__(256) void wgrad_adam_walk_kernel(WgradArgs p) {
         for (int u = 0; u < 4; ++u) {
             const long long gi = gbase + (long long)(8 * u * p.Kpad) + kt * BN;
             const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
-            const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
-            cm[u] = p.b1 * cm[u] + c1 * ge;
-            cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
-            f32x4 den;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
-            cw[u] -= step_size * (cm[u] * den);
+            mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
             stp(cm[u], (f32x4*)(p.m + gi));
             stp(cv[u], (f32x4*)(p.v + gi));
             stp(cw[u], (f32x4*)(p.w + gi));
@@ -881,22 +859,8 @@ __global__ __launch_bounds__(256) void wgrad_adam_cowalk_kernel(WgradArgs p) {
         for (int u = 0; u < 4; ++u) {
             const long long gi = gbase + (long long)(tco * BM + 8 * u) * p.Kpad;
             const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
-            if (POL & 4) {
-                const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
-                cm[u] = p.b1 * cm[u] + c1 * ge;
-                cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
-                f32x4 den;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
-                cw[u] -= step_size * (cm[u] * den);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cm[u][e] = p.b1 * cm[u][e] + (1.f - p.b1) * ge[e];
-                    cv[u][e] = p.b2 * cv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
-                    cw[u][e] -= step_size * (cm[u][e] / (sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps));
-                }
-            }
+            if (POL & 4) mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
+            else mft_adam4_exact(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
             stp(cm[u], (f32x4*)(p.m + gi));
             stp(cv[u], (f32x4*)(p.v + gi));
             stp(cw[u], (f32x4*)(p.w + gi));

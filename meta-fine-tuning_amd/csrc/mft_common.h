@@ -53,6 +53,32 @@ __device__ __forceinline__ void mft_split4_bf16(const f32x4 x, mft_u32x2& p1, mf
     p3[1] = mft_pk_bf16(r[2], r[3]);
 }
 
+// torch.optim.Adam on four consecutive parameters (finetune.py:255,299), shared by every kernel that fuses Adam into a
+// weight-gradient epilogue so that they agree BIT FOR BIT: the fused multiply-adds are written out (left to the compiler's
+// contraction pass, `b1*m + c1*g` becomes fma(b1, m, c1*g) in one kernel and fma(c1, g, b1*m) in another).
+//   m = fma(b1, m, (1-b1) g);  v = fma(b2, v, (1-b2) g^2);  w = fma(-step_size, m / (sqrt(v) * inv_sqrt_bc2 + eps), w)
+// FAST: v_sqrt_f32 / v_rcp_f32 (1 ulp each) and packed fp32 arithmetic; exact: correctly rounded sqrtf and division.
+__device__ __forceinline__ void mft_adam4_fast(f32x4& m, f32x4& v, f32x4& w, const f32x4 g, float b1, float b2, float eps,
+                                               float step_size, float inv_sqrt_bc2) {
+    const float c1 = 1.f - b1, c2 = 1.f - b2;
+    const f32x4 b1v = {b1, b1, b1, b1}, b2v = {b2, b2, b2, b2}, ns = {-step_size, -step_size, -step_size, -step_size};
+    m = __builtin_elementwise_fma(b1v, m, c1 * g);
+    v = __builtin_elementwise_fma(b2v, v, c2 * (g * g));
+    f32x4 den;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_sqrtf(v[e]), inv_sqrt_bc2, eps));
+    w = __builtin_elementwise_fma(ns, m * den, w);
+}
+__device__ __forceinline__ void mft_adam4_exact(f32x4& m, f32x4& v, f32x4& w, const f32x4 g, float b1, float b2, float eps,
+                                                float step_size, float inv_sqrt_bc2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m[e] = __builtin_fmaf(b1, m[e], (1.f - b1) * g[e]);
+        v[e] = __builtin_fmaf(b2, v[e], ((1.f - b2) * g[e]) * g[e]);
+        w[e] = __builtin_fmaf(-step_size, m[e] / __builtin_fmaf(sqrtf(v[e]), inv_sqrt_bc2, eps), w[e]);
+    }
+}
+
 // hipFuncSetAttribute applies to the CURRENT device only: a "done" flag per device (an engine may be built on cuda:1 after
 // another one ran on cuda:0 in the same process).  need() is true the first time it is asked on a device.
 struct MftPerDeviceOnce {

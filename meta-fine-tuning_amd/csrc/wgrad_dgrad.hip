@@ -139,15 +139,7 @@ __global__ __launch_bounds__(256) void wgrad_adam_dgrad_kernel(WdArgs p) {
             const f32x4 ge = *(const f32x4*)(Gs + row * GLD + 4 * q);
             wold[u] = cw[u];
             // same epilogue arithmetic as wgrad_adam_rows_kernel's default: packed moment updates, hardware rcp / sqrt (1 ulp)
-            {
-                const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
-                cm[u] = p.b1 * cm[u] + c1 * ge;
-                cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
-                f32x4 den;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
-                cw[u] -= step_size * (cm[u] * den);
-            }
+            mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
             __builtin_nontemporal_store(cm[u], (f32x4*)(p.m + gi));
             __builtin_nontemporal_store(cv[u], (f32x4*)(p.v + gi));
             __builtin_nontemporal_store(cw[u], (f32x4*)(p.w + gi));

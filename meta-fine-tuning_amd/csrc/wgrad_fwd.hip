@@ -205,22 +205,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             const int gi = lo0 + 8 * u * p.Kpad + kt * BN;
             float* gcell = Gs + (rr + 8 * u) * GLD + 4 * q;
             const f32x4 ge = *(const f32x4*)gcell;
-            if (FAST) {
-                const float c1 = 1.f - p.b1, c2 = 1.f - p.b2;
-                cm[u] = p.b1 * cm[u] + c1 * ge;
-                cv[u] = p.b2 * cv[u] + c2 * (ge * ge);
-                f32x4 den;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps);
-                cw[u] -= step_size * (cm[u] * den);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cm[u][e] = p.b1 * cm[u][e] + (1.f - p.b1) * ge[e];
-                    cv[u][e] = p.b2 * cv[u][e] + (1.f - p.b2) * ge[e] * ge[e];
-                    cw[u][e] -= step_size * (cm[u][e] / (sqrtf(cv[u][e]) * inv_sqrt_bc2 + p.eps));
-                }
-            }
+            if (FAST) mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
+            else mft_adam4_exact(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
             __builtin_nontemporal_store(cm[u], (f32x4*)(mg_ + gi));
             __builtin_nontemporal_store(cv[u], (f32x4*)(vg_ + gi));
             __builtin_nontemporal_store(cw[u], (f32x4*)(wg_ + gi));

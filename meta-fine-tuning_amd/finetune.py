@@ -494,8 +494,15 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
     pipelined = (method == "gnnnet" and not freeze_backbone and model is not None)
     engine = None
     flags, score_chunks = [], []
+    marks = [] if timings is not None else None
+
+    def mark(name):
+        if marks is not None:
+            marks.append((name, round(time.perf_counter() - t_start, 3)))
+
     ensure_gen(0)
     ensure_gen(1)
+    mark("first two batches of episodes enqueued")
     for bi, ids in enumerate(batches):
         eps, ev, bad = gens.pop(bi)
         cur.wait_event(ev)
@@ -529,9 +536,11 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
             if engine is None:
                 engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, len(eps[0]), fine_tune_epoch,
                                      episodes_per_batch, fold50=getattr(model, "FOLD50", False))
+                mark("engine built (host)")
                 if timings is not None:
                     torch.cuda.synchronize(dev)
                     timings["engine_ready_s"] = time.perf_counter() - t_start
+                    mark("engine built + episodes generated (device)")
             perms = [draw_episode_perms(method, n_way, n_shot, len(ep), fine_tune_epoch, np.random if rngs is None else rngs[k])[1]
                      for k, ep in enumerate(eps)]
             nxt = gens.get(bi + 1)
@@ -541,7 +550,9 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
                                 rngs=rngs, classifiers=cls)
         score_chunks.append(sc)
         del eps
+        mark("batch %d enqueued" % bi)
     torch.cuda.synchronize(dev)                          # deferred final passes included
+    mark("device done")
     assert not bool(torch.stack(flags).any()) if flags else True                 # finetune.py:606
     accs = []
     for sc in score_chunks:
@@ -554,6 +565,7 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         timings["total_s"] = time.perf_counter() - t_start
         timings["episodes_per_batch"] = episodes_per_batch
         timings["batches"] = len(batches)
+        timings["marks"] = marks
     if verbose and rank == 0:
         print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))))
     return accs
@@ -701,10 +713,21 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     if params.method in ('baseline', 'all'):
         state_b, main.loaded["baseline"] = _resolve_state("baseline", f_b, params.test_n_way, params.save_iter != -1, rank == 0)
     print(params.freeze_backbone)                                    # finetune.py:591
+    tm = {} if os.environ.get("MFT_TIMINGS", "0") == "1" else None
+    if tm is not None:
+        import time
+        t_main = time.time()
+        try:
+            import psutil
+            print("[timings] process start -> evaluate: %.2f s" % (t_main - psutil.Process().create_time()), file=sys.stderr)
+        except Exception:
+            pass
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
                     episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1",
-                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1")
+                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1", timings=tm)
+    if tm is not None:
+        print("[timings] evaluate: %s" % tm, file=sys.stderr)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     return accs

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 
 def is_dominant(name):
     """The fused weight-gradient + Adam launches: wgrad_adam_rows_kernel<POL> (round 2 default) or conv_wgrad_kernel<.., ADAM = true, ..>."""
-    if "wgrad_adam_rows_kernel" in name:
+    if "wgrad_adam_rows_kernel" in name or "wgrad_adam_fwd_kernel" in name:
         return True
     return "conv_wgrad_kernel" in name and "true" in name.split("conv_wgrad_kernel")[1][:40]
 
