@@ -62,13 +62,14 @@ __device__ __forceinline__ float lane8_sum(float v) {       // sum over the 8 la
     return v;
 }
 
-template <int MODE, bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void wgrad_adam_fwd_kernel(WfArgs p) {
+// NT: matrix instructions of the reduction (2 rows each; rows beyond the episode's are zeros and change no bit of the sum)
+template <int MODE, bool FAST, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_adam_fwd_kernel(WfArgs p) {
     constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4, RLD = 36, TLD = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [64][BM]   dY rows of this output-channel tile (resident for the walk)
-    float* Bs = smem + 64 * BM;           // [32][BLD]  half of the im2col rows of the current K tile
-    float* Gs = Bs + 32 * BLD;            // [32][GLD]  gradient tile, overwritten in place by the updated weight tile
+    float* As = smem;                     // [48][BM]   dY rows of this output-channel tile (resident for the walk)
+    float* Bs = smem + 48 * BM;           // [48][BLD]  im2col rows of the current K tile
+    float* Gs = Bs + 48 * BLD;            // [32][GLD]  gradient tile, overwritten in place by the updated weight tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;            // 32x32x2 fragment coordinates (reduction)
     const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates (next step's convolution)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int m = arow + 32 * j;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
-        *(f32x4*)(As + m * BM + acol) = v;
+        if (m < 48) *(f32x4*)(As + m * BM + acol) = v;
     }
     // pixel geometry, packed (image << 16 | (ih0 + 64) << 8 | (iw0 + 64)); -1 = row beyond the episode's pixels
     auto geom = [&](int m) {
@@ -101,101 +102,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     for (int j = 0; j < 6; ++j) bgeo[j] = geom(brow + 8 * j);
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) xgeo[nb] = geom(nb * 16 + fm);
-    auto pix_off = [&](int geo, int kh, int kw) -> int {             // element offset of the tap's input pixel inside the episode, or -1
-        if (geo < 0) return -1;
-        const int img = geo >> 16, ih = ((geo >> 8) & 255) - 64 + kh, iw = (geo & 255) - 64 + kw;
-        if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return -1;
-        return ((img * p.H + ih) * p.W + iw) * p.ldi;
+    // element offset of the tap's input pixel inside the episode (always a valid address) and whether the tap is inside the image:
+    // the loads are unconditional (a clamped address, then a select) -- no branch per load
+    auto pix_off = [&](int geo, int kh, int kw, bool& ok) -> int {
+        const int img = (geo >> 16) & 255, ih = ((geo >> 8) & 255) - 64 + kh, iw = (geo & 255) - 64 + kw;
+        ok = geo >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        return ok ? ((img * p.H + ih) * p.W + iw) * p.ldi : 0;
     };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // (tap, input-channel tile) of the tile the NEXT operand requests are for, carried incrementally (no division per tile)
+    int nkh = 0, nkw = 0, nci0 = 0;
+    auto advance = [&]() {
+        nci0 += BN;
+        if (nci0 == p.Cin) {
+            nci0 = 0;
+            if (++nkw == p.KW) { nkw = 0; ++nkh; }
+        }
+    };
     f32x4 vb[6];
-    auto load_b = [&](int kt) {
-        const int khkw = kt / p.tiles_ci, ci0 = (kt - khkw * p.tiles_ci) * BN;
-        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-        const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0;        // wave-uniform base; 32-bit lane offsets
+    const float* const in_e = p.in + (img0 * p.H * p.W) * p.ldi;            // wave-uniform bases; 32-bit lane offsets
+    auto load_b = [&](int kh, int kw, int ci0) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int o = pix_off(bgeo[j], kh, kw);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (o >= 0) v = *(const f32x4*)(in_g + (o + bcol));
-            vb[j] = v;
+            bool ok;
+            const int o = pix_off(bgeo[j], kh, kw, ok);
+            const f32x4 v = *(const f32x4*)(in_e + (o + ci0 + bcol));
+            vb[j] = ok ? v : zero4;
         }
     };
     f32x4 xb[3][2];
-    auto load_x = [&](int kt) {
-        const int khkw = kt / p.tiles_ci, ci0 = (kt - khkw * p.tiles_ci) * BN;
-        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-        const float* xg = p.xn + (img0 * p.H * p.W) * p.ldi + ci0;
-        const int xo = 32 * wave + 4 * fq;
+    const float* const xn_e = p.xn + (img0 * p.H * p.W) * p.ldi;
+    auto load_x = [&](int kh, int kw, int ci0) {
+        const int xo = ci0 + 32 * wave + 4 * fq;
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
-            const int o = pix_off(xgeo[nb], kh, kw);
+            bool ok;
+            const int o = pix_off(xgeo[nb], kh, kw, ok);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (o >= 0) v = *(const f32x4*)(xg + (o + xo + 16 * j));
-                xb[nb][j] = v;
+                const f32x4 v = *(const f32x4*)(xn_e + (o + xo + 16 * j));
+                xb[nb][j] = ok ? v : zero4;
             }
         }
     };
-    const int q = tid & 31, rr = tid >> 5;
     // this workgroup's 32 rows of w / m / v: wave-uniform 64-bit bases, 32-bit lane offsets (a row block is < 2^31 floats)
+    const int q = tid & 31, rr = tid >> 5;
     const long long tile_base = (long long)g * p.dwgs + (long long)co0 * p.Kpad;
     float* const wg_ = p.w + tile_base;
     float* const mg_ = p.m + tile_base;
     float* const vg_ = p.v + tile_base;
     const int lo0 = rr * p.Kpad + 4 * q;
-    f32x4 cm[4], cv[4], cw[4];
-    auto load_wmv = [&](int kt) {
+    // two register sets: while Adam consumes tile k from one, tile k+1 sits (landed or landing) in the other and tile k+2 is
+    // requested into the first as soon as Adam is done with it
+    f32x4 am[4], av[4], aw[4], bm[4], bv[4], bw[4];
+    auto load_wmv = [&](int kt, f32x4 (&M)[4], f32x4 (&V)[4], f32x4 (&W)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int gi = lo0 + 8 * u * p.Kpad + kt * BN;       // K index of tile kt = kt * 128 (tap-major)
-            cm[u] = __builtin_nontemporal_load((const f32x4*)(mg_ + gi));
-            cv[u] = __builtin_nontemporal_load((const f32x4*)(vg_ + gi));
-            cw[u] = __builtin_nontemporal_load((const f32x4*)(wg_ + gi));
+            M[u] = __builtin_nontemporal_load((const f32x4*)(mg_ + gi));
+            V[u] = __builtin_nontemporal_load((const f32x4*)(vg_ + gi));
+            W[u] = __builtin_nontemporal_load((const f32x4*)(wg_ + gi));
         }
     };
-    load_b(0);
-    load_wmv(0);
-    if (fwd) load_x(0);
+    // request order = order of need (the load counter is in order): operand rows of tile 0, of tile 1, w/m/v of tiles 0 and 1
+    load_b(0, 0, 0);
+    if (fwd) load_x(0, 0, 0);
+    load_wmv(0, am, av, aw);
+    if (n_kt > 1) load_wmv(1, bm, bv, bw);
+    advance();                            // (nkh, nkw, nci0) = tile 1
     f32x4 accf[3][2];
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) accf[nb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < 2; ++cb) accf[nb][cb] = zero4;
     const float step_size = p.hyper ? p.hyper[0] : p.step_size;
     const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
 
-    for (int kt = 0; kt < n_kt; ++kt) {
+    auto tile = [&](int kt, f32x4 (&cm)[4], f32x4 (&cv)[4], f32x4 (&cw)[4]) {
         const bool more = kt + 1 < n_kt;
         // ---- gradient tile: G[co][k] = sum_rows dY[row][co] * im2col[row][k]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[j];
+        __syncthreads();                              // (first tile: also the dY rows)
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        // chunks of 8 instructions: their 16 fragment reads are issued together, no branch inside (a fully unrolled loop lets the
+        // scheduler hoist all 2 NT reads and spill)
+#pragma unroll 1
+        for (int t0 = 0; t0 < NT; t0 += 8) {
+            const float* ap = As + (2 * t0 + h) * BM + r;
+            const float* bp = Bs + (2 * t0 + h) * BLD + wave * 32 + r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[j];
-        __syncthreads();                              // (first tile: also the dY rows)
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (2 * t < p.mma_rows) {                 // wave-uniform; rows beyond the episode's are zeros
-                const float a = As[(2 * t + h) * BM + r];
-                const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
-        if (rows > 32) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[4 + j];
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (32 + 2 * t < p.mma_rows) {
-                    const float a = As[(32 + 2 * t + h) * BM + r];
-                    const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-                }
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t * BM], bp[2 * t * BLD], acc, 0, 0, 0);
         }
-        if (more) load_b(kt + 1);                     // next tile's im2col rows (L2) under the epilogue
+        if (more) load_b(nkh, nkw, nci0);             // next tile's im2col rows (L2) under the epilogue
 #pragma unroll
         for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
         __syncthreads();
@@ -213,7 +215,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             if (p.dw) *(f32x4*)(p.dw + tile_base + gi) = ge;
             if (fwd) *(f32x4*)gcell = cw[u];
         }
-        if (more) load_wmv(kt + 1);                   // in flight under the multiplication below and the next reduction
         if (fwd) {
             __syncthreads();                          // the updated tile is complete
             // ---- step t+1: out[px][co] += w'[co][k] * im2col(x_next)[px][k] over this wave's 32 k of the tile
@@ -229,9 +230,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                         accf[nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xb[nb][j][i], accf[nb][1], 0, 0, 0);
                     }
             }
-            if (more) load_x(kt + 1);
+            if (more) load_x(nkh, nkw, nci0);
         }
+        // tile k+2's w/m/v into the set Adam has just finished with: requested AFTER everything tile k+1 needs first
+        if (kt + 2 < n_kt) load_wmv(kt + 2, cm, cv, cw);
+        advance();
         // (the next tile's first barrier separates these fragment reads of Gs from its next overwrite)
+    };
+    for (int kt = 0; kt < n_kt; kt += 2) {
+        tile(kt, am, av, aw);
+        if (kt + 1 < n_kt) tile(kt + 1, bm, bv, bw);
     }
     if (!fwd) return;
 
@@ -380,15 +388,21 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
     p.mean = mean; p.rstd = rstd; p.sc = sc_raw; p.gs = gamma_s; p.bs = beta_s; p.means = mean_s; p.rstds = rstd_s;
     p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps;
     const int groups = n_img / imgs_per_group;
-    constexpr int lds = (64 * 32 + 32 * (128 + 32) + 32 * (128 + 4)) * 4;          // 45.6 KB
+    constexpr int lds = (48 * 32 + 48 * (128 + 32) + 32 * (128 + 4)) * 4;          // 53.8 KB: two workgroups per CU
     const dim3 grid(Cout / 32, groups, 1), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define WF_LAUNCH(MODE_)                                                                           \
-    if (g_wf_exact) hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, false>), grid, block, lds, s, p); \
-    else hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, true>), grid, block, lds, s, p);
+    // matrix instructions of the reduction: 2 rows each, in chunks of 8 (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
+    const int nt = rows <= 32 ? 16 : 24;
+#define WF_LAUNCH2(MODE_, NT_)                                                                            \
+    if (g_wf_exact) hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, false, NT_>), grid, block, lds, s, p);  \
+    else hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, true, NT_>), grid, block, lds, s, p);
+#define WF_LAUNCH(MODE_)                                  \
+    if (nt == 16) { WF_LAUNCH2(MODE_, 16) }               \
+    else { WF_LAUNCH2(MODE_, 24) }
     if (mode == WF_RAW) { WF_LAUNCH(WF_RAW) }
     else if (mode == WF_ENTRY) { WF_LAUNCH(WF_ENTRY) }
     else { WF_LAUNCH(WF_EXIT) }
 #undef WF_LAUNCH
+#undef WF_LAUNCH2
     return mft_launch_status();
 }
