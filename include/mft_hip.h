@@ -217,13 +217,7 @@ int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ld
 /* 1: correctly rounded division / square root in that launch's Adam epilogue (default 0: v_rcp_f32 / v_sqrt_f32, as
  * mft_conv2d_wgrad_adam_nhwc's default).                                                                                   */
 void mft_wgrad_fwd_set_exact(int on);
-/* measurement aid for tools/: bit mask of kernel phases to skip (1 reduction MFMAs, 2 Adam arithmetic, 4 forward MFMAs, 8 / 16
- * operand-row requests of the reduction / forward, 32 w/m/v requests beyond the first two tiles, 64 w/m/v stores); results are
- * then wrong.  mft_debug_reset clears it.                                                                                    */
-void mft_wgrad_fwd_set_ablate(int mask);
-/* extra dynamic LDS the launch requests per workgroup (default 32 KB: one workgroup per CU beside a trunk convolution's ~50 KB; 0:
- * up to two per CU).  A scheduling knob: no result depends on it.                                                            */
-void mft_wgrad_fwd_set_lds_pad(int bytes);
+
 
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */
 /* F.batch_norm(training=True) statistics (backbone.py:224,227,240,409; gnn.py:65-74; gnnnet.py:30):

@@ -9,27 +9,20 @@
 // while it is still in LDS, with the next step's activation rows (which the frozen trunk, running ahead on its own stream, has
 // already produced) and accumulates the next step's convolution output of its 32 output channels along the walk.
 //
-// Structure: one workgroup (8 waves) = one episode x 32 output channels, walking all K tiles of 128 in (tap, ci) order, i.e.
-// along the 18 KB weight rows.  Per K tile:
-//   G = dY^T . im2col(x_t)             v_mfma_f32_16x16x4_f32: wave w owns k columns [16 w, 16 w + 16) of the tile, both 16-row
-//                                      blocks of output channels; reduction rows ascending, four per instruction (an fma chain
-//                                      in row order, as wgrad_adam_rows_kernel's two-per-instruction chain)
-//   (w, m, v) <- Adam(G)               row-stream layout (512 B runs, nontemporal) through LDS; w' parked in LDS over G
-//   out[48 px][32 co] += w' . im2col(x_{t+1})    same instruction, wave w the same 16 k: A = w' fragments (ds_read_b128),
-//                                      B = activation rows straight from L2
-// After the walk the eight waves' partial outputs are summed in fixed order and the layer's epilogue runs on the 32 channels the
-// workgroup owns -- every BatchNorm of the block normalises per channel over the episode's <= 48 pixels:
+// Structure (one workgroup = one episode x 32 output channels, walking all K tiles of 128 -- (tap, ci) order, i.e. along the
+// 18 KB weight rows; 4 waves):
+//   per K tile:  G = dY^T . im2col(x_t)            v_mfma_f32_32x32x2_f32, reduction rows 2t+h as wgrad_adam_rows_kernel
+//                (w, m, v) <- Adam(G)              row-stream layout, 512 B runs, nontemporal; w' also parked in LDS over G
+//                out[48 px][32 co] += w' . im2col(x_{t+1})   v_mfma_f32_16x16x4_f32, each wave a 32-wide k slice of the tile;
+//                                                  A = w' fragments (ds_read_b128), B = activation rows straight from L2
+//   after the walk: the four waves' partial outputs are summed in fixed order and the layer's epilogue runs on the 32 channels
+//   the workgroup owns -- every BatchNorm of the block normalises per channel over the episode's <= 48 pixels:
 //     RAW    shortcut 1x1 convolution: raw output only (its BatchNorm is folded into EXIT)
 //     ENTRY  C1: BatchNorm1 statistics + affine + ReLU -> r1                      (backbone.py:252-254)
 //     EXIT   C2: BatchNorm2 + BatchNorm(shortcut) + add + ReLU + global average pool   (backbone.py:255-261, :438 AvgPool2d)
-//
-// Resources are chosen for the launch's real neighbours, not for itself: the frozen trunk's convolutions of the NEXT steps run on
-// another stream at the same time (engine.inner_loop) and need ~160 VGPRs and ~50 KB of LDS per workgroup.  An earlier form of
-// this kernel (4 waves, 253 VGPRs, two workgroups per CU) was 5 % faster alone and no faster in the step: it filled every SIMD's
-// register file, the trunk's workgroups found no CU to run beside it and the two streams serialised.  Here a wave needs ~128
-// VGPRs and ONE workgroup per CU (two waves per SIMD) carries the stream: two tiles of w/m/v per workgroup are in flight (two
-// register sets; tile k+2 is requested when Adam releases tile k's registers, after everything tile k+1 needs first -- the load
-// counter is in order), the per-tile dependency chain is ~1.5 us against the 4.2 us a CU's share of HBM needs per tile.
+// The gradient and (w, m, v) are bit-identical to wgrad_adam_rows_kernel (same reduction order, same Adam expressions).
+// All request streams are one tile deep: im2col rows, then w/m/v, then next-step activation rows of tile k+1 are requested
+// while tile k is being multiplied (the load counter is in order, so the reduction never waits for the big w/m/v requests).
 #include "mft_common.h"
 #include <math.h>
 
@@ -58,29 +51,28 @@ struct WfArgs {
     const float* sc; const float* gs; const float* bs; float* means; float* rstds;      // EXIT: shortcut branch
     float* pooled; int hw;       // EXIT: [groups][ipg][Cout], pixels per image
     float bn_eps;
-    int ablate;                  // measurement aid (tools/wgrad_fwd_time.py): bit mask of phases to skip; results are then WRONG
 };
 
 enum { WF_RAW = 0, WF_ENTRY = 1, WF_EXIT = 2 };
 
-__device__ __forceinline__ float lane16_sum(float v) {      // sum over the 16 lanes that share tid >> 4
+__device__ __forceinline__ float lane8_sum(float v) {       // sum over the 8 lanes that share tid >> 3
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
     return v;
 }
 
-// NI: matrix instructions per 16 x 16 block of the reduction (4 rows each; rows beyond the episode's are zeros and change no bit)
-template <int MODE, bool FAST, int NI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) void wgrad_adam_fwd_kernel(WfArgs p) {
-    constexpr int BM = 32, BN = 128, ALD = 48, BLD = BN + 16, GLD = BN + 4, RLD = 36, TLD = 33;
+// NT: matrix instructions of the reduction (2 rows each; rows beyond the episode's are zeros and change no bit of the sum)
+template <int MODE, bool FAST, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_adam_fwd_kernel(WfArgs p) {
+    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4, RLD = 36, TLD = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [48][ALD]  dY rows of this output-channel tile (resident for the walk)
-    float* Bs = smem + 48 * ALD;          // [48][BLD]  im2col rows of the current K tile
+    float* As = smem;                     // [48][BM]   dY rows of this output-channel tile (resident for the walk)
+    float* Bs = smem + 48 * BM;           // [48][BLD]  im2col rows of the current K tile
     float* Gs = Bs + 48 * BLD;            // [32][GLD]  gradient tile, overwritten in place by the updated weight tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates
+    const int r = lane & 31, h = lane >> 5;            // 32x32x2 fragment coordinates (reduction)
+    const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates (next step's convolution)
     const int g = blockIdx.y, co0 = blockIdx.x * BM;
     const int ohw = p.OH * p.OW;
     const int rows = p.rows;
@@ -89,12 +81,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int n_kt = p.KH * p.KW * p.tiles_ci;
     const bool fwd = p.xn != nullptr;
 
-    // dY rows (resident): 48 rows x 8 float4
-    if (tid < 384) {
-        const int m = tid >> 3, acol = (tid & 7) * 4;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = arow + 32 * j;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
-        *(f32x4*)(As + m * ALD + acol) = v;
+        if (m < 48) *(f32x4*)(As + m * BM + acol) = v;
     }
     // pixel geometry, packed (image << 16 | (ih0 + 64) << 8 | (iw0 + 64)); -1 = row beyond the episode's pixels
     auto geom = [&](int m) {
@@ -103,10 +97,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int oh = (rem * p.inv_ow) >> 16, ow = rem - oh * p.OW;
         return (img << 16) | ((oh * p.stride - p.pad + 64) << 8) | (ow * p.stride - p.pad + 64);
     };
-    const int brow = tid >> 5, bcol = (tid & 31) * 4;          // staging of the reduction's operand rows: rows brow + 16 j
-    int bgeo[3], xgeo[3];
+    int bgeo[6], xgeo[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bgeo[j] = geom(brow + 16 * j);
+    for (int j = 0; j < 6; ++j) bgeo[j] = geom(brow + 8 * j);
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) xgeo[nb] = geom(nb * 16 + fm);
     // element offset of the tap's input pixel inside the episode (always a valid address) and whether the tap is inside the image:
@@ -127,31 +120,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             if (++nkw == p.KW) { nkw = 0; ++nkh; }
         }
     };
-    f32x4 vb[3];
+    f32x4 vb[6];
     const float* const in_e = p.in + (img0 * p.H * p.W) * p.ldi;            // wave-uniform bases; 32-bit lane offsets
     auto load_b = [&](int kh, int kw, int ci0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 6; ++j) {
             bool ok;
             const int o = pix_off(bgeo[j], kh, kw, ok);
             const f32x4 v = *(const f32x4*)(in_e + (o + ci0 + bcol));
             vb[j] = ok ? v : zero4;
         }
     };
-    f32x4 xb[3];
+    f32x4 xb[3][2];
     const float* const xn_e = p.xn + (img0 * p.H * p.W) * p.ldi;
     auto load_x = [&](int kh, int kw, int ci0) {
-        const int xo = ci0 + 16 * wave + 4 * fq;
+        const int xo = ci0 + 32 * wave + 4 * fq;
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
             bool ok;
             const int o = pix_off(xgeo[nb], kh, kw, ok);
-            const f32x4 v = *(const f32x4*)(xn_e + (o + xo));
-            xb[nb] = ok ? v : zero4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 v = *(const f32x4*)(xn_e + (o + xo + 16 * j));
+                xb[nb][j] = ok ? v : zero4;
+            }
         }
     };
     // this workgroup's 32 rows of w / m / v: wave-uniform 64-bit bases, 32-bit lane offsets (a row block is < 2^31 floats)
-    const int q = tid & 31, rr = tid >> 5;               // rows rr, rr + 16; floats 4 q .. 4 q + 3
+    const int q = tid & 31, rr = tid >> 5;
     const long long tile_base = (long long)g * p.dwgs + (long long)co0 * p.Kpad;
     float* const wg_ = p.w + tile_base;
     float* const mg_ = p.m + tile_base;
@@ -159,17 +155,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int lo0 = rr * p.Kpad + 4 * q;
     // two register sets: while Adam consumes tile k from one, tile k+1 sits (landed or landing) in the other and tile k+2 is
     // requested into the first as soon as Adam is done with it
-    f32x4 am[2], av[2], aw[2], bm[2], bv[2], bw[2];
-    auto load_wmv = [&](int kt, f32x4 (&M)[2], f32x4 (&V)[2], f32x4 (&W)[2]) {
+    f32x4 am[4], av[4], aw[4], bm[4], bv[4], bw[4];
+    auto load_wmv = [&](int kt, f32x4 (&M)[4], f32x4 (&V)[4], f32x4 (&W)[4]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int gi = lo0 + 16 * u * p.Kpad + kt * BN;      // K index of tile kt = kt * 128 (tap-major)
+        for (int u = 0; u < 4; ++u) {
+            const int gi = lo0 + 8 * u * p.Kpad + kt * BN;       // K index of tile kt = kt * 128 (tap-major)
             M[u] = __builtin_nontemporal_load((const f32x4*)(mg_ + gi));
             V[u] = __builtin_nontemporal_load((const f32x4*)(vg_ + gi));
             W[u] = __builtin_nontemporal_load((const f32x4*)(wg_ + gi));
         }
     };
-    // request order = order of need (the load counter is in order): operand rows of tile 0, then w/m/v of tiles 0 and 1
+    // request order = order of need (the load counter is in order): operand rows of tile 0, of tile 1, w/m/v of tiles 0 and 1
     load_b(0, 0, 0);
     if (fwd) load_x(0, 0, 0);
     load_wmv(0, am, av, aw);
@@ -183,69 +179,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float step_size = p.hyper ? p.hyper[0] : p.step_size;
     const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
 
-    auto tile = [&](int kt, f32x4 (&cm)[2], f32x4 (&cv)[2], f32x4 (&cw)[2]) {
+    auto tile = [&](int kt, f32x4 (&cm)[4], f32x4 (&cv)[4], f32x4 (&cw)[4]) {
         const bool more = kt + 1 < n_kt;
-        // ---- gradient tile: G[co][k] = sum_rows dY[row][co] * im2col[row][k]; this wave: k = 16 wave + fm, co blocks 0 and 1
+        // ---- gradient tile: G[co][k] = sum_rows dY[row][co] * im2col[row][k]
 #pragma unroll
-        for (int j = 0; j < 3; ++j) *(f32x4*)(Bs + (brow + 16 * j) * BLD + bcol) = vb[j];
+        for (int j = 0; j < 6; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[j];
         __syncthreads();                              // (first tile: also the dY rows)
-        f32x4 acc0 = zero4, acc1 = zero4;
-        if (!(p.ablate & 1)) {
-            // chunks of 4 instruction pairs: their 12 fragment reads are issued together (a fully unrolled loop lets the
-            // scheduler hoist all 3 NI reads into registers)
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        // chunks of 8 instructions: their 16 fragment reads are issued together, no branch inside (a fully unrolled loop lets the
+        // scheduler hoist all 2 NT reads and spill)
 #pragma unroll 1
-            for (int i0 = 0; i0 < NI; i0 += 4) {
-                const float* bp = Bs + (4 * i0 + fq) * BLD + 16 * wave + fm;
-                const float* ap = As + (4 * i0 + fq) * ALD + fm;
+        for (int t0 = 0; t0 < NT; t0 += 8) {
+            const float* ap = As + (2 * t0 + h) * BM + r;
+            const float* bp = Bs + (2 * t0 + h) * BLD + wave * 32 + r;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {         // rows 4 (i0 + i) + fq
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i * ALD], bp[4 * i * BLD], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * i * ALD + 16], bp[4 * i * BLD], acc1, 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t * BM], bp[2 * t * BLD], acc, 0, 0, 0);
         }
-        if (more && !(p.ablate & 8)) load_b(nkh, nkw, nci0);             // next tile's im2col rows (L2) under the epilogue
+        if (more) load_b(nkh, nkw, nci0);             // next tile's im2col rows (L2) under the epilogue
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                 // D[row = 4 fq + e][col = fm]
-            Gs[(4 * fq + e) * GLD + 16 * wave + fm] = acc0[e];
-            Gs[(16 + 4 * fq + e) * GLD + 16 * wave + fm] = acc1[e];
-        }
+        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
         __syncthreads();
         // ---- Adam on the tile (row-stream layout), updated weights back into the same LDS cells
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int gi = lo0 + 16 * u * p.Kpad + kt * BN;
-            float* gcell = Gs + (rr + 16 * u) * GLD + 4 * q;
+        for (int u = 0; u < 4; ++u) {
+            const int gi = lo0 + 8 * u * p.Kpad + kt * BN;
+            float* gcell = Gs + (rr + 8 * u) * GLD + 4 * q;
             const f32x4 ge = *(const f32x4*)gcell;
-            if (p.ablate & 2) { cm[u] += ge; cv[u] += ge; cw[u] += ge; }
-            else if (FAST) mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
+            if (FAST) mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
             else mft_adam4_exact(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
-            if (!(p.ablate & 64)) {
-                __builtin_nontemporal_store(cm[u], (f32x4*)(mg_ + gi));
-                __builtin_nontemporal_store(cv[u], (f32x4*)(vg_ + gi));
-                __builtin_nontemporal_store(cw[u], (f32x4*)(wg_ + gi));
-            }
+            __builtin_nontemporal_store(cm[u], (f32x4*)(mg_ + gi));
+            __builtin_nontemporal_store(cv[u], (f32x4*)(vg_ + gi));
+            __builtin_nontemporal_store(cw[u], (f32x4*)(wg_ + gi));
             if (p.dw) *(f32x4*)(p.dw + tile_base + gi) = ge;
             if (fwd) *(f32x4*)gcell = cw[u];
         }
         if (fwd) {
             __syncthreads();                          // the updated tile is complete
-            // ---- step t+1: out[px][co] += w'[co][k] * im2col(x_next)[px][k] over this wave's 16 k of the tile
-            if (!(p.ablate & 4)) {
-                const f32x4 a0 = *(const f32x4*)(Gs + fm * GLD + 16 * wave + 4 * fq);
-                const f32x4 a1 = *(const f32x4*)(Gs + (16 + fm) * GLD + 16 * wave + 4 * fq);
+            // ---- step t+1: out[px][co] += w'[co][k] * im2col(x_next)[px][k] over this wave's 32 k of the tile
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 a0 = *(const f32x4*)(Gs + fm * GLD + 32 * wave + 16 * j + 4 * fq);
+                const f32x4 a1 = *(const f32x4*)(Gs + (16 + fm) * GLD + 32 * wave + 16 * j + 4 * fq);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int nb = 0; nb < 3; ++nb) {
-                        accf[nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], xb[nb][i], accf[nb][0], 0, 0, 0);
-                        accf[nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xb[nb][i], accf[nb][1], 0, 0, 0);
+                        accf[nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], xb[nb][j][i], accf[nb][0], 0, 0, 0);
+                        accf[nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xb[nb][j][i], accf[nb][1], 0, 0, 0);
                     }
             }
-            if (more && !(p.ablate & 16)) load_x(nkh, nkw, nci0);
+            if (more) load_x(nkh, nkw, nci0);
         }
         // tile k+2's w/m/v into the set Adam has just finished with: requested AFTER everything tile k+1 needs first
-        if (kt + 2 < n_kt && !(p.ablate & 32)) load_wmv(kt + 2, cm, cv, cw);
+        if (kt + 2 < n_kt) load_wmv(kt + 2, cm, cv, cw);
         advance();
         // (the next tile's first barrier separates these fragment reads of Gs from its next overwrite)
     };
@@ -255,32 +243,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     if (!fwd) return;
 
-    // ---- the eight k-slices' partial outputs, summed in fixed order: waves 4-7 park theirs, waves 0-3 add their own on top
+    // ---- the four k-slices' partial outputs, summed in fixed order
     __syncthreads();
-    float* Red = smem;                    // [4][48][RLD] (27.6 KB), aliases As / Bs (36.9 KB)
-    float* myred = Red + ((wave & 3) * 48) * RLD;
-    if (wave >= 4) {
+    float* Red = smem;                    // [4][48][RLD], aliases As / Bs
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+    for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) *(f32x4*)(myred + (nb * 16 + fm) * RLD + cb * 16 + 4 * fq) = accf[nb][cb];
-    }
+        for (int cb = 0; cb < 2; ++cb)
+            *(f32x4*)(Red + ((wave * 48 + nb * 16 + fm) * RLD + cb * 16 + 4 * fq)) = accf[nb][cb];
     __syncthreads();
-    if (wave < 4) {
+    const int c = tid >> 3, pl = tid & 7;             // channel co0 + c, pixels pl + 8 i
+    float val[6];
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                float* cell = myred + (nb * 16 + fm) * RLD + cb * 16 + 4 * fq;
-                *(f32x4*)cell = accf[nb][cb] + *(const f32x4*)cell;
-            }
-    }
-    __syncthreads();
-    const int c = tid >> 4, pl = tid & 15;            // channel co0 + c, pixels pl + 16 i
-    float val[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int px = pl + 16 * i;
+    for (int i = 0; i < 6; ++i) {
+        const int px = pl + 8 * i;
         val[i] = ((Red[(px)*RLD + c] + Red[(48 + px) * RLD + c]) + Red[(96 + px) * RLD + c]) + Red[(144 + px) * RLD + c];
     }
     float* T0 = Gs;                       // [48][TLD] raw output, [48][TLD] activation (Gs is dead: 2 x 6.3 KB <= 16.9 KB)
@@ -288,22 +264,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float inv_rows = 1.f / (float)rows;
     if (MODE == WF_RAW) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) T0[(pl + 16 * i) * TLD + c] = val[i];
+        for (int i = 0; i < 6; ++i) T0[(pl + 8 * i) * TLD + c] = val[i];
     } else {
         auto stats = [&](const float* x, float& mu, float& rs) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (pl + 16 * i < rows) s += x[i];
-            mu = lane16_sum(s) * inv_rows;
+            for (int i = 0; i < 6; ++i)
+                if (pl + 8 * i < rows) s += x[i];
+            mu = lane8_sum(s) * inv_rows;
             s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (pl + 16 * i < rows) {
+            for (int i = 0; i < 6; ++i)
+                if (pl + 8 * i < rows) {
                     const float d = x[i] - mu;
                     s += d * d;
                 }
-            rs = 1.0f / sqrtf(lane16_sum(s) * inv_rows + p.bn_eps);
+            rs = 1.0f / sqrtf(lane8_sum(s) * inv_rows + p.bn_eps);
         };
         const int co = co0 + c;
         float mu, rs;
@@ -315,15 +291,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
         if (MODE == WF_ENTRY) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                T0[(pl + 16 * i) * TLD + c] = val[i];
-                T1[(pl + 16 * i) * TLD + c] = fmaxf((val[i] - mu) * rs * ga + be, 0.f);
+            for (int i = 0; i < 6; ++i) {
+                T0[(pl + 8 * i) * TLD + c] = val[i];
+                T1[(pl + 8 * i) * TLD + c] = fmaxf((val[i] - mu) * rs * ga + be, 0.f);
             }
         } else {
-            float sv[3];
+            float sv[6];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int px = pl + 16 * i;
+            for (int i = 0; i < 6; ++i) {
+                const int px = pl + 8 * i;
                 sv[i] = px < rows ? p.sc[(row0 + px) * p.Cout + co] : 0.f;
             }
             float mus, rss;
@@ -334,11 +310,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 p.rstds[(long long)g * p.Cout + co] = rss;
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 float o = (val[i] - mu) * rs * ga + be;
                 o += (sv[i] - mus) * rss * gas + bes;
-                T0[(pl + 16 * i) * TLD + c] = val[i];
-                T1[(pl + 16 * i) * TLD + c] = fmaxf(o, 0.f);
+                T0[(pl + 8 * i) * TLD + c] = val[i];
+                T1[(pl + 8 * i) * TLD + c] = fmaxf(o, 0.f);
             }
         }
     }
@@ -346,8 +322,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     // write-out: one pixel row of the 32 channels = one 128-byte line per half wave
     const int c2 = tid & 31, p2 = tid >> 5;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int px = p2 + 16 * i;
+    for (int i = 0; i < 6; ++i) {
+        const int px = p2 + 8 * i;
         if (px < rows) {
             p.raw[(row0 + px) * p.Cout + co0 + c2] = T0[px * TLD + c2];
             if (MODE != WF_RAW) p.act[(row0 + px) * p.Cout + co0 + c2] = T1[px * TLD + c2];
@@ -363,22 +339,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 }
 
-template <int MODE, bool FAST, int NI>
-void wf_launch(dim3 grid, dim3 block, int lds, hipStream_t s, const WfArgs& p) {
-    static MftPerDeviceOnce once;         // per instantiation and device: dynamic LDS beyond 64 KB has to be allowed first
-    if (once.need()) (void)hipFuncSetAttribute((const void*)wgrad_adam_fwd_kernel<MODE, FAST, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE, FAST, NI>), grid, block, lds, s, p);
-}
-
-int g_wf_lds_pad = 32 * 1024;     // extra dynamic LDS requested per workgroup (mft_wgrad_fwd_set_lds_pad): 32 KB -> one workgroup per CU next to a trunk convolution; 0 -> up to two
-int g_wf_ablate = 0;     // measurement aid, see WfArgs::ablate (mft_wgrad_fwd_set_ablate)
 int g_wf_exact = 0;      // 1: correctly rounded division / square root in the Adam epilogue (mft_wgrad_fwd_set_exact)
 
 }  // namespace
 
 extern "C" void mft_wgrad_fwd_set_exact(int on) { g_wf_exact = on ? 1 : 0; }
-extern "C" void mft_wgrad_fwd_set_ablate(int mask) { g_wf_ablate = mask; }
-extern "C" void mft_wgrad_fwd_set_lds_pad(int bytes) { g_wf_lds_pad = bytes < 0 ? 0 : (bytes > 100 * 1024 ? 100 * 1024 : bytes); }
 
 extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
                                            float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -421,21 +386,19 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
     p.hyper = hyper;
     p.xn = x_next; p.raw = raw; p.act = act; p.gamma = gamma; p.beta = beta; p.gbs = gb_group_stride;
     p.mean = mean; p.rstd = rstd; p.sc = sc_raw; p.gs = gamma_s; p.bs = beta_s; p.means = mean_s; p.rstds = rstd_s;
-    p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps; p.ablate = g_wf_ablate;
+    p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps;
     const int groups = n_img / imgs_per_group;
-    // As [48][48] + Bs [48][144] + Gs [32][132] = 53.8 KB.  g_wf_lds_pad raises the request so that only ONE workgroup fits a CU
-    // beside a trunk convolution's ~50 KB (two waves of this kernel per SIMD then leave half of every register file to the trunk)
-    const int lds = (48 * 48 + 48 * (128 + 16) + 32 * (128 + 4)) * 4 + g_wf_lds_pad;
-    const dim3 grid(Cout / 32, groups, 1), block(512);
+    constexpr int lds = (48 * 32 + 48 * (128 + 32) + 32 * (128 + 4)) * 4;          // 53.8 KB: two workgroups per CU
+    const dim3 grid(Cout / 32, groups, 1), block(256);
     hipStream_t s = (hipStream_t)stream;
-    // matrix instructions per block of the reduction: 4 rows each (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
-    const int nt = rows <= 32 ? 8 : 12;
+    // matrix instructions of the reduction: 2 rows each, in chunks of 8 (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
+    const int nt = rows <= 32 ? 16 : 24;
 #define WF_LAUNCH2(MODE_, NT_)                                                                            \
-    if (g_wf_exact) wf_launch<MODE_, false, NT_>(grid, block, lds, s, p);  \
-    else wf_launch<MODE_, true, NT_>(grid, block, lds, s, p);
+    if (g_wf_exact) hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, false, NT_>), grid, block, lds, s, p);  \
+    else hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, true, NT_>), grid, block, lds, s, p);
 #define WF_LAUNCH(MODE_)                                  \
-    if (nt == 8) { WF_LAUNCH2(MODE_, 8) }                 \
-    else { WF_LAUNCH2(MODE_, 12) }
+    if (nt == 16) { WF_LAUNCH2(MODE_, 16) }               \
+    else { WF_LAUNCH2(MODE_, 24) }
     if (mode == WF_RAW) { WF_LAUNCH(WF_RAW) }
     else if (mode == WF_ENTRY) { WF_LAUNCH(WF_ENTRY) }
     else { WF_LAUNCH(WF_EXIT) }

@@ -23,10 +23,7 @@ def timeit(fn, reps=10):
     return a.elapsed_time(b) * 1e3 / reps
 
 
-from meta_fine_tuning_amd import _lib
-for lds_pad in (32768, 0):
-  _lib.lib().mft_wgrad_fwd_set_lds_pad(lds_pad)
-  print("-- extra LDS per workgroup %d KB (%s)" % (lds_pad // 1024, "one workgroup per CU" if lds_pad else "two per CU"))
+if True:
   for name, Cin, k, stride, pad, H, mode in (("C2", 512, 3, 1, 1, 3, ops.WF_EXIT), ("C1", 256, 3, 2, 1, 6, ops.WF_ENTRY), ("shortcut", 256, 1, 2, 0, 6, ops.WF_RAW)):
       n, Cout = E * 5, 512
       OH = (H + 2 * pad - k) // stride + 1
@@ -47,26 +44,3 @@ for lds_pad in (32768, 0):
       print("%-9s E=%d  rows kernel %7.1f us (%.2f TB/s) | walk, update only %7.1f us (%.2f TB/s) | walk + next forward %7.1f us (%.2f TB/s)"
             % (name, E, t0, by / t0 / 1e6, t1, by / t1 / 1e6, t2, by / t2 / 1e6))
 
-_lib.lib().mft_wgrad_fwd_set_lds_pad(32768)
-# ablations of the fused launch on trunk.7.C2 (results wrong; time only)
-Cin, k, stride, pad, H, Cout = 512, 3, 1, 1, 3, 512
-n = E * 5
-x = torch.randn(n, H, H, Cin, device=dev, generator=g)
-dy = torch.randn(n, 3, 3, Cout, device=dev, generator=g) * 1e-3
-w = torch.randn(E, Cout, k * k * Cin, device=dev, generator=g) * 0.02
-m, v = torch.zeros_like(w), torch.zeros_like(w)
-raw, act, sc = (torch.randn(n * 9, Cout, device=dev, generator=g) for _ in range(3))
-st = [torch.empty(E, Cout, device=dev) for _ in range(4)]
-gb = torch.ones(E, Cout, device=dev)
-pooled = torch.empty(n, Cout, device=dev)
-by = 24.0 * w.numel()
-names = {0: "full", 1: "no reduction MFMAs", 2: "no Adam arithmetic", 4: "no forward MFMAs", 8: "no reduction operand requests", 16: "no forward operand requests",
-         5: "no MFMAs at all", 24: "no operand requests", 7: "no arithmetic", 31: "no arithmetic, no operand requests", 64: "no stores", 32: "no w/m/v requests after tile 1",
-         96: "no w/m/v traffic after tile 1"}
-for mask in (0, 1, 2, 4, 8, 16, 5, 24, 7, 31, 64, 32, 96, 0):
-    _lib.lib().mft_wgrad_fwd_set_ablate(mask)
-    t2 = timeit(lambda: ops.wgrad_adam_next_forward(x, dy, w, m, v, k, k, stride, pad, 3, 5, x_next=x, mode=ops.WF_EXIT, raw=raw, act=act, gamma=gb, beta=gb,
-                                                    gbs=Cout, mean=st[0], rstd=st[1], sc_raw=sc, gamma_s=gb, beta_s=gb, mean_s=st[2], rstd_s=st[3],
-                                                    pooled=pooled))
-    print("ablate %3d  %-40s %7.1f us (%.2f TB/s nominal)" % (mask, names[mask], t2, by / t2 / 1e6))
-_lib.lib().mft_wgrad_fwd_set_ablate(0)
