@@ -49,18 +49,18 @@ def conv_flops(n_img, OH, Cout, K):
     return 2.0 * n_img * OH * OH * Cout * K
 
 
-def kernel_source_sha():
-    """Identity of the dominant kernel's source (csrc/wgrad_fwd.hip + csrc/mft_common.h): a PMC traffic figure is only quoted
-    for byte-identical kernel code."""
+def kernel_source_sha(fused=False):
+    """Identity of the dominant kernel's source (csrc/conv_igemm.hip -- or csrc/wgrad_fwd.hip for the opt-in fused form -- +
+    csrc/mft_common.h): a PMC traffic figure is only quoted for byte-identical kernel code."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("meta-fine-tuning_amd/csrc/wgrad_fwd.hip", "meta-fine-tuning_amd/csrc/mft_common.h"):
+    for rel in ("meta-fine-tuning_amd/csrc/%s.hip" % ("wgrad_fwd" if fused else "conv_igemm"), "meta-fine-tuning_amd/csrc/mft_common.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(E):
+def pmc_traffic(E, fused=False):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate runs, gfx950 corrections applied; profiles/pmc_traffic.json, written by tools/pmc_traffic_json.py together with
     the commit and the kernel-source hash it was measured on).  None unless a pass exists for this E AND for exactly this kernel
@@ -68,7 +68,7 @@ def pmc_traffic(E):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             j = json.load(f)
-        if int(j["episodes_per_step"]) == int(E) and j.get("kernel_source_sha16") == kernel_source_sha():
+        if int(j["episodes_per_step"]) == int(E) and j.get("kernel_source_sha16") == kernel_source_sha(fused):
             return {"mb_per_launch": j["traffic_mb_per_launch"], "algorithmic_mb_per_launch": j["algorithmic_mb_per_launch"],
                     "source": "profiles/pmc_traffic.json (round %s, measured at commit %s, kernel source %s)"
                               % (j["round"], j.get("head", "?"), j["kernel_source_sha16"])}
@@ -670,7 +670,7 @@ def main():
                                           "wgrad_adam_rows_kernel (trunk.7 weight gradient with torch.optim.Adam fused in the "
                                           "epilogue; per-episode w,m,v streamed once per inner step)",
                 "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                "traffic": pmc_traffic(E), "launches": n_a, "avg_launch_us": round(a_ms * 1e3 / n_a, 2),
+                "traffic": pmc_traffic(E, e.fuse_next), "launches": n_a, "avg_launch_us": round(a_ms * 1e3 / n_a, 2),
                 "algorithmic_mb_per_launch": round(a_by / n_a / 1e6, 2),
                 "largest_shape": {"what": "trunk.7.C2 (512x512x3x3) x %d episodes" % E,
                                   "avg_launch_us": round(sum(t for t, _ in big) * 1e3 / len(big), 2),

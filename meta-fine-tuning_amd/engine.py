@@ -259,9 +259,14 @@ class FinetuneEngine:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)     # device-side Adam step counter / bias
         self.hyper = torch.zeros(2, device=self.dev)                           # corrections (graph replay)
         self.pipeline = pipeline
-        # the weight-gradient + Adam launches of step t also run step t+1's last-block forward (csrc/wgrad_fwd.hip): the updated
-        # weights are not read back by a forward launch.  MFT_FUSE_NEXT=0 restores the separate block-entry / block-exit launches.
-        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "1") == "1"
+        # OPT-IN (MFT_FUSE_NEXT=1 / fuse_next=True): the weight-gradient + Adam launches of step t also run step t+1's last-block
+        # forward from the weight tiles they have just updated (csrc/wgrad_fwd.hip), so the updated weights are not read back by
+        # a forward launch (7.64 -> 6.64 parameter units of HBM traffic per step).  Correct (tests) and 240 us per step faster
+        # with the GPU to itself, but no faster in the two-stream loop: the walking kernel is bound by its per-tile dependency
+        # chain per CU, not by HBM (it slows down in proportion to the CUs it loses to the trunk stream, where the one-tile-per-
+        # workgroup kernel keeps 93 % of its rate on 160 CUs) -- 78.6-81.1 vs 79.3-80.3 episodes/s over four boxes
+        # (profiles/r03_a_*).  Default: the separate block-entry / block-exit launches.
+        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "0") == "1"
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum

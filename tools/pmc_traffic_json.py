@@ -45,7 +45,7 @@ def main():
                        "--pmc WRITE_SIZE runs of bench.py; FETCH_SIZE x2 on gfx950, WRITE_SIZE x1, unit KB; calibration: "
                        "profiles/r01_c_pmc_calibration.txt).  bench.py copies `traffic` from here only when its episodes-per-step AND the "
                        "kernel-source hash match.",
-           "round": rnd, "head": head, "kernel_source_sha16": None if typed else bench.kernel_source_sha(), "episodes_per_step": E,
+           "round": rnd, "head": head, "kernel_source_sha16": None if typed else bench.kernel_source_sha(os.environ.get("MFT_FUSE_NEXT", "0") == "1"), "episodes_per_step": E,
            "kernel": "wgrad_adam_rows_kernel (fused weight gradient + Adam; conv_wgrad_kernel<64,64,ADAM> in round 1)", "launches": nf, "fetch_kb_mean_raw": round(fetch, 1), "write_kb_mean_raw": round(write, 1),
            "traffic_mb_per_launch": round((2.0 * fetch + write) * 1024 / 1e6, 1), "algorithmic_mb_per_launch": round(alg, 1)}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
