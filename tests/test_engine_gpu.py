@@ -554,6 +554,7 @@ def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
     weight norms after 105 and 500 steps against the reference's fp32 AND fp64 runs (the two differ by the Adam sign-flip
     envelope; the engine must sit in the same envelope), probe features against fp64 within 4x the reference's own distance."""
     g = _g(golden_dir, "g4b_inner_loop_long.npz")
+    gs = _g(golden_dir, "g4c_inner_loop_spread.npz")
     size = 84
     sd = synthetic.resnet10_state_dict(seed=9)
     views = synthetic.test_episode(31, 5, 5, 15, size, gen_examples=17)
@@ -574,11 +575,12 @@ def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
         for key, gk in (("trunk.7.C1.weight", "wn_c1"), ("trunk.7.C2.weight", "wn_c2"), ("trunk.7.shortcut.weight", "wn_sc")):
             n_hip = float(w[key].norm())
             n32, n64 = float(g["%s_s%d_f32" % (gk, tag)]), float(g["%s_s%d_f64" % (gk, tag)])
-            # after 500 steps equally valid fp32 variants of this engine (K-summation order of the trunk convolutions, exact vs
-            # hardware division in the Adam epilogue, tile shapes) land 88.40 .. 89.14 on trunk.7.C1 where the reference's own runs
-            # give 89.17 (fp32) / 89.37 (fp64): tools/trajectory_spread.py, profiles/r02_d_trajectory_spread.txt -- the single
-            # fp32-vs-fp64 sample of the golden underestimates that envelope, so the 500-step bound also admits 1.5 % of the norm
-            tol = max(4.0 * abs(n32 - n64), 0.02, 0.015 * n64 if tag == 500 else 0.0)
+            # the envelope comes from the REFERENCE's own fp32 variants (golden G4c: the same 500 steps re-run by the reference at
+            # 1 / 2 / 4 / 8 ATen threads and with oneDNN off -- other summation orders of the same arithmetic): after 500 steps they
+            # land 88.74 .. 89.17 on trunk.7.C1 against 89.37 in fp64.  105 steps: 4x the reference's fp32-vs-fp64 distance (the
+            # standing gate, SURVEY.md D7 ii); 500 steps: 2x the reference's WORST fp32 variant's distance to fp64.
+            spread = max(abs(float(gs["%s_s%d_%s" % (gk, tag, v)]) - n64) for v in gs["variants"])
+            tol = max(4.0 * abs(n32 - n64), 0.02) if tag == 105 else max(2.0 * spread, 0.02)
             assert abs(n_hip - n64) <= tol, (key, tag, n_hip, n32, n64)
         # probe: the first five support images through the adapted network (train-mode BatchNorm, one group of 5)
         xa = torch.cat([v[:, :5].contiguous().view(25, 3, size, size) for v in [views[0]] + views], 0)

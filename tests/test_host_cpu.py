@@ -259,12 +259,12 @@ def test_bench_helpers_and_pmc_provenance(tmp_path, monkeypatch):
         warnings.warn("profiles/pmc_traffic.json was measured on other kernel source (%s, now %s): bench.py reports "
                       "roofline.traffic = null until tools/final_profiles.sh is re-run" % (rec["kernel_source_sha16"], sha))
         assert bench.pmc_traffic(rec["episodes_per_step"]) is None
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda: rec["kernel_source_sha16"])
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda fused=False: rec["kernel_source_sha16"])
     t = bench.pmc_traffic(rec["episodes_per_step"])
     assert t is not None and 1.0 <= t["mb_per_launch"] / t["algorithmic_mb_per_launch"] < 1.1
     assert bench.pmc_traffic(rec["episodes_per_step"] + 1) is None
     # a record with a foreign hash is refused
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda fused=False: "0" * 16)
     assert bench.pmc_traffic(rec["episodes_per_step"]) is None
     # the power sampler reads hwmon files: fake one GPU under load and one idle
     import time

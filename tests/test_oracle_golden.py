@@ -403,3 +403,22 @@ def test_g18_finetune_linear_frozen_20shot(golden_dir):
     sc = O.finetune_linear_frozen_episode(sd, liz, 5, 20, torch.from_numpy(g["w0"]), torch.from_numpy(g["b0"])).numpy()
     assert np.abs(sc - g["scores"]).max() < 1e-5
     assert np.array_equal(np.random.permutation(7), g["next_perm"])
+
+
+def test_g4c_reference_fp32_spread_fixture(golden_dir):
+    """Golden G4c (oracle/make_golden_r2.py --only g4c): the REFERENCE's own 500-step trajectory of G4b re-run at 1 / 2 / 4 / 8 ATen
+    threads and with oneDNN off.  The threaded runs reproduce G4b's fp32 run (oneDNN's reductions do not depend on the thread
+    count at these sizes); the oneDNN-off run is another summation order of the same fp32 arithmetic and after 500 Adam steps it
+    sits as far from the default run as that is from fp64 -- the envelope tests/test_engine_gpu.py holds the HIP path to."""
+    g = _g(golden_dir, "g4b_inner_loop_long.npz")
+    gs = _g(golden_dir, "g4c_inner_loop_spread.npz")
+    assert list(gs["variants"]) == ["t1", "t2", "t4", "t8", "t8_nodnn"]
+    for key in ("wn_c1", "wn_c2", "wn_sc"):
+        for tag in (105, 500):
+            n32, n64 = float(g["%s_s%d_f32" % (key, tag)]), float(g["%s_s%d_f64" % (key, tag)])
+            for v in ("t1", "t2", "t4", "t8"):
+                assert abs(float(gs["%s_s%d_%s" % (key, tag, v)]) - n32) < 1e-4
+            other = float(gs["%s_s%d_t8_nodnn" % (key, tag)])
+            assert abs(other - n64) <= max(6.0 * abs(n32 - n64), 0.02)        # same order of magnitude as the default run's distance
+    d = abs(float(gs["wn_c1_s500_t8_nodnn"]) - float(g["wn_c1_s500_f32"]))
+    assert 0.1 < d < 1.0                                                       # 0.43: fp32 variants of the reference itself differ by this much
