@@ -9,28 +9,20 @@
 // while it is still in LDS, with the next step's activation rows (which the frozen trunk, running ahead on its own stream, has
 // already produced) and accumulates the next step's convolution output of its 32 output channels along the walk.
 //
-// Structure: one workgroup (4 waves) = one episode x 16 output channels, walking all K tiles of 128 in (tap, ci) order, i.e.
-// along the 18 KB weight rows.  Per K tile:
-//   G = dY^T . im2col(x_t)             v_mfma_f32_16x16x4_f32: wave w owns k columns [32 w, 32 w + 32) of the tile (two 16 x 16
-//                                      blocks); reduction rows ascending, four per instruction (an fma chain in row order, as
-//                                      wgrad_adam_rows_kernel's two-per-instruction chain: bit-identical gradient)
-//   (w, m, v) <- Adam(G)               row-stream layout (512 B runs, nontemporal) through LDS; w' parked in LDS over G
-//   out[48 px][16 co] += w' . im2col(x_{t+1})    same instruction, wave w the same 32 k: A = w' fragments (ds_read_b128),
-//                                      B = activation rows straight from L2
-// After the walk the four waves' partial outputs are summed in fixed order and the layer's epilogue runs on the 16 channels the
-// workgroup owns -- every BatchNorm of the block normalises per channel over the episode's <= 48 pixels:
+// Structure (one workgroup = one episode x 32 output channels, walking all K tiles of 128 -- (tap, ci) order, i.e. along the
+// 18 KB weight rows; 4 waves):
+//   per K tile:  G = dY^T . im2col(x_t)            v_mfma_f32_32x32x2_f32, reduction rows 2t+h as wgrad_adam_rows_kernel
+//                (w, m, v) <- Adam(G)              row-stream layout, 512 B runs, nontemporal; w' also parked in LDS over G
+//                out[48 px][32 co] += w' . im2col(x_{t+1})   v_mfma_f32_16x16x4_f32, each wave a 32-wide k slice of the tile;
+//                                                  A = w' fragments (ds_read_b128), B = activation rows straight from L2
+//   after the walk: the four waves' partial outputs are summed in fixed order and the layer's epilogue runs on the 32 channels
+//   the workgroup owns -- every BatchNorm of the block normalises per channel over the episode's <= 48 pixels:
 //     RAW    shortcut 1x1 convolution: raw output only (its BatchNorm is folded into EXIT)
 //     ENTRY  C1: BatchNorm1 statistics + affine + ReLU -> r1                      (backbone.py:252-254)
 //     EXIT   C2: BatchNorm2 + BatchNorm(shortcut) + add + ReLU + global average pool   (backbone.py:255-261, :438 AvgPool2d)
-//
-// Resources are chosen for the launch's real neighbours, not for itself: the frozen trunk's convolutions of the NEXT steps run on
-// another stream at the same time (engine.inner_loop) and need ~160 VGPRs and ~50 KB of LDS per workgroup.  Earlier forms of
-// this kernel with 32 output channels per workgroup (4 waves x 253 VGPRs, two per CU; 8 waves x 170 VGPRs, one per CU) were
-// bound by their per-tile dependency chain per CU instead of by HBM, and the first filled every SIMD's register file so that
-// the trunk's workgroups found no CU to run beside it (profiles/r03_a_*).  Half the rows per workgroup halves the registers
-// that hold w/m/v, the accumulators and the LDS (39 KB): three workgroups per CU interleave their chains, two tiles of w/m/v
-// per workgroup are in flight (two register sets; tile k+2 is requested when Adam releases tile k's registers, after
-// everything tile k+1 needs first -- the load counter is in order), and a trunk convolution still fits beside two of them.
+// The gradient and (w, m, v) are bit-identical to wgrad_adam_rows_kernel (same reduction order, same Adam expressions).
+// All request streams are one tile deep: im2col rows, then w/m/v, then next-step activation rows of tile k+1 are requested
+// while tile k is being multiplied (the load counter is in order, so the reduction never waits for the big w/m/v requests).
 #include "mft_common.h"
 #include <math.h>
 
@@ -63,24 +55,24 @@ struct WfArgs {
 
 enum { WF_RAW = 0, WF_ENTRY = 1, WF_EXIT = 2 };
 
-__device__ __forceinline__ float lane16_sum(float v) {      // sum over the 16 lanes that share tid >> 4
+__device__ __forceinline__ float lane8_sum(float v) {       // sum over the 8 lanes that share tid >> 3
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
     return v;
 }
 
-// NI: matrix instructions per 16 x 16 block of the reduction (4 rows each; rows beyond the episode's are zeros and change no bit)
-template <int MODE, bool FAST, int NI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void wgrad_adam_fwd_kernel(WfArgs p) {
-    constexpr int BM = 16, BN = 128, ALD = 16, BLD = BN + 16, GLD = BN + 4, RLD = 20, TLD = 17;
+// NT: matrix instructions of the reduction (2 rows each; rows beyond the episode's are zeros and change no bit of the sum)
+template <int MODE, bool FAST, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_adam_fwd_kernel(WfArgs p) {
+    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4, RLD = 36, TLD = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [48][ALD]  dY rows of this output-channel tile (resident for the walk)
-    float* Bs = smem + 48 * ALD;          // [48][BLD]  im2col rows of the current K tile
-    float* Gs = Bs + 48 * BLD;            // [16][GLD]  gradient tile, overwritten in place by the updated weight tile
+    float* As = smem;                     // [48][BM]   dY rows of this output-channel tile (resident for the walk)
+    float* Bs = smem + 48 * BM;           // [48][BLD]  im2col rows of the current K tile
+    float* Gs = Bs + 48 * BLD;            // [32][GLD]  gradient tile, overwritten in place by the updated weight tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates
+    const int r = lane & 31, h = lane >> 5;            // 32x32x2 fragment coordinates (reduction)
+    const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates (next step's convolution)
     const int g = blockIdx.y, co0 = blockIdx.x * BM;
     const int ohw = p.OH * p.OW;
     const int rows = p.rows;
@@ -89,12 +81,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int n_kt = p.KH * p.KW * p.tiles_ci;
     const bool fwd = p.xn != nullptr;
 
-    // dY rows (resident): 48 rows x 8 float4
-    if (tid < 192) {
-        const int m = tid >> 2, acol = (tid & 3) * 4;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = arow + 32 * j;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
-        *(f32x4*)(As + m * ALD + acol) = v;
+        if (m < 48) *(f32x4*)(As + m * BM + acol) = v;
     }
     // pixel geometry, packed (image << 16 | (ih0 + 64) << 8 | (iw0 + 64)); -1 = row beyond the episode's pixels
     auto geom = [&](int m) {
@@ -103,7 +97,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const int oh = (rem * p.inv_ow) >> 16, ow = rem - oh * p.OW;
         return (img << 16) | ((oh * p.stride - p.pad + 64) << 8) | (ow * p.stride - p.pad + 64);
     };
-    const int brow = tid >> 5, bcol = (tid & 31) * 4;          // staging of the reduction's operand rows: rows brow + 8 j
     int bgeo[6], xgeo[3];
 #pragma unroll
     for (int j = 0; j < 6; ++j) bgeo[j] = geom(brow + 8 * j);
@@ -154,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     };
     // this workgroup's 32 rows of w / m / v: wave-uniform 64-bit bases, 32-bit lane offsets (a row block is < 2^31 floats)
-    const int q = tid & 31, rr = tid >> 5;               // rows rr, rr + 8; floats 4 q .. 4 q + 3
+    const int q = tid & 31, rr = tid >> 5;
     const long long tile_base = (long long)g * p.dwgs + (long long)co0 * p.Kpad;
     float* const wg_ = p.w + tile_base;
     float* const mg_ = p.m + tile_base;
@@ -162,60 +155,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int lo0 = rr * p.Kpad + 4 * q;
     // two register sets: while Adam consumes tile k from one, tile k+1 sits (landed or landing) in the other and tile k+2 is
     // requested into the first as soon as Adam is done with it
-    f32x4 am[2], av[2], aw[2], bm[2], bv[2], bw[2];
-    auto load_wmv = [&](int kt, f32x4 (&M)[2], f32x4 (&V)[2], f32x4 (&W)[2]) {
+    f32x4 am[4], av[4], aw[4], bm[4], bv[4], bw[4];
+    auto load_wmv = [&](int kt, f32x4 (&M)[4], f32x4 (&V)[4], f32x4 (&W)[4]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int gi = lo0 + 8 * u * p.Kpad + kt * BN;       // K index of tile kt = kt * 128 (tap-major)
             M[u] = __builtin_nontemporal_load((const f32x4*)(mg_ + gi));
             V[u] = __builtin_nontemporal_load((const f32x4*)(vg_ + gi));
             W[u] = __builtin_nontemporal_load((const f32x4*)(wg_ + gi));
         }
     };
-    // request order = order of need (the load counter is in order): operand rows of tile 0, then w/m/v of tiles 0 and 1
+    // request order = order of need (the load counter is in order): operand rows of tile 0, of tile 1, w/m/v of tiles 0 and 1
     load_b(0, 0, 0);
     if (fwd) load_x(0, 0, 0);
     load_wmv(0, am, av, aw);
     if (n_kt > 1) load_wmv(1, bm, bv, bw);
     advance();                            // (nkh, nkw, nci0) = tile 1
-    f32x4 accf[3];
+    f32x4 accf[3][2];
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb) accf[nb] = zero4;
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) accf[nb][cb] = zero4;
     const float step_size = p.hyper ? p.hyper[0] : p.step_size;
     const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
 
-    auto tile = [&](int kt, f32x4 (&cm)[2], f32x4 (&cv)[2], f32x4 (&cw)[2]) {
+    auto tile = [&](int kt, f32x4 (&cm)[4], f32x4 (&cv)[4], f32x4 (&cw)[4]) {
         const bool more = kt + 1 < n_kt;
-        // ---- gradient tile: G[co][k] = sum_rows dY[row][co] * im2col[row][k]; this wave: k = 32 wave + 16 kb + fm
+        // ---- gradient tile: G[co][k] = sum_rows dY[row][co] * im2col[row][k]
 #pragma unroll
         for (int j = 0; j < 6; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[j];
         __syncthreads();                              // (first tile: also the dY rows)
-        f32x4 acc0 = zero4, acc1 = zero4;
-        {
-            // chunks of 4 instruction pairs: their 12 fragment reads are issued together (a fully unrolled loop lets the
-            // scheduler hoist all 3 NI reads into registers)
-#pragma unroll 1
-            for (int i0 = 0; i0 < NI; i0 += 4) {
-                const float* bp = Bs + (4 * i0 + fq) * BLD + 32 * wave + fm;
-                const float* ap = As + (4 * i0 + fq) * ALD + fm;
+        f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {         // rows 4 (i0 + i) + fq
-                    const float a = ap[4 * i * ALD];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[4 * i * BLD], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[4 * i * BLD + 16], acc1, 0, 0, 0);
-                }
-            }
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        // chunks of 8 instructions: their 16 fragment reads are issued together, no branch inside (a fully unrolled loop lets the
+        // scheduler hoist all 2 NT reads and spill)
+#pragma unroll 1
+        for (int t0 = 0; t0 < NT; t0 += 8) {
+            const float* ap = As + (2 * t0 + h) * BM + r;
+            const float* bp = Bs + (2 * t0 + h) * BLD + wave * 32 + r;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t * BM], bp[2 * t * BLD], acc, 0, 0, 0);
         }
         if (more) load_b(nkh, nkw, nci0);             // next tile's im2col rows (L2) under the epilogue
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                 // D[row = co 4 fq + e][col = k fm]
-            Gs[(4 * fq + e) * GLD + 32 * wave + fm] = acc0[e];
-            Gs[(4 * fq + e) * GLD + 32 * wave + 16 + fm] = acc1[e];
-        }
+        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
         __syncthreads();
         // ---- Adam on the tile (row-stream layout), updated weights back into the same LDS cells
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int gi = lo0 + 8 * u * p.Kpad + kt * BN;
             float* gcell = Gs + (rr + 8 * u) * GLD + 4 * q;
             const f32x4 ge = *(const f32x4*)gcell;
@@ -233,10 +221,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 a0 = *(const f32x4*)(Gs + fm * GLD + 32 * wave + 16 * j + 4 * fq);
+                const f32x4 a1 = *(const f32x4*)(Gs + (16 + fm) * GLD + 32 * wave + 16 * j + 4 * fq);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) accf[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], xb[nb][j][i], accf[nb], 0, 0, 0);
+                    for (int nb = 0; nb < 3; ++nb) {
+                        accf[nb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], xb[nb][j][i], accf[nb][0], 0, 0, 0);
+                        accf[nb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xb[nb][j][i], accf[nb][1], 0, 0, 0);
+                    }
             }
             if (more) load_x(nkh, nkw, nci0);
         }
@@ -253,38 +245,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 
     // ---- the four k-slices' partial outputs, summed in fixed order
     __syncthreads();
-    float* Red = smem;                    // [4][48][RLD] (15 KB), aliases As / Bs
+    float* Red = smem;                    // [4][48][RLD], aliases As / Bs
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb) *(f32x4*)(Red + ((wave * 48 + nb * 16 + fm) * RLD + 4 * fq)) = accf[nb];
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            *(f32x4*)(Red + ((wave * 48 + nb * 16 + fm) * RLD + cb * 16 + 4 * fq)) = accf[nb][cb];
     __syncthreads();
-    const int c = tid >> 4, pl = tid & 15;            // channel co0 + c, pixels pl + 16 i
-    float val[3];
+    const int c = tid >> 3, pl = tid & 7;             // channel co0 + c, pixels pl + 8 i
+    float val[6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int px = pl + 16 * i;
+    for (int i = 0; i < 6; ++i) {
+        const int px = pl + 8 * i;
         val[i] = ((Red[(px)*RLD + c] + Red[(48 + px) * RLD + c]) + Red[(96 + px) * RLD + c]) + Red[(144 + px) * RLD + c];
     }
-    float* T0 = Gs;                       // [48][TLD] raw output, [48][TLD] activation (Gs is dead: 2 x 3.3 KB <= 8.4 KB)
+    float* T0 = Gs;                       // [48][TLD] raw output, [48][TLD] activation (Gs is dead: 2 x 6.3 KB <= 16.9 KB)
     float* T1 = Gs + 48 * TLD;
     const float inv_rows = 1.f / (float)rows;
     if (MODE == WF_RAW) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) T0[(pl + 16 * i) * TLD + c] = val[i];
+        for (int i = 0; i < 6; ++i) T0[(pl + 8 * i) * TLD + c] = val[i];
     } else {
         auto stats = [&](const float* x, float& mu, float& rs) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (pl + 16 * i < rows) s += x[i];
-            mu = lane16_sum(s) * inv_rows;
+            for (int i = 0; i < 6; ++i)
+                if (pl + 8 * i < rows) s += x[i];
+            mu = lane8_sum(s) * inv_rows;
             s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (pl + 16 * i < rows) {
+            for (int i = 0; i < 6; ++i)
+                if (pl + 8 * i < rows) {
                     const float d = x[i] - mu;
                     s += d * d;
                 }
-            rs = 1.0f / sqrtf(lane16_sum(s) * inv_rows + p.bn_eps);
+            rs = 1.0f / sqrtf(lane8_sum(s) * inv_rows + p.bn_eps);
         };
         const int co = co0 + c;
         float mu, rs;
@@ -296,15 +291,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
         if (MODE == WF_ENTRY) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                T0[(pl + 16 * i) * TLD + c] = val[i];
-                T1[(pl + 16 * i) * TLD + c] = fmaxf((val[i] - mu) * rs * ga + be, 0.f);
+            for (int i = 0; i < 6; ++i) {
+                T0[(pl + 8 * i) * TLD + c] = val[i];
+                T1[(pl + 8 * i) * TLD + c] = fmaxf((val[i] - mu) * rs * ga + be, 0.f);
             }
         } else {
-            float sv[3];
+            float sv[6];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int px = pl + 16 * i;
+            for (int i = 0; i < 6; ++i) {
+                const int px = pl + 8 * i;
                 sv[i] = px < rows ? p.sc[(row0 + px) * p.Cout + co] : 0.f;
             }
             float mus, rss;
@@ -315,20 +310,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 p.rstds[(long long)g * p.Cout + co] = rss;
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 float o = (val[i] - mu) * rs * ga + be;
                 o += (sv[i] - mus) * rss * gas + bes;
-                T0[(pl + 16 * i) * TLD + c] = val[i];
-                T1[(pl + 16 * i) * TLD + c] = fmaxf(o, 0.f);
+                T0[(pl + 8 * i) * TLD + c] = val[i];
+                T1[(pl + 8 * i) * TLD + c] = fmaxf(o, 0.f);
             }
         }
     }
     __syncthreads();
-    // write-out: one pixel row of the 16 channels = 64 contiguous bytes per quarter wave
-    const int c2 = tid & 15, p2 = tid >> 4;
+    // write-out: one pixel row of the 32 channels = one 128-byte line per half wave
+    const int c2 = tid & 31, p2 = tid >> 5;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int px = p2 + 16 * i;
+    for (int i = 0; i < 6; ++i) {
+        const int px = p2 + 8 * i;
         if (px < rows) {
             p.raw[(row0 + px) * p.Cout + co0 + c2] = T0[px * TLD + c2];
             if (MODE != WF_RAW) p.act[(row0 + px) * p.Cout + co0 + c2] = T1[px * TLD + c2];
@@ -350,7 +345,6 @@ int g_wf_exact = 0;      // 1: correctly rounded division / square root in the A
 
 extern "C" void mft_wgrad_fwd_set_exact(int on) { g_wf_exact = on ? 1 : 0; }
 
-
 extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
                                            float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
                                            int stride, int pad, int imgs_per_group, long long group_stride, int step,
@@ -360,7 +354,7 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
                                            const float* sc_raw, const float* gamma_s, const float* beta_s, float* mean_s,
                                            float* rstd_s, float* pooled, float bn_eps, void* stream) {
     if (n_img <= 0 || imgs_per_group <= 0 || n_img % imgs_per_group != 0) return MFT_EINVAL;
-    if (Cin % 128 != 0 || Cout % 16 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return MFT_EINVAL;
+    if (Cin % 128 != 0 || Cout % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return MFT_EINVAL;
     if (hyper == nullptr && step < 1) return MFT_EINVAL;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     const int rows = imgs_per_group * OH * OW;
@@ -394,17 +388,17 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
     p.mean = mean; p.rstd = rstd; p.sc = sc_raw; p.gs = gamma_s; p.bs = beta_s; p.means = mean_s; p.rstds = rstd_s;
     p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps;
     const int groups = n_img / imgs_per_group;
-    constexpr int lds = (48 * 16 + 48 * (128 + 16) + 16 * (128 + 4)) * 4;          // 39.2 KB: three workgroups per CU, or two beside a trunk convolution
-    const dim3 grid(Cout / 16, groups, 1), block(256);
+    constexpr int lds = (48 * 32 + 48 * (128 + 32) + 32 * (128 + 4)) * 4;          // 53.8 KB: two workgroups per CU
+    const dim3 grid(Cout / 32, groups, 1), block(256);
     hipStream_t s = (hipStream_t)stream;
-    // matrix instructions per block of the reduction: 4 rows each (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
-    const int nt = rows <= 32 ? 8 : 12;
+    // matrix instructions of the reduction: 2 rows each, in chunks of 8 (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
+    const int nt = rows <= 32 ? 16 : 24;
 #define WF_LAUNCH2(MODE_, NT_)                                                                            \
     if (g_wf_exact) hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, false, NT_>), grid, block, lds, s, p);  \
     else hipLaunchKernelGGL((wgrad_adam_fwd_kernel<MODE_, true, NT_>), grid, block, lds, s, p);
 #define WF_LAUNCH(MODE_)                                  \
-    if (nt == 8) { WF_LAUNCH2(MODE_, 8) }                 \
-    else { WF_LAUNCH2(MODE_, 12) }
+    if (nt == 16) { WF_LAUNCH2(MODE_, 16) }               \
+    else { WF_LAUNCH2(MODE_, 24) }
     if (mode == WF_RAW) { WF_LAUNCH(WF_RAW) }
     else if (mode == WF_ENTRY) { WF_LAUNCH(WF_ENTRY) }
     else { WF_LAUNCH(WF_EXIT) }
