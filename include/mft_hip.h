@@ -407,6 +407,28 @@ int mft_pair_mlp_stats_finalize(const float* ws_mean, const float* ws_m2, const 
 int mft_pair_mlp_score(const float* h, int C, const float* scale, const float* shift, const float* w5, const float* b5,
                        float slope, float* s_ut, int n_groups, int graphs_per_group, int N, void* stream);
 int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, int N, void* stream);
+
+/* loss.backward() through gnn.Wcompute (gnn.py:78-132 under autograd, meta_template.py:76-92) on the forward's upper-triangle pair
+ * rows p(i, j), i <= j: a merged row carries the sum of the reference's (i, j) and (j, i) gradients (every operator is linear in
+ * the gradient).  Nothing of shape [B*N*N, F] is formed.
+ *  mft_pair_softmax_ut_backward: ds[r*ldds] = A_ij (dA_ij - <A_i, dA_i>) + A_ji (dA_ji - <A_j, dA_j>)  (rowdot_ws: n_graphs*N floats)
+ *  mft_pair_bn_act_backward:     BatchNorm2d(train) + leaky_relu backward of one layer over merged rows.  g = dL/d(activation)
+ *      [rows, ldg], z = the layer's RAW output [rows, C] (C = 96 | 192), scale / shift / mean / rstd as left by
+ *      mft_pair_mlp_stats_finalize; sums[2*C] <- (sum u, sum u*xhat) = (d beta, d gamma); dz [rows, C] <- gamma rstd (u - cnt
+ *      sum_u / n_tot - cnt xhat sum_ux / n_tot) with cnt = 1 on diagonal rows, 2 elsewhere, n_tot = n_graphs*N*N.
+ *      ws: mft_pair_bwd_stats_ws_floats(rows, C) floats (fixed-order partial sums: deterministic).
+ *  mft_pair_absdiff_ut:          d[r - row0][:] = |x_i - x_j| for rows row0 .. row0 + nrows (layer 1's input, a bounded chunk)
+ *  mft_pair_dx_gather:           dX[b, i, :F] += sum_j sign(x_i - x_j) * dd[p(i,j) - row0][:F] over the pairs inside the chunk     */
+int mft_pair_softmax_ut_backward(const float* A, const float* dA, const int* ij, float* rowdot_ws, float* ds, int ldds,
+                                 int n_graphs, int N, void* stream);
+long long mft_pair_bwd_stats_ws_floats(long long rows, int C);
+int mft_pair_bn_act_backward(const float* g, int ldg, const float* z, int C, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, const float* gamma, const int* ij, int N, long long rows,
+                             long long n_tot, float slope, float* ws, float* sums, float* dz, void* stream);
+int mft_pair_absdiff_ut(const float* x, int ldx, const int* ij, float* d, int Kp, int F, int N, long long row0, long long nrows,
+                        void* stream);
+int mft_pair_dx_gather(const float* x, int ldx, const float* dd, int lddd, float* dX, int lddx, int n_graphs, int N, int F,
+                       long long row0, long long nrows, void* stream);
 /* gmul (gnn.py:16-28) with J=2: y[b,i,:] = cat(x[b,i,:F], (A[b] @ x[b])[i,:F]) zero padded to ldy */
 int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy,
                         int n_graphs, int N, int F, void* stream);

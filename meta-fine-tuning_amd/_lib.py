@@ -40,6 +40,11 @@ SIGNATURES = {
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,
                                    _F, _P],
+    "mft_pair_softmax_ut_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mft_pair_bwd_stats_ws_floats": [_L, _I],
+    "mft_pair_bn_act_backward": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _L, _L, _F, _P, _P, _P, _P],
+    "mft_pair_absdiff_ut": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _P],
+    "mft_pair_dx_gather": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _L, _L, _P],
     "mft_wgrad_adam_next_forward": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _F, _F, _F,
                                     _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P],
     "mft_wgrad_fwd_set_exact": [_I],
@@ -112,7 +117,7 @@ SIGNATURES = {
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L,
-            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L}
+            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L}
 
 _lib = None
 

@@ -338,6 +338,159 @@ __global__ __launch_bounds__(256) void masked_softmax_ut_kernel(const float* __r
     for (int j = lane; j < N; j += 64) A[row * N + j] = __expf(at(j) - mx) * inv;
 }
 
+// ------------------------------------------------------------------------------------------------ backward (meta-training)
+// loss.backward() through gnn.Wcompute (gnn.py:78-132 under autograd; meta_template.py:76-92) on the SAME upper-triangle rows the
+// forward keeps.  In the reference's N x N formulation the positions (i, j) and (j, i) carry identical activations and their own
+// gradients; every backward operator of the chain is linear in the gradient, so a merged row p(i, j) that carries the SUM of the two
+// gradients gives the same parameter gradients and the same d x -- with one change: the mean-subtraction terms of the BatchNorm
+// backward count a merged off-diagonal row twice (cnt = 2; diagonal rows once), and the means are over all n_graphs * N * N
+// positions.  Nothing of shape [B * N * N, F] exists: layer outputs are [B * N(N+1)/2, <= 192], |x_i - x_j| is produced for a
+// bounded chunk of rows at a time.
+
+// rd[b, i] = sum_k A[b,i,k] * dA[b,i,k]     (one wave per row)
+__global__ __launch_bounds__(256) void softmax_rowdot_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                             float* __restrict__ rd, long long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += A[row * N + j] * dA[row * N + j];
+    s = wave_sum(s);
+    if (lane == 0) rd[row] = s;
+}
+
+// ds_ut[b, p(i,j)] = A_ij (dA_ij - rd_i) + A_ji (dA_ji - rd_j)  (i < j);  diagonal: A_ii (dA_ii - rd_i) (= 0: the masked logit)
+__global__ __launch_bounds__(256) void softmax_ut_backward_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                                  const float* __restrict__ rd, const int* __restrict__ ij,
+                                                                  float* __restrict__ ds, int ldds, int n_graphs, int N, int P) {
+    const long long total = (long long)n_graphs * P;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(r / P), pk = ij[r % P];
+        const int i = pk >> 16, j = pk & 0xffff;
+        const long long base = (long long)b * N * N, rb = (long long)b * N;
+        float v = A[base + (long long)i * N + j] * (dA[base + (long long)i * N + j] - rd[rb + i]);
+        if (i != j) v += A[base + (long long)j * N + i] * (dA[base + (long long)j * N + i] - rd[rb + j]);
+        ds[r * ldds] = v;
+    }
+}
+
+// BatchNorm + leaky_relu backward over merged rows, phase 1: per-channel sums of u = g * lrelu'(y) and u * xhat, y = z * scale +
+// shift, xhat = (z - mean) * rstd.  One block per contiguous range of rows; fixed-order partials (block, then row lane).
+__global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ z, int C,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float slope, long long rows, long long rows_per_block,
+                                                             float* __restrict__ ws) {
+    __shared__ float red[2][10][192];
+    const int q = C / 4, rp = 256 / q;                // float4 per row; rows per pass (5 at C = 192, 10 at C = 96)
+    const int c4 = (threadIdx.x % q) * 4, rl = threadIdx.x / q;
+    f32x4 su = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rp) {
+        const f32x4 sc = *(const f32x4*)(scale + c4), sh = *(const f32x4*)(shift + c4);
+        const f32x4 mu = *(const f32x4*)(mean + c4), rs = *(const f32x4*)(rstd + c4);
+        const long long r0 = (long long)blockIdx.x * rows_per_block;
+        const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+        for (long long r = r0 + rl; r < r1; r += rp) {
+            const f32x4 gv = *(const f32x4*)(g + r * ldg + c4), zv = *(const f32x4*)(z + r * C + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = zv[e] * sc[e] + sh[e];
+                const float u = y > 0.f ? gv[e] : gv[e] * slope;
+                su[e] += u;
+                sx[e] += u * ((zv[e] - mu[e]) * rs[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][rl][c4 + e] = su[e]; red[1][rl][c4 + e] = sx[e]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int k = i / C, c = i - k * C;
+        float s = 0.f;
+        for (int l = 0; l < rp; ++l) s += red[k][l][c];
+        ws[((long long)blockIdx.x * 2 + k) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_bwd_stats_final_kernel(const float* __restrict__ ws, int nblk, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // over 2 * C
+    if (i >= 2 * C) return;
+    const int k = i / C, c = i - k * C;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[((long long)b * 2 + k) * C + c];
+    sums[i] = s;
+}
+
+// phase 2: dz = gamma * rstd * (u - cnt * sum_u / n_tot - cnt * xhat * sum_ux / n_tot), cnt = 1 on diagonal rows, 2 elsewhere
+__global__ __launch_bounds__(256) void pair_bwd_dz_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ z, int C,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                          const int* __restrict__ ij, int P, float inv_n_tot, float slope,
+                                                          long long rows, float* __restrict__ dz) {
+    const int q = C / 4;
+    const long long total = rows * q;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t / q;
+        const int c4 = (int)(t - r * q) * 4;
+        const int pk = ij[r % P];
+        const float cnt = ((pk >> 16) == (pk & 0xffff)) ? 1.f : 2.f;
+        const f32x4 gv = *(const f32x4*)(g + r * ldg + c4), zv = *(const f32x4*)(z + r * C + c4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 + e;
+            const float y = zv[e] * scale[c] + shift[c];
+            const float u = y > 0.f ? gv[e] : gv[e] * slope;
+            const float xh = (zv[e] - mean[c]) * rstd[c];
+            o[e] = gamma[c] * rstd[c] * (u - cnt * (sums[c] * inv_n_tot) - cnt * xh * (sums[C + c] * inv_n_tot));
+        }
+        *(f32x4*)(dz + r * C + c4) = o;
+    }
+}
+
+// d[r][f] = |x_i[f] - x_j[f]| for the upper-triangle rows row0 .. row0 + nrows (zero beyond F up to Kp)
+__global__ __launch_bounds__(256) void pair_absdiff_ut_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ij,
+                                                              float* __restrict__ d, int Kp, int F, int N, int P, long long row0,
+                                                              long long nrows) {
+    const int q = Kp / 4;
+    const long long total = nrows * q;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long rl = t / q, r = row0 + rl;
+        const int c4 = (int)(t - rl * q) * 4;
+        const int b = (int)(r / P), pk = ij[r % P];
+        const float* xi = x + ((long long)b * N + (pk >> 16)) * ldx + c4;
+        const float* xj = x + ((long long)b * N + (pk & 0xffff)) * ldx + c4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c4 + e < F) ? fabsf(xi[e] - xj[e]) : 0.f;
+        *(f32x4*)(d + rl * Kp + c4) = o;
+    }
+}
+
+// dX[b, i, f] += sum_j sign(x_i[f] - x_j[f]) * dd[p(i, j)][f] over the pairs whose row lies in [row0, row0 + nrows)
+// (one thread per (b, i, f), j ascending: deterministic; d|a - b| / da = sign(a - b), 0 at a == b as torch.abs)
+__global__ __launch_bounds__(256) void pair_dx_gather_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dd, int lddd,
+                                                             float* __restrict__ dX, int lddx, int N, int P, int F, long long row0,
+                                                             long long nrows) {
+    const long long node = blockIdx.x;                 // b * N + i
+    const int b = (int)(node / N), i = (int)(node - (long long)b * N);
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const float xi = x[node * ldx + f];
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) {
+            if (j == i) continue;
+            const int a = i < j ? i : j, c = i < j ? j : i;
+            const long long r = (long long)b * P + (a * N - (a * (a - 1)) / 2 + (c - a)) - row0;
+            if (r < 0 || r >= nrows) continue;
+            const float df = xi - x[((long long)b * N + j) * ldx + f];
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            acc += sg * dd[r * lddd + f];
+        }
+        dX[node * lddx + f] += acc;
+    }
+}
+
 }  // namespace
 
 static int g_pair_db = 0;     // 1: double-buffered LDS form (MFT_PAIR_DB=1 at load time; A/B measurements in DESIGN.md)
@@ -413,5 +566,62 @@ extern "C" int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, 
     const long long rows = (long long)n_graphs * N;
     hipLaunchKernelGGL(masked_softmax_ut_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s_ut, A,
                        n_graphs, N, N * (N + 1) / 2);
+    return mft_launch_status();
+}
+
+/* ---- backward over upper-triangle rows (see the kernels' comments) ---- */
+extern "C" int mft_pair_softmax_ut_backward(const float* A, const float* dA, const int* ij, float* rowdot_ws, float* ds, int ldds,
+                                            int n_graphs, int N, void* stream) {
+    if (n_graphs < 1 || N < 1 || ldds < 1) return MFT_EINVAL;
+    const long long rows = (long long)n_graphs * N;
+    const int P = N * (N + 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, dA, rowdot_ws, rows, N);
+    long long blocks = ((long long)n_graphs * P + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(softmax_ut_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, dA, (const float*)rowdot_ws, ij, ds, ldds,
+                       n_graphs, N, P);
+    return mft_launch_status();
+}
+
+extern "C" long long mft_pair_bwd_stats_ws_floats(long long rows, int C) {
+    long long nblk = (rows + 511) / 512;
+    if (nblk > 1024) nblk = 1024;
+    return nblk * 2 * C;
+}
+
+extern "C" int mft_pair_bn_act_backward(const float* g, int ldg, const float* z, int C, const float* scale, const float* shift,
+                                        const float* mean, const float* rstd, const float* gamma, const int* ij, int N,
+                                        long long rows, long long n_tot, float slope, float* ws, float* sums, float* dz, void* stream) {
+    if ((C != 96 && C != 192) || ldg < C || ldg % 4 != 0 || rows < 1 || n_tot < rows) return MFT_EINVAL;
+    long long nblk = (rows + 511) / 512;
+    if (nblk > 1024) nblk = 1024;
+    const long long rpb = (rows + nblk - 1) / nblk;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pair_bwd_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean, rstd, slope, rows,
+                       rpb, ws);
+    hipLaunchKernelGGL(pair_bwd_stats_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (int)nblk, C, sums);
+    long long blocks = (rows * (C / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pair_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean, rstd, gamma,
+                       (const float*)sums, ij, N * (N + 1) / 2, 1.0f / (float)n_tot, slope, rows, dz);
+    return mft_launch_status();
+}
+
+extern "C" int mft_pair_absdiff_ut(const float* x, int ldx, const int* ij, float* d, int Kp, int F, int N, long long row0,
+                                   long long nrows, void* stream) {
+    if (Kp % 4 != 0 || F > Kp || ldx < Kp || nrows < 1) return MFT_EINVAL;
+    long long blocks = (nrows * (Kp / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pair_absdiff_ut_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, ij, d, Kp, F, N,
+                       N * (N + 1) / 2, row0, nrows);
+    return mft_launch_status();
+}
+
+extern "C" int mft_pair_dx_gather(const float* x, int ldx, const float* dd, int lddd, float* dX, int lddx, int n_graphs, int N, int F,
+                                  long long row0, long long nrows, void* stream) {
+    if (n_graphs < 1 || N < 1 || F < 1 || nrows < 1) return MFT_EINVAL;
+    hipLaunchKernelGGL(pair_dx_gather_kernel, dim3((unsigned)((long long)n_graphs * N)), dim3(256), 0, (hipStream_t)stream, x, ldx, dd,
+                       lddd, dX, lddx, N, N * (N + 1) / 2, F, row0, nrows);
     return mft_launch_status();
 }

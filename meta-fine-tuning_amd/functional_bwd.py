@@ -209,50 +209,107 @@ def _narrow(h, K):
     return h[:, :K].contiguous().view(h.shape[0], 1, 1, K)
 
 
+PAIR_CHUNK_ROWS = 8192          # pair rows whose |x_i - x_j| exist at one time in the backward of layer 1 (5 MB at F = 133)
+
+
 def wcompute_taped(G, name, x, F, n_graphs, N):
+    """gnn.Wcompute.forward (gnn.py:78-132) for one episode on the fused per-pair kernels (csrc/pair_mlp.hip), keeping what the
+    backward needs: the RAW layer outputs on the N(N+1)/2 upper-triangle pair rows [rows, 192 | 192 | 96 | 96] and every
+    BatchNorm's (scale, shift, mean, rstd).  The pair tensor |x_i - x_j| [B*N*N, F] is never formed, here or in the backward."""
     layers, (w5, b5) = G.wc[name]
+    lib = L.lib()
+    dev = x.device
+    P = N * (N + 1) // 2
+    rows = n_graphs * P
+    ij = Fn.pair_index_table(N, dev)
+    tiles_m = int(lib.mft_pair_mlp_tiles_m(n_graphs, N))
+    ws_mean, ws_m2, ws_n = _empty((tiles_m * 192,), dev), _empty((tiles_m * 192,), dev), _empty((tiles_m,), dev)
     Kp = ops.round_up(F, 32)
-    rows = n_graphs * N * N
-    d = ops.pair_absdiff(x, N, F, Kp)
-    t = {"name": name, "F": F, "Kp": Kp, "d": d, "raw": [], "act": [], "stats": []}
-    h, K = d, Kp
-    for (w, b, g, beta, cout) in layers:
-        o = _linear_fwd(h, K, w, b, cout)
-        m, s = ops.bn_stats(o, cout, rows, 1)
-        oa = ops.bn_apply(o, cout, rows, 1, m, s, g, beta, act=LRELU, out=_empty(o.shape, o.device))
-        t["raw"].append(o); t["act"].append(oa); t["stats"].append((m, s))
-        h, K = oa, cout
-    sc = _linear_fwd(h, K, w5, b5, 1)                     # [rows, 32], column 0 is the score
-    A = ops.masked_softmax(sc, N)
+    t = {"name": name, "F": F, "Kp": Kp, "ij": ij, "z": [], "bn": []}
+    h_in, ld_in, K, Kpad = x, x.shape[1], F, Kp
+    sc_prev = sh_prev = None
+    for li, (w, b, gam, beta, cout) in enumerate(layers):
+        z = _empty((rows, cout), dev)
+        sc, sh, m, s = (_empty((1, cout), dev) for _ in range(4))
+        L.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij), ops._p(sc_prev), ops._p(sh_prev), ops._p(w), K,
+                                       Kpad, ops._p(b), ops._p(z), cout, 1, n_graphs, N, ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2),
+                                       ops._p(ws_n), ops._stream()), "mft_pair_mlp_layer")
+        L.check(lib.mft_pair_mlp_stats_finalize(ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), 1, tiles_m, cout, ops._p(gam), ops._p(beta),
+                                                ops.BN_EPS, ops._p(sc), ops._p(sh), ops._p(m), ops._p(s), ops._stream()),
+                "mft_pair_mlp_stats_finalize")
+        t["z"].append(z); t["bn"].append((sc, sh, m, s))
+        h_in, ld_in, K, Kpad, sc_prev, sh_prev = z, cout, cout, cout, sc, sh
+    s_ut = _empty((rows,), dev)
+    L.check(lib.mft_pair_mlp_score(ops._p(h_in), layers[3][4], ops._p(sc_prev), ops._p(sh_prev), ops._p(w5), ops._p(b5), ops.LRELU_SLOPE,
+                                   ops._p(s_ut), 1, n_graphs, N, ops._stream()), "mft_pair_mlp_score")
+    A = _empty((n_graphs, N, N), dev)
+    L.check(lib.mft_masked_softmax_ut(ops._p(s_ut), ops._p(A), n_graphs, N, ops._stream()), "mft_masked_softmax_ut")
     t["A"] = A
     return A, t
 
 
+def _pair_activation(t, li, layers, rows):
+    """h_l = leaky_relu(BatchNorm(z_l)) of layer li as a [rows, C] operand of the generic GEMM launches (a transient)."""
+    _, _, gam, beta, cout = layers[li]
+    _, _, m, s = t["bn"][li]
+    z = t["z"][li]
+    return ops.bn_apply(z, cout, rows, 1, m, s, gam, beta, act=LRELU, out=_empty(z.shape, z.device))
+
+
 def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
-    """Accumulates d(x) into dX[:, :F]; writes parameter gradients into ``grads`` under ``prefix``."""
+    """Accumulates d(x) into dX[:, :F]; writes parameter gradients into ``grads`` under ``prefix``.  Works on the forward's
+    upper-triangle rows: a merged row carries the sum of the reference's (i, j) and (j, i) gradients (csrc/pair_mlp.hip, backward
+    section); layer 1's input |x_i - x_j| is produced for PAIR_CHUNK_ROWS rows at a time."""
     layers, (w5, b5) = G.wc[t["name"]]
-    rows = n_graphs * N * N
+    lib = L.lib()
     dev = x.device
-    ds = _zeros((rows, 32), dev)
-    L.check(L.lib().mft_masked_softmax_backward(ops._p(t["A"]), ops._p(dA), ops._p(ds), 32, n_graphs, N, ops._stream()),
-            "mft_masked_softmax_backward")
-    h4 = t["act"][3]
+    P = N * (N + 1) // 2
+    rows, n_tot = n_graphs * P, n_graphs * N * N
+    ij, F, Kp = t["ij"], t["F"], t["Kp"]
+    ds = _zeros((rows, 32), dev)                       # column 0: gradient of the compact symmetric score
+    rd = _empty((n_graphs * N,), dev)
+    L.check(lib.mft_pair_softmax_ut_backward(ops._p(t["A"]), ops._p(dA), ops._p(ij), ops._p(rd), ops._p(ds), 32, n_graphs, N,
+                                             ops._stream()), "mft_pair_softmax_ut_backward")
+    h4 = _pair_activation(t, 3, layers, rows)
     dh, dW, db = _linear_bwd(h4, 96, w5, ds, 1)
+    del h4
     grads[prefix + ".conv2d_last.weight"] = dW[:, :96].reshape(1, 96, 1, 1).contiguous()
     grads[prefix + ".conv2d_last.bias"] = db
     for li in (3, 2, 1, 0):
-        w, b, g, beta, cout = layers[li]
-        m, s = t["stats"][li]
-        do, dg, dbt = bn_bwd(t["raw"][li], dh, cout, rows, m, s, g, y_act=t["act"][li], act=LRELU)
-        grads[prefix + ".bn_%d.weight" % (li + 1)], grads[prefix + ".bn_%d.bias" % (li + 1)] = dg, dbt
-        hin = t["act"][li - 1] if li > 0 else t["d"]
-        K = layers[li - 1][4] if li > 0 else t["Kp"]
-        dh, dW, db = _linear_bwd(hin, K, w, do, cout)
-        kin = K if li > 0 else t["F"]
-        grads[prefix + ".conv2d_%d.weight" % (li + 1)] = dW[:, :kin].reshape(cout, kin, 1, 1).contiguous()
-        grads[prefix + ".conv2d_%d.bias" % (li + 1)] = db
-    L.check(L.lib().mft_pair_absdiff_backward(ops._p(x), x.shape[1], ops._p(dh), dh.shape[1], ops._p(dX), dX.shape[1],
-                                              n_graphs, N, t["F"], ops._stream()), "mft_pair_absdiff_backward")
+        w, b, gam, beta, cout = layers[li]
+        sc, sh, m, s = t["bn"][li]
+        z = t["z"][li]
+        sums = _empty((2 * cout,), dev)
+        ws = _empty((int(lib.mft_pair_bwd_stats_ws_floats(rows, cout)),), dev)
+        dz = _empty((rows, cout), dev)
+        L.check(lib.mft_pair_bn_act_backward(ops._p(dh), dh.shape[1], ops._p(z), cout, ops._p(sc), ops._p(sh), ops._p(m), ops._p(s),
+                                             ops._p(gam), ops._p(ij), N, rows, n_tot, ops.LRELU_SLOPE, ops._p(ws), ops._p(sums), ops._p(dz),
+                                             ops._stream()), "mft_pair_bn_act_backward")
+        grads[prefix + ".bn_%d.weight" % (li + 1)], grads[prefix + ".bn_%d.bias" % (li + 1)] = sums[cout:].clone(), sums[:cout].clone()
+        if li > 0:
+            K = layers[li - 1][4]
+            hin = _pair_activation(t, li - 1, layers, rows)
+            dh, dW, db = _linear_bwd(hin, K, w, dz, cout)
+            del hin
+            grads[prefix + ".conv2d_%d.weight" % (li + 1)] = dW[:, :K].reshape(cout, K, 1, 1).contiguous()
+            grads[prefix + ".conv2d_%d.bias" % (li + 1)] = db
+        else:
+            # layer 1: its input is |x_i - x_j|: generated chunk by chunk, multiplied, dropped
+            dW = None
+            wp = _pad_rows32(w)
+            for r0 in range(0, rows, PAIR_CHUNK_ROWS):
+                nr = min(PAIR_CHUNK_ROWS, rows - r0)
+                d = _empty((nr, Kp), dev)
+                L.check(lib.mft_pair_absdiff_ut(ops._p(x), x.shape[1], ops._p(ij), ops._p(d), Kp, F, N, r0, nr, ops._stream()),
+                        "mft_pair_absdiff_ut")
+                dzc = dz[r0:r0 + nr]
+                part = ops.conv2d_wgrad(d.view(nr, 1, 1, Kp), dzc.view(nr, 1, 1, cout), cout, 1, 1, 1, 0)[0][:cout]
+                dW = part if dW is None else dW + part
+                dd = ops.conv2d_dgrad(dzc.view(nr, 1, 1, cout), wp, Kp, 1, 1, 0).view(nr, Kp)
+                L.check(lib.mft_pair_dx_gather(ops._p(x), x.shape[1], ops._p(dd), Kp, ops._p(dX), dX.shape[1], n_graphs, N, F, r0, nr,
+                                               ops._stream()), "mft_pair_dx_gather")
+            grads[prefix + ".conv2d_1.weight"] = dW[:, :F].reshape(cout, F, 1, 1).contiguous()
+            grads[prefix + ".conv2d_1.bias"] = colsum(dz, cout)
 
 
 def gconv_taped(G, name, A, x, F, n_graphs, N):

@@ -337,6 +337,7 @@ def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys)
                n_episode=2, size=84)
     f = tmp_path / "checkpoints" / "miniImageNet" / "ResNet10_gnnnet_5way_5shot" / "1.tar"
     assert f.is_file() and (f.parent / "0.tar").is_file()
+    capsys.readouterr()                                               # (train's "Epoch ... Loss" lines)
     monkeypatch.setenv("MFT_EPISODES", "3")
     monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
     ft._ENGINES.clear()
