@@ -125,6 +125,10 @@ int mft_ingest_episode_views(const float* const* views, int n_views, int double_
                              int C, int H, int W, float* support_store, float* all_store, void* stream);
 /* nn.Conv2d weight OIHW -> packed [Cout][KH][KW][Cin] padded to k_pad floats per row (zeros) */
 int mft_pack_oihw(const float* w_oihw, float* w_pk, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);
+/* every OIHW -> packed repack of a model in one launch: jobs = n_jobs device records {const float* src; float* dst; int64 Cout,
+ * Cin, KH*KW, k_pad, first_element} ordered by first_element over the concatenated packed outputs (total_elements floats).
+ * The meta-training step calls it once after optimizer.step() (train.py:28, meta_template.py:87) instead of one launch per tensor. */
+int mft_pack_oihw_multi(const void* jobs, int n_jobs, long long total_elements, void* stream);
 int mft_unpack_oihw(const float* w_pk, float* w_oihw, int Cout, int Cin, int KH, int KW, int k_pad, void* stream);
 /* packed forward weights -> packed dgrad weights: wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci];
  * `groups` independent weight sets, strides in floats */

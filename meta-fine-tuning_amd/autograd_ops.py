@@ -30,11 +30,19 @@ def module_weights(mod):
     key = tuple((p.data_ptr(), p._version) for p in params)
     cache = mod.__dict__.get("_mft_pack")
     if cache is None or cache[0] != key:
-        sd = {k: v for k, v in mod.state_dict().items()}
-        W = Fn.ResNet10Weights(sd, params[0].device)
+        if cache is not None and cache[1].can_repack() and _same_storage(cache[0], key):
+            cache[1].repack()             # same tensors, new values (optimizer.step): one launch refreshes every packed copy
+            W = cache[1]
+        else:
+            sd = {k: v for k, v in mod.state_dict().items()}
+            W = Fn.ResNet10Weights(sd, params[0].device)
         cache = (key, W)
         mod.__dict__["_mft_pack"] = cache
     return cache[1]
+
+
+def _same_storage(old_key, new_key):
+    return len(old_key) == len(new_key) and all(a[0] == b[0] for a, b in zip(old_key, new_key))
 
 
 def _running(mod):
@@ -181,6 +189,10 @@ def head_weights(gnn_mod, fc_mod=None, n_way=None):
     """Packed GnnHeadWeights for a GNN_nl (and optionally GnnNet.fc), cached on the parameter versions."""
     key = _version_key(gnn_mod) + (() if fc_mod is None else _version_key(fc_mod))
     cache = gnn_mod.__dict__.get("_mft_pack")
+    if cache is not None and cache[0] != key and fc_mod is not None and cache[1].can_repack() and _same_storage(cache[0], key):
+        cache[1].repack()
+        cache = (key, cache[1])
+        gnn_mod.__dict__["_mft_pack"] = cache
     if cache is None or cache[0] != key:
         sd = {"gnn." + k: v for k, v in gnn_mod.state_dict().items()}
         if fc_mod is not None:

@@ -137,6 +137,39 @@ extern "C" int mft_pack_oihw(const float* w_oihw, float* w_pk, int Cout, int Cin
     return mft_launch_status();
 }
 
+// All weight repacks of a model in ONE launch (the meta-training step re-packs every convolution / linear weight after each
+// optimizer step: 43 tensors for GnnNet).  jobs: n_jobs records {src, dst, Cout, Cin, KH*KW, k_pad, first element} (7 x int64,
+// device memory), ordered by first element; element e of the concatenated packed outputs belongs to the last job whose first
+// element is <= e.
+struct PackJob { const float* src; float* dst; long long Cout, Cin, KHKW, k_pad, start; };
+
+__global__ __launch_bounds__(256) void pack_oihw_multi_kernel(const PackJob* __restrict__ jobs, int n_jobs, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const PackJob j = jobs[lo];
+        const long long l = i - j.start;
+        const int k = (int)(l % j.k_pad);
+        const long long co = l / j.k_pad;
+        float v = 0.f;
+        if (k < j.KHKW * j.Cin) {
+            const int ci = k % (int)j.Cin, khkw = k / (int)j.Cin;
+            v = j.src[(co * j.Cin + ci) * j.KHKW + khkw];
+        }
+        j.dst[l] = v;
+    }
+}
+
+extern "C" int mft_pack_oihw_multi(const void* jobs, int n_jobs, long long total_elements, void* stream) {
+    if (n_jobs < 1 || total_elements < 1) return MFT_EINVAL;
+    hipLaunchKernelGGL(pack_oihw_multi_kernel, dim3(lgrid(total_elements)), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                       n_jobs, total_elements);
+    return mft_launch_status();
+}
+
 extern "C" int mft_unpack_oihw(const float* w_pk, float* w_oihw, int Cout, int Cin, int KH, int KW, int k_pad,
                                void* stream) {
     if (k_pad < KH * KW * Cin) return MFT_EINVAL;

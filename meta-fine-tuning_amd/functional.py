@@ -72,12 +72,17 @@ class ResNet10Weights:
         self.conv = {}
         self.conv3 = {}
         self.bn = {}
+        self.plan = ops.PackPlan()          # sources that are live device tensors: repack() refreshes every packed copy in one launch
 
         def dev(t):
             return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
         def conv(name):
-            self.conv[name] = ops.pack_conv_weight(dev(sd[prefix + name + ".weight"]))
+            src = sd[prefix + name + ".weight"]
+            w = dev(src)
+            self.conv[name] = ops.pack_conv_weight(w)
+            if w.data_ptr() == src.data_ptr():
+                self.plan.add(w, self.conv[name])
             if x3 and name.startswith(("trunk.4", "trunk.5", "trunk.6")):
                 self.conv3[name] = ops.split_weight_x3(self.conv[name])
 
@@ -91,6 +96,16 @@ class ResNet10Weights:
             conv(p + ".C1"); bn(p + ".BN1"); conv(p + ".C2"); bn(p + ".BN2")
             if cin != cout:
                 conv(p + ".shortcut"); bn(p + ".BNshortcut")
+
+    def repack(self):
+        """The source parameters changed in place (optimizer.step): refresh every packed convolution weight with ONE launch.
+        BatchNorm weights / biases alias the parameters and need nothing.  Only valid when every convolution's source is a
+        live device tensor (``can_repack``)."""
+        assert self.can_repack()
+        self.plan.run()
+
+    def can_repack(self):
+        return len(self.plan.jobs) == len(self.conv) and not self.conv3
 
 
 class LastBlockSlab:
@@ -647,11 +662,21 @@ class GnnHeadWeights:
 
     def __init__(self, sd, device, n_way):
         self.n_way = n_way
+        self.plan = ops.PackPlan()
+        n_packed = [0]
 
         def dev(t):
             return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
-        self.fc_w = ops.pack_conv_weight(dev(sd["fc.0.weight"]))
+        def packed(src):
+            w = dev(src)
+            pk = ops.pack_conv_weight(w)
+            n_packed[0] += 1
+            if w.data_ptr() == src.data_ptr():
+                self.plan.add(w, pk)
+            return pk
+
+        self.fc_w = packed(sd["fc.0.weight"])
         self.fc_b = dev(sd["fc.0.bias"])
         self.fc_g, self.fc_beta = dev(sd["fc.1.weight"]), dev(sd["fc.1.bias"])
         self.wc = {}
@@ -659,19 +684,28 @@ class GnnHeadWeights:
         for name in ("layer_w0", "layer_w1", "w_comp_last"):
             layers = []
             for li in range(1, 5):
-                w = dev(sd["gnn.%s.conv2d_%d.weight" % (name, li)])
-                layers.append((ops.pack_conv_weight(w), dev(sd["gnn.%s.conv2d_%d.bias" % (name, li)]),
+                w = sd["gnn.%s.conv2d_%d.weight" % (name, li)]
+                layers.append((packed(w), dev(sd["gnn.%s.conv2d_%d.bias" % (name, li)]),
                                dev(sd["gnn.%s.bn_%d.weight" % (name, li)]), dev(sd["gnn.%s.bn_%d.bias" % (name, li)]),
                                w.shape[0]))
-            last = (ops.pack_conv_weight(dev(sd["gnn.%s.conv2d_last.weight" % name])),
+            last = (packed(sd["gnn.%s.conv2d_last.weight" % name]),
                     dev(sd["gnn.%s.conv2d_last.bias" % name]))
             self.wc[name] = (layers, last)
         for name, bn in (("layer_l0", True), ("layer_l1", True), ("layer_last", False)):
-            w = dev(sd["gnn.%s.fc.weight" % name])
+            w = sd["gnn.%s.fc.weight" % name]
             g = b = None
             if bn:
                 g, b = dev(sd["gnn.%s.bn.weight" % name]), dev(sd["gnn.%s.bn.bias" % name])
-            self.gc[name] = (ops.pack_conv_weight(w), dev(sd["gnn.%s.fc.bias" % name]), g, b, w.shape[0])
+            self.gc[name] = (packed(w), dev(sd["gnn.%s.fc.bias" % name]), g, b, w.shape[0])
+        self._n_packed = n_packed[0]
+
+    def can_repack(self):
+        return len(self.plan.jobs) == self._n_packed
+
+    def repack(self):
+        """Refresh every packed weight from its (in-place updated) source parameter with one launch."""
+        assert self.can_repack()
+        self.plan.run()
 
 
 _PAIR_IJ = {}

@@ -80,6 +80,34 @@ def pack_conv_weight(w):
     return pk
 
 
+class PackPlan:
+    """The OIHW -> packed copies of a set of live parameters as ONE launch (mft_pack_oihw_multi): ``add`` registers
+    (source parameter, packed destination) pairs -- both must stay where they are --, ``run`` refreshes every destination."""
+
+    def __init__(self):
+        self.jobs, self.total, self.table, self.keep = [], 0, None, []
+
+    def add(self, w, pk):
+        w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+        Cout, Cin, KH, KW = w4.shape
+        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and pk.is_contiguous() and pk.shape == (Cout, round_up(KH * KW * Cin, 32))
+        self.jobs.append((w.data_ptr(), pk.data_ptr(), Cout, Cin, KH * KW, pk.shape[1], self.total))
+        self.total += pk.numel()
+        self.keep.append((w, pk))
+        self.table = None
+
+    def sources(self):
+        return [w for w, _ in self.keep]
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self.table is None:
+            import numpy as np
+            self.table = torch.from_numpy(np.asarray(self.jobs, dtype=np.int64)).to(self.keep[0][1].device)
+        _lib.check(_lib.lib().mft_pack_oihw_multi(_p(self.table), len(self.jobs), self.total, _stream()), "mft_pack_oihw_multi")
+
+
 def unpack_conv_weight(pk, shape):
     Cout, Cin, KH, KW = shape
     w = torch.empty(shape, device=pk.device, dtype=torch.float32)

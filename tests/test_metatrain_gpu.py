@@ -359,3 +359,40 @@ def test_wcompute_backward_never_forms_the_pair_tensor(monkeypatch):
     assert len(sizes) > 50 and max(sizes) <= ut_rows * 192 < pair_tensor, (len(sizes), max(sizes), ut_rows * 192, pair_tensor)
     assert FB.PAIR_CHUNK_ROWS * 256 * 4 <= 16 << 20                               # the |x_i - x_j| chunk: a bounded workspace
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_one_launch_repack_after_in_place_update():
+    """After optimizer.step() the packed (kernel-layout) copies of all convolution / linear weights are refreshed by ONE
+    mft_pack_oihw_multi launch per module (ops.PackPlan) instead of being rebuilt tensor by tensor: the cached pack object
+    survives, and its contents equal a from-scratch pack of the updated parameters bit for bit."""
+    from meta_fine_tuning_amd import autograd_ops as AG
+    from meta_fine_tuning_amd import functional as Fn
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+    model.load_state_dict(synthetic.gnnnet_state_dict(seed=9))
+    W0 = AG.module_weights(model.feature)
+    G0 = AG.head_weights(model.gnn, model.fc, 5)
+    assert W0.can_repack() and len(W0.plan.jobs) == 12 and G0.can_repack() and len(G0.plan.jobs) == 19
+    with torch.no_grad():
+        for i, p in enumerate(model.parameters()):
+            p.add_(0.01 * torch.randn_like(p))                         # in place: same storage, new version
+    W1 = AG.module_weights(model.feature)
+    G1 = AG.head_weights(model.gnn, model.fc, 5)
+    assert W1 is W0 and G1 is G0                                       # refreshed, not rebuilt
+    Wf = Fn.ResNet10Weights({k: v for k, v in model.feature.state_dict().items()}, "cuda")
+    sd = {"gnn." + k: v for k, v in model.gnn.state_dict().items()}
+    sd.update({"fc." + k: v for k, v in model.fc.state_dict().items()})
+    Gf = Fn.GnnHeadWeights(sd, "cuda", 5)
+    for k in Wf.conv:
+        assert torch.equal(W1.conv[k], Wf.conv[k]), k
+    for k in Wf.bn:
+        assert torch.equal(W1.bn[k][0], Wf.bn[k][0]) and torch.equal(W1.bn[k][1], Wf.bn[k][1])
+    assert torch.equal(G1.fc_w, Gf.fc_w)
+    for name in G1.wc:
+        for a, b in zip(G1.wc[name][0], Gf.wc[name][0]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(G1.wc[name][1][0], Gf.wc[name][1][0])
+    for name in G1.gc:
+        assert torch.equal(G1.gc[name][0], Gf.gc[name][0])
+    # a model moved / re-created gets a new pack
+    model2 = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+    assert AG.module_weights(model2.feature) is not W0
