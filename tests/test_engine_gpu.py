@@ -297,6 +297,30 @@ def test_next_forward_fusion_matches_separate_forward_launches():
     assert frac_far < 5e-2 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))
 
 
+def test_scores_do_not_depend_on_the_slot_beyond_fp32_rounding():
+    """The reference adapts one episode at a time; the engine runs E in lockstep and an episode's BatchNorm statistics in the frozen
+    trunk are reduced tile by tile, so WHERE an episode sits in the batch (and how large E is) changes the summation order of
+    those sums -- nothing else.  Stated bound: after a short adaptation (20 Adam steps) the scores of the same episode in
+    different slots / batch sizes agree to 2e-3 with identical predictions; with no adaptation they agree to 1e-5."""
+    sd = synthetic.gnnnet_state_dict(seed=27)
+    ep = synthetic.test_episode(910, 5, 5, 15, 84, gen_examples=1)
+    other = [synthetic.test_episode(911 + i, 5, 5, 15, 84, gen_examples=1) for i in range(3)]
+    perm = [np.random.RandomState(50).permutation(100)]
+    operm = [[np.random.RandomState(60 + i).permutation(100)] for i in range(3)]
+    for epochs, tol in ((0, 1e-5), (1, 2e-3)):
+        res = []
+        for E, slot in ((1, 0), (4, 0), (4, 3), (3, 1)):
+            e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=epochs, episodes_per_batch=E, device=DEV)
+            eps, perms = list(other[:E - 1]), list(operm[:E - 1])
+            eps.insert(slot, ep)
+            perms.insert(slot, perm)
+            res.append(e.run_batch(eps, perms=[p[:epochs] for p in perms])[slot].cpu().numpy())
+            e.close()
+        for r in res[1:]:
+            assert np.abs(r - res[0]).max() <= tol, (epochs, np.abs(r - res[0]).max())
+            assert (r.argmax(1) == res[0].argmax(1)).mean() >= 0.98
+
+
 def test_two_stream_pipeline_is_bit_identical():
     """Running the frozen trunk of step t+1 on a second stream must not change a single bit."""
     sd = synthetic.gnnnet_state_dict(seed=25)
