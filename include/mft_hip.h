@@ -165,6 +165,10 @@ int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w
 int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 2: 128x128 */
 
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
+/* 1 when the library was built with -DMFT_EXPERIMENTS (MFT_EXPERIMENTS=1 python -m meta_fine_tuning_amd.build): the kernel
+ * variants DESIGN.md records as measured slower and the timing / power ablation aids exist only then (tools/); in the product
+ * build their mft_debug_set_* codes return MFT_EINVAL.                                                                       */
+int mft_has_experiments(void);
 int mft_debug_set_conv_tile(int tile);
 /* All tuning knobs (mft_debug_set_conv_tile / mft_debug_set_x3_tile) back to their defaults. */
 int mft_debug_reset(void);

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mft_unpack_oihw": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mft_pack_dgrad": [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P],
     "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "mft_has_experiments": [],
     "mft_debug_set_conv_tile": [_I],
     "mft_debug_reset": [],
     "mft_split_bf16x3": [_P, _P, _L, _P],

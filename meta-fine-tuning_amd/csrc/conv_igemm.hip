@@ -620,8 +620,11 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
                 if (32 * half + 2 * t < p.mma_rows) {            // wave-uniform
                     const float a = As[(2 * t + h) * BM + r];
                     const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
+#ifdef MFT_EXPERIMENTS
                     if constexpr (POL & 8) acc[t] += a + b;      // measurement aid (power / time without the matrix work)
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                    else
+#endif
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
                 }
             }
         }
@@ -636,9 +639,12 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
+#ifdef MFT_EXPERIMENTS
         if constexpr ((POL & 16) != 0) {                         // measurement aid: no Adam arithmetic, the stream only
             mm[u] += ge; vv[u] += ge; ww[u] += ge;
-        } else if (POL & 4) {
+        } else
+#endif
+        if (POL & 4) {
             // hardware v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences, and the moment updates as
             // packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32): the epilogue's VALU work competes with the co-running trunk
             // convolutions for issue slots (A/B in DESIGN.md: +2 % end to end)
@@ -653,6 +659,7 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
     }
 }
 
+#ifdef MFT_EXPERIMENTS      // walking forms of the kernel above: measured no faster; built only for tools/
 // EXPERIMENT (mft_debug_set_conv_tile(9504)): the same arithmetic as wgrad_adam_rows_kernel, but one workgroup WALKS all K tiles
 // of its 32 output-channel rows (tap-major, 128 input channels per tile) with the next tile's w/m/v requested one iteration ahead.
 // Purpose: does a walking workgroup keep the stream rate of the one-tile-per-workgroup form?  (It is the structure any fusion of
@@ -872,6 +879,8 @@ __global__ __launch_bounds__(256) void wgrad_adam_cowalk_kernel(WgradArgs p) {
     }
 }
 
+#endif  // MFT_EXPERIMENTS
+
 int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     WgradArgs p = a;
     p.tiles_ci = a.Cin / 128;
@@ -881,6 +890,7 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
     p.chunk_rows = (65536 + a.OH * a.OW - 1) / (a.OH * a.OW);
     p.ws_inv_ow = (65536 + a.OW - 1) / a.OW;
     p.mma_rows = g_wgrad_trim ? a.rows_per_group : 64;
+#ifdef MFT_EXPERIMENTS
     if (g_wgrad_rows == 5 && p.tiles_ci * taps >= 16) {      // (a 1x1 layer has too few K tiles to fill the CUs with walkers)
         // rows resident in LDS: 48 when the group has <= 48 reduction rows (the inner loop's 45): 47.6 KB = three workgroups per CU
         const int RP = a.rows_per_group <= 48 ? 48 : 64;
@@ -896,18 +906,25 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
         hipLaunchKernelGGL(wgrad_adam_walk_kernel<7>, dim3(p.tiles_co, groups, 1), dim3(256), lds_walk, s, p);
         return mft_launch_status();
     }
+#endif
     dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, 1);
     if (g_wgrad_pol == 7) hipLaunchKernelGGL(wgrad_adam_rows_kernel<7>, grid, dim3(256), lds, s, p);
+#ifdef MFT_EXPERIMENTS
     else if (g_wgrad_pol == 15) hipLaunchKernelGGL(wgrad_adam_rows_kernel<15>, grid, dim3(256), lds, s, p);     // timing / power aids
     else if (g_wgrad_pol == 23) hipLaunchKernelGGL(wgrad_adam_rows_kernel<23>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 31) hipLaunchKernelGGL(wgrad_adam_rows_kernel<31>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 6) hipLaunchKernelGGL(wgrad_adam_rows_kernel<6>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 5) hipLaunchKernelGGL(wgrad_adam_rows_kernel<5>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 4) hipLaunchKernelGGL(wgrad_adam_rows_kernel<4>, grid, dim3(256), lds, s, p);
+#endif
     else if (g_wgrad_pol == 3) hipLaunchKernelGGL(wgrad_adam_rows_kernel<3>, grid, dim3(256), lds, s, p);
+#ifdef MFT_EXPERIMENTS
     else if (g_wgrad_pol == 2) hipLaunchKernelGGL(wgrad_adam_rows_kernel<2>, grid, dim3(256), lds, s, p);
     else if (g_wgrad_pol == 1) hipLaunchKernelGGL(wgrad_adam_rows_kernel<1>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(wgrad_adam_rows_kernel<0>, grid, dim3(256), lds, s, p);
+#else
+    else hipLaunchKernelGGL(wgrad_adam_rows_kernel<3>, grid, dim3(256), lds, s, p);       // (any other policy code: the exact epilogue)
+#endif
     return mft_launch_status();
 }
 
@@ -1042,7 +1059,23 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     }
 }
 
+extern "C" int mft_has_experiments(void) {
+#ifdef MFT_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int mft_debug_set_conv_tile(int tile) {
+#ifndef MFT_EXPERIMENTS
+    // product build: the knobs select VALIDATED alternative paths only (tile shapes, generic vs weight-streaming per-episode kernels
+    // and their fp32 / per-tap / fragment-order forms, 64 x 64 vs 32 x 128 weight-gradient kernel, exact vs fast Adam epilogue,
+    // trimmed vs padded reduction).  The measured-slower experiment kernels and the measurement aids are not compiled in.
+    if (tile == 9502 || tile == 9504 || tile == 9505) return MFT_EINVAL;                       // order switch, walking forms
+    if (tile >= 9000 && tile < 9100 && tile != 9003 && tile != 9007) return MFT_EINVAL;        // cache-policy / ablation variants
+    if (tile > 4000 && tile < 5000) return MFT_EINVAL;                                         // occupancy throttle
+#endif
     if (tile >= 9700) mft_skinny_set_lines(tile - 9700);
     else if (tile >= 9600) g_wgrad_trim = tile - 9600;
     else if (tile >= 9500) g_wgrad_rows = tile - 9500;

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     }
 }
 
+#ifdef MFT_EXPERIMENTS      // measured slower than the default kernels; built only for tools/ (MFT_EXPERIMENTS=1)
 // ------------------------------------------------------------------------------------------------ ping-pong form
 // Ablation of conv_x3_kernel on the five trunk shapes (mft_debug_set_x3_tile(200 + bits), one process, sum of the launches):
 // full 600-670 us; without the operand split 535; without the MFMAs 412; without the K loop's global loads 445; without its
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
         }
     }
 }
+#endif  // MFT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: shared taps
 // The implicit-GEMM kernel above fetches, splits and stores the A tile of every tap separately, although the three kw taps of one
@@ -956,8 +958,13 @@ int launch_x3(X3Args p, hipStream_t s) {
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz;
+#ifdef MFT_EXPERIMENTS
     const bool xs = g_x3_row_swz == 2 && !AP && !DB && g_x3_hoist == 0 && g_x3_dbg == 0;
+#else
+    constexpr bool xs = false;
+#endif
     size_t lds = (size_t)(DB ? 2 : 1) * 3 * (BM + BN) * (xs ? 32 : X3_RS) * sizeof(unsigned short);
+#ifdef MFT_EXPERIMENTS
     if ((size_t)g_x3_min_lds_kb * 1024 > lds) lds = (size_t)g_x3_min_lds_kb * 1024;
     if (xs) {
         if constexpr (!AP && !DB) {
@@ -984,6 +991,9 @@ int launch_x3(X3Args p, hipStream_t s) {
             default: break;
         }
     }
+#else
+    auto kern = conv_x3_kernel<BM, BN, AP, DB, 0>;
+#endif
     if (lds > 64 * 1024) {                  // opt-in double-buffered / throttled forms only
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1007,7 +1017,9 @@ int launch_x3_s1(X3Args p, hipStream_t s) {
     return mft_launch_status();
 }
 
-int g_x3_pp = 0;           // 512-thread ping-pong form of the 128x64 kernel (mft_debug_set_x3_tile(70/71)).  Measured, one process: 781 us
+int g_x3_pp = 0;           // (MFT_EXPERIMENTS builds) 512-thread ping-pong form of the 128x64 kernel, mft_debug_set_x3_tile(70/71)
+#ifdef MFT_EXPERIMENTS
+// Measured, one process: 781 us
                            // over the five trunk shapes against 618 us for conv_x3_kernel, and 64.5 vs 76-77 episodes/s in the bench: with one
                            // 8-wave workgroup per CU the stage and multiply halves do overlap inside the workgroup, but the CU then runs 2
                            // waves per SIMD instead of 3 and every barrier stalls all of them -- off.
@@ -1028,6 +1040,9 @@ int launch_x3_pp(X3Args p, hipStream_t s) {
     return mft_launch_status();
 }
 
+#endif  // MFT_EXPERIMENTS
+
+#ifdef MFT_EXPERIMENTS
 // ------------------------------------------------------------------------------------------ 3x3 stride-1 "patch" form
 // The implicit-GEMM form above re-reads (and re-splits) every input element nine times, once per tap, and depends on
 // L2 for that reuse -- beside the HBM-saturating last-block stream it collapses (3x slower in situ).  For 3x3 / stride 1 /
@@ -1201,6 +1216,7 @@ bool patch_geometry(int H, int W, int* G, int* R, double* eff_out) {
     return true;
 }
 
+#endif  // MFT_EXPERIMENTS
 // Measured (tools/x3_tune.py, tools/phase_times.py, E=128): standalone the patch form wins only on 11x11 maps (157 vs 173 us)
 // and loses on 21x21 / 6x6 (tile utilisation 86 / 84 %); beside the last-block stream it is slower everywhere (61.0 / 59.7
 // vs 62.0 episodes/s) because both forms are bound by VALU + LDS issue, not by operand re-reads.  Kept as an opt-in.
@@ -1219,6 +1235,12 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 }
 
 extern "C" int mft_debug_set_x3_tile(int t) {
+#ifndef MFT_EXPERIMENTS
+    // product build: only the knobs that select VALIDATED alternative paths exist (tile shape 0-3, XCD order 20/21, staging-row
+    // assignment 40/41, shared-tap vs per-tap kernel 90/91); the measured-slower experiment kernels are not compiled in
+    const bool off = (t == 10 || t == 60 || t == 70 || t == 80 || t == 100 || t == 200);      // "experiment off" codes are no-ops
+    if (!off && ((t >= 10 && t < 20) || t == 42 || (t >= 60 && t < 90) || t >= 100)) return MFT_EINVAL;
+#endif
     if (t >= 200) g_x3_dbg = t - 200;
     else if (t >= 100) g_x3_min_lds_kb = t - 100;
     else if (t >= 90) g_x3_s1 = t - 90;
@@ -1264,6 +1286,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         p.w_bytes = (unsigned)(3 * plane_elems * 2);
         return launch_x3<128, 64, true, false>(p, (hipStream_t)stream);
     }
+#ifdef MFT_EXPERIMENTS
     if (stats_ws == nullptr && g_x3_patch && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ldi == Cin && ldo == Cout &&
         patch_geometry(H, W, &G, &R, &eff) && (g_x3_patch >= 2 || eff >= 0.9)) {
         P3Args q;
@@ -1284,6 +1307,9 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
             return mft_launch_status();
         }
     }
+#else
+    (void)G; (void)R; (void)eff;
+#endif
     int tile = g_x3_tile;
     if (tile == 0) tile = 1;       // 128x64 beats 128x128 on every trunk shape (3 vs 2 workgroups per CU)
     p.w_bytes = (unsigned)(3 * plane_elems * 2);
@@ -1307,8 +1333,10 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         const int rc = s1 ? launch_x3_s1<128, 64>(q, s)
                        : (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
                        : (tile == 3)                  ? launch_x3<64, 64, false, false>(q, s)
+#ifdef MFT_EXPERIMENTS
                        : g_x3_db                      ? launch_x3<128, 64, false, true>(q, s)
                        : (g_x3_pp && !g_x3_dbg)       ? launch_x3_pp<128, 64>(q, s)
+#endif
                                                       : launch_x3<128, 64, false, false>(q, s);
         if (rc != 0) return rc;
     }
