@@ -128,21 +128,39 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// out[c] = sum_r x[r][c], two phase (partials [chunks][C] then fixed-order sum)
+// out[c] = sum_r x[r][c], two phase (partials [chunks][C] then fixed-order sum).  V4: float4 loads, 16 row lanes x 16 channel quads
+// per block (a quarter of the serial iterations of the scalar form); fixed reduction order either way.
+template <bool V4>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, int C, long long rows,
                                                              int rows_per_chunk, float* __restrict__ ws) {
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    __shared__ float red[4][64];
-    float s = 0.f;
-    if (c < C) {
-        const long long rbeg = (long long)blockIdx.x * rows_per_chunk;
-        const long long rend = min(rbeg + rows_per_chunk, rows);
-        for (long long r = rbeg + rl; r < rend; r += 4) s += x[r * ldx + c];
+    const long long rbeg = (long long)blockIdx.x * rows_per_chunk;
+    const long long rend = min(rbeg + rows_per_chunk, rows);
+    if (V4) {
+        const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int c = blockIdx.y * 64 + 4 * cq;
+        __shared__ f32x4 red4[16][16];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (c < C)
+            for (long long r = rbeg + rl; r < rend; r += 16) s += *(const f32x4*)(x + r * ldx + c);
+        red4[rl][cq] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            f32x4 t = red4[0][cq];
+#pragma unroll
+            for (int l = 1; l < 16; ++l) t += red4[l][cq];
+            *(f32x4*)(ws + (long long)blockIdx.x * C + c) = t;
+        }
+    } else {
+        const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+        const int rl = threadIdx.x >> 6;
+        __shared__ float red[4][64];
+        float s = 0.f;
+        if (c < C)
+            for (long long r = rbeg + rl; r < rend; r += 4) s += x[r * ldx + c];
+        red[rl][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) ws[(long long)blockIdx.x * C + c] = red[0][c & 63] + red[1][c & 63] + red[2][c & 63] + red[3][c & 63];
     }
-    red[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) ws[(long long)blockIdx.x * C + c] = red[0][c & 63] + red[1][c & 63] + red[2][c & 63] + red[3][c & 63];
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int C, int chunks,
@@ -386,7 +404,10 @@ extern "C" int mft_colsum(const float* x, int ldx, int C, long long rows, float*
     // ws: >= ceil(rows/256) * C floats
     hipStream_t s = (hipStream_t)stream;
     const int chunks = (int)((rows + 255) / 256);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 256, ws);
+    if (C % 4 == 0 && ldx % 4 == 0 && (((unsigned long long)x) & 15) == 0 && (((unsigned long long)ws) & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 256, ws);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, C, rows, 256, ws);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)ws, C, chunks, out);
     return mft_launch_status();
 }

@@ -585,7 +585,7 @@ extern "C" int mft_pair_softmax_ut_backward(const float* A, const float* dA, con
 }
 
 extern "C" long long mft_pair_bwd_stats_ws_floats(long long rows, int C) {
-    long long nblk = (rows + 511) / 512;
+    long long nblk = (rows + 63) / 64;
     if (nblk > 1024) nblk = 1024;
     return nblk * 2 * C;
 }
@@ -594,7 +594,7 @@ extern "C" int mft_pair_bn_act_backward(const float* g, int ldg, const float* z,
                                         const float* mean, const float* rstd, const float* gamma, const int* ij, int N,
                                         long long rows, long long n_tot, float slope, float* ws, float* sums, float* dz, void* stream) {
     if ((C != 96 && C != 192) || ldg < C || ldg % 4 != 0 || rows < 1 || n_tot < rows) return MFT_EINVAL;
-    long long nblk = (rows + 511) / 512;
+    long long nblk = (rows + 63) / 64;            // ~64 rows per block: enough blocks to fill the CUs at the 5-shot graph size too
     if (nblk > 1024) nblk = 1024;
     const long long rpb = (rows + nblk - 1) / nblk;
     hipStream_t st = (hipStream_t)stream;
