@@ -8,7 +8,7 @@ HEAD=${3:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-standalone --validate-episodes 0 > $O/kt_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-standalone --validate-episodes 0 --strong-episodes 0 > $O/kt_bench.log 2>&1
 tail -1 $O/kt_bench.log | cut -c1-300
 python3 tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/${TAG}_kernel_stats_E128_pipelined.txt
 head -8 $O/${TAG}_kernel_stats_E128_pipelined.txt | cut -c1-180
