@@ -213,10 +213,6 @@ int mft_conv2d_wgrad_adam_nhwc(const float* in, int ldi, const float* dy, int ld
  *   1  raw + mean / rstd [groups, Cout] + act = ReLU(BN(raw))          (trunk.7.C1 + BN1 + ReLU, backbone.py:252-254)
  *   2  raw + both BatchNorms' statistics + act = ReLU(BN(raw) + BN_s(sc_raw)) + pooled [n_img, Cout] = global average pool of act
  *                                                                      (trunk.7.C2 .. AvgPool2d, backbone.py:255-261,438)
- * k_segments > 1 (with x_next): the K extent of a workgroup's 32 output channels is walked by k_segments shorter-lived workgroups
- * (the launch shares the GPU with the trunk stream: short walks hand CUs back more often); their partial outputs meet in `partials`
- * (groups * Cout/32 * k_segments * 1536 floats) and the last one to arrive -- `tickets`: groups * Cout/32 uint32, ZERO before the
- * first launch, left zero -- sums them in segment order (deterministic) and runs the epilogue.  w, m, v do not depend on it.
  * gamma / beta (and gamma_s / beta_s) are per-group with stride gb_group_stride.  MFT_EINVAL outside the domain
  * (Cin % 128, Cout % 32, imgs_per_group * OH * OW <= 48, imgs_per_group <= 8).                                             */
 int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
@@ -225,7 +221,7 @@ int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ld
                                 float beta1, float beta2, float eps, const float* x_next, int mode, float* raw, float* act,
                                 const float* gamma, const float* beta, long long gb_group_stride, float* mean, float* rstd,
                                 const float* sc_raw, const float* gamma_s, const float* beta_s, float* mean_s, float* rstd_s,
-                                float* pooled, float bn_eps, int k_segments, float* partials, unsigned* tickets, void* stream);
+                                float* pooled, float bn_eps, void* stream);
 /* 1: correctly rounded division / square root in that launch's Adam epilogue (default 0: v_rcp_f32 / v_sqrt_f32, as
  * mft_conv2d_wgrad_adam_nhwc's default).                                                                                   */
 void mft_wgrad_fwd_set_exact(int on);

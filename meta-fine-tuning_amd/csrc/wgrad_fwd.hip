@@ -51,11 +51,6 @@ struct WfArgs {
     const float* sc; const float* gs; const float* bs; float* means; float* rstds;      // EXIT: shortcut branch
     float* pooled; int hw;       // EXIT: [groups][ipg][Cout], pixels per image
     float bn_eps;
-    // K segments: a workgroup walks seg_tiles K tiles; the n_seg partial outputs of an (episode, output-channel tile) meet in
-    // `partials` [groups][Cout/32][n_seg][48*32] and the LAST workgroup to arrive (ticket counter in `tickets` [groups][Cout/32], zero
-    // before the launch, reset by that workgroup) sums them in segment order and runs the epilogue
-    int n_seg, seg_tiles;
-    float* partials; unsigned* tickets;
 };
 
 enum { WF_RAW = 0, WF_ENTRY = 1, WF_EXIT = 2 };
@@ -83,9 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rows = p.rows;
     const long long row0 = (long long)g * rows;
     const long long img0 = (long long)g * p.ipg;
-    const int n_kt_all = p.KH * p.KW * p.tiles_ci;
-    const int kt0 = blockIdx.z * p.seg_tiles;                 // this workgroup's K segment: tiles [kt0, n_kt)
-    const int n_kt = min(n_kt_all, kt0 + p.seg_tiles);
+    const int n_kt = p.KH * p.KW * p.tiles_ci;
     const bool fwd = p.xn != nullptr;
 
     const int arow = tid >> 3, acol = (tid & 7) * 4;
@@ -173,17 +166,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     // request order = order of need (the load counter is in order): operand rows of tile 0, of tile 1, w/m/v of tiles 0 and 1
-    {
-        const int khkw = kt0 / p.tiles_ci;
-        nci0 = (kt0 - khkw * p.tiles_ci) * BN;
-        nkh = khkw / p.KW;
-        nkw = khkw - nkh * p.KW;
-    }
-    load_b(nkh, nkw, nci0);
-    if (fwd) load_x(nkh, nkw, nci0);
-    load_wmv(kt0, am, av, aw);
-    if (kt0 + 1 < n_kt) load_wmv(kt0 + 1, bm, bv, bw);
-    advance();                            // (nkh, nkw, nci0) = tile kt0 + 1
+    load_b(0, 0, 0);
+    if (fwd) load_x(0, 0, 0);
+    load_wmv(0, am, av, aw);
+    if (n_kt > 1) load_wmv(1, bm, bv, bw);
+    advance();                            // (nkh, nkw, nci0) = tile 1
     f32x4 accf[3][2];
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
@@ -250,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         advance();
         // (the next tile's first barrier separates these fragment reads of Gs from its next overwrite)
     };
-    for (int kt = kt0; kt < n_kt; kt += 2) {
+    for (int kt = 0; kt < n_kt; kt += 2) {
         tile(kt, am, av, aw);
         if (kt + 1 < n_kt) tile(kt + 1, bm, bv, bw);
     }
@@ -271,33 +258,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 6; ++i) {
         const int px = pl + 8 * i;
         val[i] = ((Red[(px)*RLD + c] + Red[(48 + px) * RLD + c]) + Red[(96 + px) * RLD + c]) + Red[(144 + px) * RLD + c];
-    }
-    if (p.n_seg > 1) {
-        // park this segment's partial; the last segment to arrive sums all of them in segment order (a fixed order whatever the
-        // arrival order) and carries on with the epilogue
-        __shared__ int s_last;
-        float* mine = p.partials + (((long long)g * gridDim.x + blockIdx.x) * p.n_seg + blockIdx.z) * (48 * 32);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) mine[(pl + 8 * i) * 32 + c] = val[i];
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            unsigned* tk = p.tickets + (long long)g * gridDim.x + blockIdx.x;
-            const unsigned t = atomicAdd(tk, 1u);
-            s_last = (t == (unsigned)p.n_seg - 1u);
-            if (s_last) *tk = 0u;
-        }
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();
-        const float* all = p.partials + ((long long)g * gridDim.x + blockIdx.x) * p.n_seg * (48 * 32);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float sum = 0.f;
-            for (int sg = 0; sg < p.n_seg; ++sg)
-                sum += __hip_atomic_load(all + (long long)sg * (48 * 32) + (pl + 8 * i) * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[i] = sum;
-        }
     }
     float* T0 = Gs;                       // [48][TLD] raw output, [48][TLD] activation (Gs is dead: 2 x 6.3 KB <= 16.9 KB)
     float* T1 = Gs + 48 * TLD;
@@ -392,8 +352,7 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
                                            const float* x_next, int mode, float* raw, float* act, const float* gamma,
                                            const float* beta, long long gb_group_stride, float* mean, float* rstd,
                                            const float* sc_raw, const float* gamma_s, const float* beta_s, float* mean_s,
-                                           float* rstd_s, float* pooled, float bn_eps, int k_segments, float* partials,
-                                           unsigned* tickets, void* stream) {
+                                           float* rstd_s, float* pooled, float bn_eps, void* stream) {
     if (n_img <= 0 || imgs_per_group <= 0 || n_img % imgs_per_group != 0) return MFT_EINVAL;
     if (Cin % 128 != 0 || Cout % 32 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return MFT_EINVAL;
     if (hyper == nullptr && step < 1) return MFT_EINVAL;
@@ -428,15 +387,9 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
     p.xn = x_next; p.raw = raw; p.act = act; p.gamma = gamma; p.beta = beta; p.gbs = gb_group_stride;
     p.mean = mean; p.rstd = rstd; p.sc = sc_raw; p.gs = gamma_s; p.bs = beta_s; p.means = mean_s; p.rstds = rstd_s;
     p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps;
-    const int n_kt_all = KH * KW * (Cin / 128);
-    int n_seg = (x_next != nullptr && k_segments > 1 && partials != nullptr && tickets != nullptr) ? k_segments : 1;
-    if (n_seg > n_kt_all) n_seg = n_kt_all;
-    p.seg_tiles = (n_kt_all + n_seg - 1) / n_seg;
-    p.n_seg = (n_kt_all + p.seg_tiles - 1) / p.seg_tiles;
-    p.partials = partials; p.tickets = tickets;
     const int groups = n_img / imgs_per_group;
     constexpr int lds = (48 * 32 + 48 * (128 + 32) + 32 * (128 + 4)) * 4;          // 53.8 KB: two workgroups per CU
-    const dim3 grid(Cout / 32, groups, p.n_seg), block(256);
+    const dim3 grid(Cout / 32, groups, 1), block(256);
     hipStream_t s = (hipStream_t)stream;
     // matrix instructions of the reduction: 2 rows each, in chunks of 8 (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
     const int nt = rows <= 32 ? 16 : 24;

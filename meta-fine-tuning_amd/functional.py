@@ -621,10 +621,6 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
         adam_tail()
         kw = dict(lr=lr, hyper=hyper)
         fw = x_next is not None
-        if fw and NEXT_K_SEGMENTS > 1:            # shorter walks: partial outputs + ticket counters live in the arena (zeroed once)
-            groups_ = n // ipg
-            kw.update(k_segments=NEXT_K_SEGMENTS, partials=arena.get("nx.partials", (groups_ * (C // 32) * NEXT_K_SEGMENTS * 1536,)),
-                      tickets=_zero_once(arena, "nx.tickets", (groups_ * (C // 32),)))
         ok = ops.wgrad_adam_next_forward(x, dsc, params.scw, m_.scw, v_.scw, 1, 1, 2, 0, st, ipg, x_next=x_next, mode=ops.WF_RAW,
                                          raw=tn["sc"] if fw else None, **kw)
         ok = ok and ops.wgrad_adam_next_forward(x, dc1, params.c1w, m_.c1w, v_.c1w, 3, 3, 2, 1, st, ipg, x_next=x_next,
@@ -650,18 +646,6 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     wgrad(x, dsc, "scw", 1, 2, 0)
     if adam is not None:
         adam_tail()
-
-
-NEXT_K_SEGMENTS = int(os.environ.get("MFT_NEXT_K_SEGMENTS", "1"))
-
-
-def _zero_once(arena, name, shape):
-    key = (name, tuple(shape), torch.int32)
-    fresh = key not in arena.bufs
-    t = arena.get(name, shape, torch.int32)
-    if fresh:
-        t.zero_()
-    return t
 
 
 def next_forward_ok(ipg, H6):

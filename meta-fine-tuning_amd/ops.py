@@ -269,8 +269,7 @@ WF_RAW, WF_ENTRY, WF_EXIT = 0, 1, 2
 
 def wgrad_adam_next_forward(x, dy, w, m, v, KH, KW, stride, pad, step, imgs_per_group, x_next=None, mode=WF_RAW, raw=None, act=None,
                             gamma=None, beta=None, gbs=0, mean=None, rstd=None, sc_raw=None, gamma_s=None, beta_s=None, mean_s=None,
-                            rstd_s=None, pooled=None, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, dw=None, hyper=None, k_segments=1,
-                            partials=None, tickets=None):
+                            rstd_s=None, pooled=None, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, dw=None, hyper=None):
     """Weight gradient + Adam of (w, m, v) [groups, Cout, KH*KW*Cin] for inner step t and -- with ``x_next`` -- the same layer's
     convolution of step t+1 from the weight tiles just updated (csrc/wgrad_fwd.hip).  Returns False outside the kernel's domain."""
     _f32c(x)
@@ -281,7 +280,7 @@ def wgrad_adam_next_forward(x, dy, w, m, v, KH, KW, stride, pad, step, imgs_per_
         _p(x), Cin, _p(dy), Cout, _p(w), _p(m), _p(v), _p(dw), n, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group,
         Cout * KH * KW * Cin, 1 if hyper is not None else step, _p(hyper), lr, beta1, beta2, eps, _p(x_next), mode, _p(raw), _p(act),
         _p(gamma), _p(beta), gbs, _p(mean), _p(rstd), _p(sc_raw), _p(gamma_s), _p(beta_s), _p(mean_s), _p(rstd_s), _p(pooled),
-        BN_EPS, k_segments, _p(partials), _p(tickets), _stream())
+        BN_EPS, _stream())
     if rc == _lib.MFT_EINVAL:
         return False
     _lib.check(rc, "mft_wgrad_adam_next_forward")

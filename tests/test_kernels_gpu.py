@@ -825,29 +825,6 @@ def test_wgrad_adam_next_forward_kernel(ipg):
                 kw.update(sc_raw=sc_raw, gamma_s=gas.to(DEV), beta_s=bes.to(DEV), mean_s=means, rstd_s=rstds, pooled=pooled)
             assert ops.wgrad_adam_next_forward(xg, dyg, w, m, v, k, k, stride, pad, 7, ipg, **kw)
             assert torch.equal(dw, dwr) and torch.equal(m, mr) and torch.equal(v, vr) and torch.equal(w, wr), (name, exact)
-            # K-segmented walks (shorter-lived workgroups, partial outputs merged by the last one to arrive, in segment order): the
-            # same update bit for bit, the next step's outputs to summation-order rounding, and the ticket counters left at zero
-            w3_, m3_, v3_ = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
-            raw3, act3 = torch.full_like(raw, float("nan")), torch.full_like(raw, float("nan"))
-            pooled3 = torch.full_like(pooled, float("nan"))
-            parts = torch.full((G * (Cout // 32) * 4 * 1536,), float("nan"), device=DEV)
-            tick = torch.zeros(G * (Cout // 32), dtype=torch.int32, device=DEV)
-            kw3 = dict(kw, raw=raw3, dw=None, k_segments=4, partials=parts, tickets=tick)
-            if mode != ops.WF_RAW:
-                kw3.update(act=act3, mean=torch.empty_like(mean), rstd=torch.empty_like(rstd))
-            if mode == ops.WF_EXIT:
-                kw3.update(mean_s=torch.empty_like(means), rstd_s=torch.empty_like(rstds), pooled=pooled3)
-            for rep in range(2):                     # twice: the counters reset themselves
-                w3_.copy_(wpk); m3_.copy_(m0.to(DEV)); v3_.copy_(v0.to(DEV))
-                assert ops.wgrad_adam_next_forward(xg, dyg, w3_, m3_, v3_, k, k, stride, pad, 7, ipg, **kw3)
-                assert torch.equal(w3_, wr) and torch.equal(m3_, mr) and torch.equal(v3_, vr), (name, "segments")
-                assert int(tick.abs().sum()) == 0
-                sc_ = max(float(raw.abs().max()), 1.0)
-                assert float((raw3 - raw).abs().max()) <= 2e-6 * sc_, (name, float((raw3 - raw).abs().max()))
-                if mode != ops.WF_RAW:
-                    assert float((act3 - act).abs().max()) <= 2e-5 * max(float(act.abs().max()), 1.0)
-                if mode == ops.WF_EXIT:
-                    assert float((pooled3 - pooled).abs().max()) <= 2e-5 * max(float(pooled.abs().max()), 1.0)
             # without x_next: the same update, nothing else written
             w2, m2, v2 = wpk.clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
             assert ops.wgrad_adam_next_forward(xg, dyg, w2, m2, v2, k, k, stride, pad, 7, ipg)
