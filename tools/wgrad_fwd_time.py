@@ -42,5 +42,5 @@ if True:
                                                       gbs=Cout, mean=st[0], rstd=st[1], sc_raw=sc, gamma_s=gb, beta_s=gb, mean_s=st[2], rstd_s=st[3],
                                                       pooled=pooled))
       print("%-9s E=%d  rows kernel %7.1f us (%.2f TB/s) | walk, update only %7.1f us (%.2f TB/s) | walk + next forward %7.1f us (%.2f TB/s)"
-            % (name, E, t0, by / t0 / 1e6, t1, by / t1 / 1e6, t2, by / t2 / 1e6))
+              % (name, E, t0, by / t0 / 1e6, t1, by / t1 / 1e6, t2, by / t2 / 1e6))
 
