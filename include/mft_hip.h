@@ -26,6 +26,10 @@ extern "C" {
 #define MFT_EINVAL (-22)
 
 enum { MFT_ACT_NONE = 0, MFT_ACT_RELU = 1, MFT_ACT_LRELU = 2 };
+/* OR-ed into ``act`` of mft_bn_apply / mft_bn_apply_planes: y = fma(x, rstd*gamma, beta - mean*rstd*gamma) (aten's CPU form, the
+ * arithmetic of the frozen trunk's folded BatchNorm kernels) instead of ((x - mean) * rstd) * gamma + beta.  The folded form
+ * loses |mean| * rstd ulps to cancellation: meant for convolution outputs (|mean| ~ std), not for degenerate batches. */
+enum { MFT_BN_AFFINE_FMA = 0x100 };
 
 /* library / device ------------------------------------------------------------------ */
 int mft_version(void);                        /* 100*major + minor                          */
@@ -162,6 +166,30 @@ long long mft_conv2d_x3_stats_ws_floats(int n_img, int H, int W, int Cout, int K
 int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
                                int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd, void* stream);
+/* Frozen-trunk SimpleBlock with the BatchNorms folded into their neighbours (backbone.py:251-261; one launch per convolution,
+ * one for the block exit, none for statistics).  The statistics stay per-tile partials: pass mean = rstd = NULL to
+ * mft_conv2d_nhwc_x3_bnstats and every CONSUMER merges them itself, in the order the finalize launch used (csrc/bn_fold.h).
+ *   mft_conv2d_nhwc_x3_bnin_bnstats: 3x3 / stride 1 / pad 1 convolution of relu(BN(in)), ``in`` = raw output of the previous
+ *     convolution, in_ws = its partials, in_gamma / in_beta [Cin] (C1 -> BN1 -> ReLU -> C2 in one launch).  MFT_EINVAL when the
+ *     (scale, shift) table does not fit beside the tile at three workgroups per CU (Cin = 256 on 6x6 maps): run
+ *     mft_bn_apply_x3ws + mft_conv2d_nhwc_x3_bnstats there.
+ *   mft_bn_apply_x3ws: y = act(BN(x) [+ BN_res(res) | + res]) with both BatchNorms' statistics merged from partials
+ *     (shared gamma / beta [C]); optional mean / rstd outputs [n_groups, C].
+ *   mft_bn_relu_pooled_gather_moments: mft_bn_relu_pooled_gather with the batch statistics combined from the cached
+ *     per-image moments in the same launch (replaces mft_bn_combine_moments + gather).
+ * All BatchNorm-apply kernels of the trunk compute y = fma(x, rstd*gamma, beta - mean*rstd*gamma) (aten's CPU form).           */
+int mft_conv2d_nhwc_x3_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma, const float* in_beta,
+                                    const unsigned short* w3, long long plane_elems, float* out, int ldo, int n_img, int H, int W,
+                                    int Cin, int Cout, int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd,
+                                    void* stream);
+int mft_bn_apply_x3ws(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups, const float* ws,
+                      const float* gamma, const float* beta, const float* res, int ldr, const float* res_ws,
+                      const float* res_gamma, const float* res_beta, int act, float slope, float eps, float* mean, float* rstd,
+                      float* res_mean, float* res_rstd, void* stream);
+int mft_bn_apply_x3ws_fits(int C, int rows_per_group, int with_res_bn);  /* 1 when mft_bn_apply_x3ws can stage a group's partials in LDS */
+int mft_bn_relu_pooled_gather_moments(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH, int OW,
+                                      int C, int imgs_per_group, const float* mean_img, const float* m2_img, int rows_per_img,
+                                      float eps, const float* gamma, const float* beta, float* mean, float* rstd, void* stream);
 int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 2: 128x128 */
 
 /* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */

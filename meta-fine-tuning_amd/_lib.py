@@ -75,6 +75,10 @@ SIGNATURES = {
     "mft_stream_create_priority": [_I, _P, _P],
     "mft_ce_pool_bn_backward2": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "mft_pool_window_minmax": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "mft_conv2d_nhwc_x3_bnin_bnstats": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "mft_bn_apply_x3ws": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
+    "mft_bn_apply_x3ws_fits": [_I, _I, _I],
+    "mft_bn_relu_pooled_gather_moments": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "mft_bn_relu_pooled_gather": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_apply_planes": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
     "mft_bn_relu_maxpool_gather_planes": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],

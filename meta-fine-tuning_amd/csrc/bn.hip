@@ -7,6 +7,7 @@
 // every thread reads/writes float4 along the contiguous channel axis, reductions are fixed-order
 // (no float atomics) so reruns are bit-identical.
 #include "mft_common.h"
+#include "bn_fold.h"
 
 namespace {
 
@@ -122,7 +123,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
         const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
         const f32x4 ga = *(const f32x4*)(p.gamma + g * p.gbs + c);
         const f32x4 be = *(const f32x4*)(p.beta + g * p.gbs + c);
-        f32x4 o = (v - mu) * rs * ga + be;
+        const bool folded = (p.act & MFT_BN_AFFINE_FMA) != 0;       // the frozen trunk's arithmetic (bn_fold.h)
+        const int act = p.act & 0xff;
+        f32x4 sc, sh, o;
+        if (folded) {
+            mft_bn_fold4(mu, rs, ga, be, sc, sh);
+            o = mft_bn_affine4(v, sc, sh);
+        } else {
+            o = (v - mu) * rs * ga + be;
+        }
         if (p.res) {
             f32x4 rv = *(const f32x4*)(p.res + row * p.ldr + c);
             if (p.rmean) {
@@ -130,12 +139,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
                 const f32x4 rrs = *(const f32x4*)(p.rrstd + (long long)g * p.C + c);
                 const f32x4 rga = *(const f32x4*)(p.rgamma + g * p.gbs + c);
                 const f32x4 rbe = *(const f32x4*)(p.rbeta + g * p.gbs + c);
-                rv = (rv - rmu) * rrs * rga + rbe;
+                if (folded) {
+                    mft_bn_fold4(rmu, rrs, rga, rbe, sc, sh);
+                    rv = mft_bn_affine4(rv, sc, sh);
+                } else {
+                    rv = (rv - rmu) * rrs * rga + rbe;
+                }
             }
             o += rv;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
+        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], act, p.slope);
         if (!PLANES || p.y) *(f32x4*)(p.y + row * p.ldy + c) = o;
         if constexpr (PLANES) {
             mft_u32x2 p1, p2, p3;
@@ -145,6 +159,61 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
             *(mft_u32x2*)(q + p.plane_stride) = p2;
             *(mft_u32x2*)(q + 2 * p.plane_stride) = p3;
         }
+    }
+}
+
+// The same apply for the outputs of bf16x3 trunk convolutions whose statistics are still per-tile partials (csrc/conv_x3.hip):
+// grid (sub-blocks, groups); each workgroup first merges the partials of ITS group (bn_fold.h, the order the stand-alone finalize
+// used) into an LDS table of (scale, shift) per channel -- for the main and, if present, the residual BatchNorm -- then streams
+// its share of the group's rows.  One launch instead of finalize + finalize + apply.
+struct ApplyWsArgs {
+    const float* x; float* y; int ldx, ldy, C, rows_per_group, n_groups, M, BM;
+    const float* ws; const float* gamma; const float* beta;
+    const float* res; int ldr; const float* rws; const float* rgamma; const float* rbeta;
+    int act; float slope, eps;
+    float* mean; float* rstd; float* rmean; float* rrstd;      // optional copies of the merged statistics (written by sub-block 0)
+    int max_tiles;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_ws_kernel(ApplyWsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];         // [4][C]: scale, shift, residual scale, residual shift
+    const int g = blockIdx.y, C = p.C;
+    char* stage = reinterpret_cast<char*>(tab + 4 * C);                  // partials + tile weights of this group (bn_fold.h), x2 with a residual BatchNorm
+    char* rstage = stage + mft_x3_stage_bytes(p.max_tiles, C);
+    mft_x3_stats_stage(p.ws, C, g, p.M, p.rows_per_group, p.BM, p.max_tiles, stage, threadIdx.x, 256);
+    if (p.rws) mft_x3_stats_stage(p.rws, C, g, p.M, p.rows_per_group, p.BM, p.max_tiles, rstage, threadIdx.x, 256);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mu, rs, sc, sh;
+        mft_x3_stats_staged(stage, p.max_tiles, C, c, g, p.M, p.rows_per_group, p.BM, p.eps, mu, rs);
+        mft_bn_fold(mu, rs, p.gamma[c], p.beta[c], sc, sh);
+        tab[c] = sc; tab[C + c] = sh;
+        if (blockIdx.x == 0 && p.mean) { p.mean[(long long)g * C + c] = mu; p.rstd[(long long)g * C + c] = rs; }
+        if (p.rws) {
+            mft_x3_stats_staged(rstage, p.max_tiles, C, c, g, p.M, p.rows_per_group, p.BM, p.eps, mu, rs);
+            mft_bn_fold(mu, rs, p.rgamma[c], p.rbeta[c], sc, sh);
+            tab[2 * C + c] = sc; tab[3 * C + c] = sh;
+            if (blockIdx.x == 0 && p.rmean) { p.rmean[(long long)g * C + c] = mu; p.rrstd[(long long)g * C + c] = rs; }
+        }
+    }
+    __syncthreads();
+    const int cq = C >> 2;
+    const int total = p.rows_per_group * cq;
+    const long long row0 = (long long)g * p.rows_per_group;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int rr = i / cq;
+        const int c = (i - rr * cq) * 4;
+        const long long row = row0 + rr;
+        const f32x4 v = *(const f32x4*)(p.x + row * p.ldx + c);
+        f32x4 o = mft_bn_affine4(v, *(const f32x4*)(tab + c), *(const f32x4*)(tab + C + c));
+        if (p.res) {
+            f32x4 rv = *(const f32x4*)(p.res + row * p.ldr + c);
+            if (p.rws) rv = mft_bn_affine4(rv, *(const f32x4*)(tab + 2 * C + c), *(const f32x4*)(tab + 3 * C + c));
+            o += rv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
+        *(f32x4*)(p.y + row * p.ldy + c) = o;
     }
 }
 
@@ -183,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
                 const int iw = ow * 2 - 1 + dw;
                 if (iw < 0 || iw >= W) continue;
                 const f32x4 v = *(const f32x4*)(x + ((ns * H + ih) * W + iw) * C + c);
-                const f32x4 o = (v - mu) * rs * ga + be;
+                const f32x4 o = __builtin_elementwise_fma((v - mu) * rs, ga, be);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], o[e]);
             }
@@ -354,25 +423,48 @@ __global__ __launch_bounds__(256) void bn_image_moments_kernel(const float* __re
     }
 }
 
+// batch statistics of imgs_per_group images from their cached per-image (mean, M2): exact pooled variance.
+// mean_of(i) / m2_of(i): the channel's moments of the group's i-th image.
+template <class MeanOf, class M2Of>
+__device__ __forceinline__ void combine_moments_impl(MeanOf mean_of, M2Of m2_of, int rows_per_img, int imgs_per_group, float eps,
+                                                     float& mean, float& rstd) {
+    float mu = 0.f;
+    for (int i = 0; i < imgs_per_group; ++i) mu += mean_of(i);
+    mu /= (float)imgs_per_group;
+    float m2 = 0.f, dev = 0.f;
+    for (int i = 0; i < imgs_per_group; ++i) {
+        const float d = mean_of(i) - mu;
+        m2 += m2_of(i);
+        dev += d * d;
+    }
+    const float var = (m2 + (float)rows_per_img * dev) / ((float)rows_per_img * (float)imgs_per_group);
+    mean = mu;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void combine_moments(const float* __restrict__ mean_img, const float* __restrict__ m2_img,
+                                                const int* __restrict__ id, int C, int c, int rows_per_img, int imgs_per_group,
+                                                float eps, float& mean, float& rstd) {
+    combine_moments_impl([&](int i) { return mean_img[(long long)id[i] * C + c]; },
+                         [&](int i) { return m2_img[(long long)id[i] * C + c]; }, rows_per_img, imgs_per_group, eps, mean, rstd);
+}
+
+__device__ __forceinline__ void combine_moments_lds(const float* smean, const float* sm2, int C, int c, int rows_per_img,
+                                                    int imgs_per_group, float eps, float& mean, float& rstd) {
+    combine_moments_impl([&](int i) { return smean[i * C + c]; }, [&](int i) { return sm2[i * C + c]; }, rows_per_img,
+                         imgs_per_group, eps, mean, rstd);
+}
+
 __global__ void bn_combine_moments_kernel(const float* __restrict__ mean_img, const float* __restrict__ m2_img,
                                           const int* __restrict__ idx, int C, int rows_per_img, int imgs_per_group,
                                           float eps, float* __restrict__ mean, float* __restrict__ rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (c >= C) return;
-    const int* id = idx + (long long)g * imgs_per_group;
-    float mu = 0.f;
-    for (int i = 0; i < imgs_per_group; ++i) mu += mean_img[(long long)id[i] * C + c];
-    mu /= (float)imgs_per_group;
-    float m2 = 0.f, dev = 0.f;
-    for (int i = 0; i < imgs_per_group; ++i) {
-        const float d = mean_img[(long long)id[i] * C + c] - mu;
-        m2 += m2_img[(long long)id[i] * C + c];
-        dev += d * d;
-    }
-    const float var = (m2 + (float)rows_per_img * dev) / ((float)rows_per_img * (float)imgs_per_group);
+    float mu, rs;
+    combine_moments(mean_img, m2_img, idx + (long long)g * imgs_per_group, C, c, rows_per_img, imgs_per_group, eps, mu, rs);
     mean[(long long)g * C + c] = mu;
-    rstd[(long long)g * C + c] = 1.0f / sqrtf(var + eps);
+    rstd[(long long)g * C + c] = rs;
 }
 
 inline int grid_for(long long total, int block = 256, int cap = 256 * 8) {
@@ -427,6 +519,36 @@ extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, i
     return mft_launch_status();
 }
 
+extern "C" int mft_bn_apply_x3ws(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups, const float* ws,
+                                 const float* gamma, const float* beta, const float* res, int ldr, const float* res_ws,
+                                 const float* res_gamma, const float* res_beta, int act, float slope, float eps, float* mean,
+                                 float* rstd, float* res_mean, float* res_rstd, void* stream) {
+    if (C % 4 != 0 || C > 1024 || ldx % 4 != 0 || ldy % 4 != 0 || (res && ldr % 4 != 0) || !ws || !y || rows_per_group < 128 ||
+        n_groups <= 0 || (res_ws && (!res || !res_gamma || !res_beta)) || (mean == nullptr) != (rstd == nullptr) ||
+        (res_mean == nullptr) != (res_rstd == nullptr))
+        return MFT_EINVAL;
+    const long long M = (long long)n_groups * rows_per_group;
+    const long long per_group = (long long)rows_per_group * (C / 4);
+    if (M > 0x7fffffffLL) return MFT_EINVAL;
+    const int max_tiles = mft_x3_max_group_tiles(rows_per_group, 128);
+    const size_t lds = (size_t)4 * C * sizeof(float) + (res_ws ? 2 : 1) * mft_x3_stage_bytes_host(max_tiles, C);
+    if (lds > 64 * 1024) return MFT_EINVAL;          // very long groups (one BatchNorm batch of thousands of rows): finalize + mft_bn_apply
+    int sub = (int)((per_group + 256 * 16 - 1) / (256 * 16));         // ~16 float4 per thread: the prologue is repeated by every sub-block
+    const int cap = (2048 + n_groups - 1) / n_groups;
+    if (sub > cap) sub = cap;
+    if (sub < 1) sub = 1;
+    ApplyWsArgs p{x, y, ldx, ldy, C, rows_per_group, n_groups, (int)M, 128, ws, gamma, beta, res, ldr, res_ws, res_gamma, res_beta,
+                  act, slope, eps, mean, rstd, res_mean, res_rstd, max_tiles};
+    hipLaunchKernelGGL(bn_apply_ws_kernel, dim3(sub, n_groups), dim3(256), lds, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_apply_x3ws_fits(int C, int rows_per_group, int with_res_bn) {
+    if (C % 4 != 0 || C > 1024 || rows_per_group < 128) return 0;
+    return (size_t)4 * C * sizeof(float) + (with_res_bn ? 2 : 1) * mft_x3_stage_bytes_host(mft_x3_max_group_tiles(rows_per_group, 128), C) <=
+           64 * 1024;
+}
+
 extern "C" int mft_bn_apply_planes(const float* x, int ldx, float* y, int ldy, unsigned short* planes, long long plane_stride,
                                    int C, int rows_per_group, int n_groups, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, long long gb_group_stride, const float* res, int ldr,
@@ -478,6 +600,24 @@ __global__ __launch_bounds__(256) void pool_window_minmax_kernel(const float* __
     }
 }
 
+__device__ __forceinline__ f32x4 pooled_bn_relu(const float* __restrict__ pmax, const float* __restrict__ pmin, long long src,
+                                                const f32x4 mu, const f32x4 rs, const f32x4 ga, const f32x4 be) {
+    const bool all_pos = ga[0] >= 0.f && ga[1] >= 0.f && ga[2] >= 0.f && ga[3] >= 0.f;
+    const bool all_neg = ga[0] < 0.f && ga[1] < 0.f && ga[2] < 0.f && ga[3] < 0.f;
+    f32x4 v;
+    if (all_pos) v = *(const f32x4*)(pmax + src);
+    else if (all_neg) v = *(const f32x4*)(pmin + src);
+    else {
+        const f32x4 a = *(const f32x4*)(pmax + src), b = *(const f32x4*)(pmin + src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ga[e] >= 0.f ? a[e] : b[e];
+    }
+    f32x4 o = __builtin_elementwise_fma((v - mu) * rs, ga, be);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    return o;
+}
+
 __global__ __launch_bounds__(256) void bn_relu_pooled_gather_kernel(const float* __restrict__ pmax, const float* __restrict__ pmin,
                                                                     const int* __restrict__ src_idx, float* __restrict__ y,
                                                                     int n_img, int HW, int C, int imgs_per_group,
@@ -494,22 +634,46 @@ __global__ __launch_bounds__(256) void bn_relu_pooled_gather_kernel(const float*
         const long long src = ((long long)src_idx[n] * HW + pix) * C + c;
         const f32x4 mu = *(const f32x4*)(mean + (long long)g * C + c);
         const f32x4 rs = *(const f32x4*)(rstd + (long long)g * C + c);
-        const f32x4 ga = *(const f32x4*)(gamma + c);
-        const f32x4 be = *(const f32x4*)(beta + c);
-        const bool all_pos = ga[0] >= 0.f && ga[1] >= 0.f && ga[2] >= 0.f && ga[3] >= 0.f;
-        const bool all_neg = ga[0] < 0.f && ga[1] < 0.f && ga[2] < 0.f && ga[3] < 0.f;
-        f32x4 v;
-        if (all_pos) v = *(const f32x4*)(pmax + src);
-        else if (all_neg) v = *(const f32x4*)(pmin + src);
-        else {
-            const f32x4 a = *(const f32x4*)(pmax + src), b = *(const f32x4*)(pmin + src);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ga[e] >= 0.f ? a[e] : b[e];
-        }
-        f32x4 o = (v - mu) * rs * ga + be;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-        *(f32x4*)(y + i * 4) = o;
+        *(f32x4*)(y + i * 4) = pooled_bn_relu(pmax, pmin, src, mu, rs, *(const f32x4*)(gamma + c), *(const f32x4*)(beta + c));
+    }
+}
+
+// the same gather with the batch statistics combined in the prologue of every workgroup (grid (sub-blocks, groups)) from the
+// cached per-image moments: no bn_combine_moments launch in front of it
+__global__ __launch_bounds__(256) void bn_relu_pooled_gather_moments_kernel(
+    const float* __restrict__ pmax, const float* __restrict__ pmin, const int* __restrict__ src_idx, float* __restrict__ y, int HW,
+    int C, int imgs_per_group, const float* __restrict__ mean_img, const float* __restrict__ m2_img, int rows_per_img, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [2][C]: mean, rstd of this group; [2][imgs][C] staged moments
+    const int g = blockIdx.y;
+    const int* id = src_idx + (long long)g * imgs_per_group;
+    float* smean = tab + 2 * C;
+    float* sm2 = smean + imgs_per_group * C;
+    for (int i = threadIdx.x; i < imgs_per_group * C; i += 256) {         // independent loads first, the arithmetic runs out of LDS
+        const int im = i / C, c = i - im * C;
+        const long long src = (long long)id[im] * C + c;
+        smean[i] = mean_img[src];
+        sm2[i] = m2_img[src];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mu, rs;
+        combine_moments_lds(smean, sm2, C, c, rows_per_img, imgs_per_group, eps, mu, rs);
+        tab[c] = mu; tab[C + c] = rs;
+        if (blockIdx.x == 0 && mean) { mean[(long long)g * C + c] = mu; rstd[(long long)g * C + c] = rs; }
+    }
+    __syncthreads();
+    const int cq = C >> 2;
+    const int total = imgs_per_group * HW * cq;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = (i % cq) * 4;
+        const int t = i / cq;
+        const int pix = t % HW;
+        const int n = t / HW;
+        const long long src = ((long long)id[n] * HW + pix) * C + c;
+        const long long dst = ((long long)g * imgs_per_group * HW * cq + i) * 4;
+        *(f32x4*)(y + dst) = pooled_bn_relu(pmax, pmin, src, *(const f32x4*)(tab + c), *(const f32x4*)(tab + C + c),
+                                            *(const f32x4*)(gamma + c), *(const f32x4*)(beta + c));
     }
 }
 }  // namespace
@@ -531,6 +695,28 @@ extern "C" int mft_bn_relu_pooled_gather(const float* pmax, const float* pmin, c
     const long long total = (long long)n_img * OH * OW * (C / 4);
     hipLaunchKernelGGL(bn_relu_pooled_gather_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, pmax,
                        pmin, src_idx, y, n_img, OH * OW, C, imgs_per_group, mean, rstd, gamma, beta);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_relu_pooled_gather_moments(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img,
+                                                 int OH, int OW, int C, int imgs_per_group, const float* mean_img,
+                                                 const float* m2_img, int rows_per_img, float eps, const float* gamma,
+                                                 const float* beta, float* mean, float* rstd, void* stream) {
+    if (C % 4 != 0 || C > 1024 || !src_idx || imgs_per_group <= 0 || n_img % imgs_per_group != 0 || rows_per_img <= 0 ||
+        (mean == nullptr) != (rstd == nullptr))
+        return MFT_EINVAL;
+    const int groups = n_img / imgs_per_group;
+    const long long per_group = (long long)imgs_per_group * OH * OW * (C / 4);
+    if (per_group > 0x7fffffffLL) return MFT_EINVAL;
+    int sub = (int)((per_group + 256 * 16 - 1) / (256 * 16));         // ~16 float4 per thread: the prologue is repeated by every sub-block
+    const int cap = (2048 + groups - 1) / groups;
+    if (sub > cap) sub = cap;
+    if (sub < 1) sub = 1;
+    const size_t lds = (size_t)(2 + 2 * imgs_per_group) * C * sizeof(float);
+    if (lds > 64 * 1024) return MFT_EINVAL;
+    hipLaunchKernelGGL(bn_relu_pooled_gather_moments_kernel, dim3(sub, groups), dim3(256), lds, (hipStream_t)stream,
+                       pmax, pmin, src_idx, y, OH * OW, C, imgs_per_group, mean_img, m2_img, rows_per_img, eps, gamma, beta, mean,
+                       rstd);
     return mft_launch_status();
 }
 

@@ -13,6 +13,7 @@
 // of the A and B tiles, rows padded to 80 bytes so every ds_read_b128 fragment read (8 bf16 of one row) is
 // conflict-free; single LDS buffer, next tile prefetched into registers under the MFMAs.
 #include "mft_common.h"
+#include "bn_fold.h"
 
 namespace {
 
@@ -40,6 +41,11 @@ struct X3Args {
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
     int rows_per_group;            // >= BM when stats_ws is set
     int s1_rows;                   // conv_x3_s1_kernel: rows of the staged A image (BM + halo + one zero row per image-row boundary)
+    // conv_x3_s1_kernel<.., BNIN = true>: ``in`` is the RAW output of the previous convolution; its train-mode BatchNorm + ReLU is
+    // applied by the loader, with the statistics merged from that convolution's per-tile partials in the workgroup prologue
+    const float* bn_ws; const float* bn_gamma; const float* bn_beta;
+    float bn_eps;
+    int bn_max_tiles;              // tiles one group's rows can overlap (stride of the prologue's staging area)
 };
 
 constexpr int X3_RS = 40;          // bf16 per LDS row: 32 data + 8 pad (80 B)
@@ -664,8 +670,14 @@ __global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
 // per-lane masking is needed.  Global loads, bf16x3 splits and LDS stores of the A operand drop to a third; the weights (B) are
 // staged per tap as before.  K is walked (kh, ci, kw) instead of (kh, kw, ci): the same products, summed in another order.
 // The launch is power-limited: the saving is in joules first, in issue slots second.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
+// BNIN: the input is the raw output c of the previous 3x3 convolution and this kernel consumes relu(BatchNorm(c)) (SimpleBlock:
+// C1 -> BN1 -> ReLU -> C2, backbone.py:251-256): the input has the same pixel grid as the output (stride 1), so its BatchNorm groups
+// are the output's (rows_per_group), a tile touches at most two of them, and the prologue merges their statistics from C1's
+// partials (bn_fold.h) into an LDS table of (scale, shift) per (group, channel).  The loader then applies one FMA + max per
+// element in front of the bf16x3 split; padding and zero rows stay exact zeros.  Removes BN1's finalize and apply launches and
+// the activation they wrote and re-read.
+template <int BM, int BN, bool BNIN>
+__device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PA = BM / 32, PB = BN / 64;
     constexpr int RS = X3_RS;
@@ -674,6 +686,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* As = smem;                       // [3][s1_rows][RS]
     unsigned short* Bs = smem + 3 * A_PLANE;         // [3][BN][RS]
+    float* bn_tab = reinterpret_cast<float*>(Bs + 3 * B_PLANE);     // BNIN: [2 groups][scale | shift][Cin]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -690,13 +703,35 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int W = p.W, H = p.H;
     const int fr0 = m0 / W;                          // flat image-row index (img * H + oh) of the tile's first pixel
-
+    const int g0 = BNIN ? m0 / p.rows_per_group : 0; // first BatchNorm group of the tile
+    const bool bn_two = BNIN && (m0 + (BM < p.M - m0 ? BM : p.M - m0) - 1) / p.rows_per_group > g0;      // the tile straddles two groups
+    if constexpr (BNIN) {
+        // the partials of the tile's (one or two) groups are first copied into LDS with independent loads -- the stage aliases the
+        // A planes, which are not written yet -- then 2*Cin threads run the merge chains out of LDS
+        char* stage = reinterpret_cast<char*>(smem);
+        const size_t gstride = mft_x3_stage_bytes(p.bn_max_tiles, p.Cin);
+        const bool two = bn_two;
+        mft_x3_stats_stage(p.bn_ws, p.Cin, g0, p.M, p.rows_per_group, BM, p.bn_max_tiles, stage, tid, 256);
+        if (two) mft_x3_stats_stage(p.bn_ws, p.Cin, g0 + 1, p.M, p.rows_per_group, BM, p.bn_max_tiles, stage + gstride, tid, 256);
+        __syncthreads();
+        for (int i = tid; i < 2 * p.Cin; i += 256) {
+            const int gi = i >= p.Cin ? 1 : 0, c = i - gi * p.Cin;
+            if (gi == 0 || two) {
+                float mu, rs, sc, sh;
+                mft_x3_stats_staged(stage + gi * gstride, p.bn_max_tiles, p.Cin, c, g0 + gi, p.M, p.rows_per_group, BM, p.bn_eps, mu, rs);
+                mft_bn_fold(mu, rs, p.bn_gamma[c], p.bn_beta[c], sc, sh);
+                bn_tab[(gi * 2 + 0) * p.Cin + c] = sc;
+                bn_tab[(gi * 2 + 1) * p.Cin + c] = sh;
+            }
+        }
+        __syncthreads();                                  // the zero fill below overwrites the stage
+    }
     const int g_id = tid >> 5, g_rr = (tid >> 3) & 3;
     const int lrow = p.row_swz ? g_rr * 4 + (g_id & 3) + 16 * (g_id >> 2) : tid >> 3;
     const int c4 = (tid & 7) * 4;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
-    int a_off[PA], a_oh[PA], a_lds[PA];
+    int a_off[PA], a_oh[PA], a_lds[PA], a_tab[PA];
     bool a_ok[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
@@ -706,6 +741,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
         a_oh[j] = fr - (fr / H) * H;
         a_off[j] = ((a_ok[j] ? m : 0) * p.ldi + c4) * 4;           // (rows beyond M are never requested; keep the product in range)
         a_lds[j] = (t + 1 + fr - fr0) * RS + c4;
+        a_tab[j] = BNIN ? ((a_ok[j] ? m / p.rows_per_group - g0 : 0) * 2 * p.Cin + c4) : 0;
     }
     // halo pixels m0 - 1 and m0 + BM (threads 0-7 / 8-15): real only when they lie in the same image row as their neighbour
     const int hside = (tid >> 3) & 1;
@@ -715,6 +751,8 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     const int h_oh = frh - (frh / H) * H;
     const int h_off = ((h_ok ? mh : 0) * p.ldi + c4) * 4;
     const int h_lds = (hside ? BM + 1 + (m0 + BM - 1) / W - fr0 : 0) * RS + c4;
+    // a real halo pixel lies in the same image (hence the same group) as its neighbour inside the tile
+    const int h_tab = BNIN ? (((hside && h_ok) ? (m0 + BM - 1) / p.rows_per_group - g0 : 0) * 2 * p.Cin + c4) : 0;
 
     const int bseg = tid & 3;
     const int brow = p.row_swz ? ((tid >> 2) & 3) * 4 + ((tid >> 4) & 3) + 16 * (tid >> 6) : tid >> 2;
@@ -774,10 +812,35 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
         *(u32x2*)(As + A_PLANE + off) = p2;
         *(u32x2*)(As + 2 * A_PLANE + off) = p3;
     };
-    auto store_a = [&](const Stage& S) {
+    auto bn_relu = [&](const f32x4 v, const f32x4 sc, const f32x4 sh, bool ok) {      // relu(BatchNorm(v)); masked (padding) elements stay 0
+        f32x4 o = mft_bn_affine4(v, sc, sh);
 #pragma unroll
-        for (int j = 0; j < PA; ++j) put_a(S.ra[j], a_lds[j]);
-        if (tid < 16) put_a(S.rh, h_lds);
+        for (int e = 0; e < 4; ++e) o[e] = ok ? fmaxf(o[e], 0.f) : 0.f;
+        return o;
+    };
+    auto store_a = [&](const Stage& S, int ms) {
+        if constexpr (BNIN) {
+            const int kh = ms / n_ci, ci0 = (ms - kh * n_ci) * 32;
+            const bool okh = h_ok && (unsigned)(h_oh + kh - 1) < (unsigned)H;
+            if (!bn_two) {                      // (most tiles lie inside one group: one table row per K-slice for every pixel)
+                const f32x4 sc = *(const f32x4*)(bn_tab + ci0 + c4), sh = *(const f32x4*)(bn_tab + p.Cin + ci0 + c4);
+#pragma unroll
+                for (int j = 0; j < PA; ++j)
+                    put_a(bn_relu(S.ra[j], sc, sh, a_ok[j] && (unsigned)(a_oh[j] + kh - 1) < (unsigned)H), a_lds[j]);
+                if (tid < 16) put_a(bn_relu(S.rh, sc, sh, okh), h_lds);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PA; ++j)
+                    put_a(bn_relu(S.ra[j], *(const f32x4*)(bn_tab + a_tab[j] + ci0), *(const f32x4*)(bn_tab + a_tab[j] + p.Cin + ci0),
+                                  a_ok[j] && (unsigned)(a_oh[j] + kh - 1) < (unsigned)H), a_lds[j]);
+                if (tid < 16)
+                    put_a(bn_relu(S.rh, *(const f32x4*)(bn_tab + h_tab + ci0), *(const f32x4*)(bn_tab + h_tab + p.Cin + ci0), okh), h_lds);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PA; ++j) put_a(S.ra[j], a_lds[j]);
+            if (tid < 16) put_a(S.rh, h_lds);
+        }
     };
     auto store_b = [&](const Stage& S) {
 #pragma unroll
@@ -817,7 +880,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     load_a(0, st);
     load_b(0, 0, st);
     __syncthreads();
-    store_a(st);
+    store_a(st, 0);
     store_b(st);
     __syncthreads();
     for (int ms = 0; ms < n_ms; ++ms) {
@@ -836,7 +899,7 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
         load_b(msn, 0, st);
         compute(2);
         __syncthreads();
-        store_a(st);
+        store_a(st, msn);
         store_b(st);
         __syncthreads();
     }
@@ -896,6 +959,17 @@ __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
     }
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
+    conv_x3_s1_body<BM, BN, false>(p);
+}
+
+// (three waves per SIMD is what the trunk is tuned for: the loader-side BatchNorm must fit the same 168 registers)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_x3_s1_bnin_kernel(X3Args p) {
+    conv_x3_s1_body<BM, BN, true>(p);
+}
+
 // mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
 // (n_t, mean_t = s1/n_t, M2_t = s2 - s1^2/n_t) are merged in tile order with Chan's update.
 __global__ void x3_stats_finalize_kernel(const float* __restrict__ ws, int C, int M, int R, int BM, float eps,
@@ -903,25 +977,10 @@ __global__ void x3_stats_finalize_kernel(const float* __restrict__ ws, int C, in
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (c >= C) return;
-    const int r0 = g * R, r1 = min(r0 + R, M);
-    const int t0 = r0 / BM, t1 = (r1 - 1) / BM;
-    float n = 0.f, mu = 0.f, m2 = 0.f;
-    for (int t = t0; t <= t1; ++t) {
-        const int lo = max(t * BM, r0), hi = min(t * BM + BM, r1);
-        const float nt = (float)(hi - lo);
-        const int seg = ((t * BM) / R == g) ? 0 : 1;
-        const float* o = ws + (((long long)t * 2 + seg) * C + c) * 2;
-        const float s1 = o[0], s2 = o[1];
-        const float mt = s1 / nt;
-        const float m2t = fmaxf(s2 - s1 * mt, 0.f);
-        const float tot = n + nt;
-        const float d = mt - mu;
-        m2 += m2t + d * d * (n * nt / tot);
-        mu += d * (nt / tot);
-        n = tot;
-    }
+    float mu, rs;
+    mft_x3_stats_merge(ws, C, c, g, M, R, BM, eps, mu, rs);
     mean[(long long)g * C + c] = mu;
-    rstd[(long long)g * C + c] = 1.0f / sqrtf(m2 / n + eps);
+    rstd[(long long)g * C + c] = rs;
 }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
@@ -1005,6 +1064,12 @@ int launch_x3(X3Args p, hipStream_t s) {
 int g_x3_s1 = 1;           // 3x3 / stride 1 / pad 1 layers: A image staged once per (kh, channel slice) for its three kw taps
                            // (conv_x3_s1_kernel; mft_debug_set_x3_tile(90/91))
 
+constexpr size_t X3_S1_LDS_3PER_CU = 160 * 1024 / 3;       // three workgroups per CU: the occupancy the trunk convolutions are tuned for
+
+inline size_t x3_s1_lds(int BM, int BN, int W, int bn_cin) {
+    return (size_t)3 * (BM + 2 + (BM - 1) / W + 1 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
+}
+
 template <int BM, int BN>
 int launch_x3_s1(X3Args p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -1012,8 +1077,11 @@ int launch_x3_s1(X3Args p, hipStream_t s) {
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz != 0;
     p.s1_rows = BM + 2 + (BM - 1) / p.W + 1;
-    const size_t lds = (size_t)3 * (p.s1_rows + BN) * X3_RS * sizeof(unsigned short);
-    hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    const size_t lds = x3_s1_lds(BM, BN, p.W, p.bn_ws ? p.Cin : 0);
+    if (p.bn_ws)
+        hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
     return mft_launch_status();
 }
 
@@ -1256,9 +1324,18 @@ extern "C" int mft_debug_set_x3_tile(int t) {
 
 static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
                        int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* stats_ws,
-                       int rows_per_group, void* stream, const unsigned short* in3 = nullptr, long long in_plane_elems = 0) {
+                       int rows_per_group, void* stream, const unsigned short* in3 = nullptr, long long in_plane_elems = 0,
+                       const float* bn_ws = nullptr, const float* bn_gamma = nullptr, const float* bn_beta = nullptr,
+                       float bn_eps = 0.f) {
     if (n_img <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || ldi % 4 != 0) return MFT_EINVAL;
     X3Args p;
+    p.bn_ws = bn_ws; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_eps = bn_eps;
+    p.bn_max_tiles = bn_ws ? mft_x3_max_group_tiles(rows_per_group, 128) : 0;
+    if (bn_ws != nullptr && (in3 != nullptr || !bn_gamma || !bn_beta || rows_per_group < 128 || KH != 3 || KW != 3 || stride != 1 ||
+                             pad != 1 || x3_s1_lds(128, 64, W, Cin) > X3_S1_LDS_3PER_CU ||
+                             2 * mft_x3_stage_bytes_host(p.bn_max_tiles, Cin) >
+                                 (size_t)3 * (128 + 2 + 127 / W + 1) * X3_RS * sizeof(unsigned short)))
+        return MFT_EINVAL;                     // the loader-side BatchNorm exists in the shared-tap kernel only, at full occupancy
     p.in3 = in3;
     p.in_plane_bytes = 0;
     p.stats_ws = stats_ws;
@@ -1317,7 +1394,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
     const long long img_bytes = (long long)H * W * ldi * 4;
     const long long max_imgs = 0x7fff0000LL / img_bytes;
     if (max_imgs < 1 || 3 * plane_elems * 2 >= 0x7fff0000LL) return MFT_EINVAL;
-    if (stats_ws != nullptr && (max_imgs < n_img || rows_per_group < 128)) return MFT_EINVAL;   // tile numbering needs one launch
+    if ((stats_ws != nullptr || bn_ws != nullptr) && (max_imgs < n_img || rows_per_group < 128)) return MFT_EINVAL;   // tile numbering needs one launch
     if (stats_ws != nullptr && tile != 3) tile = 1;
     if (stats_ws != nullptr && tile == 3 && rows_per_group < 64) return MFT_EINVAL;
     for (long long i0 = 0; i0 < n_img; i0 += max_imgs) {
@@ -1329,7 +1406,8 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.in_bytes = (unsigned)(ni * img_bytes);
         const bool s1 = g_x3_s1 && tile == 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !g_x3_db && !g_x3_pp && !g_x3_dbg &&
                         g_x3_hoist == 0 && g_x3_row_swz != 2 && g_x3_min_lds_kb == 0 &&
-                        (size_t)3 * (128 + 2 + 127 / W + 1 + 64) * X3_RS * sizeof(unsigned short) <= 64 * 1024;
+                        x3_s1_lds(128, 64, W, 0) <= 64 * 1024;
+        if (bn_ws != nullptr && !s1) return MFT_EINVAL;
         const int rc = s1 ? launch_x3_s1<128, 64>(q, s)
                        : (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
                        : (tile == 3)                  ? launch_x3<64, 64, false, false>(q, s)
@@ -1364,9 +1442,29 @@ extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsign
     const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, stats_ws, R,
                                stream);
     if (rc != 0) return rc;
+    if (mean == nullptr && rstd == nullptr) return g_x3_tile == 3 ? MFT_EINVAL : 0;     // partials only: the consumer merges them (128-row tiles)
     const int groups = n_img / imgs_per_group;
     hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, groups), dim3(64), 0, (hipStream_t)stream,
                        (const float*)stats_ws, Cout, n_img * OH * OW, R, g_x3_tile == 3 ? 64 : 128, eps, mean, rstd);
+    return mft_launch_status();
+}
+
+// 3x3 / stride 1 / pad 1 convolution of relu(BatchNorm(in)) where ``in`` is the raw output of the previous bf16x3 convolution and
+// ``in_ws`` its statistics partials (SimpleBlock's C1 -> BN1 -> ReLU -> C2, backbone.py:251-256, in one launch + this
+// convolution's own partials).  MFT_EINVAL outside the shared-tap kernel's domain (the caller then runs apply + convolution).
+extern "C" int mft_conv2d_nhwc_x3_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma,
+                                               const float* in_beta, const unsigned short* w3, long long plane_elems, float* out,
+                                               int ldo, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group, float eps,
+                                               float* stats_ws, float* mean, float* rstd, void* stream) {
+    if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || stats_ws == nullptr || in_ws == nullptr ||
+        (mean == nullptr) != (rstd == nullptr) || g_x3_tile == 3)
+        return MFT_EINVAL;
+    const int R = imgs_per_group * H * W;
+    const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, 3, 3, 1, 1, stats_ws, R, stream, nullptr, 0,
+                               in_ws, in_gamma, in_beta, eps);
+    if (rc != 0 || mean == nullptr) return rc;
+    hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, n_img / imgs_per_group), dim3(64), 0, (hipStream_t)stream,
+                       (const float*)stats_ws, Cout, n_img * H * W, R, 128, eps, mean, rstd);
     return mft_launch_status();
 }
 

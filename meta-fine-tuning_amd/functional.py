@@ -25,6 +25,10 @@ FUSED_LAST_BLOCK = os.environ.get("MFT_FUSED_LAST_BLOCK", "1") == "1"   # conv +
 # producers write 1.5x the bytes -- kept for the record (tests/test_engine_gpu.py::test_presplit_activation_planes_are_bit_identical)
 X3_PLANES = os.environ.get("MFT_X3_PLANES", "0") == "1"
 X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm statistics from the bf16x3 convolution epilogue
+# frozen trunk blocks without helper launches: statistics stay per-tile partials that each consumer merges itself, BN1 + ReLU is
+# applied by C2's loader, the stem's batch statistics are combined inside the pooled gather (12-13 launches per lockstep step
+# instead of 24; MFT_X3_FOLD_BN=0 restores the separate finalize / apply / combine launches)
+X3_FOLD_BN = os.environ.get("MFT_X3_FOLD_BN", "1") == "1"
 
 STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
 
@@ -240,6 +244,16 @@ class StemCache:
         assert self.c0 is not None, "this path needs the full-resolution stem cache (StemCache(pooled=False))"
         return ops.bn_relu_maxpool_gather(self.c0, idx, n, m, s, g, b, ipg, out=out, planes=planes)
 
+    def gather_moments(self, idx, n, g, b, ipg, out, stats=None):
+        """gather() with the mini-batch statistics combined from the cached per-image moments in the same launch."""
+        assert self.pooled
+        m, s = stats if stats is not None else (None, None)
+        ops._lib.check(ops._lib.lib().mft_bn_relu_pooled_gather_moments(
+            ops._p(self.pmax), ops._p(self.pmin), ops._p(idx), ops._p(out), n, self.PH, self.PH, 64, ipg, ops._p(self.mean),
+            ops._p(self.m2), self.OH * self.OH, ops.BN_EPS, ops._p(g), ops._p(b), ops._p(m), ops._p(s), ops._stream()),
+            "mft_bn_relu_pooled_gather_moments")
+        return out
+
 
 def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, fixed=None):
     """trunk[0..upto-1] with shared (frozen) weights.  x [n,H,W,3] NHWC -> activation entering trunk[upto].
@@ -257,10 +271,12 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
         cache, idx = stem
         n = idx.numel()
         groups = n // ipg
-        m = arena.get(tag + ".bn0.mean", (groups, 64))
-        s = arena.get(tag + ".bn0.rstd", (groups, 64))
-        ops.bn_combine_moments(cache.mean, cache.m2, idx, cache.OH * cache.OH, ipg, groups, mean=m, rstd=s)
         PH = (cache.OH + 2 - 3) // 2 + 1
+        fold = X3_FOLD_BN and cache.pooled and not X3_PLANES and running is None and fixed is None
+        if not fold:
+            m = arena.get(tag + ".bn0.mean", (groups, 64))
+            s = arena.get(tag + ".bn0.rstd", (groups, 64))
+            ops.bn_combine_moments(cache.mean, cache.m2, idx, cache.OH * cache.OH, ipg, groups, mean=m, rstd=s)
         if (X3_PLANES and cache.c0 is not None and X3_FUSED_STATS and upto == 7 and running is None and fixed is None and ipg * ((PH + 3) // 4) ** 2 >= 128
                 and all(("trunk.%d.C1" % i) in W.conv3 for i in (4, 5, 6))):
             # frozen trunk on pre-split activations: each tensor between two bf16x3 convolutions is written once as three
@@ -279,7 +295,10 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
                 _, ap = r
                 OHb = (shape[1] + 2 - 3) // stride + 1
                 shape = (n, OHb, OHb, cout)
-        a = cache.gather(idx, n, m, s, g, b, ipg, arena.get(tag + ".p0", (n, PH, PH, 64)))
+        if fold:
+            a = cache.gather_moments(idx, n, g, b, ipg, arena.get(tag + ".p0", (n, PH, PH, 64)))
+        else:
+            a = cache.gather(idx, n, m, s, g, b, ipg, arena.get(tag + ".p0", (n, PH, PH, 64)))
     else:
         n = x.shape[0]
         groups = n // ipg
@@ -409,6 +428,12 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         mm, ss_ = _bn_stats4(arena, stag, o, ipg, groups, run(p + bnname), fix(p + bnname))
         return o, mm, ss_
 
+    if (X3_FOLD_BN and xp is None and fuse_stats and tape is None and out_mode == "f32"
+            and all((p + nm) in w3 for nm in ((".C1", ".C2", ".shortcut") if cin != cout else (".C1", ".C2")))):
+        r = _frozen_block_folded(W, p, x, arena, ipg, cin, cout, stride, tag)
+        if r is not None:
+            return r
+
     if xp is not None and fuse_stats and tape is None and all((p + nm) in w3 for nm in ((".C1", ".C2", ".shortcut") if cin != cout
                                                                                       else (".C1", ".C2"))):
         # pre-split activation chain: every x3 convolution reads bf16 planes written once by its producer
@@ -421,7 +446,7 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
 
         c1, m1, s1 = conv_bn_p(".C1", xp, H, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)), tag + ".bn1")
         r1p = arena.get(tag + ".r1p", (3, n * OH * OH, cout), torch.int16)
-        ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU, gb_group_stride=gbs, planes=r1p,
+        ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU, fma_affine=True, gb_group_stride=gbs, planes=r1p,
                      write_y=False)
         c2, m2, s2 = conv_bn_p(".C2", r1p, OH, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)), tag + ".bn2")
         want_f32 = out_mode in ("f32", "both")
@@ -433,17 +458,17 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         else:
             res, res_bn = x.view(-1, cin), None
         if outp is not None:
-            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=res, res_bn=res_bn, out=out,
+            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, fma_affine=True, res=res, res_bn=res_bn, out=out,
                          gb_group_stride=gbs, planes=outp, write_y=want_f32)
         else:
-            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=res, res_bn=res_bn, out=out,
+            ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, fma_affine=True, res=res, res_bn=res_bn, out=out,
                          gb_group_stride=gbs)
         out = out.view(n, OH, OH, cout) if out is not None else None
         return out if out_mode == "f32" else (out, outp)
     assert out_mode == "f32" or xp is None or not fuse_stats, "planes output requested outside the pre-split chain"
 
     c1, m1, s1 = conv_bn(".C1", ".BN1", x, c1w, 3, stride, 1, arena.get(tag + ".c1", (n, OH, OH, cout)), tag + ".bn1")
-    r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU,
+    r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, groups, m1, s1, g1, b1, act=ops.ACT_RELU, fma_affine=fuse_stats,
                       out=arena.get(tag + ".r1", (n * OH * OH, cout)), gb_group_stride=gbs).view(n, OH, OH, cout)
     c2, m2, s2 = conv_bn(".C2", ".BN2", r1, c2w, 3, 1, 1, arena.get(tag + ".c2", (n, OH, OH, cout)), tag + ".bn2")
     out = arena.get(tag + ".out", (n * OH * OH, cout))
@@ -451,15 +476,66 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
     if cin != cout:
         sc, ms, ss = conv_bn(".shortcut", ".BNshortcut", x, scw, 1, stride, 0, arena.get(tag + ".sc", (n, OH, OH, cout)),
                              tag + ".bns")
-        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=sc.view(-1, cout),
+        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, fma_affine=fuse_stats, res=sc.view(-1, cout),
                      res_bn=(ms, ss, gs, bs), out=out, gb_group_stride=gbs)
     else:
-        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, res=x.view(-1, cin),
+        ops.bn_apply(c2.view(-1, cout), cout, rows, groups, m2, s2, g2, b2, act=ops.ACT_RELU, fma_affine=fuse_stats, res=x.view(-1, cin),
                      out=out, gb_group_stride=gbs)
     out = out.view(n, OH, OH, cout)
     if tape is not None:
         tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out)
     return out
+
+
+_X3WS_FITS = {}
+
+
+def _frozen_block_folded(W, p, x, arena, ipg, cin, cout, stride, tag):
+    """SimpleBlock.forward (backbone.py:251-261) of a frozen shared-weight block in 3-5 launches: every convolution leaves its
+    BatchNorm statistics as per-tile partials, C2's loader applies BN1 + ReLU, the exit launch merges BN2's (and the shortcut
+    BatchNorm's) partials itself.  Returns None (nothing launched) when the first convolution is outside the bf16x3 domain."""
+    n, H, _, _ = x.shape
+    groups = n // ipg
+    OH = (H + 2 - 3) // stride + 1
+    rows = ipg * OH * OH
+    lib = ops._lib.lib()
+    fits = _X3WS_FITS.get((cout, rows))
+    if fits is None:
+        fits = _X3WS_FITS[(cout, rows)] = bool(lib.mft_bn_apply_x3ws_fits(cout, rows, 1))
+    if not fits:
+        return None                       # one BatchNorm batch of thousands of rows (the 100-image final pass): separate launches
+    (g1, b1), (g2, b2) = W.bn[p + ".BN1"], W.bn[p + ".BN2"]
+    w3 = W.conv3
+
+    def partials(name, inp, k, s, pd, obuf, stag):
+        ws = arena.get(stag + ".statws", (int(lib.mft_conv2d_x3_stats_ws_floats(n, inp.shape[1], inp.shape[1], cout, k, k, s, pd)),))
+        r = ops.conv2d_x3_bnstats(inp, w3[p + name], cout, k, k, s, pd, ipg, obuf, ws, None, None)
+        return None if r is None else ws
+
+    c1 = arena.get(tag + ".c1", (n, OH, OH, cout))
+    ws1 = partials(".C1", x, 3, stride, 1, c1, tag + ".bn1")
+    if ws1 is None:
+        return None
+    c2 = arena.get(tag + ".c2", (n, OH, OH, cout))
+    ws2 = arena.get(tag + ".bn2.statws", (int(lib.mft_conv2d_x3_stats_ws_floats(n, OH, OH, cout, 3, 3, 1, 1)),))
+    if ops.conv2d_x3_bnin_bnstats(c1, ws1, g1, b1, w3[p + ".C2"], cout, ipg, c2, ws2) is None:
+        # (scale, shift) table does not fit beside the tile (256 channels on 6x6 maps): BN1 as its own launch, statistics merged there
+        r1 = ops.bn_apply_x3ws(c1.view(-1, cout), cout, rows, groups, ws1, g1, b1, arena.get(tag + ".r1", (n * OH * OH, cout)),
+                               act=ops.ACT_RELU).view(n, OH, OH, cout)
+        if ops.conv2d_x3_bnstats(r1, w3[p + ".C2"], cout, 3, 3, 1, 1, ipg, c2, ws2, None, None) is None:
+            raise RuntimeError("frozen block %s: C2 outside the bf16x3 domain after C1 was inside it" % p)
+    out = arena.get(tag + ".out", (n * OH * OH, cout))
+    if cin != cout:
+        gs, bs = W.bn[p + ".BNshortcut"]
+        sc = arena.get(tag + ".sc", (n, OH, OH, cout))
+        wss = partials(".shortcut", x, 1, stride, 0, sc, tag + ".bns")
+        if wss is None:
+            raise RuntimeError("frozen block %s: shortcut outside the bf16x3 domain after C1 was inside it" % p)
+        ops.bn_apply_x3ws(c2.view(-1, cout), cout, rows, groups, ws2, g2, b2, out, act=ops.ACT_RELU, res=sc.view(-1, cout),
+                          res_ws=wss, res_gamma=gs, res_beta=bs)
+    else:
+        ops.bn_apply_x3ws(c2.view(-1, cout), cout, rows, groups, ws2, g2, b2, out, act=ops.ACT_RELU, res=x.view(-1, cin))
+    return out.view(n, OH, OH, cout)
 
 
 def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f", fixed=None):

@@ -183,6 +183,37 @@ def conv2d_x3_bnstats(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws,
     return out, mean, rstd
 
 
+def conv2d_x3_bnin_bnstats(c_raw, in_ws, in_gamma, in_beta, w3, Cout, imgs_per_group, out, ws, mean=None, rstd=None, eps=BN_EPS):
+    """3x3 / stride 1 / pad 1 conv2d_x3 of relu(BatchNorm(c_raw)): ``c_raw`` [n,H,W,Cin] is the raw output of the previous
+    bf16x3 convolution, ``in_ws`` its statistics partials (SimpleBlock's C1 -> BN1 -> ReLU -> C2, backbone.py:251-256, as one
+    launch).  This convolution's own partials go to ``ws``; ``mean`` / ``rstd`` None = leave them as partials for the consumer.
+    Returns None outside the kernel's domain."""
+    _f32c(c_raw)
+    n, H, W, Cin = c_raw.shape
+    rc = _lib.lib().mft_conv2d_nhwc_x3_bnin_bnstats(_p(c_raw), Cin, _p(in_ws), _p(in_gamma), _p(in_beta), _p(w3),
+                                                    w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout, imgs_per_group, eps,
+                                                    _p(ws), _p(mean), _p(rstd), _stream())
+    if rc == _lib.MFT_EINVAL:
+        return None
+    _lib.check(rc, "mft_conv2d_nhwc_x3_bnin_bnstats")
+    return out
+
+
+def bn_apply_x3ws(x2d, C, rows_per_group, n_groups, ws, gamma, beta, out, act=ACT_NONE, res=None, res_ws=None, res_gamma=None,
+                  res_beta=None, slope=LRELU_SLOPE, eps=BN_EPS, stats=None, res_stats=None):
+    """bn_apply for the output of a bf16x3 convolution whose statistics are still per-tile partials ``ws`` (and ``res_ws`` for a
+    BatchNorm'd residual branch): the merge happens in the prologue of the apply launch.  ``stats`` / ``res_stats`` = optional
+    (mean, rstd) [n_groups, C] buffers that receive the merged statistics."""
+    _f32c(x2d)
+    m, r = stats if stats is not None else (None, None)
+    rm, rr = res_stats if res_stats is not None else (None, None)
+    rc = _lib.lib().mft_bn_apply_x3ws(_p(x2d), x2d.shape[-1], _p(out), out.shape[-1], C, rows_per_group, n_groups, _p(ws), _p(gamma),
+                                      _p(beta), _p(res), 0 if res is None else res.shape[-1], _p(res_ws), _p(res_gamma),
+                                      _p(res_beta), act, slope, eps, _p(m), _p(r), _p(rm), _p(rr), _stream())
+    _lib.check(rc, "mft_bn_apply_x3ws")
+    return out
+
+
 def conv2d_x3p_bnstats(xp, n, H, W, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, eps=BN_EPS):
     """conv2d_x3_bnstats on a pre-split input: ``xp`` int16 [3, n*H*W, Cin] (bf16x3 planes written by bn_apply(planes=) /
     bn_relu_maxpool_gather(planes=)); the operand path of the convolution is then a plain copy."""
@@ -321,12 +352,18 @@ def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=No
     return mean, rstd
 
 
+BN_AFFINE_FMA = 0x100
+
+
 def bn_apply(x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act=ACT_NONE, res=None, res_bn=None,
-             out=None, gb_group_stride=0, slope=LRELU_SLOPE, planes=None, write_y=True):
+             out=None, gb_group_stride=0, slope=LRELU_SLOPE, planes=None, write_y=True, fma_affine=False):
     """y = act(bn(x) [+ res | + bn(res)]).  res_bn = (mean, rstd, gamma, beta) of the residual branch.
     ``planes``: int16 [3, rows, C] buffer that receives y split into its three bf16 pieces (operand of conv2d_x3p_bnstats);
-    with ``write_y=False`` the fp32 y is not written at all."""
+    with ``write_y=False`` the fp32 y is not written at all.  ``fma_affine``: y = fma(x, rstd*gamma, beta - mean*rstd*gamma), the
+    arithmetic of the frozen trunk's folded BatchNorm kernels (bit-identical to them)."""
     _f32c(x2d)
+    if fma_affine:
+        act = act | BN_AFFINE_FMA
     if out is None and (planes is None or write_y):
         out = torch.empty_like(x2d)
     rm = rr = rg = rb = None

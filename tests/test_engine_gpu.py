@@ -367,6 +367,48 @@ def test_presplit_activation_planes_are_bit_identical():
     assert float((outs[2] - outs[0]).abs().max()) < 2e-5 * float(outs[0].abs().max())      # fp32 rounding, three layers deep
 
 
+def test_folded_trunk_batchnorms_are_bit_identical():
+    """Frozen trunk without helper launches (functional.X3_FOLD_BN: statistics merged by their consumers, BN1 + ReLU in C2's loader,
+    stem moments combined inside the pooled gather) against the separate finalize / apply / combine launches: the activation
+    entering trunk.7 must match bit for bit, and so must a whole engine batch."""
+    W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=33), DEV, x3=True)
+    rs = np.random.RandomState(19)
+    x = torch.from_numpy(rs.standard_normal((60, 84, 84, 3)).astype(np.float32)).to(DEV)
+    cache = Fn.StemCache(W, 60, 84, DEV, chunk=32, pooled=True)
+    cache.fill(x)
+    idx = torch.from_numpy(rs.permutation(60)[:35].astype(np.int32)).to(DEV)
+    g, b = W.bn["trunk.1"]
+    m, s = torch.empty((7, 64), device=DEV), torch.empty((7, 64), device=DEV)
+    ops.bn_combine_moments(cache.mean, cache.m2, idx, 42 * 42, 5, 7, mean=m, rstd=s)
+    ref = cache.gather(idx, 35, m, s, g, b, 5, torch.empty((35, 21, 21, 64), device=DEV))
+    m2, s2 = torch.empty_like(m), torch.empty_like(s)
+    got = cache.gather_moments(idx, 35, g, b, 5, torch.empty((35, 21, 21, 64), device=DEV), stats=(m2, s2))
+    assert torch.equal(got, ref) and torch.equal(m2, m) and torch.equal(s2, s)
+    old = Fn.X3_FOLD_BN
+    outs, launches = [], []
+    try:
+        for fold in (False, True):
+            Fn.X3_FOLD_BN = fold
+            arena = Fn.Arena(DEV)
+            outs.append(Fn.resnet10_trunk(W, None, arena, 5, upto=7, tag="f%d" % fold, stem=(cache, idx)).clone())
+            launches.append(any(k[0].endswith(".bn2.statws") for k in arena.bufs))
+        assert launches == [False, True]                                    # the folded chain really ran / did not run
+        assert outs[0].shape == (35, 6, 6, 256)
+        assert torch.equal(outs[0], outs[1])
+        sd = synthetic.gnnnet_state_dict(seed=4)
+        eps = [synthetic.test_episode(60 + i, 5, 5, 15, 84, gen_examples=1) for i in range(7)]      # 7 groups per step: ragged tiles
+        prs = np.random.RandomState(5)
+        perms = [[prs.permutation(100) for _ in range(2)] for _ in range(7)]
+        scores = []
+        for fold in (False, True):
+            Fn.X3_FOLD_BN = fold
+            e = eng.FinetuneEngine(sd, n_views=3, fine_tune_epoch=2, episodes_per_batch=7, device=DEV)
+            scores.append(e.run_batch(eps, perms=perms).clone())
+        assert torch.equal(scores[0], scores[1])
+    finally:
+        Fn.X3_FOLD_BN = old
+
+
 def test_stem_cache_matches_recomputed_stem():
     """Cached trunk.0 outputs + recombined per-image BatchNorm moments must reproduce the per-step stem
     (conv -> batch statistics -> BN/ReLU/maxpool) to fp32 rounding, and the engine's scores must agree."""

@@ -865,3 +865,103 @@ def test_wgrad_adam_next_forward_kernel(ipg):
     dyb = torch.zeros((6, 3, 3, 512), device=DEV)
     wb = torch.zeros((1, 512, 2304), device=DEV)
     assert not ops.wgrad_adam_next_forward(xb, dyb, wb, wb.clone(), wb.clone(), 3, 3, 2, 1, 1, 6)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,ipg,G", [(64, 64, 21, 5, 6), (128, 128, 11, 5, 7), (64, 128, 11, 3, 5), (256, 256, 6, 5, 4)])
+def test_conv_x3_loader_side_batchnorm_is_bit_identical(Cin, Cout, H, ipg, G):
+    """SimpleBlock's C1 -> BN1 -> ReLU -> C2 (backbone.py:251-256) with BN1 folded into C2's loader
+    (mft_conv2d_nhwc_x3_bnin_bnstats: statistics merged from C1's partials in the workgroup prologue) against the separate
+    launches finalize -> mft_bn_apply -> mft_conv2d_nhwc_x3_bnstats: same arithmetic, so the convolution output and the
+    statistics behind it must match bit for bit (tiles straddling groups, ragged last tile, image-row boundaries, negative
+    gammas).  256 channels on 6x6 maps do not fit the table at three workgroups per CU: refused."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    n = G * ipg
+    x = nhwc(rnd((n, 64, H, H), 71) + 0.2).to(DEV)
+    w1 = ops.split_weight_x3(ops.pack_conv_weight(rnd((Cin, 64, 3, 3), 72, scale=(2.0 / (9 * Cin)) ** 0.5).to(DEV)))
+    w2 = ops.split_weight_x3(ops.pack_conv_weight(rnd((Cout, Cin, 3, 3), 73, scale=(2.0 / (9 * Cout)) ** 0.5).to(DEV)))
+    g1 = (rnd((Cin,), 74) * 0.5 + 0.3).to(DEV)                        # some negative gammas
+    b1 = (rnd((Cin,), 75) * 0.2).to(DEV)
+    c1 = torch.empty((n, H, H, Cin), device=DEV)
+    ws1 = torch.empty(int(lib.mft_conv2d_x3_stats_ws_floats(n, H, H, Cin, 3, 3, 1, 1)), device=DEV)
+    m1, s1 = torch.empty((G, Cin), device=DEV), torch.empty((G, Cin), device=DEV)
+    ops.conv2d_x3_bnstats(x, w1, Cin, 3, 3, 1, 1, ipg, c1, ws1, m1, s1)
+    rows = ipg * H * H
+    r1 = ops.bn_apply(c1.view(-1, Cin), Cin, rows, G, m1, s1, g1, b1, act=ops.ACT_RELU, fma_affine=True).view(n, H, H, Cin)
+    ws2 = torch.empty(int(lib.mft_conv2d_x3_stats_ws_floats(n, H, H, Cout, 3, 3, 1, 1)), device=DEV)
+    ref = torch.empty((n, H, H, Cout), device=DEV)
+    m2, s2 = torch.empty((G, Cout), device=DEV), torch.empty((G, Cout), device=DEV)
+    ops.conv2d_x3_bnstats(r1, w2, Cout, 3, 3, 1, 1, ipg, ref, ws2, m2, s2)
+    # the partials-only form of the first convolution leaves the same partials and launches no finalize
+    c1b, ws1b = torch.empty_like(c1), torch.empty_like(ws1)
+    assert ops.conv2d_x3_bnstats(x, w1, Cin, 3, 3, 1, 1, ipg, c1b, ws1b, None, None) is not None
+    n_part = ((n * H * H + 127) // 128) * 2 * Cin * 2
+    assert torch.equal(c1b, c1)
+    out = torch.zeros_like(ref)
+    ws2b = torch.empty_like(ws2)
+    m2b, s2b = torch.empty_like(m2), torch.empty_like(s2)
+    r = ops.conv2d_x3_bnin_bnstats(c1b, ws1b, g1, b1, w2, Cout, ipg, out, ws2b, m2b, s2b)
+    if Cin == 256:
+        assert r is None                                             # the caller runs mft_bn_apply_x3ws + the plain convolution
+        r1b = ops.bn_apply_x3ws(c1b.view(-1, Cin), Cin, rows, G, ws1b, g1, b1, torch.empty((n * H * H, Cin), device=DEV), act=ops.ACT_RELU)
+        assert torch.equal(r1b.view_as(r1), r1)
+        return
+    assert r is not None
+    assert torch.equal(out, ref)
+    assert torch.equal(m2b, m2) and torch.equal(s2b, s2)
+    # against float64: relu(BN(c1)) convolved in double
+    c1d = c1.double().cpu().view(G, rows, Cin)
+    mu, var = c1d.mean(1, keepdim=True), c1d.var(1, unbiased=False, keepdim=True)
+    r1d = torch.relu((c1d - mu) / torch.sqrt(var + 1e-5) * g1.double().cpu() + b1.double().cpu()).view(n, H, H, Cin)
+    wd = rnd((Cout, Cin, 3, 3), 73, scale=(2.0 / (9 * Cout)) ** 0.5).double()
+    od = torch.nn.functional.conv2d(r1d.permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1)
+    assert float((out.double().cpu() - od).abs().max()) < 2e-5 * max(1.0, float(od.abs().max()))
+    del n_part
+
+
+@pytest.mark.parametrize("C,H,ipg,G,res", [(64, 21, 5, 6, "identity"), (128, 11, 5, 7, "bn"), (256, 6, 5, 5, "bn"), (64, 21, 3, 4, "none")])
+def test_bn_apply_from_partials_is_bit_identical(C, H, ipg, G, res):
+    """mft_bn_apply_x3ws (statistics of the main and the residual BatchNorm merged from convolution partials inside the apply
+    launch) against finalize + finalize + mft_bn_apply: output and merged statistics bit for bit."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    n = G * ipg
+    x = nhwc(rnd((n, 64, H, H), 81) + 0.1).to(DEV)
+    rows = ipg * H * H
+
+    def conv(seed, k, pad, full):
+        w3 = ops.split_weight_x3(ops.pack_conv_weight(rnd((C, 64, k, k), seed, scale=(2.0 / (k * k * C)) ** 0.5).to(DEV)))
+        o = torch.empty((n, H, H, C), device=DEV)
+        ws = torch.empty(int(lib.mft_conv2d_x3_stats_ws_floats(n, H, H, C, k, k, 1, pad)), device=DEV)
+        m, s = (torch.empty((G, C), device=DEV), torch.empty((G, C), device=DEV)) if full else (None, None)
+        assert ops.conv2d_x3_bnstats(x, w3, C, k, k, 1, pad, ipg, o, ws, m, s) is not None
+        return o, ws, m, s
+
+    c2, ws2, m2, s2 = conv(82, 3, 1, True)
+    g2, b2 = (rnd((C,), 83) * 0.5 + 0.4).to(DEV), (rnd((C,), 84) * 0.1).to(DEV)
+    kw_ref, kw_new = {}, {}
+    if res == "bn":
+        sc, wss, ms, ss = conv(85, 1, 0, True)
+        gs, bs = (rnd((C,), 86) * 0.5 + 0.4).to(DEV), (rnd((C,), 87) * 0.1).to(DEV)
+        kw_ref = dict(res=sc.view(-1, C), res_bn=(ms, ss, gs, bs))
+        rm, rr = torch.empty((G, C), device=DEV), torch.empty((G, C), device=DEV)
+        kw_new = dict(res=sc.view(-1, C), res_ws=wss, res_gamma=gs, res_beta=bs, res_stats=(rm, rr))
+    elif res == "identity":
+        assert C == 64
+        kw_ref = kw_new = dict(res=x.view(-1, 64))
+    ref = ops.bn_apply(c2.view(-1, C), C, rows, G, m2, s2, g2, b2, act=ops.ACT_RELU, fma_affine=True, **kw_ref)
+    mo, so = torch.empty((G, C), device=DEV), torch.empty((G, C), device=DEV)
+    out = ops.bn_apply_x3ws(c2.view(-1, C), C, rows, G, ws2, g2, b2, torch.empty_like(ref), act=ops.ACT_RELU, stats=(mo, so), **kw_new)
+    assert torch.equal(out, ref)
+    assert torch.equal(mo, m2) and torch.equal(so, s2)
+    if res == "bn":
+        assert torch.equal(rm, ms) and torch.equal(rr, ss)
+    # the apply itself against float64
+    c2d = c2.double().cpu().view(G, rows, C)
+    yd = (c2d - c2d.mean(1, keepdim=True)) / torch.sqrt(c2d.var(1, unbiased=False, keepdim=True) + 1e-5) * g2.double().cpu() + b2.double().cpu()
+    if res == "identity":
+        yd = yd + x.double().cpu().view(G, rows, C)
+    if res != "bn":
+        assert float((out.double().cpu().view(G, rows, C) - torch.relu(yd)).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
+    assert lib.mft_bn_apply_x3ws(ops._p(c2), C, ops._p(out), C, C, 64, G, ops._p(ws2), ops._p(g2), ops._p(b2), None, 0, None, None, None,
+                                 1, 0.0, 1e-5, None, None, None, None, ops._stream()) == -22        # groups below one 128-row tile
