@@ -366,10 +366,16 @@ def bench_metatrain(args, rank, world, dev, dist):
     bucket = parallel.FlatGradBucket(model.parameters())
     eps = [synthetic.train_episode(5000 + 100 * rank + i, 5, 5, 16, 84).to(dev) for i in range(8)]
 
+    from meta_fine_tuning_amd import graph_step
+    graphed = graph_step.for_loop(model, model.set_forward_loss)       # the episode loop's own path (MetaTemplate._episode_loop)
+
     def step(i):
-        opt.zero_grad()
-        loss = model.set_forward_loss(eps[i % len(eps)])
-        loss.backward()
+        if graphed is not None:
+            loss = graphed(eps[i % len(eps)])                          # forward + backward: one hipGraph replay after 3 eager steps
+        else:
+            opt.zero_grad()
+            loss = model.set_forward_loss(eps[i % len(eps)])
+            loss.backward()
         bucket.allreduce_mean()
         opt.step()
         return loss
@@ -379,7 +385,7 @@ def bench_metatrain(args, rank, world, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 4 if graphed is not None else 0)):      # (the capture happens on the 4th step)
         step(i)
     sync_all()
     t0 = time.perf_counter()
@@ -399,7 +405,8 @@ def bench_metatrain(args, rank, world, dev, dist):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "meta-training step (BASELINE configs[3]): 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
                                    "flat 21.2 MB gradient all-reduce + fused outer Adam", "parallelism": "episode-parallel x%d" % world},
-            "last_loss": round(float(loss.detach().cpu()), 4), "roofline": None, "cpu_baseline": None}))
+            "last_loss": round(float(loss.detach().cpu()), 4), "graphed": graphed is not None and graphed.graph is not None,
+            "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -215,6 +215,17 @@ int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, i
  * reduced in 1024-row chunks (one workgroup column per chunk) through `ws` (mft_conv2d_wgrad_ws_floats floats; may be
  * NULL = no split) followed by a fixed-order sum.  Cin == 3 selects the 7x7 stem form.  Also nn.Linear / 1x1-conv
  * weight gradients (H=W=1, rows = n_img).                                                                          */
+/* K-sliced forms of mft_conv2d_nhwc / mft_conv2d_dgrad_nhwc for single-weight-set launches with few output tiles and a long
+ * reduction (the deep layers of ONE 105-image meta-training episode, train.py / meta_template.py:76-92): grid.z slices of the K
+ * walk write partial tiles to ws, summed in slice order (deterministic).  mft_conv_ksplit_ws_floats(rows, cols, K) = floats of
+ * workspace for rows x cols outputs over a reduction of K (0: the launch is not sliced; the *_ksplit entry points then run the
+ * plain launch).  Forward: rows = n_img*OH*OW, cols = Cout, K = roundup(KH*KW*Cin, 32); data gradient: rows = n_img*H*W,
+ * cols = Cin, K = KH*KW*Cout. */
+long long mft_conv_ksplit_ws_floats(long long rows, int cols, int K);
+int mft_conv2d_nhwc_ksplit(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, int n_img, int H, int W,
+                           int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream);
+int mft_conv2d_dgrad_nhwc_ksplit(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W, int Cin,
+                                 int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream);
 long long mft_conv2d_wgrad_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                      int imgs_per_group);
 int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, float* dw,

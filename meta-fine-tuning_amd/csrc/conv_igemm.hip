@@ -45,6 +45,8 @@ struct ConvArgs {
     int tiles_n;
     long long wgs;       // weight group stride (floats), 0 = shared
     int bt_stride;       // BT (data-gradient) mode: stride of the forward convolution
+    int ksplit;          // > 1: grid.z slices of the K walk, partial tiles to ws[z][rows][Cout] (summed in slice order afterwards)
+    float* ws;
 };
 
 constexpr int BK = 32;
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[PA], rb[PB];
-    const int nk = p.Kpad / BK;
+    const int nk_all = p.Kpad / BK;
+    const int kt0 = p.ksplit > 1 ? (int)((long long)blockIdx.z * nk_all / p.ksplit) : 0;
+    const int nk = p.ksplit > 1 ? (int)((long long)(blockIdx.z + 1) * nk_all / p.ksplit) : nk_all;
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
@@ -218,12 +222,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* As = smem + buf * (BM + BN) * LDS_LD;
         const float* Bs = As + BM * LDS_LD;
@@ -262,6 +266,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const long long out_row0 = (long long)g * p.rows_per_group;
+    if (p.ksplit > 1) {                    // partial tile of this K slice (single-group launches only)
+        float* part = p.ws + (long long)blockIdx.z * p.rows_per_group * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / WN) + j * 32 + r;
+                if (n >= p.Cout) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (m < p.rows_per_group) part[(long long)m * p.Cout + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -278,6 +298,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
 }
 
+// out[m][n] = sum over the K slices (in slice order: deterministic) of the partial tiles + bias
+__global__ __launch_bounds__(256) void reduce_ksplit_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            const float* __restrict__ bias, int rows, int C, int ldo, int splits) {
+    const int cq = C >> 2;
+    const long long total = (long long)rows * cq;
+    const long long slice = (long long)rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / cq;
+        const int c = (int)(i - m * cq) * 4;
+        f32x4 s = *(const f32x4*)(ws + m * C + c);
+        for (int z = 1; z < splits; ++z) s += *(const f32x4*)(ws + z * slice + m * C + c);
+        if (bias) s += *(const f32x4*)(bias + c);
+        *(f32x4*)(out + m * ldo + c) = s;
+    }
+}
+
+// K slices for a single-group launch of `rows` x `cols` outputs with a reduction of K: a meta-training step runs ONE episode
+// (105 images), so the deep layers are a handful of 64 x 64 tiles with 72-144 K-steps each (trunk.7: 120 tiles on 256 CUs,
+// 70 us of dependent MFMAs per tile); slicing K puts ~3 workgroups on every CU.  1 = no slicing.
+inline int conv_ksplit(long long rows, int cols, int K) {
+    if (cols % 4 != 0) return 1;
+    const long long tiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+    const int nk = K / BK;
+    if (tiles >= 512 || nk < 16) return 1;
+    long long s = (768 + tiles - 1) / tiles;
+    if (s > nk / 8) s = nk / 8;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
+}
+
 template <int BM, int BN, int WM, int WN, bool STEM, bool BT = false>
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     const int tiles_m = cdiv(a.rows_per_group, BM);
@@ -292,8 +342,16 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    dim3 grid(tiles_m * p.tiles_n, groups, 1);
+    if (p.ksplit > 1 && (groups != 1 || p.ws == nullptr)) return MFT_EINVAL;
+    dim3 grid(tiles_m * p.tiles_n, groups, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    if (p.ksplit > 1) {
+        const long long total = (long long)p.rows_per_group * (p.Cout / 4);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_ksplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.ws, p.out, p.bias,
+                           p.rows_per_group, p.Cout, p.ldo, p.ksplit);
+    }
     return mft_launch_status();
 }
 
@@ -970,6 +1028,30 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
 
 constexpr int WGRAD_CHUNK_ROWS = 1024;
 
+// split-M of the plain (no Adam) weight gradient: one workgroup per (64 x 64 tile, tap, group, chunk of rows), partial
+// gradients summed in chunk order by reduce_chunks_kernel (deterministic).  A meta-training step has ONE 105-image episode in
+// flight (train.py:28, meta_template.py:76-92), so every launch is a small GEMM with a long reduction: the chunk length is
+// chosen so that the launch has ~3 workgroups per CU -- with the 1024-row chunks of round 2 the GNN's 1x1 layers (7,440 pair
+// rows, 3-9 tiles) ran on 24-72 workgroups for 51-53 us each and trunk.7 (945 rows) on one chunk.
+inline void wgrad_chunking(long long rows, long long wgs_per_chunk, int* chunk_rows, int* chunks) {
+    *chunk_rows = (int)rows;
+    *chunks = 1;
+    if (rows <= 256) return;
+    const long long want = (768 + wgs_per_chunk - 1) / wgs_per_chunk;
+    long long cr = ((rows + want - 1) / want + 31) / 32 * 32;
+    if (cr < 128) cr = 128;
+    if (cr > WGRAD_CHUNK_ROWS) cr = WGRAD_CHUNK_ROWS;
+    const long long n = (rows + cr - 1) / cr;
+    if (n <= 1) return;
+    *chunk_rows = (int)cr;
+    *chunks = (int)n;
+}
+
+inline long long wgrad_wgs_per_chunk(int Cin, int Cout, int KH, int KW, long long groups) {
+    if (Cin == 3) return (long long)(((KH * KW * Cin + 31) / 32 * 32 + 63) / 64) * ((Cout + 63) / 64) * groups;       // stem: K-major tiles
+    return (long long)((Cin + 63) / 64) * ((Cout + 63) / 64) * KH * KW * groups;
+}
+
 int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float* ws, hipStream_t s) {
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     if (n_img % imgs_per_group != 0) return MFT_EINVAL;
@@ -984,10 +1066,7 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     a.chunk_rows = a.rows_per_group;
     a.chunks = 1;
     a.ws = ws;
-    if (!adam && ws != nullptr && a.rows_per_group > 2 * WGRAD_CHUNK_ROWS) {
-        a.chunk_rows = WGRAD_CHUNK_ROWS;
-        a.chunks = (a.rows_per_group + WGRAD_CHUNK_ROWS - 1) / WGRAD_CHUNK_ROWS;
-    }
+    if (!adam && ws != nullptr) wgrad_chunking(a.rows_per_group, wgrad_wgs_per_chunk(a.Cin, a.Cout, a.KH, a.KW, groups), &a.chunk_rows, &a.chunks);
     const int taps = a.KH * a.KW;
     if (stem) return adam ? MFT_EINVAL : launch_wgrad<64, 64, false, true>(a, 1, groups, s);
     if (adam) {
@@ -1006,9 +1085,9 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
 
 }  // namespace
 
-extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
-                               int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                               int imgs_per_group, long long w_group_stride, void* stream) {
+static int conv2d_impl(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                       int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int imgs_per_group, long long w_group_stride, float* ws, void* stream) {
     if (n_img <= 0 || Cout <= 0) return MFT_EINVAL;
     const bool stem = (Cin == 3);
     if (!stem && (Cin % 32 != 0 || ldi % 4 != 0)) return MFT_EINVAL;
@@ -1029,6 +1108,11 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
     a.bt_stride = 1;
+    a.ksplit = 1; a.ws = nullptr;
+    if (ws != nullptr && !stem && groups == 1 && ldo % 4 == 0) {
+        a.ksplit = conv_ksplit(a.rows_per_group, Cout, a.Kpad);
+        a.ws = ws;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (stem) {
         // 7x7/2 pad 3 -> 64 channels on 84x84 / 224x224 inputs: LDS-patch kernel (csrc/stem.hip)
@@ -1057,6 +1141,26 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
         case 4: return launch_conv<64, 64, 2, 2, false>(a, groups, s);
         default: return launch_conv<128, 32, 4, 1, false>(a, groups, s);
     }
+}
+
+extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                               int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int imgs_per_group, long long w_group_stride, void* stream) {
+    return conv2d_impl(in, ldi, w, bias, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride,
+                       nullptr, stream);
+}
+
+// floats of workspace the K-sliced forms want for a single-group launch producing rows x cols outputs over a reduction of K
+// (0: the launch is not sliced)
+extern "C" long long mft_conv_ksplit_ws_floats(long long rows, int cols, int K) {
+    const int s = conv_ksplit(rows, cols, K);
+    return s > 1 ? (long long)s * rows * cols : 0;
+}
+
+extern "C" int mft_conv2d_nhwc_ksplit(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
+                                      int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                      void* stream) {
+    return conv2d_impl(in, ldi, w, bias, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0, ws, stream);
 }
 
 extern "C" int mft_has_experiments(void) {
@@ -1107,9 +1211,9 @@ extern "C" int mft_debug_reset(void) {
     return 0;
 }
 
-extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
-                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                     int imgs_per_group, long long w_group_stride, void* stream) {
+static int dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
+                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                      int imgs_per_group, long long w_group_stride, float* ws, void* stream) {
     // H, W: spatial size of dx (= forward input); dy is [(H+2p-KH)/s+1, (W+2p-KW)/s+1]
     if (Cout % 32 != 0 || Cin % 4 != 0 || ldy % 4 != 0 || stride < 1) return MFT_EINVAL;
     if (imgs_per_group <= 0) imgs_per_group = n_img;
@@ -1136,9 +1240,28 @@ extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, f
     a.rows_per_group = imgs_per_group * H * W;
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
+    a.ksplit = 1; a.ws = nullptr;
+    if (ws != nullptr && groups == 1 && ldx % 4 == 0 && Cin % 64 == 0) {
+        a.ksplit = conv_ksplit(a.rows_per_group, Cin, a.Kpad);
+        a.ws = ws;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (Cin % 64 == 0) return launch_conv<64, 64, 2, 2, false, true>(a, groups, s);
     return launch_conv<128, 32, 4, 1, false, true>(a, groups, s);
+}
+
+extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
+                                     int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                     int imgs_per_group, long long w_group_stride, void* stream) {
+    return dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride, nullptr,
+                      stream);
+}
+
+// the same data gradient with the reduction over (tap, output channel) sliced across workgroups (workspace:
+// mft_conv_ksplit_ws_floats(n_img*H*W, Cin, KH*KW*Cout) floats; single weight set)
+extern "C" int mft_conv2d_dgrad_nhwc_ksplit(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
+                                            int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream) {
+    return dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0, ws, stream);
 }
 
 extern "C" long long mft_conv2d_wgrad_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
@@ -1146,8 +1269,9 @@ extern "C" long long mft_conv2d_wgrad_ws_floats(int n_img, int H, int W, int Cin
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     const long long rows = (long long)imgs_per_group * OH * OW;
-    if (rows <= 2 * WGRAD_CHUNK_ROWS) return 0;
-    const long long chunks = (rows + WGRAD_CHUNK_ROWS - 1) / WGRAD_CHUNK_ROWS;
+    int chunk_rows, chunks;
+    wgrad_chunking(rows, wgrad_wgs_per_chunk(Cin, Cout, KH, KW, n_img / imgs_per_group), &chunk_rows, &chunks);
+    if (chunks <= 1) return 0;
     const long long kpad = (KH * KW * Cin + 31) / 32 * 32;
     return (long long)(n_img / imgs_per_group) * chunks * Cout * kpad;
 }

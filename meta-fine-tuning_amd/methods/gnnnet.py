@@ -82,13 +82,24 @@ class GnnNet(MetaTemplate):
         ns = self._graph_support()
         return scores.view(self.n_query, self.n_way, ns + 1, self.n_way)[:, :, -1].permute(1, 0, 2).contiguous().view(-1, self.n_way)
 
+    def _y_query(self):
+        """np.repeat(range(n_way), n_query) on the device (gnnnet.py:220), uploaded once per (n_way, n_query): the per-step upload
+        is a synchronous copy, which a hipGraph capture of the step refuses."""
+        key = (self.n_way, self.n_query, torch.cuda.current_device())
+        y = self._yq_cache.get(key) if hasattr(self, "_yq_cache") else None
+        if y is None:
+            if not hasattr(self, "_yq_cache"):
+                self._yq_cache = {}
+            y = self._yq_cache[key] = torch.from_numpy(np.repeat(range(self.n_way), self.n_query)).cuda()
+        return y
+
     def set_forward_loss(self, x):
-        y_query = torch.from_numpy(np.repeat(range(self.n_way), self.n_query)).cuda()
+        y_query = self._y_query()
         scores = self.set_forward(x)
         return self.loss_fn(scores, y_query)
 
     def set_forward_loss_finetune(self, x):
-        y_query = torch.from_numpy(np.repeat(range(self.n_way), self.n_query)).cuda()
+        y_query = self._y_query()
         scores = self.set_forward_finetune(x)
         return self.loss_fn(scores, y_query)
 

@@ -30,18 +30,8 @@ class GnnNet(_GnnNet):
         return AG.gnnnet_head(self, feats, self.n_support, n_query, fold=True)
 
     def _loop50(self, epoch, train_loader, optimizer, loss_fn):
-        avg_loss = 0
-        for i, (x, _) in enumerate(train_loader):
-            self.n_query = x.size(1) - 50                                  # literal 50: gnnnet_copy.py:86,104
-            if self.change_way:
-                self.n_way = x.size(0)
-            optimizer.zero_grad()
-            loss = loss_fn(x)
-            loss.backward()
-            optimizer.step()
-            avg_loss = avg_loss + loss.item()
-            if i % 10 == 0:
-                print('Epoch {:d} | Batch {:d}/{:d} | Loss {:f}'.format(epoch, i, len(train_loader), avg_loss / float(i + 1)))
+        # n_query = x.size(1) - 50, the literal of gnnnet_copy.py:86,104; otherwise MetaTemplate's loop (incl. its hipGraph replay)
+        self._episode_loop(epoch, train_loader, optimizer, loss_fn, n_support_images=50)
 
     def train_loop50(self, epoch, train_loader, optimizer):
         self._loop50(epoch, train_loader, optimizer, self.set_forward_loss)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import graph_step, ops
 
 
 class MetaTemplate(nn.Module):
@@ -54,13 +54,24 @@ class MetaTemplate(nn.Module):
         return float(np.sum(pred[:, 0] == y_query)), len(y_query)
 
     # ------------------------------------------------------------------ episode loops
-    def _episode_loop(self, epoch, train_loader, optimizer, loss_fn, support_from_x=True):
+    def _episode_loop(self, epoch, train_loader, optimizer, loss_fn, support_from_x=True, n_support_images=None):
+        """``n_support_images``: support images per class in x when that is not ``self.n_support`` (gnnnet_copy's literal 50)."""
         print_freq = 10
         avg_loss = 0
+        graphed = graph_step.for_loop(self, loss_fn)      # forward + backward as one hipGraph replay (plain set_forward_loss only)
+        avg_dev = None
         for i, (x, _) in enumerate(train_loader):
-            self.n_query = x.size(1) - self.n_support
+            self.n_query = x.size(1) - (self.n_support if n_support_images is None else n_support_images)
             if self.change_way:
                 self.n_way = x.size(0)
+            if graphed is not None:
+                loss = graphed(x)
+                optimizer.step()
+                # the running sum the reference keeps in a Python float (= double), kept on the device: no host sync per step
+                avg_dev = loss.detach().double() if avg_dev is None else avg_dev + loss.detach().double()
+                if i % print_freq == 0:
+                    print('Epoch {:d} | Batch {:d}/{:d} | Loss {:f}'.format(epoch, i, len(train_loader), avg_dev.item() / float(i + 1)))
+                continue
             optimizer.zero_grad()
             loss = loss_fn(x)
             loss.backward()

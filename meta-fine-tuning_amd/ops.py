@@ -140,10 +140,31 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
         wgs = w_pk.shape[1] * w_pk.shape[2]
         if imgs_per_group <= 0 or n // imgs_per_group != w_pk.shape[0]:
             raise RuntimeError("per-group weights need imgs_per_group with n/imgs_per_group == groups")
+    if wgs == 0 and imgs_per_group <= 0 and Cin != 3:
+        # one weight set, few output tiles, long reduction (one 105-image meta-training episode): K sliced across workgroups
+        nws = _ksplit_ws(n * OH * OW, Cout, w_pk.shape[-1])
+        if nws:
+            ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
+            rc = _lib.lib().mft_conv2d_nhwc_ksplit(_p(x), Cin, _p(w_pk), _p(bias), _p(out), Cout, n, H, W, Cin, Cout, KH, KW,
+                                                   stride, pad, _p(ws), _stream())
+            _lib.check(rc, "mft_conv2d_nhwc_ksplit")
+            return out
     rc = _lib.lib().mft_conv2d_nhwc(_p(x), Cin, _p(w_pk), _p(bias), _p(out), Cout, n, H, W, Cin, Cout, KH, KW,
                                     stride, pad, imgs_per_group, wgs, _stream())
     _lib.check(rc, "mft_conv2d_nhwc")
     return out
+
+
+_KSPLIT_WS = {}
+
+
+def _ksplit_ws(rows, cols, K):
+    """floats of workspace for the K-sliced convolution / data-gradient launch of this shape (0: not sliced); memoised."""
+    key = (rows, cols, K)
+    v = _KSPLIT_WS.get(key)
+    if v is None:
+        v = _KSPLIT_WS[key] = int(_lib.lib().mft_conv_ksplit_ws_floats(rows, cols, K))
+    return v
 
 
 def split_weight_x3(w_pk):
@@ -252,6 +273,14 @@ def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None, stride=
     if out is None:
         out = torch.empty((n, H, W, Cin), device=dy.device, dtype=torch.float32)
     wgs = w_pk.shape[1] * w_pk.shape[2] if w_pk.dim() == 3 else 0
+    if wgs == 0 and imgs_per_group <= 0 and Cin % 64 == 0:
+        nws = _ksplit_ws(n * H * W, Cin, KH * KW * Cout)
+        if nws:
+            ws = torch.empty((nws,), device=dy.device, dtype=torch.float32)
+            rc = _lib.lib().mft_conv2d_dgrad_nhwc_ksplit(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                         _p(ws), _stream())
+            _lib.check(rc, "mft_conv2d_dgrad_nhwc_ksplit")
+            return out
     rc = _lib.lib().mft_conv2d_dgrad_nhwc(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride, pad,
                                           imgs_per_group, wgs, _stream())
     _lib.check(rc, "mft_conv2d_dgrad_nhwc")

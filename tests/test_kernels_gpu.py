@@ -965,3 +965,42 @@ def test_bn_apply_from_partials_is_bit_identical(C, H, ipg, G, res):
         assert float((out.double().cpu().view(G, rows, C) - torch.relu(yd)).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
     assert lib.mft_bn_apply_x3ws(ops._p(c2), C, ops._p(out), C, C, 64, G, ops._p(ws2), ops._p(g2), ops._p(b2), None, 0, None, None, None,
                                  1, 0.0, 1e-5, None, None, None, None, ops._stream()) == -22        # groups below one 128-row tile
+
+
+@pytest.mark.parametrize("n,H,Cin,Cout,k,stride,pad", [(105, 3, 512, 512, 3, 1, 1), (105, 6, 256, 512, 3, 2, 1), (105, 11, 128, 256, 3, 2, 1),
+                                                       (105, 6, 256, 256, 3, 1, 1), (21, 6, 256, 512, 1, 2, 0)])
+def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride, pad):
+    """One 105-image meta-training episode leaves the deep layers with 60-240 output tiles and 72-144 K-steps each: the K-sliced
+    forward / data-gradient launches (partials summed in slice order) against the plain launches and against float64, and the
+    adaptive split-M weight gradient against float64."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    x = nhwc(rnd((n, Cin, H, H), 91)).to(DEV)
+    w = rnd((Cout, Cin, k, k), 92, scale=(2.0 / (k * k * Cin)) ** 0.5)
+    b = rnd((Cout,), 93).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    OH = (H + 2 * pad - k) // stride + 1
+    sliced = int(lib.mft_conv_ksplit_ws_floats(n * OH * OH, Cout, wp.shape[-1])) > 0
+    assert sliced == (k == 3)                                     # the 1x1 shortcut (K = 256: 8 K-steps) is not sliced
+    out = ops.conv2d(x, wp, Cout, k, k, stride, pad, bias=b)                 # takes the sliced form where it applies
+    plain = torch.empty_like(out)
+    assert lib.mft_conv2d_nhwc(ops._p(x), Cin, ops._p(wp), ops._p(b), ops._p(plain), Cout, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
+                               ops._stream()) == 0
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double(), b.double().cpu(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    sc = float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) < 1e-5 * sc
+    assert float((out - plain).abs().max()) < 1e-5 * sc
+    dy = nhwc(rnd((n, Cout, OH, OH), 94)).to(DEV)
+    dx = ops.conv2d_dgrad(dy, wp, Cin, k, k, pad, stride=stride, in_hw=(H, H))
+    dxp = torch.empty_like(dx)
+    assert lib.mft_conv2d_dgrad_nhwc(ops._p(dy), Cout, ops._p(wp), ops._p(dxp), Cin, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
+                                     ops._stream()) == 0
+    xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    o = F.conv2d(xd, wd, stride=stride, padding=pad)
+    gx, gw = torch.autograd.grad(o, [xd, wd], dy.double().cpu().permute(0, 3, 1, 2))
+    sx = float(gx.abs().max())
+    assert float((dx.double().cpu() - gx.permute(0, 2, 3, 1)).abs().max()) < 1e-5 * sx
+    assert float((dx - dxp).abs().max()) < 1e-5 * sx
+    dw = ops.unpack_conv_weight(ops.conv2d_wgrad(x, dy, Cout, k, k, stride, pad)[0], (Cout, Cin, k, k))
+    assert float((dw.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())

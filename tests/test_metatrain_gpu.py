@@ -396,3 +396,46 @@ def test_one_launch_repack_after_in_place_update():
     # a model moved / re-created gets a new pack
     model2 = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
     assert AG.module_weights(model2.feature) is not W0
+
+
+@pytest.mark.parametrize("variant", ["gnnnet", "gnnnet_copy"])
+def test_graphed_episode_loop_is_bit_identical(variant, capsys, monkeypatch):
+    """MetaTemplate's episode loop (meta_template.py:76-92) with forward + backward replayed from ONE hipGraph after three eager
+    steps (graph_step.GraphedLossBackward) against the plain loop: the printed loss lines and every parameter after 9 steps
+    with the fused outer Adam must match bit for bit -- also after the loader changes the episode's shape (recapture) and when
+    the optimizer runs between replays."""
+    from meta_fine_tuning_amd import graph_step, optim
+    from meta_fine_tuning_amd.methods import gnnnet_copy
+    cls, n_shot, size = (GnnNet, 5, 84) if variant == "gnnnet" else (gnnnet_copy.GnnNet, 50, 42)
+    eps = [synthetic.train_episode(700 + i, 5, n_shot, 16, size) for i in range(5)]              # host tensors, as a DataLoader yields
+    eps += [synthetic.train_episode(710 + i, 5, n_shot, 12, size) for i in range(4)]             # the loader switches to 12 queries
+
+    class Loader:
+        def __len__(self):
+            return len(eps)
+
+        def __iter__(self):
+            for x in eps:
+                yield x, None
+
+    def run(graphed):
+        monkeypatch.setattr(graph_step, "ENABLED", graphed)
+        torch.manual_seed(0)
+        model = cls(model_dict['ResNet10'], n_way=5, n_support=n_shot).cuda()
+        model.load_state_dict(synthetic.gnnnet_state_dict(seed=27))
+        model.train()
+        opt = optim.Adam(model.parameters())
+        capsys.readouterr()
+        (model.train_loop if variant == "gnnnet" else model.train_loop50)(0, Loader(), opt)
+        out = capsys.readouterr().out
+        st = model.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss")
+        return out, [p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()], st
+
+    out_e, par_e, buf_e, st_e = run(False)
+    out_g, par_g, buf_g, st_g = run(True)
+    assert st_e is None and st_g is not None and st_g.graph is not None and not st_g.failed           # the second shape was captured too
+    assert out_g == out_e and out_e.count("Loss") == 1
+    for a, b in zip(par_e, par_g):
+        assert torch.equal(a, b)
+    for a, b in zip(buf_e, buf_g):
+        assert torch.equal(a, b)
