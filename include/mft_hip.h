@@ -232,6 +232,12 @@ int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, fl
                           int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int imgs_per_group, long long dw_group_stride, float* ws, void* stream);
 
+/* mft_conv2d_wgrad_nhwc for one weight set, gradient written as torch's [Cout][Cin][KH][KW] (Conv2d.weight.grad): the sum over
+ * the split-M partials does the permutation (replaces wgrad + mft_unpack_oihw in the meta-training backward). */
+long long mft_conv2d_wgrad_oihw_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, int ldy, float* dw_oihw, int n_img, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream);
+
 /* conv weight gradient with torch.optim.Adam.step fused into the epilogue (finetune.py:293-299): the gradient tile stays
  * in MFMA accumulators; w, m, v (same packed layout / group stride as dw) are updated in place.  dw_or_null, when given,
  * also receives the gradient.  Same Adam form as mft_adam_step (no weight decay).                                    */

@@ -40,6 +40,8 @@ SIGNATURES = {
     "mft_conv_ksplit_ws_floats": [_L, _I, _I],
     "mft_conv2d_nhwc_ksplit": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_dgrad_nhwc_ksplit": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "mft_conv2d_wgrad_oihw_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "mft_conv2d_wgrad_oihw": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,
@@ -126,7 +128,7 @@ SIGNATURES = {
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L,
-            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L, "mft_conv_ksplit_ws_floats": _L}
+            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L, "mft_conv_ksplit_ws_floats": _L, "mft_conv2d_wgrad_oihw_ws_floats": _L}
 
 _lib = None
 

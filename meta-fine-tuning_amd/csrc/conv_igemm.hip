@@ -47,10 +47,12 @@ struct ConvArgs {
     int bt_stride;       // BT (data-gradient) mode: stride of the forward convolution
     int ksplit;          // > 1: grid.z slices of the K walk, partial tiles to ws[z][rows][Cout] (summed in slice order afterwards)
     float* ws;
+    int parity;          // BT with bt_stride == 2, one weight set: blockIdx.y = parity class (h & 1, w & 1) of the dx pixels of the tile
 };
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
+int g_dgrad_parity = 1; // stride-2 data gradients by pixel parity class (mft_debug_set_conv_tile(9800/9801))
 int g_wgrad_tile = 64; // 64 (default: 17 KB LDS lets conv workgroups of the other stream co-reside) or 128
 int g_conv_tile = 0;   // 0 = automatic; 1..5 force a tile (mft_debug_set_conv_tile, tuning only)
 int g_wgrad_pol = 7;          // w/m/v cache policy: bit 0 nontemporal loads, bit 1 nontemporal stores; bit 2 (wgrad_adam_rows_kernel):
@@ -91,12 +93,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     const int nt = tile_id % p.tiles_n;
     const int mt = tile_id / p.tiles_n;
-    const int g = blockIdx.y;
+    // Data gradient of a stride-2 convolution: dx pixel (h, w) receives only the taps with kh = (h + pad) mod 2, kw = (w + pad) mod 2
+    // (1, 2 or 4 of 9 for 3x3 / pad 1; 1 or 0 for the 1x1 shortcut) -- walking all nine with zero rows wastes 3/4 of the matrix work.
+    // In parity mode a tile holds dx pixels of ONE class (ph, pw) = blockIdx.y, numbered (img, i, j) with h = 2i + ph, w = 2j + pw,
+    // and its K walk covers that class's taps only.
+    const bool par = BT && p.parity != 0;
+    const int g = par ? 0 : blockIdx.y;
+    const int ph = par ? (int)(blockIdx.y >> 1) : 0, pw = par ? (int)(blockIdx.y & 1) : 0;
+    const int Hc = par ? (p.OH - ph + 1) / 2 : p.OH, Wc = par ? (p.OW - pw + 1) / 2 : p.OW;
+    const int rows = par ? p.imgs_per_group * Hc * Wc : p.rows_per_group;      // rows of this launch slice (class or group)
     const int m0 = mt * BM, n0 = nt * BN;
+    if (par && m0 >= rows) return;
+    const int kh0 = par ? ((ph - p.pad) & 1) : 0, kw0 = par ? ((pw - p.pad) & 1) : 0;         // p.pad = -pad_fwd in BT mode
+    const int nkh = par ? (p.KH - kh0 + 1) / 2 : p.KH, nkw = par ? (p.KW - kw0 + 1) / 2 : p.KW;
 
     const int lrow = tid >> 3;        // 0..31
     const int c4 = (tid & 7) * 4;     // 0..28
-    const int ohw = p.OH * p.OW;
+    const int ohw = Hc * Wc;
 
     // per-thread A row descriptors
     long long a_base[PA];
@@ -105,11 +118,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         int m = m0 + lrow + 32 * j;
-        a_ok[j] = m < p.rows_per_group;
+        a_ok[j] = m < rows;
         int mm = a_ok[j] ? m : 0;
         int img = mm / ohw;
         int rem = mm - img * ohw;
-        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int oh = rem / Wc, ow = rem - oh * Wc;
+        if (par) { oh = 2 * oh + ph; ow = 2 * ow + pw; }
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
         a_base[j] = (long long)(g * p.imgs_per_group + img) * p.H * p.W;
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[PA], rb[PB];
-    const int nk_all = p.Kpad / BK;
+    const int nk_all = par ? nkh * nkw * (p.Cin / BK) : p.Kpad / BK;
     const int kt0 = p.ksplit > 1 ? (int)((long long)blockIdx.z * nk_all / p.ksplit) : 0;
     const int nk = p.ksplit > 1 ? (int)((long long)(blockIdx.z + 1) * nk_all / p.ksplit) : nk_all;
 
@@ -151,7 +165,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         if (!STEM) {
             const int khkw = k0 / p.Cin;
             const int ci0 = k0 - khkw * p.Cin;
-            const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
+            int kh = khkw / nkw, kw = khkw - kh * nkw;
+            if (par) { kh = kh0 + 2 * kh; kw = kw0 + 2 * kw; }
 #pragma unroll
             for (int j = 0; j < PA; ++j) {
                 int ih, iw;
@@ -197,8 +212,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 rb[j] = v;
             }
         } else {
-            const int khkw = k0 / p.Cin;                 // p.Cin = forward Cout (reduction channels)
+            int khkw = k0 / p.Cin;                       // p.Cin = forward Cout (reduction channels)
             const int co0 = k0 - khkw * p.Cin;
+            if (par) { const int a = khkw / nkw; khkw = (kh0 + 2 * a) * p.KW + kw0 + 2 * (khkw - a * nkw); }
             const long long off = (long long)co0 * ((long long)p.KH * p.KW * p.Cout) + (long long)khkw * p.Cout;
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
@@ -222,8 +238,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
-    load_tile(kt0);
-    store_tile(0);
+    if (kt0 < nk) {
+        load_tile(kt0);
+        store_tile(0);
+    }
     __syncthreads();
 
     for (int kt = kt0; kt < nk; ++kt) {
@@ -293,7 +311,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int m = m0 + wm * (BM / WM) + i * 32 + row;
-                if (m < p.rows_per_group) p.out[(out_row0 + m) * p.ldo + n] = acc[i][j][e] + bias;
+                if (m >= rows) continue;
+                long long orow = out_row0 + m;
+                if (par) {                                   // class-local (img, i, j) -> dx pixel (img, 2i + ph, 2j + pw)
+                    const int img = m / ohw, rem = m - img * ohw;
+                    const int ii = rem / Wc, jj = rem - ii * Wc;
+                    orow = ((long long)img * p.OH + 2 * ii + ph) * p.OW + 2 * jj + pw;
+                }
+                p.out[orow * p.ldo + n] = acc[i][j][e] + bias;
             }
         }
 }
@@ -342,7 +367,13 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (p.ksplit > 1 && (groups != 1 || p.ws == nullptr)) return MFT_EINVAL;
+    if (p.ksplit > 1 && (groups != 1 || p.ws == nullptr || p.parity)) return MFT_EINVAL;
+    if (p.parity) {
+        if (!BT || groups != 1 || p.bt_stride != 2) return MFT_EINVAL;
+        const int tm = cdiv(p.imgs_per_group * ((p.OH + 1) / 2) * ((p.OW + 1) / 2), BM);       // the largest class
+        hipLaunchKernelGGL(kern, dim3(tm * p.tiles_n, 4, 1), dim3(256), lds, s, p);
+        return mft_launch_status();
+    }
     dim3 grid(tiles_m * p.tiles_n, groups, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (p.ksplit > 1) {
@@ -374,6 +405,7 @@ struct WgradArgs {
     // split-M: grid.z chunks of chunk_rows rows each write partial gradients to ws (reduced afterwards)
     int chunk_rows, chunks;
     float* ws;
+    int oihw;            // plain weight gradient: partials always go through ws and the chunk sum writes torch's [Cout][Cin][KH][KW] layout
     int ws_inv_ow;       // wgrad_adam_rows_kernel: ceil(65536 / OW) (chunk_rows then holds ceil(65536 / (OH*OW)))
     int mma_rows;        // wgrad_adam_rows_kernel: reduction rows that get matrix instructions (rows_per_group, or 64 = the padded form)
 };
@@ -508,8 +540,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
     if (!ADAM) {
-        float* dwg = (p.chunks > 1) ? p.ws + ((long long)g * p.chunks + blockIdx.z) * p.dwgs
-                                    : p.dw + (long long)g * p.dwgs;
+        float* dwg = (p.chunks > 1 || p.oihw) ? p.ws + ((long long)g * p.chunks + blockIdx.z) * p.dwgs
+                                              : p.dw + (long long)g * p.dwgs;
         const int ci_lim = STEMW ? p.Kpad : p.Cin;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -996,6 +1028,22 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
     }
 }
 
+// the chunk sum writing the gradient where autograd wants it: packed [Cout][(tap, ci)] partials -> dw[Cout][Cin][KH][KW]
+// (one launch instead of reduce + mft_unpack_oihw; single weight set)
+__global__ __launch_bounds__(256) void reduce_chunks_oihw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout,
+                                                                 int Cin, int taps, int Kpad, int chunks) {
+    const long long n = (long long)Cout * Kpad;
+    const int K = taps * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Kpad), k = (int)(i - (long long)co * Kpad);
+        if (k >= K) continue;
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += ws[(long long)c * n + i];
+        const int tap = k / Cin, ci = k - tap * Cin;
+        dw[((long long)co * Cin + ci) * taps + tap] = s;
+    }
+}
+
 template <int BM, int BN, bool ADAM, bool STEMW = false, bool EARLYT = false, int POL = 3>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
@@ -1016,7 +1064,13 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     p.tiles_co = (a.Cout + BM - 1) / BM;
     dim3 grid(p.tiles_ci * p.tiles_co * taps, groups, p.chunks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    if (p.chunks > 1) {
+    if (p.oihw) {
+        const long long n = (long long)a.Cout * a.Kpad;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_chunks_oihw_kernel, dim3(blocks), dim3(256), 0, s, (const float*)p.ws, p.dw, a.Cout, a.Cin,
+                           a.KH * a.KW, a.Kpad, p.chunks);
+    } else if (p.chunks > 1) {
         const long long n = (long long)a.Cout * a.Kpad;
         int blocks = (int)((n + 255) / 256);
         if (blocks > 2048) blocks = 2048;
@@ -1066,6 +1120,7 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     a.chunk_rows = a.rows_per_group;
     a.chunks = 1;
     a.ws = ws;
+    if (a.oihw && (adam || ws == nullptr || groups != 1)) return MFT_EINVAL;
     if (!adam && ws != nullptr) wgrad_chunking(a.rows_per_group, wgrad_wgs_per_chunk(a.Cin, a.Cout, a.KH, a.KW, groups), &a.chunk_rows, &a.chunks);
     const int taps = a.KH * a.KW;
     if (stem) return adam ? MFT_EINVAL : launch_wgrad<64, 64, false, true>(a, 1, groups, s);
@@ -1108,7 +1163,7 @@ static int conv2d_impl(const float* in, int ldi, const float* w, const float* bi
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
     a.bt_stride = 1;
-    a.ksplit = 1; a.ws = nullptr;
+    a.ksplit = 1; a.ws = nullptr; a.parity = 0;
     if (ws != nullptr && !stem && groups == 1 && ldo % 4 == 0) {
         a.ksplit = conv_ksplit(a.rows_per_group, Cout, a.Kpad);
         a.ws = ws;
@@ -1180,7 +1235,8 @@ extern "C" int mft_debug_set_conv_tile(int tile) {
     if (tile >= 9000 && tile < 9100 && tile != 9003 && tile != 9007) return MFT_EINVAL;        // cache-policy / ablation variants
     if (tile > 4000 && tile < 5000) return MFT_EINVAL;                                         // occupancy throttle
 #endif
-    if (tile >= 9700) mft_skinny_set_lines(tile - 9700);
+    if (tile >= 9800) g_dgrad_parity = tile - 9800;          // 9800 / 9801: stride-2 data gradient over all taps / by pixel parity class
+    else if (tile >= 9700) mft_skinny_set_lines(tile - 9700);
     else if (tile >= 9600) g_wgrad_trim = tile - 9600;
     else if (tile >= 9500) g_wgrad_rows = tile - 9500;
     else if (tile >= 9100) mft_skinny_set_nw(tile - 9100);
@@ -1204,7 +1260,7 @@ extern "C" int mft_debug_set_x3_tile(int t);
 extern "C" void mft_wgrad_fwd_set_exact(int on);
 extern "C" int mft_debug_reset(void) {
     mft_wgrad_fwd_set_exact(0);
-    g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
+    g_dgrad_parity = 1; g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
     mft_skinny_set_lines(1); mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(70); mft_debug_set_x3_tile(80); mft_debug_set_x3_tile(91); mft_debug_set_x3_tile(100); mft_debug_set_x3_tile(200);
@@ -1241,7 +1297,8 @@ static int dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int l
     a.wgs = (groups > 1) ? w_group_stride : 0;
     a.tiles_n = 0;
     a.ksplit = 1; a.ws = nullptr;
-    if (ws != nullptr && groups == 1 && ldx % 4 == 0 && Cin % 64 == 0) {
+    a.parity = (groups == 1 && stride == 2 && g_dgrad_parity) ? 1 : 0;
+    if (!a.parity && ws != nullptr && groups == 1 && ldx % 4 == 0 && Cin % 64 == 0) {
         a.ksplit = conv_ksplit(a.rows_per_group, Cin, a.Kpad);
         a.ws = ws;
     }
@@ -1284,6 +1341,26 @@ extern "C" int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, 
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.dwgs = dw_group_stride;
     return wgrad_dispatch(a, n_img, imgs_per_group, false, ws, (hipStream_t)stream);
+}
+
+// mft_conv2d_wgrad_nhwc for ONE weight set with the gradient written in torch's [Cout][Cin][KH][KW] layout (what
+// Conv2d.weight.grad holds): the partial-gradient sum does the permutation.  ws: mft_conv2d_wgrad_oihw_ws_floats floats.
+extern "C" long long mft_conv2d_wgrad_oihw_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    int chunk_rows, chunks;
+    wgrad_chunking((long long)n_img * OH * OW, wgrad_wgs_per_chunk(Cin, Cout, KH, KW, 1), &chunk_rows, &chunks);
+    return (long long)chunks * Cout * ((KH * KW * Cin + 31) / 32 * 32);
+}
+
+extern "C" int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, int ldy, float* dw_oihw, int n_img, int H, int W,
+                                     int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream) {
+    if (ws == nullptr) return MFT_EINVAL;
+    WgradArgs a = {};
+    a.in = in; a.dy = dy; a.dw = dw_oihw; a.ldi = ldi; a.ldy = ldy;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.oihw = 1;
+    a.dwgs = (long long)Cout * ((KH * KW * Cin + 31) / 32 * 32);
+    return wgrad_dispatch(a, n_img, 0, false, ws, (hipStream_t)stream);
 }
 
 static int wgrad_adam_impl(const float* in, int ldi, const float* dy, int ldy, float* w, float* m, float* v,

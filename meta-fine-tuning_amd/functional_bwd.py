@@ -132,24 +132,21 @@ def resnet10_backward(W, t, dfeat, need):
         dc2, dg, db = bn_bwd(b["c2"].view(-1, cout), d2, cout, rows, b["m2"], b["s2"], g2, y_act=o2, act=RELU)
         grads[p + ".BN2.weight"], grads[p + ".BN2.bias"] = dg, db
         dc2 = dc2.view(out.shape)
-        grads[p + ".C2.weight"] = ops.unpack_conv_weight(
-            ops.conv2d_wgrad(b["r1"], dc2, cout, 3, 3, 1, 1)[0], (cout, cout, 3, 3))
+        grads[p + ".C2.weight"] = ops.conv2d_wgrad_oihw(b["r1"], dc2, cout, 3, 3, 1, 1)
         dr1 = ops.conv2d_dgrad(dc2, W.conv[p + ".C2"], cout, 3, 3, 1)
         g1 = W.bn[p + ".BN1"][0]
         dc1, dg, db = bn_bwd(b["c1"].view(-1, cout), dr1.view(-1, cout), cout, rows, b["m1"], b["s1"], g1,
                              y_act=b["r1"].view(-1, cout), act=RELU)
         grads[p + ".BN1.weight"], grads[p + ".BN1.bias"] = dg, db
         dc1 = dc1.view(out.shape)
-        grads[p + ".C1.weight"] = ops.unpack_conv_weight(
-            ops.conv2d_wgrad(x_in, dc1, cout, 3, 3, stride, 1)[0], (cout, cin, 3, 3))
+        grads[p + ".C1.weight"] = ops.conv2d_wgrad_oihw(x_in, dc1, cout, 3, 3, stride, 1)
         dx = ops.conv2d_dgrad(dc1, W.conv[p + ".C1"], cin, 3, 3, 1, stride=stride, in_hw=(H_in, H_in))
         if cin != cout:
             gs = W.bn[p + ".BNshortcut"][0]
             dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU)
             grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dg, db
             dsc = dsc.view(out.shape)
-            grads[p + ".shortcut.weight"] = ops.unpack_conv_weight(
-                ops.conv2d_wgrad(x_in, dsc, cout, 1, 1, stride, 0)[0], (cout, cin, 1, 1))
+            grads[p + ".shortcut.weight"] = ops.conv2d_wgrad_oihw(x_in, dsc, cout, 1, 1, stride, 0)
             dxs = ops.conv2d_dgrad(dsc, W.conv[p + ".shortcut"], cin, 1, 1, 0, stride=stride, in_hw=(H_in, H_in))
             act_backward(dxs.view(-1, cin), dxs.view(-1, cin), dx.view(-1, cin), cin, NONE, True)
         else:
@@ -164,8 +161,7 @@ def resnet10_backward(W, t, dfeat, need):
     g0 = W.bn["trunk.1"][0]
     dc0, dg, db = bn_bwd(c0.view(-1, 64), d_bn0.view(-1, 64), 64, n * H0 * H0, t["m0"], t["s0"], g0)
     grads["trunk.1.weight"], grads["trunk.1.bias"] = dg, db
-    dw0 = ops.conv2d_wgrad(t["x"], dc0.view(c0.shape), 64, 7, 7, 2, 3)[0]
-    grads["trunk.0.weight"] = ops.unpack_conv_weight(dw0, (64, 3, 7, 7))
+    grads["trunk.0.weight"] = ops.conv2d_wgrad_oihw(t["x"], dc0.view(c0.shape), 64, 7, 7, 2, 3)
     return grads
 
 

@@ -304,6 +304,20 @@ def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None, l
     return out
 
 
+def conv2d_wgrad_oihw(x, dy, Cout, KH, KW, stride, pad):
+    """Weight gradient of a shared-weight convolution as torch lays Conv2d.weight.grad out: [Cout, Cin, KH, KW]."""
+    _f32c(x)
+    _f32c(dy)
+    n, H, W, Cin = x.shape
+    out = torch.empty((Cout, Cin, KH, KW), device=x.device, dtype=torch.float32)
+    ws = torch.empty((int(_lib.lib().mft_conv2d_wgrad_oihw_ws_floats(n, H, W, Cin, Cout, KH, KW, stride, pad)),), device=x.device,
+                     dtype=torch.float32)
+    rc = _lib.lib().mft_conv2d_wgrad_oihw(_p(x), Cin, _p(dy), dy.shape[-1], _p(out), n, H, W, Cin, Cout, KH, KW, stride, pad, _p(ws),
+                                          _stream())
+    _lib.check(rc, "mft_conv2d_wgrad_oihw")
+    return out
+
+
 def conv2d_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group=0, lr=0.01, beta1=0.9,
                       beta2=0.999, eps=1e-8, dw=None, hyper=None):
     """Weight gradient of a conv with the Adam update of (w, m, v) [groups, Cout, KH*KW*Cin] fused in the epilogue.

@@ -339,8 +339,12 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
     ref = F.conv2d(x.double(), w.double(), None, stride, pad)
     xg = nhwc(x).to(DEV)
     wpk = ops.pack_conv_weight(w.to(DEV))
-    y32 = nchw(ops.conv2d(xg, wpk, Cout, k, k, stride, pad).cpu()).double()
     from meta_fine_tuning_amd import _lib
+    OH = (H + 2 * pad - k) // stride + 1
+    y32g = torch.empty((n, OH, OH, Cout), device=DEV)          # the fp32-MFMA kernel walking K in one piece (ops.conv2d slices K on small batches)
+    assert _lib.lib().mft_conv2d_nhwc(ops._p(xg), Cin, ops._p(wpk), None, ops._p(y32g), Cout, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
+                                      ops._stream()) == 0
+    y32 = nchw(y32g.cpu()).double()
     scale = max(float(ref.abs().max()), 1.0)
     e32 = float((y32 - ref).abs().max())
     w3 = ops.split_weight_x3(wpk)
@@ -968,7 +972,8 @@ def test_bn_apply_from_partials_is_bit_identical(C, H, ipg, G, res):
 
 
 @pytest.mark.parametrize("n,H,Cin,Cout,k,stride,pad", [(105, 3, 512, 512, 3, 1, 1), (105, 6, 256, 512, 3, 2, 1), (105, 11, 128, 256, 3, 2, 1),
-                                                       (105, 6, 256, 256, 3, 1, 1), (21, 6, 256, 512, 1, 2, 0)])
+                                                       (105, 6, 256, 256, 3, 1, 1), (21, 6, 256, 512, 1, 2, 0), (9, 21, 64, 128, 3, 2, 1),
+                                                       (7, 11, 128, 256, 1, 2, 0)])
 def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride, pad):
     """One 105-image meta-training episode leaves the deep layers with 60-240 output tiles and 72-144 K-steps each: the K-sliced
     forward / data-gradient launches (partials summed in slice order) against the plain launches and against float64, and the
@@ -981,7 +986,7 @@ def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride,
     wp = ops.pack_conv_weight(w.to(DEV))
     OH = (H + 2 * pad - k) // stride + 1
     sliced = int(lib.mft_conv_ksplit_ws_floats(n * OH * OH, Cout, wp.shape[-1])) > 0
-    assert sliced == (k == 3)                                     # the 1x1 shortcut (K = 256: 8 K-steps) is not sliced
+    assert sliced == (k == 3)                                     # the 1x1 shortcuts (K <= 256: 8 K-steps) are not sliced
     out = ops.conv2d(x, wp, Cout, k, k, stride, pad, bias=b)                 # takes the sliced form where it applies
     plain = torch.empty_like(out)
     assert lib.mft_conv2d_nhwc(ops._p(x), Cin, ops._p(wp), ops._p(b), ops._p(plain), Cout, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
@@ -993,8 +998,12 @@ def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride,
     dy = nhwc(rnd((n, Cout, OH, OH), 94)).to(DEV)
     dx = ops.conv2d_dgrad(dy, wp, Cin, k, k, pad, stride=stride, in_hw=(H, H))
     dxp = torch.empty_like(dx)
-    assert lib.mft_conv2d_dgrad_nhwc(ops._p(dy), Cout, ops._p(wp), ops._p(dxp), Cin, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
-                                     ops._stream()) == 0
+    lib.mft_debug_set_conv_tile(9800)                             # all nine taps with zero rows instead of the parity-class walk (stride 2)
+    try:
+        assert lib.mft_conv2d_dgrad_nhwc(ops._p(dy), Cout, ops._p(wp), ops._p(dxp), Cin, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
+                                         ops._stream()) == 0
+    finally:
+        lib.mft_debug_reset()
     xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
     wd = w.double().requires_grad_(True)
     o = F.conv2d(xd, wd, stride=stride, padding=pad)
@@ -1004,3 +1013,20 @@ def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride,
     assert float((dx - dxp).abs().max()) < 1e-5 * sx
     dw = ops.unpack_conv_weight(ops.conv2d_wgrad(x, dy, Cout, k, k, stride, pad)[0], (Cout, Cin, k, k))
     assert float((dw.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
+
+
+@pytest.mark.parametrize("n,H,Cin,Cout,k,stride,pad", [(105, 21, 64, 64, 3, 1, 1), (105, 6, 256, 512, 3, 2, 1), (21, 11, 128, 256, 1, 2, 0),
+                                                       (4, 84, 3, 64, 7, 2, 3), (3, 6, 256, 256, 3, 1, 1)])
+def test_conv_wgrad_written_as_oihw(n, H, Cin, Cout, k, stride, pad):
+    """mft_conv2d_wgrad_oihw (the split-M partial sum writes Conv2d.weight.grad's layout) against wgrad + mft_unpack_oihw (bit for
+    bit: same partials, same summation order) and against float64."""
+    x = nhwc(rnd((n, Cin, H, H), 95)).to(DEV)
+    OH = (H + 2 * pad - k) // stride + 1
+    dy = nhwc(rnd((n, Cout, OH, OH), 96)).to(DEV)
+    got = ops.conv2d_wgrad_oihw(x, dy, Cout, k, k, stride, pad)
+    ref = ops.unpack_conv_weight(ops.conv2d_wgrad(x, dy, Cout, k, k, stride, pad)[0], (Cout, Cin, k, k))
+    assert got.shape == (Cout, Cin, k, k) and torch.equal(got, ref)
+    xd = x.double().cpu().permute(0, 3, 1, 2)
+    wd = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    gw, = torch.autograd.grad(F.conv2d(xd, wd, stride=stride, padding=pad), wd, dy.double().cpu().permute(0, 3, 1, 2))
+    assert float((got.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
