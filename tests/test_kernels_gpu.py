@@ -1030,3 +1030,28 @@ def test_conv_wgrad_written_as_oihw(n, H, Cin, Cout, k, stride, pad):
     wd = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
     gw, = torch.autograd.grad(F.conv2d(xd, wd, stride=stride, padding=pad), wd, dy.double().cpu().permute(0, 3, 1, 2))
     assert float((got.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
+
+
+@pytest.mark.parametrize("n,H,C", [(5, 42, 64), (3, 13, 32), (2, 8, 6)])
+def test_maxpool_relu_backward_matches_autograd(n, H, C):
+    """BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) of the stem (backbone.py:295-297) with the argmax recorded, and its gradient w.r.t.
+    the BatchNorm output (four channels per thread where C % 4 == 0, scalar otherwise) against torch autograd."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    x = nhwc(rnd((n, C, H, H), 97)).to(DEV)
+    PH = (H + 2 - 3) // 2 + 1
+    y = torch.empty((n, PH, PH, C), device=DEV)
+    arg = torch.empty((n, PH, PH, C), device=DEV, dtype=torch.uint8)
+    zeros, ones = torch.zeros((1, C), device=DEV), torch.ones((1, C), device=DEV)
+    rstd = torch.full((1, C), float(1.0 / np.sqrt(1.0 + 1e-5)), device=DEV)
+    assert lib.mft_bn_relu_maxpool_arg(ops._p(x), ops._p(y), ops._p(arg), n, H, H, C, n, ops._p(zeros), ops._p(ones), ops._p(ones),
+                                       ops._p(zeros), ops._stream()) == 0
+    del rstd
+    xa = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    ya = F.max_pool2d(F.relu(xa), 3, 2, 1)
+    assert float((y.double().cpu().permute(0, 3, 1, 2) - ya).abs().max()) < 1e-6
+    dy = nhwc(rnd((n, C, PH, PH), 98)).to(DEV)
+    gx, = torch.autograd.grad(ya, xa, dy.double().cpu().permute(0, 3, 1, 2))
+    dx = torch.empty_like(x)
+    assert lib.mft_maxpool_relu_backward(ops._p(dy), ops._p(arg), ops._p(y), ops._p(dx), n, H, H, C, ops._stream()) == 0
+    assert float((dx.double().cpu().permute(0, 3, 1, 2) - gx).abs().max()) < 1e-6
