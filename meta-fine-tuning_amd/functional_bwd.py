@@ -281,7 +281,7 @@ def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
         L.check(lib.mft_pair_bn_act_backward(ops._p(dh), dh.shape[1], ops._p(z), cout, ops._p(sc), ops._p(sh), ops._p(m), ops._p(s),
                                              ops._p(gam), ops._p(ij), N, rows, n_tot, ops.LRELU_SLOPE, ops._p(ws), ops._p(sums), ops._p(dz),
                                              ops._stream()), "mft_pair_bn_act_backward")
-        grads[prefix + ".bn_%d.weight" % (li + 1)], grads[prefix + ".bn_%d.bias" % (li + 1)] = sums[cout:].clone(), sums[:cout].clone()
+        grads[prefix + ".bn_%d.weight" % (li + 1)], grads[prefix + ".bn_%d.bias" % (li + 1)] = sums[cout:], sums[:cout]      # (views of this layer's own buffer)
         if li > 0:
             K = layers[li - 1][4]
             hin = _pair_activation(t, li - 1, layers, rows)
