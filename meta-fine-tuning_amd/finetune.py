@@ -700,7 +700,7 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     if model_cls is None:
         model_cls = gnnnet_copy.GnnNet if params.n_shot == 50 else GnnNet
     if episodes_per_batch is None:
-        episodes_per_batch = int(os.environ.get("MFT_EPISODES_PER_BATCH", {5: 128, 20: 64}.get(params.n_shot, 32)))
+        episodes_per_batch = int(os.environ.get("MFT_EPISODES_PER_BATCH", {5: 128, 20: 96, 50: 64}.get(params.n_shot, 32)))
     model = state = state_b = None
     f_gnn, f_b = checkpoint_files(params)
     main.loaded = {"gnnnet": None, "baseline": None}                 # what was actually read (tests, logs)
