@@ -36,9 +36,12 @@ def main():
         from meta_fine_tuning_amd import configs
         configs.save_dir = tempfile.mkdtemp()
         torch.manual_seed(0)
-        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=2 * W + (W - 1), size=84)          # n_episode % W != 0: every rank must still run 2 steps
+        steps = int(os.environ.get("MFT_TEST_TRAIN_STEPS", "2"))
+        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=steps * W + (W - 1), size=84)          # n_episode % W != 0: every rank must still run `steps` steps
         out = {k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k in
                ("fc.0.weight", "gnn.layer_last.fc.weight", "feature.trunk.7.C2.weight", "feature.trunk.0.weight")}
+        st = m.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss")
+        out["graphed"] = np.int32(1 if (st is not None and st.graph is not None) else 0)
         np.savez(a.out + ".%d.npz" % rank, **out)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

@@ -220,8 +220,8 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, out, nproc):
-    env = dict(os.environ, MFT_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+def _run_ranks(mode, out, nproc, **extra_env):
+    env = dict(os.environ, MFT_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **extra_env)
     worker = os.path.join(ROOT, "tests", "dist_worker.py")
     if nproc == 1:
         cmd = [sys.executable, worker, "--mode", mode, "--out", out]
@@ -250,9 +250,10 @@ def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
     gradients / 2, the same fused Adam step on both ranks.  Both ranks end with identical parameters, and they equal the
     single-process emulation "accumulate the 2 episodes' gradients from common parameters, divide by 2, one Adam step"."""
     _run_ranks("train", str(tmp_path / "t2"), 2)
-    p0 = np.load(str(tmp_path / "t2.0.npz"))
-    p1 = np.load(str(tmp_path / "t2.1.npz"))
-    for k in p0.files:
+    p0 = dict(np.load(str(tmp_path / "t2.0.npz")))
+    p1 = dict(np.load(str(tmp_path / "t2.1.npz")))
+    assert int(p0.pop("graphed")) == 0 and int(p1.pop("graphed")) == 0          # two steps per rank: still in the eager warm-up
+    for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
     # emulation in this process: 2 epoch-steps x 2 episodes each (n_episode = 4: rank r takes episodes r, r+2)
     from meta_fine_tuning_amd import optim
@@ -273,10 +274,24 @@ def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
             p.grad = g / 2
         opt.step()
     named = dict(model.named_parameters())
-    for k in p0.files:
+    for k in p0:
         d = np.abs(named[k].detach().cpu().numpy() - p0[k])
         # two Adam steps of <= lr = 1e-3 each; identical up to summation-order rounding on near-zero gradients
         assert (d < 2e-5).mean() > 0.995 and d.max() <= 2.1e-3, (k, d.max(), (d < 2e-5).mean())
+
+
+def test_two_rank_meta_training_graphed_equals_eager(tmp_path):
+    """Episode-parallel meta-training with the forward + backward replayed from a hipGraph (captured on every rank's 4th step;
+    the flat-bucket all-reduce and the fused Adam step stay outside the graph) against the same 2-rank run with eager launches:
+    six steps per rank, both ranks, bit for bit."""
+    _run_ranks("train", str(tmp_path / "g"), 2, MFT_TEST_TRAIN_STEPS="6", MFT_TRAIN_GRAPH="1")
+    _run_ranks("train", str(tmp_path / "e"), 2, MFT_TEST_TRAIN_STEPS="6", MFT_TRAIN_GRAPH="0")
+    for r in range(2):
+        g, e = np.load(str(tmp_path / ("g.%d.npz" % r))), np.load(str(tmp_path / ("e.%d.npz" % r)))
+        assert int(g["graphed"]) == 1 and int(e["graphed"]) == 0
+        for k in e.files:
+            if k != "graphed":
+                assert np.array_equal(g[k], e[k]), (r, k)
 
 
 @pytest.mark.gpu
