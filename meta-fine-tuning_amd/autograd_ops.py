@@ -245,6 +245,16 @@ def invalidate(mod):
         m.__dict__.pop("_mft_pack", None)
 
 
+def touch(mod):
+    """Mark the cached packed weights stale but keep them: the next lookup refreshes every packed copy IN PLACE (one launch) instead
+    of rebuilding the pack -- for in-place parameter updates that do not bump autograd's version counters (kernels writing
+    ``p.data``).  Anything recorded against the pack's buffers (a captured inner loop) stays valid."""
+    for m in mod.modules():
+        c = m.__dict__.get("_mft_pack")
+        if c is not None:
+            m.__dict__["_mft_pack"] = (tuple((k[0], -1) for k in c[0]), c[1])
+
+
 def gnnnet_head(model, feats, n_support, n_query, fold=False):
     """GnnNet.fc + z_stack + forward_gnn for one episode (gnnnet.py:76-87,210-217): feats [n_way*(S+n_query), 512]
     -> scores [n_way*n_query, n_way].  Differentiable (hand-written backward) when autograd is recording."""

@@ -731,36 +731,41 @@ _ADAPT_STREAMS = {}
 _ADAPT_ARENAS = {}
 
 
-def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=None):
-    """The inner loop of GnnNet.set_forward_finetune (gnnnet.py:126-177) for one episode: Adam(lr=0.01) on the last
-    ResNet block of a *copy* of ``feature_mod`` over ``epochs`` permutations of the support set in mini-batches of
-    ``batch_size`` (ragged tail allowed).  x_a: [n,3,H,W] device NCHW; y_a: int32 numpy labels.
-    Returns {state_dict key: tensor} for the nine adapted tensors and the BatchNorm running buffers."""
+ADAPT_GRAPH = os.environ.get("MFT_ADAPT_GRAPH", "1") == "1"
+_ADAPT_GRAPHS = {}
+
+
+class _AdaptLoop:
+    """Static buffers (and, from the second call on, ONE hipGraph) of adapt_last_block for one (module weights, episode shape):
+    the inner loop of a meta-fine-tuning training episode is ~105 Adam steps x ~45 launches on FOUR images each -- 57 ms of
+    launch overhead per episode when issued from Python, and the same launch sequence every episode (the step sizes, the Adam
+    step numbers and every buffer are fixed; only the support images, the permutation tables and the weights' VALUES change)."""
+
+    def __init__(self, W, dev, n, H, n_steps_idx):
+        self.W, self.dev = W, dev
+        self.ad = AdaptState(1, dev)
+        self.Xs = torch.empty((n, H * H * 3), device=dev, dtype=torch.float32)
+        self.idx_all = torch.zeros((n_steps_idx,), device=dev, dtype=torch.int32)
+        self.lab_all = torch.zeros((n_steps_idx,), device=dev, dtype=torch.int32)
+        self.running = None          # name -> (running_mean, running_var) static copies
+        self.graph = None
+        self.out = None
+        self.calls = 0
+
+
+def _adapt_body(st, feature_mod, plan, n, H, lr):
+    """The launches of one episode's inner loop on ``st``'s static buffers (eager, or being recorded into st.graph)."""
     from . import autograd_ops as AG
-    dev = x_a.device
-    n, _, H, _ = x_a.shape
-    W = AG.module_weights(feature_mod)
+    W, dev, ad = st.W, st.dev, st.ad
     arena = AG.arena_for(dev)
-    ad = AdaptState(1, dev)
     ad.reset(W)
-    running, nbt = {}, {}
-    for name, m in feature_mod.named_modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            running[name] = (m.running_mean.detach().clone(), m.running_var.detach().clone())
-            nbt[name] = m.num_batches_tracked.detach().clone()
-    Xs = ops.nchw_to_nhwc(x_a.contiguous().float()).view(n, -1)
-    # all index / label tables go to the device in ONE copy each before the loop: a per-step pageable host-to-device
-    # copy is stream-ordered and would drain the queue every step
-    plan, flat_idx, flat_lab = [], [], []
-    for ep in range(epochs):
-        rand_id = np.random.permutation(n) if perms is None else perms[ep]
-        for j in range(0, n, batch_size):
-            ids = np.asarray(rand_id[j:min(j + batch_size, n)])
-            plan.append((len(flat_idx), len(ids)))
-            flat_idx.extend(ids.tolist())
-            flat_lab.extend(np.asarray(y_a)[ids].tolist())
-    idx_all = torch.from_numpy(np.asarray(flat_idx, dtype=np.int32)).to(dev)
-    lab_all = torch.from_numpy(np.asarray(flat_lab, dtype=np.int32)).to(dev)
+    mods = [(name, m) for name, m in feature_mod.named_modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if st.running is None:
+        st.running = {name: (m.running_mean.detach().clone(), m.running_var.detach().clone()) for name, m in mods}
+    else:
+        torch._foreach_copy_([t for name, _ in mods for t in st.running[name]],
+                             [t for _, m in mods for t in (m.running_mean.detach(), m.running_var.detach())])
+    running = st.running
     # frozen trunk.0-6 of step t+1 on a second stream while the last block of step t is adapted (as in FinetuneEngine)
     cur = torch.cuda.current_stream(dev)
     s_trunk = _ADAPT_STREAMS.get(dev)
@@ -771,14 +776,13 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
         arena_t = _ADAPT_ARENAS[dev] = Fn.Arena(dev)
     s_trunk.wait_stream(cur)
     done = [None, None]
-    steps = 0
     for t, (off, k) in enumerate(plan):
-        idx, lab = idx_all[off:off + k], lab_all[off:off + k]
+        idx, lab = st.idx_all[off:off + k], st.lab_all[off:off + k]
         par = t & 1
         with torch.cuda.stream(s_trunk):
             if done[par] is not None:
                 s_trunk.wait_event(done[par])
-            xb = ops.gather_rows(Xs, idx, out=arena_t.get("ad.xb%d.%d" % (k, par), (k, Xs.shape[1])))
+            xb = ops.gather_rows(st.Xs, idx, out=arena_t.get("ad.xb%d.%d" % (k, par), (k, st.Xs.shape[1])))
             x6 = Fn.resnet10_trunk(W, xb.view(k, H, H, 3), arena_t, k, upto=7, running=running, tag="adt%d.%d" % (k, par))
             ready = torch.cuda.Event()
             ready.record(s_trunk)
@@ -792,11 +796,61 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
         ev = torch.cuda.Event()
         ev.record(cur)
         done[par] = ev
-        steps += 1
     cur.wait_stream(s_trunk)
-    out = ad.w.export(0)
-    for name, (rm, rv) in running.items():
+    return ad.w.export(0)
+
+
+def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=None):
+    """The inner loop of GnnNet.set_forward_finetune (gnnnet.py:126-177) for one episode: Adam(lr=0.01) on the last
+    ResNet block of a *copy* of ``feature_mod`` over ``epochs`` permutations of the support set in mini-batches of
+    ``batch_size`` (ragged tail allowed).  x_a: [n,3,H,W] device NCHW; y_a: int32 numpy labels.
+    Returns {state_dict key: tensor} for the nine adapted tensors and the BatchNorm running buffers (valid until the next call).
+    From the second episode of a shape on, the whole loop is ONE hipGraph replay (MFT_ADAPT_GRAPH=0: eager launches)."""
+    from . import autograd_ops as AG
+    dev = x_a.device
+    n, _, H, _ = x_a.shape
+    W = AG.module_weights(feature_mod)                 # refreshed in place when the module's parameters moved on
+    # all index / label tables go to the device in ONE copy each before the loop: a per-step pageable host-to-device
+    # copy is stream-ordered and would drain the queue every step
+    plan, flat_idx, flat_lab = [], [], []
+    for ep in range(epochs):
+        rand_id = np.random.permutation(n) if perms is None else perms[ep]
+        for j in range(0, n, batch_size):
+            ids = np.asarray(rand_id[j:min(j + batch_size, n)])
+            plan.append((len(flat_idx), len(ids)))
+            flat_idx.extend(ids.tolist())
+            flat_lab.extend(np.asarray(y_a)[ids].tolist())
+    key = (dev.index, id(W), n, H, epochs, batch_size, float(lr))
+    st = _ADAPT_GRAPHS.get(key)
+    if st is None:
+        for k_old in [k for k, v in _ADAPT_GRAPHS.items() if k[0] == dev.index and k[2:] == key[2:]]:
+            del _ADAPT_GRAPHS[k_old]                   # the module's packed weights were rebuilt: drop the loop recorded on the old ones
+        st = _ADAPT_GRAPHS[key] = _AdaptLoop(W, dev, n, H, len(flat_idx))
+        st.keep = feature_mod                         # (keeps id(W) unique while the entry lives)
+    st.idx_all.copy_(torch.from_numpy(np.asarray(flat_idx, dtype=np.int32)))
+    st.lab_all.copy_(torch.from_numpy(np.asarray(flat_lab, dtype=np.int32)))
+    st.Xs.copy_(ops.nchw_to_nhwc(x_a.contiguous().float()).view(n, -1))
+    nbt = {name: m.num_batches_tracked.detach().clone() for name, m in feature_mod.named_modules()
+           if isinstance(m, torch.nn.BatchNorm2d)}
+    st.calls += 1
+    if ADAPT_GRAPH and st.calls >= 2 and st.graph is None and st.graph is not False:
+        try:                                           # (the first call ran eagerly: every arena buffer exists)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st.out = _adapt_body(st, feature_mod, plan, n, H, lr)
+            st.graph = g
+        except Exception as e:   # noqa: BLE001 -- whatever the runtime refuses to record: stay on the eager loop
+            import warnings
+            warnings.warn("hipGraph capture of the meta-fine-tuning inner loop failed (%s: %s); continuing without it" % (type(e).__name__, e))
+            st.graph = False
+            torch.cuda.synchronize()
+    if st.graph:
+        st.graph.replay()
+        out = dict(st.out)
+    else:
+        out = _adapt_body(st, feature_mod, plan, n, H, lr)
+    for name, (rm, rv) in st.running.items():
         out[name + ".running_mean"] = rm
         out[name + ".running_var"] = rv
-        out[name + ".num_batches_tracked"] = nbt[name] + steps
+        out[name + ".num_batches_tracked"] = nbt[name] + len(plan)
     return out

@@ -114,7 +114,7 @@ class GnnNet(MetaTemplate):
                                                self.feature3.named_parameters()):
             if name not in keep:
                 ops.maml_delta(p.data, p2.data.contiguous(), p3.data.contiguous())
-        AG.invalidate(self.feature)
+        AG.touch(self.feature)                 # p.data was written by a kernel: packed copies refreshed in place at the next use
 
     INNER_EPOCHS = 15
 
@@ -136,12 +136,12 @@ class GnnNet(MetaTemplate):
         adapted = eng.adapt_last_block(self.feature, x_a, y_a, epochs=self.INNER_EPOCHS, batch_size=batch_size)
         if self.first:
             self.first = False
-        self.feature2 = copy.deepcopy(self.feature)                # theta_pre      (gnnnet.py:185)
-        feat_network = copy.deepcopy(self.feature)
-        feat_network.load_state_dict(adapted, strict=False)
-        self.feature3 = feat_network                               # theta_adapted  (gnnnet.py:186)
-        self.feature.load_state_dict(feat_network.state_dict())    # incl. BN running stats (gnnnet.py:187)
-        AG.invalidate(self.feature)
+        # theta_pre = copy of the backbone, theta_adapted = that copy with the inner loop's result loaded, and the backbone itself
+        # takes theta_adapted's state (gnnnet.py:185-187).  Same values with two multi-tensor copies into the holders created on
+        # the first episode instead of two deepcopies + two full load_state_dicts per episode (12 ms of 73).
+        self.feature2 = _copy_module(getattr(self, "feature2", None), self.feature)     # theta_pre      (gnnnet.py:185)
+        self.feature.load_state_dict(adapted, strict=False)        # nine tensors + BN running stats, in place (version counters bump)
+        self.feature3 = _copy_module(getattr(self, "feature3", None), self.feature)     # theta_adapted  (gnnnet.py:186)
         for p in self.feature.parameters():
             p.requires_grad = True
         out_s = self.feature(x_a).view(self.n_way, n_sup, -1)
@@ -149,6 +149,22 @@ class GnnNet(MetaTemplate):
         final = torch.cat((out_s, out_q), dim=1)
         assert (final.size(1) == n_sup + 16)
         return AG.gnnnet_head(self, final.view(-1, final.size(-1)), self._graph_support(), self.n_query, fold=self.FOLD50)
+
+
+def _copy_module(dst, src):
+    """``copy.deepcopy(src)`` the first time; afterwards the same values written into the existing holder with one multi-tensor
+    copy for the parameters and one per buffer dtype."""
+    if dst is None:
+        return copy.deepcopy(src)
+    dp, sp = list(dst.parameters()), list(src.parameters())
+    db, sb = list(dst.buffers()), list(src.buffers())
+    if len(dp) != len(sp) or len(db) != len(sb) or any(a.shape != b.shape for a, b in zip(dp + db, sp + sb)):
+        return copy.deepcopy(src)
+    with torch.no_grad():
+        torch._foreach_copy_(dp, sp)
+        for dt in {a.dtype for a in db}:
+            torch._foreach_copy_([a for a in db if a.dtype == dt], [b for a, b in zip(db, sb) if a.dtype == dt])
+    return dst
 
 
 def _support_label(n_way, n_support):
