@@ -186,6 +186,12 @@ int mft_bn_apply_x3ws(const float* x, int ldx, float* y, int ldy, int C, int row
                       const float* gamma, const float* beta, const float* res, int ldr, const float* res_ws,
                       const float* res_gamma, const float* res_beta, int act, float slope, float eps, float* mean, float* rstd,
                       float* res_mean, float* res_rstd, void* stream);
+/* BatchNorm running_mean / running_var after n_steps train-mode forwards (torch: running = (1 - momentum) * running + momentum *
+ * batch value, unbiased variance) whose batch statistics (mean, rstd [groups, C]) came out of grouped launches: step t used group
+ * (order[t] & 0xffffff) of set a (order[t] >> 24 == 0) or b.  rows_a / rows_b = rows per group (for the unbiased factor). */
+int mft_bn_running_ema(const float* mean_a, const float* rstd_a, int rows_a, const float* mean_b, const float* rstd_b, int rows_b,
+                       const int* order, int n_steps, int C, float eps, float momentum, float* running_mean, float* running_var,
+                       void* stream);
 int mft_bn_apply_x3ws_fits(int C, int rows_per_group, int with_res_bn);  /* 1 when mft_bn_apply_x3ws can stage a group's partials in LDS */
 int mft_bn_relu_pooled_gather_moments(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH, int OW,
                                       int C, int imgs_per_group, const float* mean_img, const float* m2_img, int rows_per_img,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mft_conv2d_nhwc_x3_bnin_bnstats": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_bn_apply_x3ws": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
     "mft_bn_apply_x3ws_fits": [_I, _I, _I],
+    "mft_bn_running_ema": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _P, _P, _P],
     "mft_bn_relu_pooled_gather_moments": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "mft_bn_relu_pooled_gather": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_apply_planes": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],

@@ -543,6 +543,43 @@ extern "C" int mft_bn_apply_x3ws(const float* x, int ldx, float* y, int ldy, int
     return mft_launch_status();
 }
 
+// BatchNorm running statistics after a SEQUENCE of train-mode forwards whose batch statistics were computed in grouped launches
+// (the meta-fine-tuning inner loop: the frozen trunk of all ~105 mini-batches of an episode runs as two grouped passes, full and
+// ragged mini-batches; gnnnet.py:126-177 runs them one by one): step t used group (order[t] & 0xffffff) of statistics set
+// (order[t] >> 24), and torch updates running = (1 - momentum) * running + momentum * batch value, variance unbiased, in step order.
+namespace {
+__global__ void bn_running_ema_kernel(const float* __restrict__ mean_a, const float* __restrict__ rstd_a, float unb_a,
+                                      const float* __restrict__ mean_b, const float* __restrict__ rstd_b, float unb_b,
+                                      const int* __restrict__ order, int n_steps, int C, float eps, float momentum,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int t = 0; t < n_steps; ++t) {
+        const int o = order[t], g = o & 0xffffff;
+        const bool b = (o >> 24) != 0;
+        const float m = (b ? mean_b : mean_a)[(long long)g * C + c];
+        const float rs = (b ? rstd_b : rstd_a)[(long long)g * C + c];
+        const float var = fmaxf(1.0f / (rs * rs) - eps, 0.f);
+        rm = (1.f - momentum) * rm + momentum * m;
+        rv = (1.f - momentum) * rv + momentum * (var * (b ? unb_b : unb_a));
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+}
+}  // namespace
+
+extern "C" int mft_bn_running_ema(const float* mean_a, const float* rstd_a, int rows_a, const float* mean_b, const float* rstd_b,
+                                  int rows_b, const int* order, int n_steps, int C, float eps, float momentum, float* running_mean,
+                                  float* running_var, void* stream) {
+    if (!mean_a || !rstd_a || rows_a < 1 || !order || n_steps < 1 || C < 1 || !running_mean || !running_var) return MFT_EINVAL;
+    const float ua = (float)rows_a / (float)(rows_a > 1 ? rows_a - 1 : 1);
+    const float ub = (float)rows_b / (float)(rows_b > 1 ? rows_b - 1 : 1);
+    hipLaunchKernelGGL(bn_running_ema_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean_a, rstd_a, ua, mean_b, rstd_b, ub,
+                       order, n_steps, C, eps, momentum, running_mean, running_var);
+    return mft_launch_status();
+}
+
 extern "C" int mft_bn_apply_x3ws_fits(int C, int rows_per_group, int with_res_bn) {
     if (C % 4 != 0 || C > 1024 || rows_per_group < 128) return 0;
     return (size_t)4 * C * sizeof(float) + (with_res_bn ? 2 : 1) * mft_x3_stage_bytes_host(mft_x3_max_group_tiles(rows_per_group, 128), C) <=

@@ -732,6 +732,7 @@ _ADAPT_ARENAS = {}
 
 
 ADAPT_GRAPH = os.environ.get("MFT_ADAPT_GRAPH", "1") == "1"
+ADAPT_BATCHED_TRUNK = os.environ.get("MFT_ADAPT_BATCHED_TRUNK", "1") == "1"
 _ADAPT_GRAPHS = {}
 
 
@@ -741,12 +742,21 @@ class _AdaptLoop:
     launch overhead per episode when issued from Python, and the same launch sequence every episode (the step sizes, the Adam
     step numbers and every buffer are fixed; only the support images, the permutation tables and the weights' VALUES change)."""
 
-    def __init__(self, W, dev, n, H, n_steps_idx):
+    def __init__(self, W, dev, n, H, n_steps_idx, plan):
         self.W, self.dev = W, dev
         self.ad = AdaptState(1, dev)
         self.Xs = torch.empty((n, H * H * 3), device=dev, dtype=torch.float32)
         self.idx_all = torch.zeros((n_steps_idx,), device=dev, dtype=torch.int32)
         self.lab_all = torch.zeros((n_steps_idx,), device=dev, dtype=torch.int32)
+        # batched trunk: the mini-batch sizes that occur (full, ragged tail), each step's (kind, group) and the image indices per kind
+        self.kinds = sorted({k for _, k in plan}, reverse=True)
+        count = {k: 0 for k in self.kinds}
+        self.where = []
+        for _, k in plan:
+            self.where.append((self.kinds.index(k), count[k]))
+            count[k] += 1
+        self.idx_kind = {k: torch.zeros((count[k] * k,), device=dev, dtype=torch.int32) for k in self.kinds}
+        self.order = torch.tensor([(ki << 24) | g for ki, g in self.where], dtype=torch.int32).to(dev)
         self.running = None          # name -> (running_mean, running_var) static copies
         self.graph = None
         self.out = None
@@ -766,14 +776,35 @@ def _adapt_body(st, feature_mod, plan, n, H, lr):
         torch._foreach_copy_([t for name, _ in mods for t in st.running[name]],
                              [t for _, m in mods for t in (m.running_mean.detach(), m.running_var.detach())])
     running = st.running
-    # frozen trunk.0-6 of step t+1 on a second stream while the last block of step t is adapted (as in FinetuneEngine)
     cur = torch.cuda.current_stream(dev)
-    s_trunk = _ADAPT_STREAMS.get(dev)
-    if s_trunk is None:
-        s_trunk = _ADAPT_STREAMS[dev] = torch.cuda.Stream(device=dev)
     arena_t = _ADAPT_ARENAS.get(dev)
     if arena_t is None:
         arena_t = _ADAPT_ARENAS[dev] = Fn.Arena(dev)
+    if ADAPT_BATCHED_TRUNK and len(st.kinds) <= 2:
+        # The trunk below the adapted block is frozen for the whole inner loop and a mini-batch's trunk output depends on that
+        # mini-batch only (train-mode BatchNorm over its own images): the ~105 trunk forwards of the episode run as ONE grouped
+        # pass per mini-batch size (group = step), ~60 launches instead of ~3,000.  Their BatchNorm running statistics are then
+        # advanced through the steps in order by one small launch per layer (mft_bn_running_ema).
+        x6_of = []
+        for k in st.kinds:
+            idx_k = st.idx_kind[k]
+            xb = ops.gather_rows(st.Xs, idx_k, out=arena_t.get("adb.xb%d" % k, (idx_k.numel(), st.Xs.shape[1])))
+            x6_of.append(Fn.resnet10_trunk(W, xb.view(-1, H, H, 3), arena_t, k, upto=7, running=None, tag="adb%d" % k))
+        _trunk_running_ema(st, arena_t, running, H)
+        for t, (off, k) in enumerate(plan):
+            ki, g = st.where[t]
+            x6 = x6_of[ki][g * k:(g + 1) * k]
+            lab = st.lab_all[off:off + k]
+            tape = {}
+            feat = Fn.last_block_forward(W, x6, arena, k, slab=ad.w, tape=tape, running=running, tag="ad%d" % k)
+            ad.step += 1
+            Fn.last_block_backward(tape, None, ad.w, ad.g, arena, ipg=k, tag="adbw%d" % k,
+                                   adam=(ad.m, ad.v, ad.step, lr), ce=(feat, lab, arena.get("ad.loss", (1,))))
+        return ad.w.export(0)
+    # frozen trunk.0-6 of step t+1 on a second stream while the last block of step t is adapted (as in FinetuneEngine)
+    s_trunk = _ADAPT_STREAMS.get(dev)
+    if s_trunk is None:
+        s_trunk = _ADAPT_STREAMS[dev] = torch.cuda.Stream(device=dev)
     s_trunk.wait_stream(cur)
     done = [None, None]
     for t, (off, k) in enumerate(plan):
@@ -798,6 +829,33 @@ def _adapt_body(st, feature_mod, plan, n, H, lr):
         done[par] = ev
     cur.wait_stream(s_trunk)
     return ad.w.export(0)
+
+
+def _trunk_running_ema(st, arena_t, running, H):
+    """running_mean / running_var of the nine BatchNorms of trunk.1-6 after the episode's steps, from the per-group statistics the
+    grouped passes left in the arena (one launch per layer)."""
+    lib = ops._lib.lib()
+    oh0 = (H + 6 - 7) // 2 + 1
+    sp = {4: (oh0 + 2 - 3) // 2 + 1}
+    sp[5] = (sp[4] + 2 - 3) // 2 + 1
+    sp[6] = (sp[5] + 2 - 3) // 2 + 1
+    layers = [("trunk.1", ".bn0", oh0, 64)]
+    for bi in (4, 5, 6):
+        cout = Fn.STAGES[bi][1]
+        layers += [("trunk.%d.BN1" % bi, ".trunk.%d.bn1" % bi, sp[bi], cout), ("trunk.%d.BN2" % bi, ".trunk.%d.bn2" % bi, sp[bi], cout)]
+        if Fn.STAGES[bi][0] != cout:
+            layers.append(("trunk.%d.BNshortcut" % bi, ".trunk.%d.bns" % bi, sp[bi], cout))
+    for name, suffix, hw, C in layers:
+        rm, rv = running[name]
+        sets = []
+        for k in st.kinds:
+            G = st.idx_kind[k].numel() // k
+            sets.append((arena_t.get("adb%d%s.mean" % (k, suffix), (G, C)), arena_t.get("adb%d%s.rstd" % (k, suffix), (G, C)), k * hw * hw))
+        if len(sets) == 1:
+            sets.append((None, None, 1))
+        (ma, ra, na), (mb, rb, nb) = sets
+        ops._lib.check(lib.mft_bn_running_ema(ops._p(ma), ops._p(ra), na, ops._p(mb), ops._p(rb), nb, ops._p(st.order), st.order.numel(), C,
+                                              ops.BN_EPS, 0.1, ops._p(rm), ops._p(rv), ops._stream()), "mft_bn_running_ema")
 
 
 def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=None):
@@ -825,10 +883,13 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
     if st is None:
         for k_old in [k for k, v in _ADAPT_GRAPHS.items() if k[0] == dev.index and k[2:] == key[2:]]:
             del _ADAPT_GRAPHS[k_old]                   # the module's packed weights were rebuilt: drop the loop recorded on the old ones
-        st = _ADAPT_GRAPHS[key] = _AdaptLoop(W, dev, n, H, len(flat_idx))
+        st = _ADAPT_GRAPHS[key] = _AdaptLoop(W, dev, n, H, len(flat_idx), plan)
         st.keep = feature_mod                         # (keeps id(W) unique while the entry lives)
-    st.idx_all.copy_(torch.from_numpy(np.asarray(flat_idx, dtype=np.int32)))
+    fi = np.asarray(flat_idx, dtype=np.int32)
+    st.idx_all.copy_(torch.from_numpy(fi))
     st.lab_all.copy_(torch.from_numpy(np.asarray(flat_lab, dtype=np.int32)))
+    for k in st.kinds:
+        st.idx_kind[k].copy_(torch.from_numpy(np.concatenate([fi[off:off + kk] for off, kk in plan if kk == k])))
     st.Xs.copy_(ops.nchw_to_nhwc(x_a.contiguous().float()).view(n, -1))
     nbt = {name: m.num_batches_tracked.detach().clone() for name, m in feature_mod.named_modules()
            if isinstance(m, torch.nn.BatchNorm2d)}

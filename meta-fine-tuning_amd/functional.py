@@ -566,7 +566,9 @@ def _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, 
     """Data gradient of trunk.7.C2 followed by the BatchNorm1 + ReLU backward -> dc1 (separate pass over C2's weights)."""
     # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
     rc = ops._lib.MFT_EINVAL
-    if FUSED_LAST_BLOCK:
+    if FUSED_LAST_BLOCK and n != ipg:
+        # (one group -- a single episode, the meta-fine-tuning training loop: the weight-streaming kernel would run on 16 workgroups;
+        #  the K-sliced implicit GEMM + the BatchNorm backward launches below take a sixth of its time)
         # data gradient of C2 with the BatchNorm1 + ReLU backward in its epilogue (dr1 is not materialised)
         dc1 = arena.get(tag + ".dc1", tuple(c1.shape))
         w2 = params.c2w

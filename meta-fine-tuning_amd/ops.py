@@ -140,7 +140,7 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
         wgs = w_pk.shape[1] * w_pk.shape[2]
         if imgs_per_group <= 0 or n // imgs_per_group != w_pk.shape[0]:
             raise RuntimeError("per-group weights need imgs_per_group with n/imgs_per_group == groups")
-    if wgs == 0 and imgs_per_group <= 0 and Cin != 3:
+    if ((wgs == 0 and imgs_per_group <= 0) or (w_pk.dim() == 3 and w_pk.shape[0] == 1)) and Cin != 3:        # (one group = one weight set)
         # one weight set, few output tiles, long reduction (one 105-image meta-training episode): K sliced across workgroups
         nws = _ksplit_ws(n * OH * OW, Cout, w_pk.shape[-1])
         if nws:
@@ -273,7 +273,7 @@ def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None, stride=
     if out is None:
         out = torch.empty((n, H, W, Cin), device=dy.device, dtype=torch.float32)
     wgs = w_pk.shape[1] * w_pk.shape[2] if w_pk.dim() == 3 else 0
-    if wgs == 0 and imgs_per_group <= 0 and Cin % 64 == 0:
+    if ((wgs == 0 and imgs_per_group <= 0) or (w_pk.dim() == 3 and w_pk.shape[0] == 1)) and Cin % 64 == 0:
         nws = _ksplit_ws(n * H * W, Cin, KH * KW * Cout)
         if nws:
             ws = torch.empty((nws,), device=dy.device, dtype=torch.float32)

@@ -439,3 +439,51 @@ def test_graphed_episode_loop_is_bit_identical(variant, capsys, monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(buf_e, buf_g):
         assert torch.equal(a, b)
+
+
+def test_inner_loop_batched_trunk_and_graph_match_step_by_step():
+    """engine.adapt_last_block (gnnnet.py:126-177: 15 epochs of mini-batches of 4 over the 25 supports, 105 Adam steps on trunk.7):
+    the frozen trunk of all steps as two grouped passes + one running-statistics launch per BatchNorm layer, and the whole loop
+    replayed from a hipGraph, against the step-by-step loop on the same permutations -- trunk BatchNorm running statistics to fp32
+    rounding, adapted tensors inside the Adam-noise envelope (grouped launches tile and slice K differently: not bit-identical)."""
+    from meta_fine_tuning_amd import engine as eng
+    from meta_fine_tuning_amd import backbone
+    torch.manual_seed(3)
+    sd = synthetic.resnet10_state_dict(seed=41)
+    x_a = synthetic.train_episode(77, 5, 5, 16, 84)[:, :5].reshape(25, 3, 84, 84).cuda()
+    y_a = np.repeat(range(5), 5).astype(np.int32)
+    perms = [np.random.RandomState(100 + e).permutation(25) for e in range(15)]
+    res = {}
+    old = (eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH)
+    try:
+        for name, batched, graph, calls in (("steps", False, False, 1), ("batched", True, False, 1), ("graphed", True, True, 3)):
+            eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH = batched, graph
+            eng._ADAPT_GRAPHS.clear()
+            mod = backbone.ResNet10().cuda()
+            mod.load_state_dict(sd)
+            mod.train()
+            for _ in range(calls):                                  # the third call of "graphed" is a replay
+                out = eng.adapt_last_block(mod, x_a, y_a, epochs=15, batch_size=4, perms=perms)
+            res[name] = {k: v.detach().clone() for k, v in out.items()}
+            if graph:
+                assert all(st.graph for st in eng._ADAPT_GRAPHS.values()) and len(eng._ADAPT_GRAPHS) == 1
+    finally:
+        eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH = old
+        eng._ADAPT_GRAPHS.clear()
+    ref = res["steps"]
+    assert any(k.endswith("running_mean") for k in ref) and "trunk.7.C2.weight" in ref
+    for k, v in ref.items():
+        b, g = res["batched"][k], res["graphed"][k]
+        assert torch.equal(b, g), k                                  # the replay repeats the eager batched loop bit for bit
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(v, b), k
+        elif "running" in k and not k.startswith("trunk.7"):
+            assert float((v - b).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+        elif "running" in k:
+            assert float((v - b).norm()) <= 0.05 * float(v.norm()), k      # statistics of the ADAPTED block's activations follow its weights' drift
+        else:
+            # 105 Adam steps of lr 0.01 each: two fp32 implementations drift apart by a handful of steps on the entries whose gradient
+            # sign is noise -- measured against the size of the update itself
+            init = sd[k].to(v.device)
+            rel = float((v - b).norm()) / float((v - init).norm())
+            assert rel < 0.08 and float((v - b).abs().max()) <= 0.15, (k, rel)
