@@ -87,17 +87,47 @@ class GraphedLossBackward:
         return self.static_loss
 
 
+class _PreparedStep:
+    """Meta-fine-tuning episode (gnnnet.py:106-231): the host-driven half (MAML_update, inner loop, theta_pre / theta_adapted)
+    runs eagerly -- its inner loop is a graph of its own (engine.adapt_last_block) -- then the differentiable half (two backbone
+    forwards, fc + GNN, loss, backward) is replayed from a hipGraph."""
+
+    def __init__(self, model):
+        self.model = model
+        self.inner = GraphedLossBackward(model, model.set_forward_loss_finetune_prepared)
+
+    @property
+    def graph(self):
+        return self.inner.graph
+
+    @property
+    def failed(self):
+        return self.inner.failed
+
+    def __call__(self, x):
+        x = x.cuda() if not x.is_cuda else x
+        self.model._finetune_prepare(x)
+        return self.inner(x)
+
+
 def for_loop(model, loss_fn):
-    """A GraphedLossBackward for ``model``'s episode loop, or None when the step cannot be replayed: only the plain
-    ``set_forward_loss`` of a CUDA model is (the meta-fine-tuning variant runs a host-driven inner loop per episode)."""
+    """The graphed step for ``model``'s episode loop, or None when it cannot be replayed.  ``set_forward_loss``: forward + backward
+    in one graph; ``set_forward_loss_finetune``: the differentiable half after the eagerly driven inner loop."""
     if not ENABLED or not torch.cuda.is_available():
-        return None
-    if getattr(loss_fn, "__func__", None) is not getattr(type(model), "set_forward_loss", None):
         return None
     if not all(p.is_cuda for p in model.parameters()):
         return None
+    fn = getattr(loss_fn, "__func__", None)
     cache = model.__dict__.setdefault("_mft_graph_steps", {})
-    st = cache.get("set_forward_loss")
-    if st is None:
-        st = cache["set_forward_loss"] = GraphedLossBackward(model, loss_fn)
-    return st
+    if fn is not None and fn is getattr(type(model), "set_forward_loss", None):
+        st = cache.get("set_forward_loss")
+        if st is None:
+            st = cache["set_forward_loss"] = GraphedLossBackward(model, loss_fn)
+        return st
+    if (fn is not None and fn is getattr(type(model), "set_forward_loss_finetune", None)
+            and hasattr(model, "_finetune_prepare") and hasattr(model, "set_forward_loss_finetune_prepared")):
+        st = cache.get("set_forward_loss_finetune")
+        if st is None:
+            st = cache["set_forward_loss_finetune"] = _PreparedStep(model)
+        return st
+    return None

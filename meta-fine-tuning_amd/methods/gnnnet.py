@@ -123,6 +123,17 @@ class GnnNet(MetaTemplate):
         copy of the backbone's last block on the support set, swap it in, then score support (BN batch 25) and
         query (BN batch 80) separately through fc + GNN."""
         x = x.cuda()
+        self._finetune_prepare(x)
+        return self._finetune_scores(x)
+
+    def set_forward_loss_finetune_prepared(self, x):
+        """The differentiable half of set_forward_loss_finetune, after ``_finetune_prepare(x)``: what the episode loop replays from
+        a hipGraph (graph_step.for_loop)."""
+        return self.loss_fn(self._finetune_scores(x.cuda()), self._y_query())
+
+    def _finetune_prepare(self, x):
+        """gnnnet.py:106-187: MAML_update, the inner loop on the support set, theta_pre / theta_adapted, the backbone takes the
+        adapted state.  Host-driven (numpy permutations); its launches are recorded separately (engine.adapt_last_block)."""
         batch_size = 4
         n_sup = self._image_support()
         support_size = self.n_way * n_sup
@@ -130,7 +141,6 @@ class GnnNet(MetaTemplate):
             p.requires_grad = True
         y_a = np.repeat(range(self.n_way), n_sup).astype(np.int32)
         self.MAML_update()
-        x_b = x[:, n_sup:].contiguous().view(self.n_way * self.n_query, *x.size()[2:])
         x_a = x[:, :n_sup].contiguous().view(support_size, *x.size()[2:])
         Classifier(self.feat_dim, self.n_way)                      # RNG-stream parity only (gnnnet.py:127)
         adapted = eng.adapt_last_block(self.feature, x_a, y_a, epochs=self.INNER_EPOCHS, batch_size=batch_size)
@@ -144,6 +154,13 @@ class GnnNet(MetaTemplate):
         self.feature3 = _copy_module(getattr(self, "feature3", None), self.feature)     # theta_adapted  (gnnnet.py:186)
         for p in self.feature.parameters():
             p.requires_grad = True
+
+    def _finetune_scores(self, x):
+        """gnnnet.py:189-208: support (BN batch 25) and query (BN batch 80) through the adapted backbone, fc + GNN."""
+        n_sup = self._image_support()
+        support_size = self.n_way * n_sup
+        x_b = x[:, n_sup:].contiguous().view(self.n_way * self.n_query, *x.size()[2:])
+        x_a = x[:, :n_sup].contiguous().view(support_size, *x.size()[2:])
         out_s = self.feature(x_a).view(self.n_way, n_sup, -1)
         out_q = self.feature(x_b).view(self.n_way, self.n_query, -1)
         final = torch.cat((out_s, out_q), dim=1)

@@ -487,3 +487,46 @@ def test_inner_loop_batched_trunk_and_graph_match_step_by_step():
             init = sd[k].to(v.device)
             rel = float((v - b).norm()) / float((v - init).norm())
             assert rel < 0.08 and float((v - b).abs().max()) <= 0.15, (k, rel)
+
+
+def test_graphed_meta_finetune_loop_is_bit_identical(capsys, monkeypatch):
+    """train.py --fine_tune through MetaTemplate.train_loop_finetune: the differentiable half of every episode (two backbone
+    forwards on the adapted weights, fc + GNN, loss, backward) replayed from a hipGraph after three eager episodes, the inner loop
+    from its own graph, against the fully eager loop: printed line, parameters, theta_pre / theta_adapted holders and buffers
+    after 6 episodes bit for bit."""
+    from meta_fine_tuning_amd import engine as eng
+    from meta_fine_tuning_amd import graph_step, optim
+    eps = [synthetic.train_episode(800 + i, 5, 5, 16, 84) for i in range(6)]
+
+    class Loader:
+        def __len__(self):
+            return len(eps)
+
+        def __iter__(self):
+            for x in eps:
+                yield x, None
+
+    def run(graphed):
+        monkeypatch.setattr(graph_step, "ENABLED", graphed)
+        monkeypatch.setattr(eng, "ADAPT_GRAPH", graphed)
+        eng._ADAPT_GRAPHS.clear()
+        torch.manual_seed(0)
+        np.random.seed(10)
+        model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+        model.load_state_dict(synthetic.gnnnet_state_dict(seed=27))
+        model.train()
+        opt = optim.Adam(model.parameters())
+        capsys.readouterr()
+        model.train_loop_finetune(0, Loader(), opt)
+        out = capsys.readouterr().out
+        st = model.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss_finetune")
+        return out, {k: v.detach().clone() for k, v in model.state_dict().items()}, st
+
+    out_e, sd_e, st_e = run(False)
+    out_g, sd_g, st_g = run(True)
+    eng._ADAPT_GRAPHS.clear()
+    assert st_e is None and st_g is not None and st_g.graph is not None and not st_g.failed
+    assert out_g == out_e and "Loss" in out_e
+    assert any(k.startswith("feature3.") for k in sd_e) and sd_e.keys() == sd_g.keys()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k

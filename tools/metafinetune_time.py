@@ -1,32 +1,42 @@
 #!/usr/bin/env python3
-"""Time one meta-fine-tuning training step (train.py --fine_tune: GnnNet.set_forward_loss_finetune + backward + outer Adam)."""
+"""Time one meta-fine-tuning training step (train.py --fine_tune: GnnNet.set_forward_loss_finetune + backward + outer Adam,
+gnnnet.py:106-231) the way MetaTemplate.train_loop_finetune runs it.   python tools/metafinetune_time.py [steps]
+MFT_TRAIN_GRAPH=0 / MFT_ADAPT_GRAPH=0 / MFT_ADAPT_BATCHED_TRUNK=0 switch the round-3 pieces off one by one."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import meta_fine_tuning_amd  # noqa
-from meta_fine_tuning_amd import optim, synthetic
+from meta_fine_tuning_amd import graph_step, optim, synthetic
 from meta_fine_tuning_amd.io_utils import model_dict
 from meta_fine_tuning_amd.methods.gnnnet import GnnNet
 
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 model = GnnNet(model_dict["ResNet10"], n_way=5, n_support=5).cuda()
 model.load_state_dict(synthetic.gnnnet_state_dict(seed=0))
 model.train(); model.n_query = 16
 opt = optim.Adam(model.parameters())
 eps = [synthetic.train_episode(100 + i, 5, 5, 16, 84).cuda() for i in range(4)]
 np.random.seed(10)
+graphed = graph_step.for_loop(model, model.set_forward_loss_finetune)
 
 
 def step(i):
-    opt.zero_grad()
-    loss = model.set_forward_loss_finetune(eps[i % 4])
-    loss.backward()
+    if graphed is not None:
+        loss = graphed(eps[i % 4])
+    else:
+        opt.zero_grad()
+        loss = model.set_forward_loss_finetune(eps[i % 4])
+        loss.backward()
     opt.step()
     return loss
 
 
-step(0); torch.cuda.synchronize()
-t0 = time.perf_counter()
 for i in range(5):
     step(i)
 torch.cuda.synchronize()
-print("meta-fine-tuning step: %.1f ms per episode" % ((time.perf_counter() - t0) / 5 * 1e3))
+t0 = time.perf_counter()
+for i in range(steps):
+    step(i)
+torch.cuda.synchronize()
+print("meta-fine-tuning step: %.1f ms per episode (outer half graphed: %s)" % ((time.perf_counter() - t0) / steps * 1e3,
+                                                                            graphed is not None and graphed.graph is not None))
