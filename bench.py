@@ -367,14 +367,18 @@ def bench_metatrain(args, rank, world, dev, dist):
     eps = [synthetic.train_episode(5000 + 100 * rank + i, 5, 5, 16, 84).to(dev) for i in range(8)]
 
     from meta_fine_tuning_amd import graph_step
-    graphed = graph_step.for_loop(model, model.set_forward_loss)       # the episode loop's own path (MetaTemplate._episode_loop)
+    finetune = args.workload == "metafinetune"                        # train.py --fine_tune: set_forward_loss_finetune (gnnnet.py:106-231)
+    loss_fn = model.set_forward_loss_finetune if finetune else model.set_forward_loss
+    graphed = graph_step.for_loop(model, loss_fn)                      # the episode loop's own path (MetaTemplate._episode_loop)
+    if finetune:
+        np.random.seed(10 + rank)
 
     def step(i):
         if graphed is not None:
             loss = graphed(eps[i % len(eps)])                          # forward + backward: one hipGraph replay after 3 eager steps
         else:
             opt.zero_grad()
-            loss = model.set_forward_loss(eps[i % len(eps)])
+            loss = loss_fn(eps[i % len(eps)])
             loss.backward()
         bucket.allreduce_mean()
         opt.step()
@@ -403,7 +407,9 @@ def bench_metatrain(args, rank, world, dev, dist):
             "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "meta-training step (BASELINE configs[3]): 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
+            "config": {"workload": ("meta-fine-tuning training step (train.py --fine_tune, gnnnet.py:106-231: 105 inner Adam steps on trunk.7 per "
+                                    "episode, then the outer step)" if finetune else "meta-training step (BASELINE configs[3])") +
+                                   ": 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
                                    "flat 21.2 MB gradient all-reduce + fused outer Adam", "parallelism": "episode-parallel x%d" % world},
             "last_loss": round(float(loss.detach().cpu()), 4), "graphed": graphed is not None and graphed.graph is not None,
             "roofline": None, "cpu_baseline": None}))
@@ -425,7 +431,7 @@ def main():
     ap.add_argument("--device-aug", action="store_true",
                     help="generate the 2+G views on the GPU from resident uint8 64x64 (EuroSAT-shaped) source images inside the timed "
                          "region (mft_augment_views) instead of ingesting pre-made fp32 views; extra measurement")
-    ap.add_argument("--workload", default="finetune", choices=["finetune", "metatrain"],
+    ap.add_argument("--workload", default="finetune", choices=["finetune", "metatrain", "metafinetune"],
                     help="finetune = BASELINE configs[1] (the metric, default); metatrain = configs[3]: one meta-training episode per "
                          "rank per step (set_forward_loss -> full backward -> flat-bucket RCCL all-reduce -> fused outer Adam)")
     ap.add_argument("--image-size", type=int, default=84, help="84 = BASELINE configs (the metric); 224 = the reference's hard-coded "
@@ -493,7 +499,7 @@ def main():
     from meta_fine_tuning_amd import engine as eng
     from meta_fine_tuning_amd import ops, synthetic
 
-    if args.workload == "metatrain":
+    if args.workload in ("metatrain", "metafinetune"):
         return bench_metatrain(args, rank, world, dev, dist)
     if args.strong_only:
         rec = strong_scaling_leg(args.strong_episodes, g9_state(), rank, world, dev, e_max=args.episodes_per_batch)

@@ -883,8 +883,9 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
     if st is None:
         for k_old in [k for k, v in _ADAPT_GRAPHS.items() if k[0] == dev.index and k[2:] == key[2:]]:
             del _ADAPT_GRAPHS[k_old]                   # the module's packed weights were rebuilt: drop the loop recorded on the old ones
-        st = _ADAPT_GRAPHS[key] = _AdaptLoop(W, dev, n, H, len(flat_idx), plan)
-        st.keep = feature_mod                         # (keeps id(W) unique while the entry lives)
+        while len(_ADAPT_GRAPHS) >= 4:                 # each entry pins ~75 MB of slabs + its graph's pool: keep the four most recent
+            del _ADAPT_GRAPHS[next(iter(_ADAPT_GRAPHS))]
+        st = _ADAPT_GRAPHS[key] = _AdaptLoop(W, dev, n, H, len(flat_idx), plan)      # (st.W keeps id(W) unique while the entry lives)
     fi = np.asarray(flat_idx, dtype=np.int32)
     st.idx_all.copy_(torch.from_numpy(fi))
     st.lab_all.copy_(torch.from_numpy(np.asarray(flat_lab, dtype=np.int32)))
