@@ -757,6 +757,7 @@ class _AdaptLoop:
             count[k] += 1
         self.idx_kind = {k: torch.zeros((count[k] * k,), device=dev, dtype=torch.int32) for k in self.kinds}
         self.order = torch.tensor([(ki << 24) | g for ki, g in self.where], dtype=torch.int32).to(dev)
+        self.order_steps = torch.tensor([(ki << 24) | t for t, (ki, _) in enumerate(self.where)], dtype=torch.int32).to(dev)    # row t, kind's row count
         self.running = None          # name -> (running_mean, running_var) static copies
         self.graph = None
         self.out = None
@@ -791,15 +792,30 @@ def _adapt_body(st, feature_mod, plan, n, H, lr):
             xb = ops.gather_rows(st.Xs, idx_k, out=arena_t.get("adb.xb%d" % k, (idx_k.numel(), st.Xs.shape[1])))
             x6_of.append(Fn.resnet10_trunk(W, xb.view(-1, H, H, 3), arena_t, k, upto=7, running=None, tag="adb%d" % k))
         _trunk_running_ema(st, arena_t, running, H)
+        # the adapted block's three BatchNorms: every step writes its batch statistics into row t of a per-episode table (one
+        # small launch does statistics + normalise + ReLU [+ add + pool]); their running statistics follow after the loop
+        n_steps = len(plan)
+        sink = {nm: (arena.get("ad.sink.%s.mean" % nm, (n_steps, 512)), arena.get("ad.sink.%s.rstd" % nm, (n_steps, 512)))
+                for nm in ("bn1", "bn2", "bns")}
         for t, (off, k) in enumerate(plan):
             ki, g = st.where[t]
             x6 = x6_of[ki][g * k:(g + 1) * k]
             lab = st.lab_all[off:off + k]
             tape = {}
-            feat = Fn.last_block_forward(W, x6, arena, k, slab=ad.w, tape=tape, running=running, tag="ad%d" % k)
+            feat = Fn.last_block_forward(W, x6, arena, k, slab=ad.w, tape=tape, running=None, tag="ad%d" % k,
+                                         stats_out={nm: (m[t:t + 1], r[t:t + 1]) for nm, (m, r) in sink.items()})
             ad.step += 1
             Fn.last_block_backward(tape, None, ad.w, ad.g, arena, ipg=k, tag="adbw%d" % k,
                                    adam=(ad.m, ad.v, ad.step, lr), ce=(feat, lab, arena.get("ad.loss", (1,))))
+        h7 = x6_of[0].shape[1]
+        h7 = (h7 + 2 - 3) // 2 + 1
+        rows = [k * h7 * h7 for k in st.kinds] + [1]
+        lib = ops._lib.lib()
+        for nm, bn in (("bn1", "trunk.7.BN1"), ("bn2", "trunk.7.BN2"), ("bns", "trunk.7.BNshortcut")):
+            m, r = sink[nm]
+            rm, rv = running[bn]
+            ops._lib.check(lib.mft_bn_running_ema(ops._p(m), ops._p(r), rows[0], ops._p(m), ops._p(r), rows[1], ops._p(st.order_steps),
+                                                  n_steps, 512, ops.BN_EPS, 0.1, ops._p(rm), ops._p(rv), ops._stream()), "mft_bn_running_ema")
         return ad.w.export(0)
     # frozen trunk.0-6 of step t+1 on a second stream while the last block of step t is adapted (as in FinetuneEngine)
     s_trunk = _ADAPT_STREAMS.get(dev)

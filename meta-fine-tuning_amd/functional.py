@@ -314,15 +314,14 @@ def resnet10_trunk(W, x, arena, ipg, upto=7, running=None, tag="t", stem=None, f
     return a
 
 
-def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=None, b2=None, res=None, pooled=None, hw=0):
+def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=None, b2=None, res=None, pooled=None, hw=0, stats=None,
+              stats2=None):
     """stats + normalise (+ second normalised branch | + residual) + ReLU (+ global average pool) in one launch
     (groups of <= 64 rows, csrc/bn.hip).  Returns (mean1, rstd1, mean2, rstd2)."""
-    m1 = arena.get(tag + ".mean", (groups, C))
-    s1 = arena.get(tag + ".rstd", (groups, C))
+    m1, s1 = stats if stats is not None else (arena.get(tag + ".mean", (groups, C)), arena.get(tag + ".rstd", (groups, C)))
     m2 = s2 = None
     if x2 is not None:
-        m2 = arena.get(tag + ".mean2", (groups, C))
-        s2 = arena.get(tag + ".rstd2", (groups, C))
+        m2, s2 = stats2 if stats2 is not None else (arena.get(tag + ".mean2", (groups, C)), arena.get(tag + ".rstd2", (groups, C)))
     rc = ops._lib.lib().mft_bn_small_forward(ops._p(x1), C, ops._p(x2), C, ops._p(res), C, ops._p(out), C, C, rows, groups,
                                              ops._p(g1), ops._p(b1), ops._p(g2), ops._p(b2), gbs, ops._p(m1), ops._p(s1),
                                              ops._p(m2), ops._p(s2), ops.ACT_RELU, 0.0, ops.BN_EPS, ops._p(pooled), hw,
@@ -332,13 +331,15 @@ def _bn_small(arena, tag, x1, g1, b1, rows, groups, C, gbs, out, x2=None, g2=Non
 
 
 def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", slab=None, tape=None, pooled=None, fixed=None,
-                 xp=None, xshape=None, out_mode="f32"):
+                 xp=None, xshape=None, out_mode="f32", stats_out=None):
     """SimpleBlock.forward (backbone.py:251-261).  ``slab``: per-group parameters (LastBlockSlab) or None for W's.
     ``pooled``: optional [n, cout] buffer; filled with the global average pool of the block output when the fused
     small-group path applies (``tape['pooled']`` is then True and the caller skips its own pooling launch).
     ``xp``: the block input pre-split into bf16x3 planes (int16 [3, n*H*W, cin]); frozen x3 blocks then keep their internal
     activation in planes too, and ``out_mode`` ("f32" | "planes" | "both") selects the form(s) of the block output
-    (returns ``out`` or ``(out, out_planes)``; ``x`` may be None when only its planes are needed, with ``xshape`` = its shape)."""
+    (returns ``out`` or ``(out, out_planes)``; ``x`` may be None when only its planes are needed, with ``xshape`` = its shape).
+    ``stats_out`` (small-group slab path): {"bn1" | "bn2" | "bns": (mean, rstd) [groups, cout]} -- where the three BatchNorms'
+    batch statistics are written instead of arena buffers (the caller advances the running statistics from them afterwards)."""
     n, H, Wd, _ = x.shape if x is not None else xshape
     groups = n // ipg
     OH = (H + 2 - 3) // stride + 1
@@ -370,11 +371,14 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
     rows = ipg * OH * OH
     if slab is not None and rows <= 64 and cout % 64 == 0 and cin != cout and running is None:
         # adapted last block in the episode-batched loop: 3 fused launches instead of 10 around the three convolutions
+        so = stats_out or {}
         c1 = arena.get(tag + ".c1", (n, OH, OH, cout))
         r1 = arena.get(tag + ".r1", (n * OH * OH, cout))
         sc = arena.get(tag + ".sc", (n, OH, OH, cout))
         rc = ops._lib.MFT_EINVAL
-        if FUSED_LAST_BLOCK and c1w.dim() == 3 and scw.dim() == 3:
+        # (one group = a single episode: the weight-streaming kernels would run on a handful of workgroups; the K-sliced
+        #  implicit GEMM + one small BatchNorm launch is several times faster there)
+        if FUSED_LAST_BLOCK and c1w.dim() == 3 and scw.dim() == 3 and groups > 1 and not so:
             # C1 + BatchNorm + ReLU and the shortcut convolution (which samples C1's centre tap) in one launch
             m1 = arena.get(tag + ".bn1.mean", (groups, cout))
             s1 = arena.get(tag + ".bn1.rstd", (groups, cout))
@@ -386,13 +390,13 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
                 ops._lib.check(rc, "mft_block_entry_small_forward")
         if rc == ops._lib.MFT_EINVAL:                      # outside the fused kernel's domain: three launches
             conv(".C1", x, c1w, 3, stride, 1, c1)
-            m1, s1, _, _ = _bn_small(arena, tag + ".bn1", c1, g1, b1, rows, groups, cout, gbs, r1)
+            m1, s1, _, _ = _bn_small(arena, tag + ".bn1", c1, g1, b1, rows, groups, cout, gbs, r1, stats=so.get("bn1"))
             conv(".shortcut", x, scw, 1, stride, 0, sc)
         r1 = r1.view(n, OH, OH, cout)
         c2 = arena.get(tag + ".c2", (n, OH, OH, cout))
         out = arena.get(tag + ".out", (n * OH * OH, cout))
         rc = ops._lib.MFT_EINVAL
-        if FUSED_LAST_BLOCK and pooled is not None and c2w.dim() == 3:
+        if FUSED_LAST_BLOCK and pooled is not None and c2w.dim() == 3 and groups > 1 and not so:
             # C2 + both BatchNorms + residual add + ReLU + global average pool in one launch
             m2, s2, ms, ss = (arena.get(tag + ".bn2." + k, (groups, cout)) for k in ("mean", "rstd", "mean2", "rstd2"))
             rc = ops._lib.lib().mft_block_exit_small_forward(
@@ -404,7 +408,7 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         if rc == ops._lib.MFT_EINVAL:
             conv(".C2", r1, c2w, 3, 1, 1, c2)
             m2, s2, ms, ss = _bn_small(arena, tag + ".bn2", c2, g2, b2, rows, groups, cout, gbs, out, x2=sc, g2=gs, b2=bs,
-                                       pooled=pooled, hw=OH * OH)
+                                       pooled=pooled, hw=OH * OH, stats=so.get("bn2"), stats2=so.get("bns"))
         out = out.view(n, OH, OH, cout)
         if tape is not None:
             tape.update(x=x, c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, sc=sc, ms=ms, ss=ss, out=out,
@@ -538,13 +542,13 @@ def _frozen_block_folded(W, p, x, arena, ipg, cin, cout, stride, tag):
     return out.view(n, OH, OH, cout)
 
 
-def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f", fixed=None):
+def last_block_forward(W, a, arena, ipg, slab=None, tape=None, running=None, tag="f", fixed=None, stats_out=None):
     """trunk.7 + global average pool on the activation ``a`` [n,h,w,256] entering the last block -> features [n,512]."""
     n = a.shape[0]
     feat = arena.get(tag + ".feat", (n, 512))
     info = tape if tape is not None else {}
     out = simple_block(W, "trunk.7", a, arena, ipg, 256, 512, 2, running, tag + ".trunk.7", slab=slab, tape=info, pooled=feat,
-                       fixed=fixed)
+                       fixed=fixed, stats_out=stats_out)
     if not info.get("pooled", False):
         ops._lib.check(ops._lib.lib().mft_global_avgpool(ops._p(out), ops._p(feat), n, out.shape[1] * out.shape[2], 512,
                                                          ops._stream()), "mft_global_avgpool")
