@@ -30,6 +30,7 @@ class GraphedLossBackward:
         self.static_x = self.static_loss = None
         self.side = None
         self.failed = False
+        self.rekeyed = 0
 
     def _key(self, x):
         return (tuple(x.shape), x.dtype, self.model.n_way, self.model.n_query, tuple(p.data_ptr() for p in self.params))
@@ -68,6 +69,11 @@ class GraphedLossBackward:
         if self.failed:
             return self._eager(x)
         if key != self.key:                         # new shape / new parameter tensors: start over
+            if self.graph is not None:
+                self.rekeyed += 1
+                if self.rekeyed > 4:                # a loader that keeps changing the episode shape: recording costs more than it saves
+                    self.failed, self.graph = True, None
+                    return self._eager(x)
             self.key, self.seen, self.graph = key, 0, None
         if self.graph is None:
             if self.seen < self.warmup:
