@@ -405,3 +405,25 @@ def test_placement_hint_roundtrip(tmp_path, monkeypatch):
     engine._placement_hint("k", {"chosen": [1, 2, 3, 4], "chosen_gbs": 6.1, "chosen_alt_gbs": 6.0})
     engine._PLACEMENT_HINTS.clear()                                   # another process: the file answers
     assert engine._placement_hint("k")["chosen"] == [1, 2, 3, 4] and engine._placement_hint("other") is None
+
+
+def test_graphed_step_is_only_offered_where_it_can_replay(monkeypatch):
+    """graph_step.for_loop: a hipGraph replay of the episode's forward + backward exists only for CUDA models and only for the two
+    loss functions it knows (plain set_forward_loss; the differentiable half of set_forward_loss_finetune) -- a CPU model or a
+    disabled switch get None and MetaTemplate's loop runs the reference's eager body."""
+    import torch
+    from meta_fine_tuning_amd import graph_step
+    from meta_fine_tuning_amd.io_utils import model_dict
+    from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5)          # parameters on the CPU
+    assert graph_step.for_loop(model, model.set_forward_loss) is None
+    assert graph_step.for_loop(model, model.set_forward_loss_finetune) is None
+    assert "_mft_graph_steps" not in model.__dict__ or not model.__dict__["_mft_graph_steps"]
+    monkeypatch.setattr(graph_step, "ENABLED", False)
+    assert graph_step.for_loop(model, model.set_forward_loss) is None
+    # a step that gave up (capture refused, or a loader that keeps changing the episode shape) runs the eager body
+    st = graph_step.GraphedLossBackward(model, model.set_forward_loss)
+    calls = []
+    monkeypatch.setattr(st, "_eager", lambda x, stream=None: calls.append(tuple(x.shape)) or "eager")
+    st.failed = True
+    assert st(torch.zeros(5, 21, 3, 8, 8)) == "eager" and calls
