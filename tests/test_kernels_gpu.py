@@ -1055,3 +1055,28 @@ def test_maxpool_relu_backward_matches_autograd(n, H, C):
     dx = torch.empty_like(x)
     assert lib.mft_maxpool_relu_backward(ops._p(dy), ops._p(arg), ops._p(y), ops._p(dx), n, H, H, C, ops._stream()) == 0
     assert float((dx.double().cpu().permute(0, 3, 1, 2) - gx).abs().max()) < 1e-6
+
+
+def test_bn_running_ema_matches_sequential_torch_updates():
+    """mft_bn_running_ema: running_mean / running_var after a sequence of train-mode BatchNorm forwards whose batch statistics came
+    out of two grouped launches (full and ragged mini-batches), against F.batch_norm(training=True) applied step by step."""
+    from meta_fine_tuning_amd import _lib
+    C, rows_a, rows_b = 96, 36, 9
+    rs = np.random.RandomState(5)
+    xa = torch.from_numpy(rs.standard_normal((6, rows_a, C)).astype(np.float32) * 1.5 + 0.3)
+    xb = torch.from_numpy(rs.standard_normal((3, rows_b, C)).astype(np.float32) * 0.7 - 0.2)
+    order = [(0, 0), (0, 1), (1, 0), (0, 2), (0, 3), (1, 1), (0, 4), (1, 2), (0, 5)]
+    rm, rv = torch.zeros(C), torch.ones(C)
+    for kind, g in order:                                   # torch's own running-statistics update, one forward at a time
+        x = (xa, xb)[kind][g]
+        F.batch_norm(x, rm, rv, None, None, True, 0.1, 1e-5)
+    ma, ra = ops.bn_stats(xa.view(-1, C).to(DEV), C, rows_a, 6)
+    mb, rb = ops.bn_stats(xb.view(-1, C).to(DEV), C, rows_b, 3)
+    od = torch.tensor([(k << 24) | g for k, g in order], dtype=torch.int32, device=DEV)
+    grm, grv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    assert _lib.lib().mft_bn_running_ema(ops._p(ma), ops._p(ra), rows_a, ops._p(mb), ops._p(rb), rows_b, ops._p(od), len(order), C, 1e-5, 0.1,
+                                         ops._p(grm), ops._p(grv), ops._stream()) == 0
+    np.testing.assert_allclose(grm.cpu().numpy(), rm.numpy(), atol=2e-6)
+    np.testing.assert_allclose(grv.cpu().numpy(), rv.numpy(), rtol=2e-5)
+    assert _lib.lib().mft_bn_running_ema(ops._p(ma), ops._p(ra), 0, None, None, 1, ops._p(od), len(order), C, 1e-5, 0.1, ops._p(grm),
+                                         ops._p(grv), ops._stream()) == -22
