@@ -894,7 +894,10 @@ def adapt_last_block(feature_mod, x_a, y_a, epochs, batch_size, lr=0.01, perms=N
             plan.append((len(flat_idx), len(ids)))
             flat_idx.extend(ids.tolist())
             flat_lab.extend(np.asarray(y_a)[ids].tolist())
-    key = (dev.index, id(W), n, H, epochs, batch_size, float(lr))
+    # (the recorded loop reads the module's BatchNorm buffers through their addresses: a module whose buffers were re-allocated
+    #  gets a fresh recording)
+    bufs = tuple(b.data_ptr() for b in feature_mod.buffers())
+    key = (dev.index, id(W), n, H, epochs, batch_size, float(lr), bufs)
     st = _ADAPT_GRAPHS.get(key)
     if st is None:
         for k_old in [k for k, v in _ADAPT_GRAPHS.items() if k[0] == dev.index and k[2:] == key[2:]]:
