@@ -850,6 +850,31 @@ def main():
                        "frac": round(ach3 / (PEAK_BF16_MFMA / 6e12), 4), "launches": len(x3_events),
                        "avg_launch_us": round(x_ms * 1e3 / len(x3_events), 2),
                        "vs_fp32_mfma_peak": round(ach3 / (PEAK_F32_MFMA / 1e12), 3)}
+            if not args.no_standalone:
+                # the same convolutions with the GPU to themselves: six trunk steps on one stream, no last-block stream beside them
+                try:
+                    n0 = len(x3_events)
+                    prs = [eng.draw_perms(e.n_total, e.epochs, np.random.RandomState(900 + i)) for i in range(E)]
+                    tabs = [t_ for t_ in e.step_tables(prs, E) if t_[0] == e.bs][:7]
+                    e.trunk_step(torch.from_numpy(tabs[0][1]).to(dev), e.bs, 0)
+                    torch.cuda.synchronize()
+                    timing["on"] = True
+                    for t_ in tabs[1:]:
+                        e.trunk_step(torch.from_numpy(t_[1]).to(dev), e.bs, 0)
+                    torch.cuda.synchronize()
+                    timing["on"] = False
+                    alone = x3_events[n0:]
+                    s_ms = sum(a.elapsed_time(b) for a, b, _ in alone)
+                    s_fl = sum(f for _, _, f in alone)
+                    del x3_events[n0:]
+                    if alone and s_ms > 0:
+                        sa = s_fl / (s_ms * 1e-3) / 1e12
+                        roof_x3["standalone"] = {"what": "the same eight convolutions per step with no co-running last-block stream (6 trunk steps)",
+                                                 "achieved": round(sa, 2), "frac": round(sa / (PEAK_BF16_MFMA / 6e12), 4),
+                                                 "avg_launch_us": round(s_ms * 1e3 / len(alone), 2)}
+                except Exception as ex:   # noqa: BLE001 -- an extra measurement must not cost the line
+                    timing["on"] = False
+                    roof_x3["standalone"] = {"error": str(ex)[:120]}
         roof_mfma = {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_conv_kernel (fp32 MFMA implicit GEMM: stem, "
                                                 "weight-streaming per-episode trunk.7 launches, GNN GEMMs)",
                      "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
