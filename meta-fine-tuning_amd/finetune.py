@@ -534,8 +534,9 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
             sc = torch.stack(sc)
         elif pipelined:
             if engine is None:
-                engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, len(eps[0]), fine_tune_epoch,
-                                     episodes_per_batch, fold50=getattr(model, "FOLD50", False))
+                with eng.slab_candidates(8 if len(batches) <= 8 else None):          # a short job: the cheaper placement scan
+                    engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, len(eps[0]), fine_tune_epoch,
+                                         episodes_per_batch, fold50=getattr(model, "FOLD50", False))
                 mark("engine built (host)")
                 if timings is not None:
                     torch.cuda.synchronize(dev)
