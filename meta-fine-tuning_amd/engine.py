@@ -291,7 +291,10 @@ class FinetuneEngine:
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
-        self.trunk_chunk = int(os.environ.get("MFT_TRUNK_CHUNK", "1")) if trunk_chunk is None else int(trunk_chunk)
+        # a single episode (the reference's per-episode finetune() call without the LookaheadLoader): the frozen trunk of 32 steps per
+        # set of launches -- at E = 1 a trunk pass is 5 images and pure launch latency (5.4 -> 12.3 episodes/s, tools/small_e.py)
+        self.trunk_chunk = (int(os.environ.get("MFT_TRUNK_CHUNK", "32" if episodes_per_batch == 1 else "1")) if trunk_chunk is None
+                            else int(trunk_chunk))
         # Queue priorities: the last-block stream is the critical path (its 8 launches per step are serial and HBM-bound), the
         # trunk stream only has to stay one step ahead.  A/B (one session, two runs each): last high / trunk normal 68.1, 68.1;
         # trunk high / last normal 67.4; both normal 67.2, 67.2 episodes/s.
