@@ -228,6 +228,14 @@ int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, float* dx, i
  * plain launch).  Forward: rows = n_img*OH*OW, cols = Cout, K = roundup(KH*KW*Cin, 32); data gradient: rows = n_img*H*W,
  * cols = Cin, K = KH*KW*Cout. */
 long long mft_conv_ksplit_ws_floats(long long rows, int cols, int K);
+/* ... and for a few weight sets in lockstep (2-8 episodes; per-episode weights w[g], imgs_per_group images each): grid.y = episode */
+long long mft_conv_ksplit_grouped_ws_floats(long long rows_per_group, int cols, int K, int groups);
+int mft_conv2d_nhwc_ksplit_grouped(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W, int Cin,
+                                   int Cout, int KH, int KW, int stride, int pad, int imgs_per_group, long long w_group_stride,
+                                   float* ws, void* stream);
+int mft_conv2d_dgrad_nhwc_ksplit_grouped(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W, int Cin,
+                                         int Cout, int KH, int KW, int stride, int pad, int imgs_per_group, long long w_group_stride,
+                                         float* ws, void* stream);
 int mft_conv2d_nhwc_ksplit(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo, int n_img, int H, int W,
                            int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream);
 int mft_conv2d_dgrad_nhwc_ksplit(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W, int Cin,

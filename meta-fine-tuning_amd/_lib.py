@@ -38,6 +38,9 @@ SIGNATURES = {
     "mft_conv2d_nhwc_x3_bnstats": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_conv2d_dgrad_nhwc": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_conv_ksplit_ws_floats": [_L, _I, _I],
+    "mft_conv_ksplit_grouped_ws_floats": [_L, _I, _I, _I],
+    "mft_conv2d_nhwc_ksplit_grouped": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
+    "mft_conv2d_dgrad_nhwc_ksplit_grouped": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_nhwc_ksplit": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_dgrad_nhwc_ksplit": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_wgrad_oihw_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
@@ -129,7 +132,7 @@ SIGNATURES = {
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L,
-            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L, "mft_conv_ksplit_ws_floats": _L, "mft_conv2d_wgrad_oihw_ws_floats": _L}
+            "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L, "mft_conv_ksplit_ws_floats": _L, "mft_conv2d_wgrad_oihw_ws_floats": _L, "mft_conv_ksplit_grouped_ws_floats": _L}
 
 _lib = None
 

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const long long out_row0 = (long long)g * p.rows_per_group;
-    if (p.ksplit > 1) {                    // partial tile of this K slice (single-group launches only)
-        float* part = p.ws + (long long)blockIdx.z * p.rows_per_group * p.Cout;
+    if (p.ksplit > 1) {                    // partial tile of this K slice: ws[slice][all groups' rows][Cout]
+        float* part = p.ws + ((long long)blockIdx.z * gridDim.y * p.rows_per_group + out_row0) * p.Cout;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256) void reduce_ksplit_kernel(const float* __restr
 // K slices for a single-group launch of `rows` x `cols` outputs with a reduction of K: a meta-training step runs ONE episode
 // (105 images), so the deep layers are a handful of 64 x 64 tiles with 72-144 K-steps each (trunk.7: 120 tiles on 256 CUs,
 // 70 us of dependent MFMAs per tile); slicing K puts ~3 workgroups on every CU.  1 = no slicing.
-inline int conv_ksplit(long long rows, int cols, int K) {
+inline int conv_ksplit(long long rows, int cols, int K, int groups = 1) {
     if (cols % 4 != 0) return 1;
-    const long long tiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+    const long long tiles = (long long)groups * ((rows + 63) / 64) * ((cols + 63) / 64);      // rows: per group
     const int nk = K / BK;
     if (tiles >= 512 || nk < 16) return 1;
     long long s = (768 + tiles - 1) / tiles;
@@ -367,7 +367,7 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (p.ksplit > 1 && (groups != 1 || p.ws == nullptr || p.parity)) return MFT_EINVAL;
+    if (p.ksplit > 1 && (p.ws == nullptr || p.parity)) return MFT_EINVAL;
     if (p.parity) {
         if (!BT || groups != 1 || p.bt_stride != 2) return MFT_EINVAL;
         const int tm = cdiv(p.imgs_per_group * ((p.OH + 1) / 2) * ((p.OW + 1) / 2), BM);       // the largest class
@@ -377,11 +377,11 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     dim3 grid(tiles_m * p.tiles_n, groups, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (p.ksplit > 1) {
-        const long long total = (long long)p.rows_per_group * (p.Cout / 4);
+        const long long total = (long long)groups * p.rows_per_group * (p.Cout / 4);
         long long blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(reduce_ksplit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)p.ws, p.out, p.bias,
-                           p.rows_per_group, p.Cout, p.ldo, p.ksplit);
+                           groups * p.rows_per_group, p.Cout, p.ldo, p.ksplit);
     }
     return mft_launch_status();
 }
@@ -1176,8 +1176,8 @@ static int conv2d_impl(const float* in, int ldi, const float* w, const float* bi
     a.tiles_n = 0;
     a.bt_stride = 1;
     a.ksplit = 1; a.ws = nullptr; a.parity = 0;
-    if (ws != nullptr && !stem && groups == 1 && ldo % 4 == 0) {
-        a.ksplit = conv_ksplit(a.rows_per_group, Cout, a.Kpad);
+    if (ws != nullptr && !stem && ldo % 4 == 0) {
+        a.ksplit = conv_ksplit(a.rows_per_group, Cout, a.Kpad, groups);
         a.ws = ws;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1190,7 +1190,7 @@ static int conv2d_impl(const float* in, int ldi, const float* w, const float* bi
         }
         return launch_conv<128, 64, 2, 2, true>(a, groups, s);
     }
-    if (g_skinny && groups > 1 && w_group_stride != 0 && bias == nullptr) {
+    if (g_skinny && groups > 1 && w_group_stride != 0 && bias == nullptr && ws == nullptr) {
         // per-episode weights, <= 48 output pixels per episode: weight-streaming skinny kernel (csrc/skinny.hip)
         const int rc = mft_skinny_fwd_dispatch(in, ldi, w, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
                                                imgs_per_group, w_group_stride, s);
@@ -1222,6 +1222,21 @@ extern "C" int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const f
 extern "C" long long mft_conv_ksplit_ws_floats(long long rows, int cols, int K) {
     const int s = conv_ksplit(rows, cols, K);
     return s > 1 ? (long long)s * rows * cols : 0;
+}
+
+// The K-sliced forms for a FEW weight sets (2 <= episodes <= 8 in lockstep: grid.y = episode): the weight-streaming per-episode
+// kernels put one workgroup set per episode on the GPU, which leaves most CUs idle below ~16 episodes.
+extern "C" long long mft_conv_ksplit_grouped_ws_floats(long long rows_per_group, int cols, int K, int groups) {
+    const int s = conv_ksplit(rows_per_group, cols, K, groups);
+    return s > 1 ? (long long)s * groups * rows_per_group * cols : 0;
+}
+
+extern "C" int mft_conv2d_nhwc_ksplit_grouped(const float* in, int ldi, const float* w, float* out, int ldo, int n_img, int H, int W,
+                                              int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                                              long long w_group_stride, float* ws, void* stream) {
+    if (ws == nullptr || imgs_per_group <= 0) return MFT_EINVAL;
+    return conv2d_impl(in, ldi, w, nullptr, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride, ws,
+                       stream);
 }
 
 extern "C" int mft_conv2d_nhwc_ksplit(const float* in, int ldi, const float* w, const float* bias, float* out, int ldo,
@@ -1287,7 +1302,7 @@ static int dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int l
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     if (n_img % imgs_per_group != 0) return MFT_EINVAL;
     const int groups = n_img / imgs_per_group;
-    if (g_skinny && groups > 1 && w_group_stride != 0) {
+    if (g_skinny && groups > 1 && w_group_stride != 0 && ws == nullptr) {
         const int rc = mft_skinny_dgrad_dispatch(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad,
                                                  imgs_per_group, w_group_stride, (hipStream_t)stream);
         if (rc != MFT_EINVAL) return rc;
@@ -1310,8 +1325,8 @@ static int dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int l
     a.tiles_n = 0;
     a.ksplit = 1; a.ws = nullptr;
     a.parity = (groups == 1 && stride == 2 && g_dgrad_parity) ? 1 : 0;
-    if (!a.parity && ws != nullptr && groups == 1 && ldx % 4 == 0 && Cin % 64 == 0) {
-        a.ksplit = conv_ksplit(a.rows_per_group, Cin, a.Kpad);
+    if (!a.parity && ws != nullptr && ldx % 4 == 0 && Cin % 64 == 0) {
+        a.ksplit = conv_ksplit(a.rows_per_group, Cin, a.Kpad, groups);
         a.ws = ws;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1324,6 +1339,13 @@ extern "C" int mft_conv2d_dgrad_nhwc(const float* dy, int ldy, const float* w, f
                                      int imgs_per_group, long long w_group_stride, void* stream) {
     return dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride, nullptr,
                       stream);
+}
+
+extern "C" int mft_conv2d_dgrad_nhwc_ksplit_grouped(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H,
+                                                    int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
+                                                    long long w_group_stride, float* ws, void* stream) {
+    if (ws == nullptr || imgs_per_group <= 0 || stride != 1) return MFT_EINVAL;
+    return dgrad_impl(dy, ldy, w, dx, ldx, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, w_group_stride, ws, stream);
 }
 
 // the same data gradient with the reduction over (tap, output channel) sliced across workgroups (workspace:

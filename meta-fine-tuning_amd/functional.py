@@ -378,7 +378,7 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         rc = ops._lib.MFT_EINVAL
         # (one group = a single episode: the weight-streaming kernels would run on a handful of workgroups; the K-sliced
         #  implicit GEMM + one small BatchNorm launch is several times faster there)
-        if FUSED_LAST_BLOCK and c1w.dim() == 3 and scw.dim() == 3 and groups > 1 and not so:
+        if FUSED_LAST_BLOCK and c1w.dim() == 3 and scw.dim() == 3 and groups > ops.SMALL_GROUPS and not so:
             # C1 + BatchNorm + ReLU and the shortcut convolution (which samples C1's centre tap) in one launch
             m1 = arena.get(tag + ".bn1.mean", (groups, cout))
             s1 = arena.get(tag + ".bn1.rstd", (groups, cout))
@@ -396,7 +396,7 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         c2 = arena.get(tag + ".c2", (n, OH, OH, cout))
         out = arena.get(tag + ".out", (n * OH * OH, cout))
         rc = ops._lib.MFT_EINVAL
-        if FUSED_LAST_BLOCK and pooled is not None and c2w.dim() == 3 and groups > 1 and not so:
+        if FUSED_LAST_BLOCK and pooled is not None and c2w.dim() == 3 and groups > ops.SMALL_GROUPS and not so:
             # C2 + both BatchNorms + residual add + ReLU + global average pool in one launch
             m2, s2, ms, ss = (arena.get(tag + ".bn2." + k, (groups, cout)) for k in ("mean", "rstd", "mean2", "rstd2"))
             rc = ops._lib.lib().mft_block_exit_small_forward(
@@ -570,7 +570,7 @@ def _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, 
     """Data gradient of trunk.7.C2 followed by the BatchNorm1 + ReLU backward -> dc1 (separate pass over C2's weights)."""
     # dgrad of C2 must read the pre-update weights: it runs before the fused wgrad+Adam of C2
     rc = ops._lib.MFT_EINVAL
-    if FUSED_LAST_BLOCK and n != ipg:
+    if FUSED_LAST_BLOCK and n // ipg > ops.SMALL_GROUPS:
         # (one group -- a single episode, the meta-fine-tuning training loop: the weight-streaming kernel would run on 16 workgroups;
         #  the K-sliced implicit GEMM + the BatchNorm backward launches below take a sixth of its time)
         # data gradient of C2 with the BatchNorm1 + ReLU backward in its epilogue (dr1 is not materialised)

@@ -6,6 +6,7 @@ activations are NHWC fp32 CUDA tensors.  Nothing in this module falls back to
 torch math: a CPU tensor or a missing library raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -149,21 +150,34 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
                                                    stride, pad, _p(ws), _stream())
             _lib.check(rc, "mft_conv2d_nhwc_ksplit")
             return out
+    if w_pk.dim() == 3 and 1 < w_pk.shape[0] <= SMALL_GROUPS and bias is None and Cin != 3:
+        # a few episodes in lockstep: grid.y = episode on the K-sliced implicit GEMM (the weight-streaming kernels need >= 16
+        # episodes to fill the GPU)
+        G = w_pk.shape[0]
+        nws = _ksplit_ws(imgs_per_group * OH * OW, Cout, w_pk.shape[-1], G)
+        if nws:
+            ws = torch.empty((nws,), device=x.device, dtype=torch.float32)
+            rc = _lib.lib().mft_conv2d_nhwc_ksplit_grouped(_p(x), Cin, _p(w_pk), _p(out), Cout, n, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                           imgs_per_group, wgs, _p(ws), _stream())
+            _lib.check(rc, "mft_conv2d_nhwc_ksplit_grouped")
+            return out
     rc = _lib.lib().mft_conv2d_nhwc(_p(x), Cin, _p(w_pk), _p(bias), _p(out), Cout, n, H, W, Cin, Cout, KH, KW,
                                     stride, pad, imgs_per_group, wgs, _stream())
     _lib.check(rc, "mft_conv2d_nhwc")
     return out
 
 
+SMALL_GROUPS = int(os.environ.get("MFT_SMALL_GROUPS", "8"))      # up to this many per-episode weight sets take the K-sliced GEMM route
 _KSPLIT_WS = {}
 
 
-def _ksplit_ws(rows, cols, K):
+def _ksplit_ws(rows, cols, K, groups=1):
     """floats of workspace for the K-sliced convolution / data-gradient launch of this shape (0: not sliced); memoised."""
-    key = (rows, cols, K)
+    key = (rows, cols, K, groups)
     v = _KSPLIT_WS.get(key)
     if v is None:
-        v = _KSPLIT_WS[key] = int(_lib.lib().mft_conv_ksplit_ws_floats(rows, cols, K))
+        v = _KSPLIT_WS[key] = int(_lib.lib().mft_conv_ksplit_ws_floats(rows, cols, K) if groups == 1 else
+                                  _lib.lib().mft_conv_ksplit_grouped_ws_floats(rows, cols, K, groups))
     return v
 
 
@@ -280,6 +294,14 @@ def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None, stride=
             rc = _lib.lib().mft_conv2d_dgrad_nhwc_ksplit(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride, pad,
                                                          _p(ws), _stream())
             _lib.check(rc, "mft_conv2d_dgrad_nhwc_ksplit")
+            return out
+    if w_pk.dim() == 3 and 1 < w_pk.shape[0] <= SMALL_GROUPS and Cin % 64 == 0 and stride == 1 and imgs_per_group > 0:
+        nws = _ksplit_ws(imgs_per_group * H * W, Cin, KH * KW * Cout, w_pk.shape[0])
+        if nws:
+            ws = torch.empty((nws,), device=dy.device, dtype=torch.float32)
+            rc = _lib.lib().mft_conv2d_dgrad_nhwc_ksplit_grouped(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride,
+                                                                 pad, imgs_per_group, wgs, _p(ws), _stream())
+            _lib.check(rc, "mft_conv2d_dgrad_nhwc_ksplit_grouped")
             return out
     rc = _lib.lib().mft_conv2d_dgrad_nhwc(_p(dy), Cout, _p(w_pk), _p(out), Cin, n, H, W, Cin, Cout, KH, KW, stride, pad,
                                           imgs_per_group, wgs, _stream())

@@ -232,7 +232,7 @@ def test_fused_wgrad_adam_equals_unfused():
         sc = e.run_batch(eps, perms=perms)
         outs.append((sc.clone(), e.adapt.w.flat.clone(), e.adapt.m.flat.clone(), e.adapt.v.flat.clone()))
     (s0, w0, m0, v0), (s1, w1, m1, v1) = outs
-    assert float((m0 - m1).abs().max()) < 1e-5 and float((v0 - v1).abs().max()) < 1e-7     # after 15 chaotic Adam steps
+    assert float((m0 - m1).abs().max()) < 2e-5 and float((v0 - v1).abs().max()) < 1e-7     # after 15 chaotic Adam steps
     frac_far = float(((w0 - w1).abs() > 1e-4).float().mean())
     assert frac_far < 1e-3 and float((s0 - s1).abs().max()) < 5e-3, (frac_far, float((s0 - s1).abs().max()))
 

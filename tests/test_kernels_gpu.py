@@ -519,11 +519,13 @@ def test_fused_small_group_kernels_match_unfused(ipg):
 
 
 @pytest.mark.parametrize("ipg", [5, 4, 1])
-def test_fused_block_entry_and_dgrad_bn_backward(ipg):
+def test_fused_block_entry_and_dgrad_bn_backward(ipg, monkeypatch):
     """mft_block_entry_small_forward (C1 + BatchNorm + ReLU + shortcut conv in one launch) and
-    mft_conv2d_dgrad_bn_backward_small (C2 data gradient + BatchNorm/ReLU backward) against the launch sequences they replace."""
+    mft_conv2d_dgrad_bn_backward_small (C2 data gradient + BatchNorm/ReLU backward) against the launch sequences they replace
+    (the weight-streaming bf16x3 kernels of large episode batches: ops.SMALL_GROUPS = 0 keeps the three test episodes on them)."""
     from meta_fine_tuning_amd import _lib
     lib = _lib.lib()
+    monkeypatch.setattr(ops, "SMALL_GROUPS", 0)
     G, Cin, C, H = 3, 256, 512, 6
     n = G * ipg
     rows = ipg * 9
@@ -1080,3 +1082,33 @@ def test_bn_running_ema_matches_sequential_torch_updates():
     np.testing.assert_allclose(grv.cpu().numpy(), rv.numpy(), rtol=2e-5)
     assert _lib.lib().mft_bn_running_ema(ops._p(ma), ops._p(ra), 0, None, None, 1, ops._p(od), len(order), C, 1e-5, 0.1, ops._p(grm),
                                          ops._p(grv), ops._stream()) == -22
+
+
+@pytest.mark.parametrize("G,ipg,H,Cin,Cout,k,stride,pad", [(4, 5, 6, 256, 512, 3, 2, 1), (3, 4, 3, 512, 512, 3, 1, 1), (8, 5, 6, 256, 512, 1, 2, 0),
+                                                           (2, 1, 3, 512, 512, 3, 1, 1)])
+def test_grouped_k_sliced_convolutions_match_float64(G, ipg, H, Cin, Cout, k, stride, pad, monkeypatch):
+    """A few episodes in lockstep (2-8 per-episode weight sets): forward and data gradient on the K-sliced implicit GEMM with
+    grid.y = episode, against float64 per episode and against the weight-streaming kernels large batches use."""
+    from meta_fine_tuning_amd import _lib
+    n = G * ipg
+    x = nhwc(rnd((n, Cin, H, H), 111)).to(DEV)
+    ws_ = [rnd((Cout, Cin, k, k), 120 + g, scale=(2.0 / (k * k * Cin)) ** 0.5) for g in range(G)]
+    wp = torch.stack([ops.pack_conv_weight(w.to(DEV)) for w in ws_])
+    OH = (H + 2 * pad - k) // stride + 1
+    assert (int(_lib.lib().mft_conv_ksplit_grouped_ws_floats(ipg * OH * OH, Cout, wp.shape[-1], G)) > 0) == (k == 3)
+    out = ops.conv2d(x, wp, Cout, k, k, stride, pad, imgs_per_group=ipg)
+    monkeypatch.setattr(ops, "SMALL_GROUPS", 0)
+    big = ops.conv2d(x, wp, Cout, k, k, stride, pad, imgs_per_group=ipg)            # weight-streaming bf16x3 kernels
+    monkeypatch.undo()
+    xd = x.double().cpu().permute(0, 3, 1, 2)
+    ref = torch.cat([F.conv2d(xd[g * ipg:(g + 1) * ipg], ws_[g].double(), stride=stride, padding=pad) for g in range(G)]).permute(0, 2, 3, 1)
+    sc = float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) < 1e-5 * sc
+    assert float((out - big).abs().max()) < 2e-5 * sc
+    if stride == 1:
+        dy = nhwc(rnd((n, Cout, OH, OH), 112)).to(DEV)
+        dx = ops.conv2d_dgrad(dy, wp, Cin, k, k, pad, imgs_per_group=ipg)
+        dyd = dy.double().cpu().permute(0, 3, 1, 2)
+        gref = torch.cat([torch.nn.grad.conv2d_input((ipg, Cin, H, H), ws_[g].double(), dyd[g * ipg:(g + 1) * ipg], padding=pad)
+                          for g in range(G)]).permute(0, 2, 3, 1)
+        assert float((dx.double().cpu() - gref).abs().max()) < 1e-5 * float(gref.abs().max())
