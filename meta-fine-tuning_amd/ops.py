@@ -167,7 +167,7 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
     return out
 
 
-SMALL_GROUPS = int(os.environ.get("MFT_SMALL_GROUPS", "8"))      # up to this many per-episode weight sets take the K-sliced GEMM route
+SMALL_GROUPS = int(os.environ.get("MFT_SMALL_GROUPS", "12"))     # up to this many per-episode weight sets take the K-sliced GEMM route
 _KSPLIT_WS = {}
 
 
