@@ -547,8 +547,9 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
             nxt = gens.get(bi + 1)
             sc = engine.run_batch(eps, perms=perms, defer_final=True, prefetch=None if nxt is None else nxt[0])
         else:
-            sc = scores_batched(method, eps, model, state, state_b, fine_tune_epoch, n_way, n_shot, episodes_per_batch,
-                                rngs=rngs, classifiers=cls)
+            with eng.slab_candidates(8 if len(batches) <= 8 else None):              # (engines are built on the first batch)
+                sc = scores_batched(method, eps, model, state, state_b, fine_tune_epoch, n_way, n_shot, episodes_per_batch,
+                                    rngs=rngs, classifiers=cls)
         score_chunks.append(sc)
         del eps
         mark("batch %d enqueued" % bi)
