@@ -365,6 +365,7 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
         if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
+            attr_once.mark();
         }
     }
     if (p.ksplit > 1 && (p.ws == nullptr || p.parity)) return MFT_EINVAL;
@@ -1071,6 +1072,7 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
         if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
+            attr_once.mark();
         }
     }
     WgradArgs p = a;

@@ -19,6 +19,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -74,6 +76,28 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
     p3[1] = pk_bf16(r[2], r[3]);
 }
 
+// ------------------------------------------------------------------------------------------ "f16x2": two fp16 pieces, three products
+// NP = 2 forms of the kernels below.  x = hi + 2^-11 lo with hi = fp16(x) (round to nearest even) and lo = fp16((x - hi) * 2^11):
+// the residual x - hi is exact in fp32, the scaled residual has the magnitude of x itself -- so lo is a NORMAL fp16 number
+// whenever hi is, whatever the magnitude of x -- and |x - (hi + 2^-11 lo)| <= 2^-22 |x|.  A product is then
+//     a b = a_hi b_hi + 2^-11 (a_hi b_lo + a_lo b_hi) + O(2^-22 a b):
+// THREE fp16 MFMAs per K-step instead of the six bf16 ones (same matrix rate per instruction: half the matrix work, two LDS
+// planes per operand instead of three), with the leading term and the cross terms in two separate fp32 accumulators that the
+// epilogue combines (acc0 + 2^-11 acc1) -- which also keeps the small terms from being rounded against the large partial sum.
+// Error: 2^-22 relative per PRODUCT (random sign) against the fp32 rounding of every PARTIAL SUM that any fp32-accumulating
+// GEMM makes; measured against float64 on the trunk shapes it stays below the fp32-MFMA kernel's error
+// (tests/test_kernels_gpu.py::test_conv2d_f16x2_is_fp32_accurate).  Range: the operands must lie inside fp16's (|x| < 65504).  The
+// callers are the frozen trunk's convolutions, whose inputs are train-mode BatchNorm outputs, |x| <= |gamma| sqrt(n) + |beta|, and
+// whose weights are checked at load time (functional.ResNet10Weights: any tensor outside the bound keeps the bf16x3 kernels).
+__device__ __forceinline__ void split4_h2(const f32x4 x, u32x2& p1, u32x2& p2) {
+    const f16x4 hi = __builtin_convertvector(x, f16x4);
+    const f32x4 r = (x - __builtin_convertvector(hi, f32x4)) * 2048.f;
+    const f16x4 lo = __builtin_convertvector(r, f16x4);
+    p1 = __builtin_bit_cast(u32x2, hi);
+    p2 = __builtin_bit_cast(u32x2, lo);
+}
+constexpr float X3_H2_LO_SCALE = 1.0f / 2048.f;
+
 // AP = true: the activation arrives already split into its three bf16 planes (the producing BatchNorm-apply / pooling kernel
 // split every element ONCE, instead of this loader re-splitting it for each of the 9 taps and each n-tile): the A path is
 // then the same plain 16-byte copy into LDS as the weight path, with no VALU work between the loads and the MFMAs.
@@ -87,8 +111,10 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& p1, u32x2& p2, u32x
 // XS: 64-byte LDS rows (no padding) with an XOR swizzle of the four 16-byte chunks of a row, chunk' = chunk ^ ((row >> 2) & 3):
 // fragment reads (16 lanes = 16 consecutive rows, one chunk) and staging writes (consecutive rows, whole rows) stay
 // conflict-free, and the tile takes 36 KB instead of 46 KB of LDS -> FOUR workgroups per CU instead of three.
-template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0, bool XS = false>
+template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0, bool XS = false, int NP = 3>
 __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
+    static_assert(NP == 3 || (NP == 2 && !AP && !DB && HOIST == 0 && DBG == 0 && !XS), "f16x2: the plain single-buffer form only");
+    constexpr int NACC = NP == 3 ? 1 : 2;
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
     constexpr int TN = BN / 64;
     constexpr int PA = AP ? BM / 64 : BM / 32;   // A passes: fp32: 32 rows x 8 threads x float4; planes: 64 rows x 4 threads x 16 B
@@ -101,9 +127,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
         else return row * X3_RS + c;
     };
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    unsigned short* As = smem;                    // [3][BM][RS]
-    unsigned short* Bs = smem + 3 * A_PLANE;      // [3][BN][RS]
-    constexpr int BUF = 3 * (A_PLANE + B_PLANE);  // elements per LDS buffer (DB: two of them)
+    unsigned short* As = smem;                    // [NP][BM][RS]
+    unsigned short* Bs = smem + NP * A_PLANE;     // [NP][BN][RS]
+    constexpr int BUF = NP * (A_PLANE + B_PLANE);  // elements per LDS buffer (DB: two of them)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -163,19 +189,26 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
     for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
     const int plane_bytes = (int)(p.plane * 2);
 
-    f32x16 acc[TM][TN];
+    f32x16 accs[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accs[q][i][j][e] = 0.f;
+    auto& acc = accs[0];
+    auto val = [&](int i, int j, int e) -> float {      // the finished output element
+        if constexpr (NP == 3) return accs[0][i][j][e];
+        else return __builtin_fmaf(accs[NACC - 1][i][j][e], X3_H2_LO_SCALE, accs[0][i][j][e]);
+    };
 
     // register stage: the operands of K-step kt+1 are in flight while kt is multiplied
     struct Stage {
         f32x4 ra[AP ? 1 : PA];
         u32x4 ra3[AP ? PA : 1][3];
-        u32x4 rb[PB][3];
+        u32x4 rb[PB][NP];
     };
     Stage st0;
     const int nk = p.Kpad / 32;
@@ -208,16 +241,21 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 S.rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
     };
     auto store_tile = [&](const Stage& S, int buf) {
         unsigned short* As = smem + buf * BUF;
-        unsigned short* Bs = As + 3 * A_PLANE;
+        unsigned short* Bs = As + NP * A_PLANE;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int off = lo(lrow + RPP * j, c4);
-            if constexpr (AP) {
+            if constexpr (NP == 2) {
+                u32x2 p1, p2;
+                split4_h2(S.ra[j], p1, p2);
+                *(u32x2*)(As + off) = p1;
+                *(u32x2*)(As + A_PLANE + off) = p2;
+            } else if constexpr (AP) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) *(u32x4*)(As + pl * A_PLANE + off) = S.ra3[j][pl];
             } else {
@@ -236,13 +274,41 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 *(u32x4*)(Bs + pl * B_PLANE + lo(brow + 64 * j, bseg * 8)) = S.rb[j][pl];
     };
 
     auto compute = [&](int buf) {
         const unsigned short* As = smem + buf * BUF;
-        const unsigned short* Bs = As + 3 * A_PLANE;
+        const unsigned short* Bs = As + NP * A_PLANE;
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f16x8 a[TM][2], b[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        a[i][pl] = *(const f16x8*)(As + pl * A_PLANE + lo(wm * (BM / 2) + i * 32 + r, kk * 16 + h * 8));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        b[j][pl] = *(const f16x8*)(Bs + pl * B_PLANE + lo(wn * (BN / 2) + j * 32 + r, kk * 16 + h * 8));
+                constexpr int TA[3] = {0, 1, 0};
+                constexpr int TB[3] = {1, 0, 0};
+                constexpr int TQ[3] = {1, 1, 0};          // cross products -> accumulator 1, leading product -> accumulator 0
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            accs[TQ[t] ? NACC - 1 : 0][i][j] =
+                                __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], b[j][TB[t]], accs[TQ[t] ? NACC - 1 : 0][i][j], 0, 0, 0);
+            }
+            return;
+        }
         // ALL fragment reads of the K-step (both 16-wide halves: 2 x 3 x (TM + TN) ds_read_b128) are issued before the first
         // MFMA and pinned there (sched_barrier): left to itself the scheduler sinks each read to just before the MFMA that
         // consumes it to save registers, which exposes one LDS round trip per MFMA (ISA of round 1: "ds_read, s_waitcnt, mfma"
@@ -388,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int m = m0 + wm * (BM / 2) + i * 32 + row;
-                if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
+                if (m < p.M) p.out[(long long)m * p.ldo + n] = val(i, j, e);
             }
         }
     // Fused BatchNorm statistics (the consumer of every trunk convolution is a train-mode BatchNorm, backbone.py:224-227):
@@ -409,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[i][j][e];
+                    const float v = val(i, j, e);
                     if (m < p.M) {
                         if (m < split) { a1 += v; a2 += v * v; }
                         else { b1 += v; b2 += v * v; }
@@ -676,17 +742,19 @@ __global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
 // partials (bn_fold.h) into an LDS table of (scale, shift) per (group, channel).  The loader then applies one FMA + max per
 // element in front of the bf16x3 split; padding and zero rows stay exact zeros.  Removes BN1's finalize and apply launches and
 // the activation they wrote and re-read.
-template <int BM, int BN, bool BNIN>
+template <int BM, int BN, bool BNIN, int NP = 3>
 __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
+    static_assert(NP == 3 || NP == 2, "3 bf16 pieces (six products) or 2 fp16 pieces (three products)");
+    constexpr int NACC = NP == 3 ? 1 : 2;           // f16x2: leading products / cross products in separate accumulators
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PA = BM / 32, PB = BN / 64;
     constexpr int RS = X3_RS;
     constexpr int B_PLANE = BN * RS;
     const int A_PLANE = p.s1_rows * RS;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    unsigned short* As = smem;                       // [3][s1_rows][RS]
-    unsigned short* Bs = smem + 3 * A_PLANE;         // [3][BN][RS]
-    float* bn_tab = reinterpret_cast<float*>(Bs + 3 * B_PLANE);     // BNIN: [2 groups][scale | shift][Cin]
+    unsigned short* As = smem;                       // [NP][s1_rows][RS]
+    unsigned short* Bs = smem + NP * A_PLANE;        // [NP][BN][RS]
+    float* bn_tab = reinterpret_cast<float*>(Bs + NP * B_PLANE);     // BNIN: [2 groups][scale | shift][Cin]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -769,18 +837,24 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
         fa[i] = (t + 1 + (m0 + t) / W - fr0) * RS;
     }
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
+    auto val = [&](int i, int j, int e) -> float {      // the finished output element
+        if constexpr (NP == 3) return acc[0][i][j][e];
+        else return __builtin_fmaf(acc[1][i][j][e], X3_H2_LO_SCALE, acc[0][i][j][e]);
+    };
 
     struct Stage {
         f32x4 ra[PA];
         f32x4 rh;
-        u32x4 rb[PB][3];
+        u32x4 rb[PB][NP];
     };
     Stage st;
     const int n_ci = p.Cin / 32;
@@ -802,15 +876,22 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 S.rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
     };
     auto put_a = [&](const f32x4 v, int off) {
-        u32x2 p1, p2, p3;
-        split4(v, p1, p2, p3);
-        *(u32x2*)(As + off) = p1;
-        *(u32x2*)(As + A_PLANE + off) = p2;
-        *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+        if constexpr (NP == 3) {
+            u32x2 p1, p2, p3;
+            split4(v, p1, p2, p3);
+            *(u32x2*)(As + off) = p1;
+            *(u32x2*)(As + A_PLANE + off) = p2;
+            *(u32x2*)(As + 2 * A_PLANE + off) = p3;
+        } else {
+            u32x2 p1, p2;
+            split4_h2(v, p1, p2);
+            *(u32x2*)(As + off) = p1;
+            *(u32x2*)(As + A_PLANE + off) = p2;
+        }
     };
     auto bn_relu = [&](const f32x4 v, const f32x4 sc, const f32x4 sh, bool ok) {      // relu(BatchNorm(v)); masked (padding) elements stay 0
         f32x4 o = mft_bn_affine4(v, sc, sh);
@@ -846,37 +927,63 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * RS + bseg * 8) = S.rb[j][pl];
     };
     auto compute = [&](int kw) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
+            if constexpr (NP == 3) {
+                bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[0][i][j], 0, 0, 0);
+            } else {
+                f16x8 a[TM][2], b[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        a[i][pl] = *(const f16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        b[j][pl] = *(const f16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
+                // cross products first (hi x lo, lo x hi -> acc 1), leading product last (-> acc 0): neighbouring MFMAs of one
+                // (i, j) alternate between the two accumulators, so none waits for its predecessor's result
+                constexpr int TA[3] = {0, 1, 0};
+                constexpr int TB[3] = {1, 0, 0};
+                constexpr int TQ[3] = {1, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[TQ[t]][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][TA[t]], b[j][TB[t]], acc[TQ[t]][i][j], 0, 0, 0);
+            }
         }
     };
 
     // the zero rows (image-row boundaries, halo rows that fall outside their image row) are written once and never touched again
-    for (int i = tid; i < 3 * A_PLANE / 8; i += 256) ((u32x4*)As)[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < NP * A_PLANE / 8; i += 256) ((u32x4*)As)[i] = (u32x4){0u, 0u, 0u, 0u};
     load_a(0, st);
     load_b(0, 0, st);
     __syncthreads();
@@ -914,7 +1021,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int m = m0 + wm * (BM / 2) + i * 32 + row;
-                if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
+                if (m < p.M) p.out[(long long)m * p.ldo + n] = val(i, j, e);
             }
         }
     if (p.stats_ws != nullptr) {
@@ -930,7 +1037,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[i][j][e];
+                    const float v = val(i, j, e);
                     if (m < p.M) {
                         if (m < split) { a1 += v; a2 += v * v; }
                         else { b1 += v; b2 += v * v; }
@@ -959,15 +1066,15 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NP = 3>
 __global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
-    conv_x3_s1_body<BM, BN, false>(p);
+    conv_x3_s1_body<BM, BN, false, NP>(p);
 }
 
 // (three waves per SIMD is what the trunk is tuned for: the loader-side BatchNorm must fit the same 168 registers)
-template <int BM, int BN>
+template <int BM, int BN, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_x3_s1_bnin_kernel(X3Args p) {
-    conv_x3_s1_body<BM, BN, true>(p);
+    conv_x3_s1_body<BM, BN, true, NP>(p);
 }
 
 // mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
@@ -1012,11 +1119,20 @@ int g_x3_xcd = 1;          // XCD-aware tile order (mft_debug_set_x3_tile(20/21)
 int g_x3_min_lds_kb = 0;   // throttle: pad the workgroup's LDS so fewer fit per CU (mft_debug_set_x3_tile(100 + KB))
 
 template <int BM, int BN, bool AP, bool DB>
-int launch_x3(X3Args p, hipStream_t s) {
+int launch_x3(X3Args p, hipStream_t s, int np = 3) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz;
+    if (np == 2) {                                  // f16x2: two planes per operand, the plain single-buffer kernel
+        if constexpr (!AP && !DB) {
+            p.row_swz = g_x3_row_swz != 0;
+            const size_t lds2 = (size_t)2 * (BM + BN) * X3_RS * sizeof(unsigned short);
+            hipLaunchKernelGGL((conv_x3_kernel<BM, BN, false, false, 0, 0, false, 2>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds2, s, p);
+            return mft_launch_status();
+        }
+        return MFT_EINVAL;
+    }
 #ifdef MFT_EXPERIMENTS
     const bool xs = g_x3_row_swz == 2 && !AP && !DB && g_x3_hoist == 0 && g_x3_dbg == 0;
 #else
@@ -1066,22 +1182,27 @@ int g_x3_s1 = 1;           // 3x3 / stride 1 / pad 1 layers: A image staged once
 
 constexpr size_t X3_S1_LDS_3PER_CU = 160 * 1024 / 3;       // three workgroups per CU: the occupancy the trunk convolutions are tuned for
 
-inline size_t x3_s1_lds(int BM, int BN, int W, int bn_cin) {
-    return (size_t)3 * (BM + 2 + (BM - 1) / W + 1 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
+inline size_t x3_s1_lds(int BM, int BN, int W, int bn_cin, int np = 3) {
+    return (size_t)np * (BM + 2 + (BM - 1) / W + 1 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
 }
 
 template <int BM, int BN>
-int launch_x3_s1(X3Args p, hipStream_t s) {
+int launch_x3_s1(X3Args p, hipStream_t s, int np = 3) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz != 0;
     p.s1_rows = BM + 2 + (BM - 1) / p.W + 1;
-    const size_t lds = x3_s1_lds(BM, BN, p.W, p.bn_ws ? p.Cin : 0);
-    if (p.bn_ws)
-        hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
-    else
-        hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    const size_t lds = x3_s1_lds(BM, BN, p.W, p.bn_ws ? p.Cin : 0, np);
+    const dim3 grid((unsigned)(tiles_m * p.tiles_n));
+    if (np == 2) {
+        if (p.bn_ws) hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN, 2>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN, 2>), grid, dim3(256), lds, s, p);
+    } else if (p.bn_ws) {
+        hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN>), grid, dim3(256), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN>), grid, dim3(256), lds, s, p);
+    }
     return mft_launch_status();
 }
 
@@ -1103,6 +1224,7 @@ int launch_x3_pp(X3Args p, hipStream_t s) {
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_x3_pp_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
+        attr_once.mark();
     }
     hipLaunchKernelGGL((conv_x3_pp_kernel<BM, BN>), dim3((unsigned)(tiles_m * p.tiles_n)), dim3(512), lds, s, p);
     return mft_launch_status();
@@ -1326,15 +1448,18 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
                        int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* stats_ws,
                        int rows_per_group, void* stream, const unsigned short* in3 = nullptr, long long in_plane_elems = 0,
                        const float* bn_ws = nullptr, const float* bn_gamma = nullptr, const float* bn_beta = nullptr,
-                       float bn_eps = 0.f) {
-    if (n_img <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || ldi % 4 != 0) return MFT_EINVAL;
+                       float bn_eps = 0.f, int np = 3) {
+    if (n_img <= 0 || Cin % 32 != 0 || Cout % 64 != 0 || ldi % 4 != 0 || (np != 3 && np != 2)) return MFT_EINVAL;
+    if (np == 2 && (in3 != nullptr || g_x3_tile > 1 || g_x3_db || g_x3_pp || g_x3_dbg || g_x3_hoist || g_x3_row_swz == 2 || g_x3_min_lds_kb ||
+                    g_x3_patch))
+        return MFT_EINVAL;                     // f16x2 exists for the default 128x64 kernels only
     X3Args p;
     p.bn_ws = bn_ws; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_eps = bn_eps;
     p.bn_max_tiles = bn_ws ? mft_x3_max_group_tiles(rows_per_group, 128) : 0;
     if (bn_ws != nullptr && (in3 != nullptr || !bn_gamma || !bn_beta || rows_per_group < 128 || KH != 3 || KW != 3 || stride != 1 ||
-                             pad != 1 || x3_s1_lds(128, 64, W, Cin) > X3_S1_LDS_3PER_CU ||
+                             pad != 1 || x3_s1_lds(128, 64, W, Cin, np) > X3_S1_LDS_3PER_CU ||
                              2 * mft_x3_stage_bytes_host(p.bn_max_tiles, Cin) >
-                                 (size_t)3 * (128 + 2 + 127 / W + 1) * X3_RS * sizeof(unsigned short)))
+                                 (size_t)np * (128 + 2 + 127 / W + 1) * X3_RS * sizeof(unsigned short)))
         return MFT_EINVAL;                     // the loader-side BatchNorm exists in the shared-tap kernel only, at full occupancy
     p.in3 = in3;
     p.in_plane_bytes = 0;
@@ -1378,6 +1503,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
             hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                64 * 1024);
             if (e != hipSuccess) return (int)e;
+            attr_once.mark();
         }
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(conv3x3_patch_x3_kernel, dim3((unsigned)(img_groups * q.row_blocks * q.tiles_n)), dim3(256), lds, s, q);
@@ -1389,7 +1515,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
 #endif
     int tile = g_x3_tile;
     if (tile == 0) tile = 1;       // 128x64 beats 128x128 on every trunk shape (3 vs 2 workgroups per CU)
-    p.w_bytes = (unsigned)(3 * plane_elems * 2);
+    p.w_bytes = (unsigned)(np * plane_elems * 2);
     // buffer extents must stay below 2^31 bytes: split the batch over images when the input is larger
     const long long img_bytes = (long long)H * W * ldi * 4;
     const long long max_imgs = 0x7fff0000LL / img_bytes;
@@ -1406,9 +1532,10 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
         q.in_bytes = (unsigned)(ni * img_bytes);
         const bool s1 = g_x3_s1 && tile == 1 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !g_x3_db && !g_x3_pp && !g_x3_dbg &&
                         g_x3_hoist == 0 && g_x3_row_swz != 2 && g_x3_min_lds_kb == 0 &&
-                        x3_s1_lds(128, 64, W, 0) <= 64 * 1024;
+                        x3_s1_lds(128, 64, W, 0, np) <= 64 * 1024;
         if (bn_ws != nullptr && !s1) return MFT_EINVAL;
-        const int rc = s1 ? launch_x3_s1<128, 64>(q, s)
+        const int rc = s1 ? launch_x3_s1<128, 64>(q, s, np)
+                       : np == 2 ? launch_x3<128, 64, false, false>(q, s, 2)
                        : (tile == 2 && Cout % 128 == 0) ? launch_x3<128, 128, false, false>(q, s)
                        : (tile == 3)                  ? launch_x3<64, 64, false, false>(q, s)
 #ifdef MFT_EXPERIMENTS

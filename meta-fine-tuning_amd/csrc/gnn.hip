@@ -218,6 +218,7 @@ extern "C" int mft_graph_aggregate(const float* A, const float* x, int ldx, floa
             hipError_t e = hipFuncSetAttribute((const void*)graph_aggregate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                150 * 1024);
             if (e != hipSuccess) return (int)e;
+            attr_once.mark();
         }
         hipLaunchKernelGGL(graph_aggregate_lds_kernel, dim3(n_graphs), dim3(256), lds, (hipStream_t)stream, A, x, ldx, y, ldy, N, F);
         return mft_launch_status();

@@ -578,6 +578,7 @@ static int linear_head_run(const float* z_support, const int* y_support, const i
             e = hipFuncSetAttribute((const void*)linear_head_sgd_kernel<ADAM, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024);
         if (e != hipSuccess) return (int)e;
+        attr_once.mark();
     }
     if (lds_z <= 150 * 1024)
         hipLaunchKernelGGL((linear_head_sgd_kernel<ADAM, true>), dim3(n_groups), dim3(256), lds_z, (hipStream_t)stream, z_support,

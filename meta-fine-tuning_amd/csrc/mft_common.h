@@ -1,6 +1,8 @@
 // Shared helpers for the gfx950 kernels of libmft_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include "mft_hip.h"
 
@@ -80,15 +82,26 @@ __device__ __forceinline__ void mft_adam4_exact(f32x4& m, f32x4& v, f32x4& w, co
 }
 
 // hipFuncSetAttribute applies to the CURRENT device only: a "done" flag per device (an engine may be built on cuda:1 after
-// another one ran on cuda:0 in the same process).  need() is true the first time it is asked on a device.
+// another one ran on cuda:0 in the same process, and per-thread multi-device engines are a supported pattern).
+//   if (once.need()) { e = hipFuncSetAttribute(...); if (e != hipSuccess) return e; once.mark(); }
+// need() is true until mark() was called on this device: a FAILED attribute call is retried (and reported again) by the next
+// launch instead of leaving every later launch to die with an opaque launch error.  The flags are atomics: two threads may both
+// set the (idempotent) attribute, neither can skip it before it succeeded.
 struct MftPerDeviceOnce {
-    bool done[64] = {};
-    bool need() {
+    std::atomic<unsigned char> done[64];
+    MftPerDeviceOnce() { for (auto& d : done) d.store(0, std::memory_order_relaxed); }
+    static int device() {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return -1;
+        return d;
+    }
+    bool need() const {
+        const int d = device();
+        return d < 0 || !done[d].load(std::memory_order_acquire);
+    }
+    void mark() {
+        const int d = device();
+        if (d >= 0) done[d].store(1, std::memory_order_release);
     }
 };
 

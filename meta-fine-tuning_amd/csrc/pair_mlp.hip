@@ -542,6 +542,7 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
         if (e != hipSuccess) return (int)e;
+        attr_once.mark();
     }
     hipStream_t st = (hipStream_t)stream;
     if (g_pair_db) {

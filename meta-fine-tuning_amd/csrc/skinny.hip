@@ -1094,17 +1094,26 @@ int launch_big_lds(K kern, size_t max_lds, dim3 grid, dim3 block, size_t lds, hi
     // the dynamic-LDS limit is raised once per kernel instantiation (instantiations of one template share the pointer TYPE, so
     // the "done" set is keyed by the function address)
     // (per device: the attribute belongs to the current device's copy of the code object)
+    // Entries are added only after the attribute call succeeded (a failure is retried and reported by the next launch), under a
+    // mutex: engines on several devices may launch from their own threads.
+    static std::mutex mu;
     static const void* done[256];
     static int done_dev[256];
     static int n_done = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     bool seen = false;
-    for (int i = 0; i < n_done; ++i) seen = seen || (done[i] == (const void*)kern && done_dev[i] == dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < n_done; ++i) seen = seen || (done[i] == (const void*)kern && done_dev[i] == dev);
+    }
     if (!seen) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return (int)e;
-        if (n_done < 256) { done[n_done] = (const void*)kern; done_dev[n_done++] = dev; }
+        std::lock_guard<std::mutex> lock(mu);
+        bool dup = false;
+        for (int i = 0; i < n_done; ++i) dup = dup || (done[i] == (const void*)kern && done_dev[i] == dev);
+        if (!dup && n_done < 256) { done[n_done] = (const void*)kern; done_dev[n_done] = dev; ++n_done; }
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
     return mft_launch_status();
@@ -1192,6 +1201,7 @@ static int skinny_fwd_impl(const float* in, int ldi, const float* w, float* out,
         hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            110 * 1024);
         if (e != hipSuccess) return (int)e;
+        attr_once.mark();
     }
     hipLaunchKernelGGL(skinny_conv_fwd_kernel, grid, dim3(1024), lds, s, p);
     return mft_launch_status();
@@ -1233,6 +1243,7 @@ static int skinny_dgrad_impl(const float* dy, int ldy, const float* w, float* dx
         hipError_t e = hipFuncSetAttribute((const void*)skinny_conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            110 * 1024);
         if (e != hipSuccess) return (int)e;
+        attr_once.mark();
     }
     hipLaunchKernelGGL(skinny_conv_dgrad_kernel, grid, dim3(512), lds, s, p);
     return mft_launch_status();

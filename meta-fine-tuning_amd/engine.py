@@ -60,34 +60,82 @@ class slab_candidates:
         _SLAB_CANDIDATES = self.old
 
 
-def _placement_hint(key, store=None):
+def _valid_hint(h, K=None):
+    """A usable hint is a dict with four DISTINCT candidate indices (w, m, v, alternate w) and the two stream rates the scan
+    measured for them.  Anything else -- a stale schema, a foreign or truncated file -- is "no hint"."""
+    try:
+        c = h["chosen"]
+        if not (isinstance(c, (list, tuple)) and len(c) == 4 and all(type(i) is int and i >= 0 for i in c) and len(set(c)) == 4):
+            return False
+        if K is not None and max(c) >= K:
+            return False
+        return all(isinstance(h[k], (int, float)) and not isinstance(h[k], bool) and 0.0 < float(h[k]) < 1e6
+                   for k in ("chosen_gbs", "chosen_alt_gbs"))
+    except (KeyError, TypeError, ValueError):
+        return False
+
+
+def _hint_dir():
+    """A directory only this user can write (0700): ~/.cache/mft, else a per-user directory in the temp directory that is
+    verified to be OURS and not a symlink (a sticky shared /tmp is not trusted with a predictable file name)."""
+    import stat
+    import tempfile
+    for d in (os.path.join(os.path.expanduser("~"), ".cache", "mft"), os.path.join(tempfile.gettempdir(), "mft-%d" % os.getuid())):
+        try:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.lstat(d)
+            if stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022):
+                return d
+        except OSError:
+            continue
+    return None
+
+
+def _placement_hint(key, store=None, K=None):
     """Read (or, with ``store``, record) the slab-placement choice of an earlier scan: in-process dict first, then a JSON file
-    in the temp directory shared by the processes of one box.  Best effort -- any I/O problem just means "no hint"."""
+    in a per-user 0700 directory shared by the processes of one box.  Best effort -- any I/O problem, and any entry that does not
+    pass ``_valid_hint``, just means "no hint" (the full scan runs)."""
     import json
     import tempfile
-    path = os.path.join(tempfile.gettempdir(), "mft_slab_placement_%d.json" % os.getuid())
+    d = _hint_dir()
+    path = None if d is None else os.path.join(d, "slab_placement.json")
     if store is not None:
         _PLACEMENT_HINTS[key] = store
+        if path is None:
+            return store
         try:
             disk = {}
-            if os.path.isfile(path):
+            try:
                 with open(path) as f:
                     disk = json.load(f)
+            except (OSError, ValueError):
+                pass                                                               # (absent or broken: start over)
+            if not isinstance(disk, dict):
+                disk = {}
             disk[key] = store
-            tmp = path + ".%d" % os.getpid()
-            with open(tmp, "w") as f:
-                json.dump(disk, f)
-            os.replace(tmp, path)
-        except (OSError, ValueError):
+            fd, tmp = tempfile.mkstemp(dir=d, prefix=".slab_placement.")          # O_EXCL, 0600, unpredictable name
+            try:
+                with os.fdopen(fd, "w") as f:
+                    json.dump(disk, f)
+                os.replace(tmp, path)
+            except BaseException:
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
+                raise
+        except (OSError, ValueError, TypeError):
             pass
         return store
-    if key in _PLACEMENT_HINTS:
-        return _PLACEMENT_HINTS[key]
-    try:
-        with open(path) as f:
-            return json.load(f).get(key)
-    except (OSError, ValueError):
-        return None
+    h = _PLACEMENT_HINTS.get(key)
+    if h is None and path is not None:
+        try:
+            with open(path) as f:
+                disk = json.load(f)
+            h = disk.get(key) if isinstance(disk, dict) else None
+        except (OSError, ValueError):
+            h = None
+    return h if _valid_hint(h, K) else None
 
 
 class AdaptState:
@@ -156,9 +204,9 @@ class AdaptState:
             # re-used when ONE probe of its two triples confirms the rates it promised (within 3 %); otherwise the full scan
             # runs (1.5 s at E = 128 -- a quarter of a 600-episode evaluation's fixed cost).  MFT_SLAB_HINTS=0 turns it off.
             hint_key = "%s|%d|%d|%.2f" % (torch.cuda.get_device_name(dev), total, K, ballast_gb)
-            hint = _placement_hint(hint_key) if os.environ.get("MFT_SLAB_HINTS", "1") == "1" else None
+            hint = _placement_hint(hint_key, K=K) if os.environ.get("MFT_SLAB_HINTS", "1") == "1" else None
             best = rates = None
-            if hint is not None and max(hint["chosen"]) < K:
+            if hint is not None:
                 w_, m_, v_, w2_ = hint["chosen"]
                 r1, r2 = rate(tuple(sorted((w_, m_, v_))), 2), rate(tuple(sorted((w2_, m_, v_))), 2)
                 if r1 >= 0.97 * hint["chosen_gbs"] and r2 >= 0.97 * hint["chosen_alt_gbs"]:
@@ -890,7 +938,9 @@ def _trunk_running_ema(st, arena_t, running, H):
         sets = []
         for k in st.kinds:
             G = st.idx_kind[k].numel() // k
-            sets.append((arena_t.get("adb%d%s.mean" % (k, suffix), (G, C)), arena_t.get("adb%d%s.rstd" % (k, suffix), (G, C)), k * hw * hw))
+            # (Arena.existing: if resnet10_trunk stops leaving (mean, rstd) under these names, this raises instead of advancing the
+            # running statistics from an uninitialised buffer)
+            sets.append((arena_t.existing("adb%d%s.mean" % (k, suffix), (G, C)), arena_t.existing("adb%d%s.rstd" % (k, suffix), (G, C)), k * hw * hw))
         if len(sets) == 1:
             sets.append((None, None, 1))
         (ma, ra, na), (mb, rb, nb) = sets

@@ -438,7 +438,7 @@ def balanced_batch(n_mine, e_max):
 
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
              episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None,
-             device_episodes=False, balance=False, timings=None):
+             device_episodes=False, balance=False, timings=None, note=""):
     """The episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies (all ranks' episodes, in
     episode order, on every rank).
 
@@ -569,7 +569,7 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         timings["batches"] = len(batches)
         timings["marks"] = marks
     if verbose and rank == 0:
-        print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))))
+        print('%d Test Acc = %4.2f%% +- %4.2f%%' % (len(accs), accs.mean(), 1.96 * accs.std() / np.sqrt(len(accs))) + note)
     return accs
 
 
@@ -668,17 +668,29 @@ def standin_state(kind, n_way):
     return synthetic.gnnnet_state_dict(seed=0, n_way=n_way)
 
 
+def standin_allowed():
+    """Stand-in weights are an explicit opt-in (``MFT_STANDIN_WEIGHTS=1``): a mis-pointed ``configs.save_dir`` must not print a
+    plausible accuracy (the reference's torch.load raises on a missing file, finetune.py:498)."""
+    return os.environ.get("MFT_STANDIN_WEIGHTS", "0") == "1"
+
+
 def _resolve_state(kind, modelfile, n_way, explicit, verbose):
-    """Load ``modelfile`` if it exists.  A missing file is an error when the user named an epoch AND its checkpoint directory
-    exists (the reference's torch.load raises there, finetune.py:498); otherwise the stand-in weights are used and said so."""
+    """Load ``modelfile`` if it exists.  A missing checkpoint is an ERROR, as it is in the reference (torch.load raises,
+    finetune.py:498) -- whether the user named the epoch (``explicit``) or get_best_file / get_resume_file found nothing.  Only
+    under ``MFT_STANDIN_WEIGHTS=1`` are the deterministic stand-in weights used instead; the caller then tags its stdout."""
     if modelfile is not None and os.path.isfile(modelfile):
         if verbose:
             print("loading %s checkpoint %s" % (kind, modelfile), file=sys.stderr)          # (stdout keeps the reference's lines only)
         return load_checkpoint_state(modelfile), modelfile
-    if modelfile is not None and explicit and os.path.isdir(os.path.dirname(modelfile)):
-        raise FileNotFoundError(modelfile)
+    if not standin_allowed():
+        from . import configs
+        raise FileNotFoundError("%s checkpoint %s not found (configs.save_dir = %r%s); set MFT_STANDIN_WEIGHTS=1 to evaluate the "
+                                "synthetic stand-in weights instead" % (kind, "<none: empty checkpoint directory>" if modelfile is None
+                                                                        else modelfile, configs.save_dir,
+                                                                        ", epoch named on the command line" if explicit else ""))
     if verbose:
-        print("no %s checkpoint%s: synthetic stand-in weights" % (kind, "" if modelfile is None else " at " + modelfile), file=sys.stderr)
+        print("no %s checkpoint%s: synthetic stand-in weights (MFT_STANDIN_WEIGHTS=1)" % (kind, "" if modelfile is None else " at " + modelfile),
+              file=sys.stderr)
     return standin_state(kind, n_way), None
 
 
@@ -714,6 +726,7 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
         model.load_state_dict(state)                                 # finetune.py:512,540
     if params.method in ('baseline', 'all'):
         state_b, main.loaded["baseline"] = _resolve_state("baseline", f_b, params.test_n_way, params.save_iter != -1, rank == 0)
+    used = [k for k in ("gnnnet", "baseline") if params.method in (k, "all")]
     print(params.freeze_backbone)                                    # finetune.py:591
     tm = {} if os.environ.get("MFT_TIMINGS", "0") == "1" else None
     if tm is not None:
@@ -727,7 +740,8 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
                     episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1",
-                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1", timings=tm)
+                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1", timings=tm,
+                    note="" if all(main.loaded[k] is not None for k in used) else "   [SYNTHETIC stand-in weights, MFT_STANDIN_WEIGHTS=1]")
     if tm is not None:
         print("[timings] evaluate: %s" % tm, file=sys.stderr)
     if torch.distributed.is_initialized():

@@ -62,6 +62,15 @@ class Arena:
             self.bufs[key] = t
         return t
 
+    def existing(self, name, shape, dtype=torch.float32):
+        """A buffer some earlier launch WROTE under this name and shape: a miss is a KeyError, never a fresh (uninitialised)
+        allocation -- for readers that reconstruct a producer's key (engine._trunk_running_ema)."""
+        key = (name, tuple(shape), dtype)
+        if key not in self.bufs:
+            near = sorted(str(k) for k in self.bufs if k[0] == name)
+            raise KeyError("arena has no buffer %r with shape %s%s" % (name, tuple(shape), "; same name, other shapes: " + ", ".join(near) if near else ""))
+        return self.bufs[key]
+
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 

@@ -17,13 +17,20 @@ ENABLED = os.environ.get("MFT_TRAIN_GRAPH", "1") == "1"
 
 
 class GraphedLossBackward:
-    """``loss = step(x)`` leaves the loss in a static tensor and the gradients in ``p.grad`` exactly as
+    """``loss = step(x, optimizer)`` leaves the loss in a static tensor and the gradients in ``p.grad`` exactly as
     ``optimizer.zero_grad(); loss = loss_fn(x); loss.backward()`` would.  The caller must not drop the gradients between
-    steps (no ``zero_grad(set_to_none=True)``): the replay overwrites them in place."""
+    steps (no ``zero_grad(set_to_none=True)``): the replay overwrites them in place.
+
+    Everything the recording bakes in is part of the replay key: input shape / dtype, n_way / n_query, every parameter's address
+    AND requires_grad flag, every sub-module's train / eval mode and BatchNorm momentum.  A freeze / unfreeze, an ``eval()`` call
+    or a changed momentum between two calls therefore starts over (eager warm-up steps, new recording) instead of replaying a
+    graph of the old configuration; the trainable list is rebuilt with it.  Parameters the optimizer owns but this step does
+    not produce a gradient for get ``grad = None`` every step, as ``optimizer.zero_grad()`` in the eager loop gives them."""
 
     def __init__(self, model, loss_fn, warmup=3):
         self.model, self.loss_fn, self.warmup = model, loss_fn, warmup
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self._opt_id, self._opt_others = None, ()
         self.seen = 0
         self.graph = None
         self.key = None
@@ -33,7 +40,22 @@ class GraphedLossBackward:
         self.rekeyed = 0
 
     def _key(self, x):
-        return (tuple(x.shape), x.dtype, self.model.n_way, self.model.n_query, tuple(p.data_ptr() for p in self.params))
+        ps = list(self.model.parameters())
+        mods = tuple((m.training, getattr(m, "momentum", None)) for m in self.model.modules())
+        return (tuple(x.shape), x.dtype, self.model.n_way, self.model.n_query, tuple((p.data_ptr(), p.requires_grad) for p in ps), mods)
+
+    def _clear_foreign_grads(self, optimizer):
+        """What ``optimizer.zero_grad()`` does for the parameters this step does not differentiate (frozen, or not the model's):
+        a stale ``.grad`` must not keep feeding ``optimizer.step()``."""
+        if optimizer is None:
+            return
+        ident = (id(optimizer), self.key)
+        if ident != self._opt_id:
+            mine = {id(p) for p in self.params}
+            self._opt_others = tuple(p for g in optimizer.param_groups for p in g["params"] if id(p) not in mine)
+            self._opt_id = ident
+        for p in self._opt_others:
+            p.grad = None
 
     def _eager(self, x, stream=None):
         for p in self.params:
@@ -64,17 +86,18 @@ class GraphedLossBackward:
                 self.static_loss.backward()
         self.graph = g
 
-    def __call__(self, x):
+    def __call__(self, x, optimizer=None):
         key = self._key(x)
-        if self.failed:
-            return self._eager(x)
-        if key != self.key:                         # new shape / new parameter tensors: start over
+        if key != self.key:                         # new shape / parameter tensors / requires_grad flags / train-eval modes: start over
             if self.graph is not None:
                 self.rekeyed += 1
                 if self.rekeyed > 4:                # a loader that keeps changing the episode shape: recording costs more than it saves
-                    self.failed, self.graph = True, None
-                    return self._eager(x)
+                    self.failed = True
             self.key, self.seen, self.graph = key, 0, None
+            self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self._clear_foreign_grads(optimizer)
+        if self.failed:
+            return self._eager(x)
         if self.graph is None:
             if self.seen < self.warmup:
                 self.seen += 1
@@ -110,10 +133,10 @@ class _PreparedStep:
     def failed(self):
         return self.inner.failed
 
-    def __call__(self, x):
+    def __call__(self, x, optimizer=None):
         x = x.cuda() if not x.is_cuda else x
         self.model._finetune_prepare(x)
-        return self.inner(x)
+        return self.inner(x, optimizer)
 
 
 def for_loop(model, loss_fn):

@@ -65,7 +65,7 @@ class MetaTemplate(nn.Module):
             if self.change_way:
                 self.n_way = x.size(0)
             if graphed is not None:
-                loss = graphed(x)
+                loss = graphed(x, optimizer)     # (grads of parameters outside the recorded step are dropped as zero_grad() would)
                 optimizer.step()
                 # the running sum the reference keeps in a Python float (= double), kept on the device: no host sync per step
                 avg_dev = loss.detach().double() if avg_dev is None else avg_dev + loss.detach().double()

@@ -190,16 +190,19 @@ def test_finetune_main_cli(argv, monkeypatch, capsys):
     """finetune.py:424-682's command line: every README method value, --freeze_backbone, --n_shot 50 (gnnnet_copy)."""
     monkeypatch.setenv("MFT_EPISODES", "3")
     monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
+    monkeypatch.setenv("MFT_STANDIN_WEIGHTS", "1")                    # no checkpoints on this box: explicit opt-in
     accs = ft.main(argv + ["--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
     out = capsys.readouterr().out
     assert len(accs) == 3 and np.all((accs >= 0) & (accs <= 100))
     assert "3 Test Acc = " in out and out.splitlines()[0] in ("True", "False")
+    assert "SYNTHETIC stand-in weights" in [ln for ln in out.splitlines() if "Test Acc" in ln][0]     # never an untagged number
     ft._ENGINES.clear(); ft._LIN_ENGINES.clear()
 
 
 def test_finetune_50_main_cli(monkeypatch, capsys):
     monkeypatch.setenv("MFT_EPISODES", "2")
     monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
+    monkeypatch.setenv("MFT_STANDIN_WEIGHTS", "1")
     accs = ft50.main(["--method", "gnnnet", "--n_shot", "50", "--fine_tune_epoch", "1", "--gen_examples", "0", "--model", "ResNet10"])
     assert len(accs) == 2 and ft50.params.n_shot == 50
     ft._ENGINES.clear()
@@ -360,6 +363,7 @@ def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys)
     cap = capsys.readouterr()
     assert ft.main.loaded["gnnnet"] == str(f) and ("loading gnnnet checkpoint %s" % f) in cap.err
     assert cap.out.splitlines()[0] == "False" and "3 Test Acc = " in cap.out            # stdout: the reference's lines only
+    assert "SYNTHETIC" not in cap.out
     state = torch.load(str(f), map_location="cpu")["state"]
     state = {k: v for k, v in state.items() if "feature2." not in k and "feature3." not in k}
     model = _model(state)
@@ -368,13 +372,19 @@ def test_train_main_then_finetune_main_round_trip(tmp_path, monkeypatch, capsys)
     ref = ft.evaluate(model, state, 3, 5, 5, 15, 84, 1, 1, episodes_per_batch=2, verbose=False, method="gnnnet",
                       device_episodes=True, balance=True)
     assert np.array_equal(accs, ref)
-    # the trained weights are not the stand-ins: the stand-in run differs
+    # a mis-pointed save_dir is an error (the reference's torch.load raises), never a plausible number
     monkeypatch.setattr(configs, "save_dir", str(tmp_path / "empty"))
+    monkeypatch.delenv("MFT_STANDIN_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError):
+        ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
+    # the trained weights are not the stand-ins: the (opted-in) stand-in run differs
+    monkeypatch.setenv("MFT_STANDIN_WEIGHTS", "1")
     accs2 = ft.main(["--method", "gnnnet", "--save_iter", "1", "--fine_tune_epoch", "1", "--gen_examples", "1", "--model", "ResNet10"])
     assert ft.main.loaded["gnnnet"] is None and "synthetic stand-in weights" in capsys.readouterr().err
     assert accs2.mean() > 40.0                                        # G9's meta-trained head, not a random one (chance = 20 %)
     # an epoch that was never written, in a directory that exists: the reference's torch.load raises
     monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    monkeypatch.delenv("MFT_STANDIN_WEIGHTS", raising=False)
     with pytest.raises(FileNotFoundError):
         ft.main(["--method", "gnnnet", "--save_iter", "5", "--fine_tune_epoch", "1", "--gen_examples", "1"])
     ft._ENGINES.clear()

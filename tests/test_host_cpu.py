@@ -365,9 +365,13 @@ def test_checkpoint_lookup_mirrors_the_reference(tmp_path, monkeypatch):
     torch.save({"epoch": 1, "state": {"feature.a": torch.ones(2), "feature2.a": torch.zeros(2), "feature3.trunk.b": torch.zeros(1),
                                       "fc.0.weight": torch.ones(1)}}, str(f))
     assert sorted(ft.load_checkpoint_state(str(f))) == ["fc.0.weight", "feature.a"]
-    # an epoch the user named, in a directory that exists, must exist (the reference's torch.load raises)
-    with pytest.raises(FileNotFoundError):
-        ft._resolve_state("gnnnet", str(d / "77.tar"), 5, True, False)
+    # a missing checkpoint is an error, as the reference's torch.load is (finetune.py:498) -- named epoch or not, directory or not
+    monkeypatch.delenv("MFT_STANDIN_WEIGHTS", raising=False)
+    for path, explicit in ((str(d / "77.tar"), True), (str(tmp_path / "nowhere" / "1.tar"), True), (None, False)):
+        with pytest.raises(FileNotFoundError):
+            ft._resolve_state("gnnnet", path, 5, explicit, False)
+    # the stand-in weights are an explicit opt-in
+    monkeypatch.setenv("MFT_STANDIN_WEIGHTS", "1")
     sd, used = ft._resolve_state("gnnnet", str(tmp_path / "nowhere" / "1.tar"), 5, True, False)
     assert used is None and len(sd) == 140
     hz = np.load(os.path.join(ROOT, "tests", "golden", "g9_head.npz"))
@@ -398,13 +402,42 @@ def test_balanced_batches_and_lookahead_guard():
 
 
 def test_placement_hint_roundtrip(tmp_path, monkeypatch):
-    import tempfile
-    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    import json
+    import stat
+    monkeypatch.setenv("HOME", str(tmp_path))                         # -> ~/.cache/mft under the test's own directory
     engine._PLACEMENT_HINTS.clear()
     assert engine._placement_hint("k") is None
-    engine._placement_hint("k", {"chosen": [1, 2, 3, 4], "chosen_gbs": 6.1, "chosen_alt_gbs": 6.0})
+    good = {"chosen": [1, 2, 3, 4], "chosen_gbs": 6.1, "chosen_alt_gbs": 6.0}
+    engine._placement_hint("k", good)
+    d = engine._hint_dir()
+    assert d.startswith(str(tmp_path)) and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    path = os.path.join(d, "slab_placement.json")
+    assert stat.S_IMODE(os.lstat(path).st_mode) == 0o600 and sorted(os.listdir(d)) == ["slab_placement.json"]   # no temp file left
     engine._PLACEMENT_HINTS.clear()                                   # another process: the file answers
     assert engine._placement_hint("k")["chosen"] == [1, 2, 3, 4] and engine._placement_hint("other") is None
+    assert engine._placement_hint("k", K=4) is None                   # an index beyond this engine's candidates: no hint
+    # a stale, foreign or truncated-schema entry is "no hint", never an exception in FinetuneEngine's constructor
+    bad = [{"chosen": [1, 2, 3]}, {"chosen": [1, 1, 2, 3], "chosen_gbs": 6.0, "chosen_alt_gbs": 6.0}, {"chosen": "1234"}, [1, 2, 3, 4],
+           {"chosen": [1, 2, 3, 4], "chosen_gbs": "fast", "chosen_alt_gbs": 6.0}, {"chosen": [1, 2, 3, 4], "chosen_gbs": 6.0},
+           {"chosen": [1.0, 2, 3, 4], "chosen_gbs": 6.0, "chosen_alt_gbs": 6.0}, {"chosen": [-1, 2, 3, 4], "chosen_gbs": 6.0, "chosen_alt_gbs": 6.0},
+           None, 7]
+    for b in bad:
+        with open(path, "w") as f:
+            json.dump({"k": b}, f)
+        engine._PLACEMENT_HINTS.clear()
+        assert engine._placement_hint("k") is None, b
+    for raw in ("", "{", "[1, 2]", '"x"'):
+        with open(path, "w") as f:
+            f.write(raw)
+        engine._PLACEMENT_HINTS.clear()
+        assert engine._placement_hint("k") is None
+        engine._placement_hint("k2", good)                            # and recording over a broken file repairs it
+        engine._PLACEMENT_HINTS.clear()
+        assert engine._placement_hint("k2")["chosen"] == [1, 2, 3, 4]
+    # a hint directory somebody else could write into is not used
+    os.chmod(d, 0o777)
+    assert engine._hint_dir() != d
+    os.chmod(d, 0o700)
 
 
 def test_graphed_step_is_only_offered_where_it_can_replay(monkeypatch):

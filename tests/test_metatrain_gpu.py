@@ -441,6 +441,50 @@ def test_graphed_episode_loop_is_bit_identical(variant, capsys, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_graphed_step_follows_a_freeze_between_epochs(capsys, monkeypatch):
+    """The recorded step is cached on the model across epochs.  Freezing the backbone between two epochs (requires_grad = False
+    on feature.*) changes what the backward produces: the cached graph must NOT be replayed (it would keep writing the frozen
+    parameters' static .grad tensors, and the optimizer would keep stepping them).  Every parameter after epoch 2 equals the
+    eager loop's bit for bit, the frozen ones did not move, and their stale gradients are gone."""
+    from meta_fine_tuning_amd import graph_step, optim
+    eps = [synthetic.train_episode(900 + i, 5, 5, 16, 84) for i in range(5)]
+
+    class Loader:
+        def __len__(self):
+            return len(eps)
+
+        def __iter__(self):
+            for x in eps:
+                yield x, None
+
+    def run(graphed):
+        monkeypatch.setattr(graph_step, "ENABLED", graphed)
+        torch.manual_seed(0)
+        model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+        model.load_state_dict(synthetic.gnnnet_state_dict(seed=29))
+        model.train()
+        opt = optim.Adam(model.parameters())
+        model.train_loop(0, Loader(), opt)
+        st = model.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss")
+        g0 = None if st is None else st.graph
+        frozen = [p for n, p in model.named_parameters() if n.startswith("feature.")]
+        before = [p.detach().clone() for p in frozen]
+        for p in frozen:
+            p.requires_grad = False                                   # (their .grad tensors of epoch 0 are still attached)
+        model.train_loop(1, Loader(), opt)
+        capsys.readouterr()
+        assert all(torch.equal(a, b) for a, b in zip(before, frozen))
+        assert all(p.grad is None for p in frozen)
+        return [p.detach().clone() for p in model.parameters()], st, g0
+
+    par_e, _, _ = run(False)
+    par_g, st, g0 = run(True)
+    assert g0 is not None and st.graph is not None and st.graph is not g0 and not st.failed          # re-recorded for the new trainable set
+    assert len(st.params) == len([1 for _ in par_g]) - 36                                             # 36 backbone tensors frozen
+    for a, b in zip(par_e, par_g):
+        assert torch.equal(a, b)
+
+
 def test_inner_loop_batched_trunk_and_graph_match_step_by_step():
     """engine.adapt_last_block (gnnnet.py:126-177: 15 epochs of mini-batches of 4 over the 25 supports, 105 Adam steps on trunk.7):
     the frozen trunk of all steps as two grouped passes + one running-statistics launch per BatchNorm layer, and the whole loop
@@ -487,6 +531,46 @@ def test_inner_loop_batched_trunk_and_graph_match_step_by_step():
             init = sd[k].to(v.device)
             rel = float((v - b).norm()) / float((v - init).norm())
             assert rel < 0.08 and float((v - b).abs().max()) <= 0.15, (k, rel)
+
+
+def test_inner_loop_running_statistics_teacher_forced():
+    """The adapted block's BatchNorm running statistics, with the weights held IDENTICAL in both loops (lr = 0: Adam moves nothing):
+    the per-step table + mft_bn_running_ema after the loop must reproduce the step-by-step momentum updates to fp32 rounding --
+    including the unbiased-variance factor n / (n - 1) = 36 / 35 (4 images x 3 x 3 pixels; 9 / 8 for the ragged 1-image step),
+    which the 5 % bound of the drifting-weights test above could not see."""
+    from meta_fine_tuning_amd import engine as eng
+    from meta_fine_tuning_amd import backbone
+    sd = synthetic.resnet10_state_dict(seed=43)
+    x_a = synthetic.train_episode(78, 5, 5, 16, 84)[:, :5].reshape(25, 3, 84, 84).cuda()
+    y_a = np.repeat(range(5), 5).astype(np.int32)
+    perms = [np.random.RandomState(200 + e).permutation(25) for e in range(3)]
+    res = {}
+    old = (eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH)
+    try:
+        for name, batched in (("steps", False), ("batched", True)):
+            eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH = batched, False
+            eng._ADAPT_GRAPHS.clear()
+            mod = backbone.ResNet10().cuda()
+            mod.load_state_dict(sd)
+            mod.train()
+            out = eng.adapt_last_block(mod, x_a, y_a, epochs=3, batch_size=4, lr=0.0, perms=perms)
+            res[name] = {k: v.detach().clone() for k, v in out.items()}
+    finally:
+        eng.ADAPT_BATCHED_TRUNK, eng.ADAPT_GRAPH = old
+        eng._ADAPT_GRAPHS.clear()
+    seen = 0
+    for k, v in res["steps"].items():
+        b = res["batched"][k]
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(v, b), k
+        elif "running" in k:
+            seen += k.startswith("trunk.7")
+            assert float((v - b).abs().max()) <= 2e-5 * max(1.0, float(v.abs().max())), (k, float((v - b).abs().max()))
+            init = sd[k].to(v.device)
+            assert float((v - init).abs().max()) > 1e-3, k                       # (the statistics did move: 21 momentum updates)
+        else:
+            assert torch.equal(v, sd[k].to(v.device)), k                             # lr = 0: the nine tensors are untouched
+    assert seen == 6
 
 
 def test_graphed_meta_finetune_loop_is_bit_identical(capsys, monkeypatch):
