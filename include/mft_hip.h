@@ -182,6 +182,23 @@ int mft_conv2d_nhwc_x3_bnin_bnstats(const float* in, int ldi, const float* in_ws
                                     const unsigned short* w3, long long plane_elems, float* out, int ldo, int n_img, int H, int W,
                                     int Cin, int Cout, int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd,
                                     void* stream);
+/* "f16x2" forms of the three frozen-trunk convolutions above (csrc/conv_x3.hip, NP = 2): every fp32 operand is split into TWO fp16
+ * pieces, x = hi + 2^-11 lo with lo = fp16((x - hi) * 2^11) (|x - hi - 2^-11 lo| <= 2^-22 |x|), and the three leading piece
+ * products run on the fp16 matrix cores into two fp32 accumulators (leading / cross terms) combined in the epilogue: half the
+ * matrix work and two thirds of the LDS traffic of the bf16x3 forms at an error that stays below an fp32-accumulating GEMM's.
+ * Operands must lie inside fp16's range (|x| < 65504): BatchNorm outputs do; the Python side checks the weights and the
+ * BatchNorm affine parameters at load time and keeps the bf16x3 forms otherwise.  mft_split_f16x2: fp32 [n] -> planes [2][n].
+ * Same arguments, workspaces and partial-statistics layout as the _x3 functions (their consumers do not care which form ran). */
+int mft_split_f16x2(const float* w, unsigned short* planes, long long n, void* stream);
+int mft_conv2d_nhwc_h2(const float* in, int ldi, const unsigned short* w2, long long plane_elems, float* out, int ldo,
+                       int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+int mft_conv2d_nhwc_h2_bnstats(const float* in, int ldi, const unsigned short* w2, long long plane_elems, float* out, int ldo,
+                               int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd, void* stream);
+int mft_conv2d_nhwc_h2_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma, const float* in_beta,
+                                    const unsigned short* w2, long long plane_elems, float* out, int ldo, int n_img, int H, int W,
+                                    int Cin, int Cout, int imgs_per_group, float eps, float* stats_ws, float* mean, float* rstd,
+                                    void* stream);
 int mft_bn_apply_x3ws(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups, const float* ws,
                       const float* gamma, const float* beta, const float* res, int ldr, const float* res_ws,
                       const float* res_gamma, const float* res_beta, int act, float slope, float eps, float* mean, float* rstd,

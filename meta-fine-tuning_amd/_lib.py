@@ -84,6 +84,10 @@ SIGNATURES = {
     "mft_ce_pool_bn_backward2": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "mft_pool_window_minmax": [_P, _P, _P, _L, _I, _I, _I, _P],
     "mft_conv2d_nhwc_x3_bnin_bnstats": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "mft_split_f16x2": [_P, _P, _L, _P],
+    "mft_conv2d_nhwc_h2": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mft_conv2d_nhwc_h2_bnstats": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "mft_conv2d_nhwc_h2_bnin_bnstats": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_bn_apply_x3ws": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
     "mft_bn_apply_x3ws_fits": [_I, _I, _I],
     "mft_bn_running_ema": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _P, _P, _P],

@@ -112,7 +112,7 @@ constexpr float X3_H2_LO_SCALE = 1.0f / 2048.f;
 // fragment reads (16 lanes = 16 consecutive rows, one chunk) and staging writes (consecutive rows, whole rows) stay
 // conflict-free, and the tile takes 36 KB instead of 46 KB of LDS -> FOUR workgroups per CU instead of three.
 template <int BM, int BN, bool AP, bool DB, int HOIST = 0, int DBG = 0, bool XS = false, int NP = 3>
-__global__ __launch_bounds__(256) void conv_x3_kernel(X3Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 3 : 1))) void conv_x3_kernel(X3Args p) {
     static_assert(NP == 3 || (NP == 2 && !AP && !DB && HOIST == 0 && DBG == 0 && !XS), "f16x2: the plain single-buffer form only");
     constexpr int NACC = NP == 3 ? 1 : 2;
     constexpr int TM = BM / 64;           // 32-row blocks per wave (waves 2 x 2)
@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
 }
 
 template <int BM, int BN, int NP = 3>
-__global__ __launch_bounds__(256) void conv_x3_s1_kernel(X3Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 3 : 1))) void conv_x3_s1_kernel(X3Args p) {
     conv_x3_s1_body<BM, BN, false, NP>(p);
 }
 
@@ -1102,6 +1102,17 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
         out[i] = (unsigned short)q1;
         out[n + i] = (unsigned short)q2;
         out[2 * n + i] = (unsigned short)q3;
+    }
+}
+
+// weights for the f16x2 kernels: [2][n] fp16 planes (hi, lo * 2^11), the same arithmetic as split4_h2
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
+        out[i] = __builtin_bit_cast(unsigned short, hi);
+        out[n + i] = __builtin_bit_cast(unsigned short, lo);
     }
 }
 
@@ -1554,20 +1565,35 @@ extern "C" int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short
     return x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, 0, stream);
 }
 
+extern "C" int mft_split_f16x2(const float* w, unsigned short* planes, long long n, void* stream) {
+    if (n <= 0) return MFT_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, planes, n);
+    return mft_launch_status();
+}
+
+extern "C" int mft_conv2d_nhwc_h2(const float* in, int ldi, const unsigned short* w2, long long plane_elems, float* out,
+                                  int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                  int pad, void* stream) {
+    return x3_dispatch(in, ldi, w2, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, 0, stream, nullptr, 0,
+                       nullptr, nullptr, nullptr, 0.f, 2);
+}
+
 extern "C" long long mft_conv2d_x3_stats_ws_floats(int n_img, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
     const long long OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     return ((long long)n_img * OH * OW + 63) / 64 * 2 * Cout * 2;          // sized for the smallest tile (64 rows)
 }
 
-extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems,
-                                          float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
-                                          int stride, int pad, int imgs_per_group, float eps, float* stats_ws,
-                                          float* mean, float* rstd, void* stream) {
+static int x3_bnstats(int np, const float* in, int ldi, const unsigned short* w3, long long plane_elems,
+                      float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                      int stride, int pad, int imgs_per_group, float eps, float* stats_ws,
+                      float* mean, float* rstd, void* stream) {
     if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || stats_ws == nullptr) return MFT_EINVAL;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     const int R = imgs_per_group * OH * OW;
     const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, stats_ws, R,
-                               stream);
+                               stream, nullptr, 0, nullptr, nullptr, nullptr, 0.f, np);
     if (rc != 0) return rc;
     if (mean == nullptr && rstd == nullptr) return g_x3_tile == 3 ? MFT_EINVAL : 0;     // partials only: the consumer merges them (128-row tiles)
     const int groups = n_img / imgs_per_group;
@@ -1576,23 +1602,55 @@ extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsign
     return mft_launch_status();
 }
 
+extern "C" int mft_conv2d_nhwc_x3_bnstats(const float* in, int ldi, const unsigned short* w3, long long plane_elems,
+                                          float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                                          int stride, int pad, int imgs_per_group, float eps, float* stats_ws,
+                                          float* mean, float* rstd, void* stream) {
+    return x3_bnstats(3, in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, eps, stats_ws, mean,
+                      rstd, stream);
+}
+
+extern "C" int mft_conv2d_nhwc_h2_bnstats(const float* in, int ldi, const unsigned short* w2, long long plane_elems,
+                                          float* out, int ldo, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
+                                          int stride, int pad, int imgs_per_group, float eps, float* stats_ws,
+                                          float* mean, float* rstd, void* stream) {
+    return x3_bnstats(2, in, ldi, w2, plane_elems, out, ldo, n_img, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, eps, stats_ws, mean,
+                      rstd, stream);
+}
+
 // 3x3 / stride 1 / pad 1 convolution of relu(BatchNorm(in)) where ``in`` is the raw output of the previous bf16x3 convolution and
 // ``in_ws`` its statistics partials (SimpleBlock's C1 -> BN1 -> ReLU -> C2, backbone.py:251-256, in one launch + this
 // convolution's own partials).  MFT_EINVAL outside the shared-tap kernel's domain (the caller then runs apply + convolution).
-extern "C" int mft_conv2d_nhwc_x3_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma,
-                                               const float* in_beta, const unsigned short* w3, long long plane_elems, float* out,
-                                               int ldo, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group, float eps,
-                                               float* stats_ws, float* mean, float* rstd, void* stream) {
+static int x3_bnin_bnstats(int np, const float* in, int ldi, const float* in_ws, const float* in_gamma,
+                           const float* in_beta, const unsigned short* w3, long long plane_elems, float* out,
+                           int ldo, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group, float eps,
+                           float* stats_ws, float* mean, float* rstd, void* stream) {
     if (imgs_per_group <= 0 || n_img % imgs_per_group != 0 || stats_ws == nullptr || in_ws == nullptr ||
         (mean == nullptr) != (rstd == nullptr) || g_x3_tile == 3)
         return MFT_EINVAL;
     const int R = imgs_per_group * H * W;
     const int rc = x3_dispatch(in, ldi, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, 3, 3, 1, 1, stats_ws, R, stream, nullptr, 0,
-                               in_ws, in_gamma, in_beta, eps);
+                               in_ws, in_gamma, in_beta, eps, np);
     if (rc != 0 || mean == nullptr) return rc;
     hipLaunchKernelGGL(x3_stats_finalize_kernel, dim3((Cout + 63) / 64, n_img / imgs_per_group), dim3(64), 0, (hipStream_t)stream,
                        (const float*)stats_ws, Cout, n_img * H * W, R, 128, eps, mean, rstd);
     return mft_launch_status();
+}
+
+extern "C" int mft_conv2d_nhwc_x3_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma,
+                                               const float* in_beta, const unsigned short* w3, long long plane_elems, float* out,
+                                               int ldo, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group, float eps,
+                                               float* stats_ws, float* mean, float* rstd, void* stream) {
+    return x3_bnin_bnstats(3, in, ldi, in_ws, in_gamma, in_beta, w3, plane_elems, out, ldo, n_img, H, W, Cin, Cout, imgs_per_group, eps,
+                           stats_ws, mean, rstd, stream);
+}
+
+extern "C" int mft_conv2d_nhwc_h2_bnin_bnstats(const float* in, int ldi, const float* in_ws, const float* in_gamma,
+                                               const float* in_beta, const unsigned short* w2, long long plane_elems, float* out,
+                                               int ldo, int n_img, int H, int W, int Cin, int Cout, int imgs_per_group, float eps,
+                                               float* stats_ws, float* mean, float* rstd, void* stream) {
+    return x3_bnin_bnstats(2, in, ldi, in_ws, in_gamma, in_beta, w2, plane_elems, out, ldo, n_img, H, W, Cin, Cout, imgs_per_group, eps,
+                           stats_ws, mean, rstd, stream);
 }
 
 extern "C" int mft_conv2d_nhwc_x3p_bnstats(const unsigned short* in_planes, long long in_plane_elems, int ldi,

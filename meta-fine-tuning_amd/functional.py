@@ -29,6 +29,50 @@ X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm 
 # applied by C2's loader, the stem's batch statistics are combined inside the pooled gather (12-13 launches per lockstep step
 # instead of 24; MFT_X3_FOLD_BN=0 restores the separate finalize / apply / combine launches)
 X3_FOLD_BN = os.environ.get("MFT_X3_FOLD_BN", "1") == "1"
+# frozen trunk.4-6 convolutions on two fp16 pieces per operand (three products, csrc/conv_x3.hip "f16x2") instead of three bf16
+# pieces (six products): half the matrix work at an error below an fp32-accumulating GEMM's.  Taken only when the state dict
+# passes ``f16x2_safe`` (every operand provably inside fp16's range); MFT_TRUNK_F16X2=0 keeps the bf16x3 kernels.
+TRUNK_F16X2 = os.environ.get("MFT_TRUNK_F16X2", "1") == "1"
+F16X2_BOUND = 3.0e4              # < 65504 with a factor 2 in hand
+F16X2_FLOOR = 2.0 ** -10          # typical operand magnitude that keeps the pieces normal fp16 numbers
+F16X2_MAX_ROWS = 1 << 20         # largest BatchNorm group (images x pixels) the bound is proven for (engine: 100 x 21 x 21 = 44,100)
+
+
+def f16x2_safe(sd, prefix=""):
+    """Can every operand of the frozen trunk.4-6 convolutions be split into fp16 pieces with full relative accuracy?
+    Upper range -- weights: |w| < F16X2_BOUND; activations: each of these convolutions reads relu(BN(.)) or relu(BN(.) + BN(.)) /
+    relu(BN(.) + x) (backbone.py:251-261), and a train-mode BatchNorm output over n rows is bounded by |gamma| sqrt(n - 1) + |beta|
+    (a z-score cannot exceed sqrt(n - 1)); with n <= F16X2_MAX_ROWS that bound must stay below F16X2_BOUND for every input
+    (reference initialisation, gamma = 1, beta = 0, backbone.py:11-16: 1024 / 2048).
+    Lower range -- a piece below fp16's smallest normal number (6.1e-5) keeps an ABSOLUTE error of 2^-36 instead of a relative 2^-22:
+    harmless beside O(1) operands, so the TYPICAL magnitude of every operand tensor must be well inside the normal range: rms weight
+    and median |gamma| >= 2^-10 (He-initialised 3x3 weights: 0.03-0.06)."""
+    import math
+
+    def g(name):
+        w, b = sd[prefix + name + ".weight"].detach().float(), sd[prefix + name + ".bias"].detach().float()
+        if not float(w.abs().median()) >= F16X2_FLOOR:
+            return float("inf")
+        return float(w.abs().max()) * math.sqrt(F16X2_MAX_ROWS) + float(b.abs().max())
+
+    try:
+        x_in = g("trunk.1")                                     # stem BatchNorm -> ReLU -> max pool -> trunk.4
+        for idx, (cin, cout, _s) in STAGES.items():
+            if idx == 7:
+                break
+            p = "trunk.%d" % idx
+            for cname in (".C1", ".C2") + ((".shortcut",) if cin != cout else ()):
+                w = sd[prefix + p + cname + ".weight"].detach().float()
+                if not (float(w.abs().max()) < F16X2_BOUND and float(w.pow(2).mean().sqrt()) >= F16X2_FLOOR):
+                    return False
+            r1 = g(p + ".BN1")
+            x_out = g(p + ".BN2") + (g(p + ".BNshortcut") if cin != cout else x_in)
+            if not (x_in < F16X2_BOUND and r1 < F16X2_BOUND):  # inputs of C1 / shortcut, and of C2 (NaN compares False)
+                return False
+            x_in = x_out
+        return True                                             # (trunk.6's output feeds the per-episode fp32 / bf16x3 kernels)
+    except KeyError:
+        return False
 
 STAGES = {4: (64, 64, 1), 5: (64, 128, 2), 6: (128, 256, 2), 7: (256, 512, 2)}
 
@@ -78,12 +122,17 @@ class Arena:
 class ResNet10Weights:
     """Packed device copy of a backbone.ResNet10 state dict (keys 'trunk.*' under ``prefix``)."""
 
-    def __init__(self, sd, device, prefix="", x3=False):
-        """``x3``: also keep bf16x3 planes of the frozen trunk.4-6 weights (csrc/conv_x3.hip: fp32-accurate convolution
-        on the bf16 matrix cores); used wherever these layers run with shared weights."""
+    def __init__(self, sd, device, prefix="", x3=False, f16x2=None):
+        """``x3``: also keep split planes of the frozen trunk.4-6 weights (csrc/conv_x3.hip: fp32-accurate convolution on the
+        bf16 / fp16 matrix cores); used wherever these layers run with shared weights.  ``f16x2``: two fp16 planes (three
+        products) instead of three bf16 planes (six); None = TRUNK_F16X2 and f16x2_safe(sd)."""
         self.device = device
         self.conv = {}
         self.conv3 = {}
+        if f16x2 is None:
+            f16x2 = bool(x3) and TRUNK_F16X2 and not X3_PLANES and f16x2_safe(sd, prefix)
+        self.f16x2 = bool(f16x2)
+        split = ops.split_weight_h2 if self.f16x2 else ops.split_weight_x3
         self.bn = {}
         self.plan = ops.PackPlan()          # sources that are live device tensors: repack() refreshes every packed copy in one launch
 
@@ -97,7 +146,7 @@ class ResNet10Weights:
             if w.data_ptr() == src.data_ptr():
                 self.plan.add(w, self.conv[name])
             if x3 and name.startswith(("trunk.4", "trunk.5", "trunk.6")):
-                self.conv3[name] = ops.split_weight_x3(self.conv[name])
+                self.conv3[name] = split(self.conv[name])
 
         def bn(name):
             self.bn[name] = (dev(sd[prefix + name + ".weight"]), dev(sd[prefix + name + ".bias"]))

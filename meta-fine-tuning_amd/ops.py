@@ -189,18 +189,34 @@ def split_weight_x3(w_pk):
     return planes
 
 
+def split_weight_h2(w_pk):
+    """packed fp32 weights [Cout, Kpad] -> two fp16 planes [2, Cout, Kpad] (int16 storage): hi = fp16(w), lo = fp16((w - hi) * 2^11)
+    (csrc/conv_x3.hip, "f16x2").  The conv2d_x3* wrappers below take either kind of planes and launch the matching kernels."""
+    _f32c(w_pk)
+    planes = torch.empty((2,) + tuple(w_pk.shape), device=w_pk.device, dtype=torch.int16)
+    _lib.check(_lib.lib().mft_split_f16x2(_p(w_pk), _p(planes), w_pk.numel(), _stream()), "mft_split_f16x2")
+    return planes
+
+
+def _x3_fn(w3, stem):
+    """The C entry point for these weight planes: three bf16 planes -> mft_conv2d_nhwc_x3*, two fp16 planes -> mft_conv2d_nhwc_h2*."""
+    kind = {3: "x3", 2: "h2"}[int(w3.shape[0])]
+    name = "mft_conv2d_nhwc_%s%s" % (kind, stem)
+    return getattr(_lib.lib(), name), name
+
+
 def conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out=None):
-    """conv2d for frozen shared weights on bf16 MFMA with fp32 accuracy (6-term bf16x3 products).  x [n,H,W,Cin] fp32,
-    w3 = split_weight_x3(pack_conv_weight(w)) -> [n,OH,OW,Cout] fp32."""
+    """conv2d for frozen shared weights on the bf16 / fp16 matrix cores with fp32 accuracy (6-term bf16x3 or 3-term f16x2 products,
+    by the kind of ``w3``).  x [n,H,W,Cin] fp32, w3 = split_weight_x3 / split_weight_h2(pack_conv_weight(w)) -> [n,OH,OW,Cout] fp32."""
     _f32c(x)
     n, H, W, Cin = x.shape
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     if out is None:
         out = torch.empty((n, OH, OW, Cout), device=x.device, dtype=torch.float32)
-    rc = _lib.lib().mft_conv2d_nhwc_x3(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout,
-                                       KH, KW, stride, pad, _stream())
-    _lib.check(rc, "mft_conv2d_nhwc_x3")
+    fn, name = _x3_fn(w3, "")
+    rc = fn(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout, KH, KW, stride, pad, _stream())
+    _lib.check(rc, name)
     return out
 
 
@@ -209,12 +225,12 @@ def conv2d_x3_bnstats(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws,
     (computed from the output tiles while they are still in registers).  ``ws``: >= mft_conv2d_x3_stats_ws_floats floats."""
     _f32c(x)
     n, H, W, Cin = x.shape
-    rc = _lib.lib().mft_conv2d_nhwc_x3_bnstats(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin,
-                                               Cout, KH, KW, stride, pad, imgs_per_group, eps, _p(ws), _p(mean), _p(rstd),
-                                               _stream())
+    fn, name = _x3_fn(w3, "_bnstats")
+    rc = fn(_p(x), Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, eps,
+            _p(ws), _p(mean), _p(rstd), _stream())
     if rc == _lib.MFT_EINVAL:
         return None                       # outside the fused form's domain (e.g. an input of 2 GiB or more): caller uses conv + bn_stats
-    _lib.check(rc, "mft_conv2d_nhwc_x3_bnstats")
+    _lib.check(rc, name)
     return out, mean, rstd
 
 
@@ -225,12 +241,12 @@ def conv2d_x3_bnin_bnstats(c_raw, in_ws, in_gamma, in_beta, w3, Cout, imgs_per_g
     Returns None outside the kernel's domain."""
     _f32c(c_raw)
     n, H, W, Cin = c_raw.shape
-    rc = _lib.lib().mft_conv2d_nhwc_x3_bnin_bnstats(_p(c_raw), Cin, _p(in_ws), _p(in_gamma), _p(in_beta), _p(w3),
-                                                    w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout, imgs_per_group, eps,
-                                                    _p(ws), _p(mean), _p(rstd), _stream())
+    fn, name = _x3_fn(w3, "_bnin_bnstats")
+    rc = fn(_p(c_raw), Cin, _p(in_ws), _p(in_gamma), _p(in_beta), _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout, n, H, W, Cin, Cout,
+            imgs_per_group, eps, _p(ws), _p(mean), _p(rstd), _stream())
     if rc == _lib.MFT_EINVAL:
         return None
-    _lib.check(rc, "mft_conv2d_nhwc_x3_bnin_bnstats")
+    _lib.check(rc, name)
     return out
 
 
@@ -253,6 +269,8 @@ def conv2d_x3p_bnstats(xp, n, H, W, w3, Cout, KH, KW, stride, pad, imgs_per_grou
     """conv2d_x3_bnstats on a pre-split input: ``xp`` int16 [3, n*H*W, Cin] (bf16x3 planes written by bn_apply(planes=) /
     bn_relu_maxpool_gather(planes=)); the operand path of the convolution is then a plain copy."""
     Cin = xp.shape[2]
+    if w3.shape[0] != 3:
+        raise ValueError("pre-split activation planes exist for the bf16x3 kernels only")
     rc = _lib.lib().mft_conv2d_nhwc_x3p_bnstats(_p(xp), xp.shape[1] * Cin, Cin, _p(w3), w3.shape[1] * w3.shape[2], _p(out), Cout,
                                                 n, H, W, Cin, Cout, KH, KW, stride, pad, imgs_per_group, eps, _p(ws), _p(mean),
                                                 _p(rstd), _stream())

@@ -341,7 +341,7 @@ def test_presplit_activation_planes_are_bit_identical():
     """Frozen trunk on pre-split bf16x3 activation planes (producers split once: mft_bn_apply_planes /
     mft_bn_relu_maxpool_gather_planes, consumer mft_conv2d_nhwc_x3p_bnstats) against the same trunk splitting inside every
     convolution tile: the pieces are the same numbers, so the activation entering trunk.7 must match bit for bit."""
-    W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=31), DEV, x3=True)
+    W = Fn.ResNet10Weights(synthetic.resnet10_state_dict(seed=31), DEV, x3=True, f16x2=False)       # (the planes chain is a bf16x3 form)
     rs = np.random.RandomState(9)
     x = torch.from_numpy(rs.standard_normal((60, 84, 84, 3)).astype(np.float32)).to(DEV)
     cache = Fn.StemCache(W, 60, 84, DEV, chunk=32, pooled=False)      # the planes chain reads the full-resolution cache

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import meta_fine_tuning_amd  # noqa: F401
-from meta_fine_tuning_amd import ops
+from meta_fine_tuning_amd import ops, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -361,6 +361,77 @@ def test_conv2d_bf16x3_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H):
         assert e3 <= 2e-5 * scale, (name, patch_mode, e3)
         assert e3 <= 2.0 * e32 + 1e-7 * scale, (name, patch_mode, e3, e32)
     _lib.lib().mft_debug_reset()
+
+
+@pytest.mark.parametrize("xscale", [1.0, 1e3, 1e-3])
+@pytest.mark.parametrize("name,Cin,Cout,k,stride,pad,H", [c for c in CONV_SHAPES if c[1] % 32 == 0 and c[2] % 64 == 0 and c[0].startswith(("trunk.4", "trunk.5", "trunk.6"))])
+def test_conv2d_f16x2_is_fp32_accurate(name, Cin, Cout, k, stride, pad, H, xscale):
+    """3-term f16x2 convolution (two fp16 pieces per operand, lo piece pre-scaled by 2^11, leading / cross products in separate fp32
+    accumulators; csrc/conv_x3.hip NP = 2) against float64 on the frozen-trunk shapes: the tolerance of the fp32-MFMA kernel, and an
+    error no larger than 2x that kernel's own (the same two gates as the bf16x3 form).  ReLU-shaped (non-negative) activations as in
+    the trunk, at three magnitudes: the scaled lo piece keeps the RELATIVE accuracy wherever the hi piece is a normal fp16 number."""
+    from meta_fine_tuning_amd import _lib
+    n = 7
+    x = torch.relu(rnd((n, Cin, H, H), 11) + 0.3) * xscale
+    w = rnd((Cout, Cin, k, k), 12, scale=(2.0 / (k * k * Cout)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    xg = nhwc(x).to(DEV)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    OH = (H + 2 * pad - k) // stride + 1
+    y32g = torch.empty((n, OH, OH, Cout), device=DEV)
+    assert _lib.lib().mft_conv2d_nhwc(ops._p(xg), Cin, ops._p(wpk), None, ops._p(y32g), Cout, n, H, H, Cin, Cout, k, k, stride, pad, 0, 0,
+                                      ops._stream()) == 0
+    e32 = float((nchw(y32g.cpu()).double() - ref).abs().max())
+    scale = max(float(ref.abs().max()), 1e-30)
+    w2 = ops.split_weight_h2(wpk)
+    assert w2.shape == (2,) + tuple(wpk.shape)
+    y3 = nchw(ops.conv2d_x3(xg, ops.split_weight_x3(wpk), Cout, k, k, stride, pad).cpu()).double()
+    for mode in (10, 90):                                     # default (shared-tap kernel on 3x3 / stride 1), per-tap kernel
+        _lib.lib().mft_debug_reset()
+        assert _lib.lib().mft_debug_set_x3_tile(mode) == 0
+        y2 = nchw(ops.conv2d_x3(xg, w2, Cout, k, k, stride, pad).cpu()).double()
+        e2 = float((y2 - ref).abs().max())
+        assert e2 <= 2e-5 * scale, (name, mode, e2, scale)
+        assert e2 <= 2.0 * e32 + 1e-7 * scale, (name, mode, e2, e32)
+        assert float((y2 - y3).abs().max()) <= 4e-6 * scale      # and it agrees with the bf16x3 form
+    _lib.lib().mft_debug_reset()
+    # the 64x64-tile and other alternative forms exist for bf16x3 only: refused, never silently another kernel
+    assert _lib.lib().mft_debug_set_x3_tile(3) == 0
+    out = torch.empty((n, OH, OH, Cout), device=DEV)
+    assert _lib.lib().mft_conv2d_nhwc_h2(ops._p(xg), Cin, ops._p(w2), w2.shape[1] * w2.shape[2], ops._p(out), Cout, n, H, H, Cin, Cout, k, k,
+                                         stride, pad, ops._stream()) == _lib.MFT_EINVAL
+    _lib.lib().mft_debug_reset()
+
+
+def test_f16x2_split_and_range_guard():
+    """mft_split_f16x2 against the same arithmetic in torch (hi = fp16(w), lo = fp16((w - hi) * 2^11): |w - hi - lo / 2^11| <= 2^-22 |w|
+    wherever hi is a normal fp16 number), and functional.f16x2_safe: reference-style weights pass, a BatchNorm gamma or a weight that
+    could leave fp16's range keeps the bf16x3 kernels."""
+    from meta_fine_tuning_amd import functional as Fn
+    w = torch.cat([rnd((4096,), 5) * 0.05, torch.tensor([0.0, 1.0, -1.0, 65000.0, 6.2e-5, 1e-7, -3e-6, 1.00048828125])])
+    pl = ops.split_weight_h2(w.view(1, -1).to(DEV).contiguous()).cpu()
+    hi, lo = pl[0, 0].view(torch.float16), pl[1, 0].view(torch.float16)
+    hi_ref = w.to(torch.float16)
+    lo_ref = ((w - hi_ref.float()) * 2048.0).to(torch.float16)
+    assert torch.equal(hi, hi_ref) and torch.equal(lo, lo_ref)
+    rec = hi.double() + lo.double() / 2048.0
+    normal = w.abs() >= 6.2e-5
+    assert float(((rec - w.double()).abs() / w.double().abs().clamp_min(1e-30))[normal].max()) <= 2.0 ** -22
+    assert float((rec - w.double()).abs()[~normal].max()) <= 2.0 ** -35
+    sd = synthetic.resnet10_state_dict(seed=3)
+    assert Fn.f16x2_safe(sd)
+    W = Fn.ResNet10Weights(sd, DEV, x3=True)
+    assert W.f16x2 == Fn.TRUNK_F16X2 and W.conv3["trunk.4.C1"].shape[0] == (2 if Fn.TRUNK_F16X2 else 3)
+    for key, val in (("trunk.5.BN1.weight", 40.0), ("trunk.4.BN2.bias", 4e4), ("trunk.6.C2.weight", 7e4), ("trunk.1.weight", float("nan")),
+                     ("trunk.6.BN1.weight", None), ("trunk.5.C1.weight", None)):
+        bad = dict(sd)
+        bad[key] = sd[key].clone()
+        if val is None:
+            bad[key] *= 1e-5                                          # a whole tensor far below fp16's normal range
+        else:
+            bad[key].view(-1)[0] = val
+        assert not Fn.f16x2_safe(bad), key
+        assert Fn.ResNet10Weights(bad, DEV, x3=True).conv3["trunk.4.C1"].shape[0] == 3
 
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(7, 5, 5, 32, 64), (3, 13, 13, 64, 128), (1, 21, 21, 64, 64), (9, 7, 9, 96, 64), (2, 9, 4, 32, 64),
