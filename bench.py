@@ -844,10 +844,15 @@ def main():
             x_ms = sum(a.elapsed_time(b) for a, b, _ in x3_events)
             x_fl = sum(f for _, _, f in x3_events)
             ach3 = x_fl / (x_ms * 1e-3) / 1e12
-            roof_x3 = {"bound": "mfma", "kernel": "conv_x3_kernel / conv_x3_s1_kernel / conv_x3_s1_bnin_kernel (frozen trunk.4-6: fp32-accurate 6-term bf16x3 products on bf16 MFMA; BatchNorm statistics partials in the epilogue, BN1 + ReLU in C2's loader on trunk.4 / trunk.5)",
-                       "achieved": round(ach3, 2), "peak": round(PEAK_BF16_MFMA / 6e12, 1), "unit": "TFLOP/s (fp32-equivalent: "
-                       "algorithmic 2*M*N*K; the kernel executes 6 bf16 MFMA flops per algorithmic flop, peak = 2500/6)",
-                       "frac": round(ach3 / (PEAK_BF16_MFMA / 6e12), 4), "launches": len(x3_events),
+            n_prod = 3 if e.W.f16x2 else 6            # matrix-core flops executed per algorithmic flop
+            roof_x3 = {"bound": "mfma", "kernel": ("conv_x3_kernel / conv_x3_s1_kernel / conv_x3_s1_bnin_kernel, NP = 2 (frozen trunk.4-6: fp32-accurate 3-term "
+                                                   "f16x2 products on fp16 MFMA, two accumulators; bf16x3 / six products when MFT_TRUNK_F16X2=0 or the range guard "
+                                                   "refuses the weights;") if e.W.f16x2 else "conv_x3_kernel / conv_x3_s1_kernel / conv_x3_s1_bnin_kernel (frozen trunk.4-6: fp32-accurate 6-term bf16x3 products on bf16 MFMA; BatchNorm statistics partials in the epilogue, BN1 + ReLU in C2's loader on trunk.4 / trunk.5)",
+                       "achieved": round(ach3, 2), "peak": round(PEAK_BF16_MFMA / n_prod / 1e12, 1), "unit": "TFLOP/s (fp32-equivalent: "
+                       "algorithmic 2*M*N*K; the kernel executes %d 16-bit MFMA flops per algorithmic flop, peak = 2500/%d; in situ these "
+                       "launches share the GPU with the HBM-bound last-block stream and stretch to what it leaves -- see standalone)" % (n_prod, n_prod),
+                       "products_per_flop": n_prod,
+                       "frac": round(ach3 / (PEAK_BF16_MFMA / n_prod / 1e12), 4), "launches": len(x3_events),
                        "avg_launch_us": round(x_ms * 1e3 / len(x3_events), 2),
                        "vs_fp32_mfma_peak": round(ach3 / (PEAK_F32_MFMA / 1e12), 3)}
             if not args.no_standalone:
@@ -870,7 +875,8 @@ def main():
                     if alone and s_ms > 0:
                         sa = s_fl / (s_ms * 1e-3) / 1e12
                         roof_x3["standalone"] = {"what": "the same eight convolutions per step with no co-running last-block stream (6 trunk steps)",
-                                                 "achieved": round(sa, 2), "frac": round(sa / (PEAK_BF16_MFMA / 6e12), 4),
+                                                 "achieved": round(sa, 2), "frac": round(sa / (PEAK_BF16_MFMA / n_prod / 1e12), 4),
+                                                 "vs_fp32_mfma_peak": round(sa / (PEAK_F32_MFMA / 1e12), 3),
                                                  "avg_launch_us": round(s_ms * 1e3 / len(alone), 2)}
                 except Exception as ex:   # noqa: BLE001 -- an extra measurement must not cost the line
                     timing["on"] = False
@@ -889,14 +895,21 @@ def main():
         value = total_eps / dt
         fl = episode_flops(n_way, n_shot, n_query, views, args.epochs)
         n_steps_ep = args.epochs * n_way * n_shot * (views + 1) // 5
+        gb_step = 0.1122 - (0.0147 if e.fuse_next else 0.0)          # adaptable-state GB per episode and inner step
         out = {
             "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node",
             "value": round(value, 3), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "all arithmetic is fp32-accurate: fp32 MFMA everywhere except the frozen trunk.4-6 convolutions, which run as "
-                          "exact 3-way bf16 splits with the six leading products accumulated in fp32 (error <= fp32 GEMM rounding; "
-                          "tests/test_kernels_gpu.py::test_conv2d_bf16x3_is_fp32_accurate)", "data": "synthetic",
+            "dtype_note": ("all arithmetic is fp32-accurate: fp32 MFMA everywhere except the frozen trunk.4-6 convolutions, which split every "
+                           "fp32 operand into two fp16 pieces (hi + 2^-11 lo, |residual| <= 2^-22) and accumulate the three leading piece "
+                           "products in two fp32 accumulators (measured error vs float64: 0.45x the fp32-MFMA kernel's, "
+                           "profiles/r04_a_f16x2_accuracy_and_time.txt; tests/test_kernels_gpu.py::test_conv2d_f16x2_is_fp32_accurate), and "
+                           "the per-episode last-block forward / data-gradient launches, which use exact 3-way bf16 splits with six products"
+                           if e.W.f16x2 else
+                           "all arithmetic is fp32-accurate: fp32 MFMA everywhere except the frozen trunk.4-6 convolutions, which run as "
+                           "exact 3-way bf16 splits with the six leading products accumulated in fp32 (error <= fp32 GEMM rounding; "
+                           "tests/test_kernels_gpu.py::test_conv2d_bf16x3_is_fp32_accurate)"), "data": "synthetic",
             "config": {"workload": "5-way %d-shot ResNet10+GNN test-time finetune, 84x84, fine_tune_epoch=%d, "
                                    "gen_examples=%d (%d inner Adam steps/episode), 15 queries" %
                                    (n_shot, args.epochs, args.gen_examples, args.epochs * n_way * n_shot * (views + 1) // 5),
@@ -914,9 +927,12 @@ def main():
             # whole path against the same HBM roof: the adaptable-state bytes an episode moves (per inner step: forward weights
             # 14.7 MB + data-gradient re-read 9.4 MB + Adam read/write of w, m, v 88.2 MB) over the wall time of
             # the timed region, everything else (trunk, final pass, ingest, host) counted as zero bytes
-            "whole_path_hbm": {"algorithmic_gb_per_episode": round(0.1122 * n_steps_ep, 2),
-                               "achieved": round(value / world * 0.1122 * n_steps_ep, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(value / world * 0.1122 * n_steps_ep / PEAK_HBM_GBS, 4)},
+            # (with the fused next-step forward the forward's 14.7 MB weight read does not exist: 97.5 MB per step)
+            "whole_path_hbm": {"algorithmic_gb_per_episode": round(gb_step * n_steps_ep, 2),
+                               "per_inner_step_mb": round(gb_step * 1e3, 1),
+                               "achieved": round(value / world * gb_step * n_steps_ep, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(value / world * gb_step * n_steps_ep / PEAK_HBM_GBS, 4),
+                               "fused_next_forward": bool(e.fuse_next)},
             "power": power if power is None else dict(power, joules_per_episode=round(power["socket_w_median"] * dt / (E * args.steps), 2)),
             "slab_placement": placement,
             "strong_scaling": strong,

@@ -138,6 +138,15 @@ def _placement_hint(key, store=None, K=None):
     return h if _valid_hint(h, K) else None
 
 
+def fuse_next_policy(setting, E, stem_cached, image_size, f16x2):
+    """``setting``: "1" / "0" / "auto" (MFT_FUSE_NEXT) -> bool.  auto = where the fused next-step forward measured faster (round 4,
+    FinetuneEngine._build): whole waves of the walking kernel (E % 32 == 0), a light trunk stream beside it (stem cache, f16x2
+    convolutions), the 84 x 84 maps it was tuned on."""
+    if setting in ("0", "1"):
+        return setting == "1"
+    return bool(E >= 32 and E % 32 == 0 and stem_cached and f16x2 and image_size <= 84)
+
+
 class AdaptState:
     """Per-episode adaptable parameters + gradient + Adam moments (four tensor-major slabs)."""
 
@@ -328,14 +337,16 @@ class FinetuneEngine:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)     # device-side Adam step counter / bias
         self.hyper = torch.zeros(2, device=self.dev)                           # corrections (graph replay)
         self.pipeline = pipeline
-        # OPT-IN (MFT_FUSE_NEXT=1 / fuse_next=True): the weight-gradient + Adam launches of step t also run step t+1's last-block
-        # forward from the weight tiles they have just updated (csrc/wgrad_fwd.hip), so the updated weights are not read back by
-        # a forward launch (7.64 -> 6.64 parameter units of HBM traffic per step).  Correct (tests) and 240 us per step faster
-        # with the GPU to itself, but no faster in the two-stream loop: the walking kernel is bound by its per-tile dependency
-        # chain per CU, not by HBM (it slows down in proportion to the CUs it loses to the trunk stream, where the one-tile-per-
-        # workgroup kernel keeps 93 % of its rate on 160 CUs) -- 78.6-81.1 vs 79.3-80.3 episodes/s over four boxes
-        # (profiles/r03_a_*).  Default: the separate block-entry / block-exit launches.
-        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "0") == "1"
+        # The weight-gradient + Adam launches of step t can also run step t+1's last-block forward from the weight tiles they have
+        # just updated (csrc/wgrad_fwd.hip, fuse_next): the updated weights are then not read back by a forward launch (7.64 ->
+        # 6.64 parameter units of HBM traffic per step).  The launch is a WALKING kernel (one long-lived workgroup per (episode, 32
+        # output channels), two per CU), bound by its per-tile chain rather than by HBM, so it pays only where (a) its E * 16
+        # workgroups fill whole waves of the 512 resident slots (E a multiple of 32) and (b) the trunk stream beside it is light
+        # (stem cache present; since round 4 the f16x2 trunk convolutions).  Same-lease A/B, round 4
+        # (profiles/r04_b_fuse_next_*.txt): E = 128: 85.4 -> 87.1 episodes/s, E = 32: 59.4 -> 68.7, 20-shot E = 96: 20.3 -> 21.3;
+        # but E = 120: 84.0 -> 80.3 (3.75 waves), 50-shot E = 128 (no stem cache): 7.93 -> 7.48, 224x224: 19.8 -> 19.6.
+        # MFT_FUSE_NEXT = auto (default: that rule, fuse_next_policy, applied once the stem cache is decided) | 1 | 0.
+        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "auto")
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
@@ -365,9 +376,10 @@ class FinetuneEngine:
                                "mft_stream_create_cumask")
                 return out.value
             self._raw_stream = masked([i for i in range(256) if (i // 8) >= 32 - n_tr])
-            self._raw_last = masked([i for i in range(256) if (i // 8) < 32 - n_tr])
             self.s_trunk = torch.cuda.ExternalStream(self._raw_stream, device=self.dev)
-            self.s_last = torch.cuda.ExternalStream(self._raw_last, device=self.dev)
+            if os.environ.get("MFT_TRUNK_CUS_ONLY", "0") != "1":      # (=1: only the trunk is confined; the last block may run anywhere)
+                self._raw_last = masked([i for i in range(256) if (i // 8) < 32 - n_tr])
+                self.s_last = torch.cuda.ExternalStream(self._raw_last, device=self.dev)
         elif pipeline and prio > 0:              # below torch's range: a HIP stream at the device's least priority
             out = ctypes.c_void_p()
             with torch.cuda.device(self.dev):
@@ -394,6 +406,7 @@ class FinetuneEngine:
         # (the opt-in pre-split-planes trunk reads the full-resolution cache; the default is the pooled (max, min) form)
         self._stem_pooled = False if Fn.X3_PLANES else None
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev, pooled=self._stem_pooled) if stem_cache else None
+        self.fuse_next = fuse_next_policy(self.fuse_next, self.E, self.stem is not None, image_size, self.W.f16x2)
 
     # ------------------------------------------------------------------ ingest
     @_on_device

@@ -21,6 +21,14 @@ def world():
     return 0, 1
 
 
+def collectives_forced():
+    """MFT_FORCE_COLLECTIVES=1 with an initialised process group: run the collectives even with ONE rank instead of taking the
+    single-process shortcuts -- so that a one-GPU box executes the real RCCL calls (communicator set-up, all-reduce of the flat
+    gradient bucket, all-gather, broadcast) on the tensors the multi-GPU drivers use (tests/test_drivers_gpu.py)."""
+    import os
+    return os.environ.get("MFT_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def shard_indices(n_items, rank, world_size):
     """Episode i belongs to rank i mod W."""
     return list(range(rank, n_items, world_size))
@@ -39,7 +47,7 @@ def episode_torch_seed(seed, episode_index):
 def gather_episode_values(local_values, n_items, device="cpu"):
     """All ranks' per-episode values (sharded with ``shard_indices``) -> full array in episode order on every rank."""
     rank, W = world()
-    if W == 1:
+    if W == 1 and not collectives_forced():
         return np.asarray(local_values, dtype=np.float64)
     per = (n_items + W - 1) // W
     buf = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
@@ -71,7 +79,7 @@ class FlatGradBucket:
         """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place).  With one rank nothing is exchanged
         and the gradients stay where autograd put them."""
         _, W = world()
-        if W == 1:
+        if W == 1 and not collectives_forced():
             for p in self.params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
@@ -95,7 +103,7 @@ def broadcast_buffers(module, src=0):
     """BatchNorm running statistics diverge per rank (each saw its own episodes) and are never read on the hot path;
     checkpoints take rank ``src``'s copy."""
     _, W = world()
-    if W == 1:
+    if W == 1 and not collectives_forced():
         return
     for b in module.buffers():
         if b.is_cuda and dist.get_backend() == "gloo":
@@ -110,7 +118,7 @@ def broadcast_parameters(module, src=0):
     """Rank ``src``'s parameters to every rank (once, before the first step: all ranks then stay identical because they apply
     the same averaged gradient)."""
     _, W = world()
-    if W == 1:
+    if W == 1 and not collectives_forced():
         return
     with torch.no_grad():
         for p in module.parameters():

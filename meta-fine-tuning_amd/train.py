@@ -72,7 +72,7 @@ class AllReduceAdam:
     def __init__(self, params_iter, **kw):
         ps = list(params_iter)
         self.opt = optim.Adam(ps, **kw)          # torch.optim.Adam semantics, fused HIP update (train.py:28)
-        self.bucket = parallel.FlatGradBucket(ps) if parallel.world()[1] > 1 else None
+        self.bucket = parallel.FlatGradBucket(ps) if (parallel.world()[1] > 1 or parallel.collectives_forced()) else None
         self.param_groups, self.state = self.opt.param_groups, self.opt.state
 
     def zero_grad(self, *a, **k):

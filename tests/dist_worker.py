@@ -43,6 +43,45 @@ def main():
         st = m.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss")
         out["graphed"] = np.int32(1 if (st is not None and st.graph is not None) else 0)
         np.savez(a.out + ".%d.npz" % rank, **out)
+    elif a.mode == "rccl1":
+        # ONE rank, backend "nccl" (= RCCL), collectives forced: the calls the 8-GPU drivers make, executed for real on this box's GPU
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and W == 1 and parallel.collectives_forced()
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(s_, device="cuda")) for s_ in ((512, 512, 3, 3), (128, 512), (5,), (1179648,))]
+        for p_ in ps[:-1]:
+            p_.grad = torch.randn_like(p_)
+        bucket = parallel.FlatGradBucket(ps)                                   # (the last parameter has no gradient: zeros)
+        want = [torch.zeros_like(p_) if p_.grad is None else p_.grad.clone() for p_ in ps]
+        bucket.allreduce_mean()                                                # pack -> ncclAllReduce(SUM) over 1 rank -> / 1 -> unpack
+        torch.cuda.synchronize()
+        ok_ar = all(torch.equal(p_.grad, w_) for p_, w_ in zip(ps, want))
+        vals = parallel.gather_episode_values([1.5, 2.5, 99.0], 3, device="cuda")       # ncclAllGather on float64 device buffers
+        lin = torch.nn.Linear(8, 4).cuda()
+        before = [t.detach().clone() for t in list(lin.parameters()) + list(lin.buffers())]
+        parallel.broadcast_parameters(lin, src=0)
+        parallel.broadcast_buffers(torch.nn.BatchNorm1d(4).cuda(), src=0)
+        torch.cuda.synchronize()
+        ok_bc = all(torch.equal(a_, b_) for a_, b_ in zip(before, list(lin.parameters()) + list(lin.buffers())))
+        # the sharded evaluation loop end to end on this process group (accuracy gather on the device through RCCL)
+        from meta_fine_tuning_amd.io_utils import model_dict
+        from meta_fine_tuning_amd.methods.gnnnet import GnnNet
+        state = synthetic.gnnnet_state_dict(seed=0)
+        model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+        model.load_state_dict(state)
+        accs = finetune.evaluate(model, state, 3, 5, 5, 15, 84, 1, 1, seed0=500, episodes_per_batch=2, verbose=False, method="gnnnet", rng_seed=10)
+        # and one episode-parallel meta-training epoch: AllReduceAdam's flat-bucket all-reduce in front of every outer step
+        import tempfile
+        from meta_fine_tuning_amd import configs
+        configs.save_dir = tempfile.mkdtemp()
+        torch.manual_seed(0)
+        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=2, size=84)
+        try:
+            ver = np.asarray(torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            ver = np.asarray([-1])
+        np.savez(a.out + ".%d.npz" % rank, ok_allreduce=np.int32(ok_ar), ok_broadcast=np.int32(ok_bc), vals=vals, accs=accs,
+                 fc=m.state_dict()["fc.0.weight"].detach().cpu().numpy(), nccl_version=ver)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

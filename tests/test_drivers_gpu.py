@@ -248,6 +248,41 @@ def test_two_rank_sharded_evaluation_equals_one_rank(tmp_path):
     assert np.array_equal(a0, b), (a0, b)
 
 
+def test_rccl_collectives_execute_on_one_rank(tmp_path):
+    """backend "nccl" (RCCL) on this box's single GPU, collectives FORCED at world size 1 (MFT_FORCE_COLLECTIVES=1): communicator
+    set-up, the flat 21 MB-style gradient bucket all-reduce, the float64 accuracy all-gather on the device, parameter / buffer
+    broadcasts, then finetune.evaluate and a train.main epoch on that process group.  Every multi-GPU code path of the drivers
+    has then executed against the real library (the 2-rank tests above run gloo on one device); values equal the plain
+    single-process run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MFT_FORCE_COLLECTIVES="1", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("MFT_ONE_DEVICE", None)
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    r = subprocess.run([sys.executable, worker, "--mode", "rccl1", "--out", str(tmp_path / "r1")], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(str(tmp_path / "r1.0.npz"))
+    assert int(z["ok_allreduce"]) == 1 and int(z["ok_broadcast"]) == 1
+    assert np.array_equal(z["vals"], [1.5, 2.5, 99.0])
+    # the same evaluation / training epoch without a process group
+    env2 = {k: v for k, v in env.items() if k not in ("MFT_FORCE_COLLECTIVES", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r2 = subprocess.run([sys.executable, "-c",
+                         "import sys, numpy as np, torch, tempfile; sys.path.insert(0, %r); import meta_fine_tuning_amd\n"
+                         "from meta_fine_tuning_amd import finetune, synthetic, train, configs\n"
+                         "from meta_fine_tuning_amd.io_utils import model_dict\n"
+                         "from meta_fine_tuning_amd.methods.gnnnet import GnnNet\n"
+                         "state = synthetic.gnnnet_state_dict(seed=0)\n"
+                         "model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda(); model.load_state_dict(state)\n"
+                         "accs = finetune.evaluate(model, state, 3, 5, 5, 15, 84, 1, 1, seed0=500, episodes_per_batch=2, verbose=False, method='gnnnet', rng_seed=10)\n"
+                         "configs.save_dir = tempfile.mkdtemp(); torch.manual_seed(0)\n"
+                         "m = train.main(['--method', 'gnnnet', '--model', 'ResNet10', '--stop_epoch', '1', '--save_freq', '1'], n_episode=2, size=84)\n"
+                         "np.savez(%r, accs=accs, fc=m.state_dict()['fc.0.weight'].detach().cpu().numpy())\n" % (ROOT, str(tmp_path / "plain.npz"))],
+                        env=env2, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    p = np.load(str(tmp_path / "plain.npz"))
+    assert np.array_equal(z["accs"], p["accs"]) and np.array_equal(z["fc"], p["fc"])
+
+
 def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
     """train.main under torchrun with 2 ranks: each rank runs its own episode, one flat-bucket all-reduce of the outer
     gradients / 2, the same fused Adam step on both ranks.  Both ranks end with identical parameters, and they equal the

@@ -401,6 +401,14 @@ def test_balanced_batches_and_lookahead_guard():
     assert list(la) == [1, 2, 3] and not ft._READY
 
 
+def test_fuse_next_policy():
+    """MFT_FUSE_NEXT=auto: the fused next-step forward only where it measured faster (whole waves of the walking kernel, light trunk)."""
+    f = engine.fuse_next_policy
+    assert f("1", 7, False, 224, False) is True and f("0", 128, True, 84, True) is False
+    assert [E for E in (1, 16, 31, 32, 64, 96, 120, 128, 160) if f("auto", E, True, 84, True)] == [32, 64, 96, 128, 160]
+    assert not f("auto", 128, False, 84, True) and not f("auto", 128, True, 224, True) and not f("auto", 128, True, 84, False)
+
+
 def test_placement_hint_roundtrip(tmp_path, monkeypatch):
     import json
     import stat
