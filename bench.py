@@ -160,18 +160,8 @@ def host_threads():
     """Threads the CPU baseline may use: the cores this process can actually run on (affinity mask and cgroup CPU
     quota), capped at 32 -- the 5-image convolutions of one inner step do not scale past that, and oversubscribing an
     OpenMP pool on a quota-limited box makes it pathologically slow."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, 32))
+    from meta_fine_tuning_amd import parallel
+    return parallel.host_threads(32)
 
 
 def cpu_baseline(state, episode, leg_budget_s=12.0):
@@ -482,12 +472,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the product path")
     if world > 1:
         torch.set_num_threads(max(1, host_threads() // world))     # W ranks share the host: no oversubscribed OpenMP pools
+    else:
+        torch.set_num_threads(min(torch.get_num_threads(), host_threads()))     # (torch sizes its pool by os.cpu_count(), not by the cgroup quota)
     if os.environ.get("MFT_BENCH_ONE_DEVICE"):          # test hook: run W ranks on one GPU (with MFT_DIST_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    # MFT_FORCE_COLLECTIVES=1 with RANK / MASTER_* set: ONE rank still forms an RCCL process group and runs every collective of the
+    # N-rank path (timing all-reduce, accuracy all-gather, barriers) -- what a one-GPU box can execute of `--gpus N` (tests)
+    forced = world == 1 and os.environ.get("MFT_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
+    if world > 1 or forced:
         import torch.distributed as dist
         backend = os.environ.get("MFT_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":

@@ -703,6 +703,7 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     global params
     np.random.seed(10)                                               # finetune.py:425
     params = parse_args('train', argv)
+    parallel.limit_host_threads()
     _init_distributed()
     rank, _W = parallel.world()
     from .methods.gnnnet import GnnNet

@@ -10,6 +10,8 @@ gnnnet.py:168-177), gnn.GNN_nl / Wcompute / Gconv (gnn.py:16-166), GnnNet.fc and
 """
 import os
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -49,11 +51,14 @@ def f16x2_safe(sd, prefix=""):
     and median |gamma| >= 2^-10 (He-initialised 3x3 weights: 0.03-0.06)."""
     import math
 
+    def arr(key):              # numpy on purpose: the first torch CPU reduction of a process spins up the intra-op thread pool (1-2 s on a 256-core host)
+        return np.abs(sd[prefix + key].detach().float().cpu().numpy())
+
     def g(name):
-        w, b = sd[prefix + name + ".weight"].detach().float(), sd[prefix + name + ".bias"].detach().float()
-        if not float(w.abs().median()) >= F16X2_FLOOR:
+        w, b = arr(name + ".weight"), arr(name + ".bias")
+        if not float(np.median(w)) >= F16X2_FLOOR:
             return float("inf")
-        return float(w.abs().max()) * math.sqrt(F16X2_MAX_ROWS) + float(b.abs().max())
+        return float(w.max()) * math.sqrt(F16X2_MAX_ROWS) + float(b.max())
 
     try:
         x_in = g("trunk.1")                                     # stem BatchNorm -> ReLU -> max pool -> trunk.4
@@ -62,8 +67,8 @@ def f16x2_safe(sd, prefix=""):
                 break
             p = "trunk.%d" % idx
             for cname in (".C1", ".C2") + ((".shortcut",) if cin != cout else ()):
-                w = sd[prefix + p + cname + ".weight"].detach().float()
-                if not (float(w.abs().max()) < F16X2_BOUND and float(w.pow(2).mean().sqrt()) >= F16X2_FLOOR):
+                w = arr(p + cname + ".weight")
+                if not (float(w.max()) < F16X2_BOUND and float(np.sqrt(np.mean(np.square(w, dtype=np.float64)))) >= F16X2_FLOOR):
                     return False
             r1 = g(p + ".BN1")
             x_out = g(p + ".BN2") + (g(p + ".BNshortcut") if cin != cout else x_in)

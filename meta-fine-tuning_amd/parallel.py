@@ -15,6 +15,43 @@ import torch
 import torch.distributed as dist
 
 
+def host_threads(cap=32):
+    """CPU threads this process may really use: affinity mask and cgroup CPU quota (a GPU box typically grants a container 16 of
+    its 256 cores), capped at ``cap``."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+_THREADS_LIMITED = False
+
+
+def limit_host_threads():
+    """torch sizes its intra-op pool by os.cpu_count() (256 on an MI355X host); under a 16-core cgroup quota the first parallel CPU
+    op of the process then stalls for seconds (measured: 1-3 s of a 600-episode evaluation's fixed cost).  The drivers' host work is
+    a few small tensor ops: cap the pool at the granted cores, divided over the ranks of this node.  OMP_NUM_THREADS (the user's
+    choice, and what torchrun sets) wins; idempotent."""
+    global _THREADS_LIMITED
+    import os
+    if _THREADS_LIMITED or "OMP_NUM_THREADS" in os.environ:
+        return
+    _THREADS_LIMITED = True
+    W = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    n = max(1, host_threads(16) // max(1, W))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

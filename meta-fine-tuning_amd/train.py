@@ -116,6 +116,7 @@ def train(base_loader, model, optimization, start_epoch, stop_epoch, params, var
 def main(argv=None, n_episode=100, size=84, variant50=False):
     params = parse_args('train', argv)
     from .finetune import _init_distributed
+    parallel.limit_host_threads()
     _init_distributed()                                                  # under torchrun: one process per GPU, RCCL
     rank, W = parallel.world()
     if not params.start_epoch > 0:

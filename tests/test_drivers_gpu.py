@@ -365,6 +365,29 @@ def test_bench_two_ranks_one_json_line(workload, launcher):
         assert "cpu_baseline" not in d                                   # rank 0 at N = 1 only
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["finetune", "metatrain"])
+def test_bench_collectives_on_rccl_with_one_rank(workload):
+    """bench.py's N-rank code path on backend "nccl" (RCCL) with ONE rank (MFT_FORCE_COLLECTIVES=1): process group bound to the
+    device, barriers around the timed steps, the MAX all-reduce of the time, the all-gather of accuracies (finetune) / the flat
+    gradient-bucket all-reduce in front of every outer step (metatrain) -- executed against the real library on this box's GPU,
+    which the gloo one-device tests above cannot do."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", MFT_FORCE_COLLECTIVES="1", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("MFT_BENCH_ONE_DEVICE", "MFT_DIST_BACKEND", "MFT_ONE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", workload]
+    if workload == "finetune":
+        cmd += ["--episodes-per-batch", "8", "--epochs", "1", "--gen-examples", "2", "--no-standalone", "--no-cpu-baseline", "--strong-episodes", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "episodes/s"
+
+
 def test_bench_self_launch_propagates_failure():
     """The self-launching parent exits with the ranks' status: without the one-device hook rank 1 of `--gpus 2` asks for cuda:1,
     which a one-GPU box does not have (on a multi-GPU node the command simply succeeds and the test has nothing to show)."""
