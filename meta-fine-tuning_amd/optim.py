@@ -45,12 +45,18 @@ class Adam(torch.optim.Optimizer):
                 for off in range(0, n, CHUNK):
                     rows.append((pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(CHUNK, n - off)))
             if step is not None and step > 0:
-                # all tensors of the group in ONE launch (104 tensors for GnnNet): a device table of (p, g, m, v, n) chunks
-                table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device)
+                # all tensors of the group in ONE launch (104 tensors for GnnNet): a device table of (p, g, m, v, n) chunks.  The
+                # table is rebuilt (one small pageable host-to-device copy, which drains the stream) only when an address in it
+                # changed: under the graphed episode loop parameters, static gradients and moments never move.
+                key = (ps[0].device, tuple(rows))
+                tables = self.__dict__.setdefault("_tables", {})
+                cached = tables.get(id(group))
+                if cached is None or cached[0] != key:
+                    cached = tables[id(group)] = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device))
+                table = cached[1]
                 rc = ops._lib.lib().mft_adam_multi(ops._p(table), len(rows), step, group["lr"], b1, b2, group["eps"],
                                                    group["weight_decay"], ops._stream())
                 ops._lib.check(rc, "mft_adam_multi")
-                self._keep = table                 # the launch is asynchronous: keep the table alive until the next step
             else:
                 for p in ps:
                     st = self.state[p]
