@@ -44,7 +44,9 @@ class slab_candidates:
     """``with slab_candidates(8): FinetuneEngine(...)``: fewer candidate buffers for the slab-placement scan of engines built
     inside the block (C(8,3) = 56 triples instead of 220: 0.2 s instead of 0.8 s and 30 GB less transient memory) -- for short
     jobs such as one rank's share of a 600-episode evaluation, where the full scan costs what the better placement returns.
-    The MFT_SLAB_CANDIDATES environment variable still wins."""
+    ``slab_candidates(0)``: no scan at all (plain allocations) -- a job of ONE lockstep batch (one rank's 75 episodes of a
+    600-episode evaluation on 8 GPUs runs for about a second: the scan costs more than any placement returns);
+    ``slab_candidates(None)``: the default.  The MFT_SLAB_CANDIDATES environment variable still wins."""
 
     def __init__(self, k):
         self.k = k
@@ -52,7 +54,7 @@ class slab_candidates:
     def __enter__(self):
         global _SLAB_CANDIDATES
         self.old = _SLAB_CANDIDATES
-        if self.k:
+        if self.k is not None:
             _SLAB_CANDIDATES = int(self.k)
 
     def __exit__(self, *a):
