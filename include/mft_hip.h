@@ -301,6 +301,9 @@ int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ld
 /* 1: correctly rounded division / square root in that launch's Adam epilogue (default 0: v_rcp_f32 / v_sqrt_f32, as
  * mft_conv2d_wgrad_adam_nhwc's default).                                                                                   */
 void mft_wgrad_fwd_set_exact(int on);
+/* 1 (default): the Cout / 32 workgroups of an episode are placed on ONE XCD (they re-read the same activation rows through that
+ * XCD's L2); 0: natural workgroup order.  Placement only: no result changes.  Takes effect when the group count is a multiple of 8. */
+void mft_wgrad_fwd_set_xcd(int on);
 
 
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */

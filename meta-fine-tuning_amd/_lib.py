@@ -58,6 +58,7 @@ SIGNATURES = {
     "mft_wgrad_adam_next_forward": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _F, _F, _F,
                                     _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P],
     "mft_wgrad_fwd_set_exact": [_I],
+    "mft_wgrad_fwd_set_xcd": [_I],
     "mft_bn_stats_ws_floats": [_I, _I, _I],
     "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P],
     "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],

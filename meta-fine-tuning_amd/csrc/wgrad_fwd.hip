@@ -51,6 +51,8 @@ struct WfArgs {
     const float* sc; const float* gs; const float* bs; float* means; float* rstds;      // EXIT: shortcut branch
     float* pooled; int hw;       // EXIT: [groups][ipg][Cout], pixels per image
     float bn_eps;
+    int co_blocks;               // Cout / 32: workgroups per episode
+    int xcd_groups;              // 1: all workgroups of an episode on ONE XCD (needs groups % 8 == 0)
 };
 
 enum { WF_RAW = 0, WF_ENTRY = 1, WF_EXIT = 2 };
@@ -73,7 +75,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;            // 32x32x2 fragment coordinates (reduction)
     const int fm = lane & 15, fq = lane >> 4;          // 16x16x4 fragment coordinates (next step's convolution)
-    const int g = blockIdx.y, co0 = blockIdx.x * BM;
+    // Workgroup -> (episode, 32 output channels).  The co_blocks workgroups of one episode read the SAME activation rows (x_t for the
+    // gradient, x_{t+1} for the next step's forward: 92 KB each for trunk.7.C2, re-read 9 x 16 times through L2).  Workgroup ids
+    // are dealt round-robin to the 8 XCDs, each with its own 4 MB L2: in the natural order an episode's 16 workgroups land on all
+    // eight XCDs, every L2 holds the rows of all ~32 episodes in flight beside the w / m / v stream, and 43 % of those re-reads
+    // missed (PMC: FETCH_SIZE 1.21x the w / m / v bytes).  Remapped: XCD x works through episodes x, x + 8, ... with all of an
+    // episode's workgroups, so an L2 holds 4 episodes' rows at a time.
+    int g, co0;
+    if (p.xcd_groups) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = (slot / p.co_blocks) * 8 + xcd;
+        co0 = (slot % p.co_blocks) * BM;
+    } else {
+        g = blockIdx.x / p.co_blocks;
+        co0 = (blockIdx.x % p.co_blocks) * BM;
+    }
     const int ohw = p.OH * p.OW;
     const int rows = p.rows;
     const long long row0 = (long long)g * rows;
@@ -340,10 +356,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 int g_wf_exact = 0;      // 1: correctly rounded division / square root in the Adam epilogue (mft_wgrad_fwd_set_exact)
+int g_wf_xcd = 1;        // 1: an episode's workgroups share one XCD's L2 (mft_wgrad_fwd_set_xcd; 0 = natural order, for A/B)
 
 }  // namespace
 
 extern "C" void mft_wgrad_fwd_set_exact(int on) { g_wf_exact = on ? 1 : 0; }
+extern "C" void mft_wgrad_fwd_set_xcd(int on) { g_wf_xcd = on ? 1 : 0; }
 
 extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ldy, float* w, float* m, float* v,
                                            float* dw_or_null, int n_img, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -389,7 +407,9 @@ extern "C" int mft_wgrad_adam_next_forward(const float* x, int ldx, const float*
     p.pooled = pooled; p.hw = OH * OW; p.bn_eps = bn_eps;
     const int groups = n_img / imgs_per_group;
     constexpr int lds = (48 * 32 + 48 * (128 + 32) + 32 * (128 + 4)) * 4;          // 53.8 KB: two workgroups per CU
-    const dim3 grid(Cout / 32, groups, 1), block(256);
+    p.co_blocks = Cout / 32;
+    p.xcd_groups = (g_wf_xcd && groups % 8 == 0) ? 1 : 0;
+    const dim3 grid((unsigned)(p.co_blocks * groups), 1, 1), block(256);
     hipStream_t s = (hipStream_t)stream;
     // matrix instructions of the reduction: 2 rows each, in chunks of 8 (<= 32 / <= 48 rows; rows beyond the episode's are zeros)
     const int nt = rows <= 32 ? 16 : 24;

@@ -349,6 +349,7 @@ class FinetuneEngine:
         # but E = 120: 84.0 -> 80.3 (3.75 waves), 50-shot E = 128 (no stem cache): 7.93 -> 7.48, 224x224: 19.8 -> 19.6.
         # MFT_FUSE_NEXT = auto (default: that rule, fuse_next_policy, applied once the stem cache is decided) | 1 | 0.
         self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "auto")
+        ops._lib.lib().mft_wgrad_fwd_set_xcd(int(os.environ.get("MFT_WF_XCD", "1")))      # (A/B hook: workgroup -> XCD order of the fused launch)
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum

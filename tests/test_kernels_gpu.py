@@ -944,6 +944,40 @@ def test_wgrad_adam_next_forward_kernel(ipg):
     assert not ops.wgrad_adam_next_forward(xb, dyb, wb, wb.clone(), wb.clone(), 3, 3, 2, 1, 1, 6)
 
 
+@pytest.mark.parametrize("G", [16, 24, 12])
+def test_wgrad_adam_next_forward_xcd_order_is_bit_identical(G):
+    """The fused launch places all workgroups of an episode on one XCD (mft_wgrad_fwd_set_xcd, default on when the episode count is
+    a multiple of 8): placement only -- w, m, v, the gradient and every output of the next step's forward equal the natural
+    workgroup order bit for bit (16 / 24 episodes: remapped; 12: not a multiple of 8, natural order either way)."""
+    from meta_fine_tuning_amd import _lib
+    lib = _lib.lib()
+    ipg, Cin, Cout, k, stride, pad, H = 5, 256, 512, 3, 2, 1, 6
+    n = G * ipg
+    OH = (H + 2 * pad - k) // stride + 1
+    xg, xng = nhwc(rnd((n, Cin, H, H), 401)).to(DEV), nhwc(rnd((n, Cin, H, H), 402)).to(DEV)
+    dyg = nhwc(rnd((n, Cout, OH, OH), 403) * 1e-2).to(DEV)
+    w0 = rnd((G, Cout, k * k * Cin), 404, scale=0.02).to(DEV)
+    m0, v0 = (rnd((G, Cout, k * k * Cin), 405) * 1e-3).to(DEV), (rnd((G, Cout, k * k * Cin), 406).abs() * 1e-6).to(DEV)
+    gam, bet = (1.0 + 0.1 * rnd((G, Cout), 407)).to(DEV), (0.1 * rnd((G, Cout), 408)).to(DEV)
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.mft_wgrad_fwd_set_xcd(on)
+            w, m, v = w0.clone(), m0.clone(), v0.clone()
+            dw = torch.zeros_like(w)
+            raw = torch.full((n * OH * OH, Cout), float("nan"), device=DEV)
+            act = torch.full_like(raw, float("nan"))
+            mean, rstd = torch.full((G, Cout), float("nan"), device=DEV), torch.full((G, Cout), float("nan"), device=DEV)
+            assert ops.wgrad_adam_next_forward(xg, dyg, w, m, v, k, k, stride, pad, 3, ipg, x_next=xng, mode=ops.WF_ENTRY, raw=raw, act=act,
+                                               gamma=gam, beta=bet, gbs=Cout, mean=mean, rstd=rstd, dw=dw)
+            outs.append((w, m, v, dw, raw, act, mean, rstd))
+    finally:
+        lib.mft_wgrad_fwd_set_xcd(1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert not torch.equal(outs[0][0], w0)
+
+
 @pytest.mark.parametrize("Cin,Cout,H,ipg,G", [(64, 64, 21, 5, 6), (128, 128, 11, 5, 7), (64, 128, 11, 3, 5), (256, 256, 6, 5, 4)])
 def test_conv_x3_loader_side_batchnorm_is_bit_identical(Cin, Cout, H, ipg, G):
     """SimpleBlock's C1 -> BN1 -> ReLU -> C2 (backbone.py:251-256) with BN1 folded into C2's loader
