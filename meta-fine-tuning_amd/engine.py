@@ -631,12 +631,17 @@ class FinetuneEngine:
                     launch_trunk(t + 2)               # its buffer was last read by step t-1, whose completion event it waits for
                 with torch.cuda.stream(self.s_last):
                     self.s_last.wait_event(ready[t])
-                    x6n = tn = None
+                    x6n = tn = wait_next = None
                     if t + 1 < n_steps:
-                        self.s_last.wait_event(ready[t + 1])
+                        # x6[t+1] is first read by the fused launches, AFTER this step's cross entropy, BatchNorm backward and data
+                        # gradient (0.3 ms): the wait goes there.  Waiting here, at the top of the step, left the last-block queue
+                        # idle for ~0.2 ms per step while the trunk stream -- starved by the fused trunk.7.C2 launch it ran beside
+                        # -- finished the tail of its own step (kernel timeline, profiles/r04_d_timeline_*.txt).
                         x6n = x6s[t + 1]
                         tn = self._next_tape(x6n, k0, (t + 1) & 1)
-                    self.last_step(x6s[t], lab_all[t], k0, nxt=(x6n, tn), tape=tape)
+                        ev_next = ready[t + 1]
+                        wait_next = (lambda ev=ev_next: self.s_last.wait_event(ev))
+                    self.last_step(x6s[t], lab_all[t], k0, nxt=(x6n, tn, wait_next), tape=tape)
                     tape = tn
                     ev = torch.cuda.Event()
                     ev.record(self.s_last)

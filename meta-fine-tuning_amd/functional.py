@@ -35,6 +35,10 @@ X3_FOLD_BN = os.environ.get("MFT_X3_FOLD_BN", "1") == "1"
 # pieces (six products): half the matrix work at an error below an fp32-accumulating GEMM's.  Taken only when the state dict
 # passes ``f16x2_safe`` (every operand provably inside fp16's range); MFT_TRUNK_F16X2=0 keeps the bf16x3 kernels.
 TRUNK_F16X2 = os.environ.get("MFT_TRUNK_F16X2", "1") == "1"
+# fused next-step forward (engine.fuse_next), opt-in variant: only trunk.7.C2's launch is the fused walking kernel, C1 / shortcut keep
+# the plain gradient + Adam launches + one entry launch (last_block_backward).  Alone that chain is 100 us shorter, in situ it is
+# slower: 87.2 vs 88.8-89.0 episodes/s (profiles/r04_d_fuse_c2_only_ab.txt) -- default 0 = all three layers fused
+FUSE_NEXT_C2_ONLY = os.environ.get("MFT_FUSE_NEXT_C2_ONLY", "0") == "1"
 F16X2_BOUND = 3.0e4              # < 65504 with a factor 2 in hand
 F16X2_FLOOR = 2.0 ** -10          # typical operand magnitude that keeps the pieces normal fp16 numbers
 F16X2_MAX_ROWS = 1 << 20         # largest BatchNorm group (images x pixels) the bound is proven for (engine: 100 x 21 x 21 = 44,100)
@@ -669,7 +673,7 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
     ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
     ``adam`` = (m_slab, v_slab, step, lr): fuse the Adam update of the three conv weights into the wgrad
     epilogues (their gradients are then not materialised) and update the BatchNorm affine tail separately.
-    ``nxt`` = (x_next | None, tape_next | None) (needs ``adam``): the three weight-gradient + Adam launches also run the NEXT inner
+    ``nxt`` = (x_next | None, tape_next | None[, callable run right before the first launch that reads x_next]) (needs ``adam``): the three weight-gradient + Adam launches also run the NEXT inner
     step's trunk.7 forward on ``x_next`` from the weight tiles they have just updated and fill ``tape_next`` (next_step_tape) --
     no forward launch reads the updated weights back (csrc/wgrad_fwd.hip).  The BatchNorm-affine Adam tail then runs BEFORE them
     (their epilogues apply the updated gamma / beta), C1 and the shortcut before C2 (whose forward consumes r1 and sc of step
@@ -758,20 +762,45 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
 
     if nxt is not None:
         assert adam is not None and not done_c2
-        x_next, tn = nxt
+        x_next, tn = nxt[0], nxt[1]
         m_, v_, step, lr = adam
         hyper = step if torch.is_tensor(step) else None
         st = 1 if hyper is not None else step
         dc1 = _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd)
         adam_tail()
+        wait_next = nxt[2] if len(nxt) > 2 else None      # the caller's stream wait for x_next, issued where x_next is first read
         kw = dict(lr=lr, hyper=hyper)
         fw = x_next is not None
-        ok = ops.wgrad_adam_next_forward(x, dsc, params.scw, m_.scw, v_.scw, 1, 1, 2, 0, st, ipg, x_next=x_next, mode=ops.WF_RAW,
-                                         raw=tn["sc"] if fw else None, **kw)
-        ok = ok and ops.wgrad_adam_next_forward(x, dc1, params.c1w, m_.c1w, v_.c1w, 3, 3, 2, 1, st, ipg, x_next=x_next,
-                                                mode=ops.WF_ENTRY, raw=tn["c1"] if fw else None, act=tn["r1"] if fw else None,
-                                                gamma=params.bn1g, beta=params.bn1b, gbs=C, mean=tn["m1"] if fw else None,
-                                                rstd=tn["s1"] if fw else None, **kw)
+        ok = hybrid = False
+        if FUSE_NEXT_C2_ONLY and FUSED_LAST_BLOCK and groups > ops.SMALL_GROUPS:
+            # Only trunk.7.C2 takes the fused launch (opt-in).  Alone, C1's and the shortcut's fused launches are 154 + 50 us longer
+            # than the plain gradient + Adam launches and save the 137 us entry launch; the entry forward of step t+1 then reads the
+            # updated C1 / shortcut weights once more (1.3 of the 14.7 MB per episode).  In situ the trunk stream finishes no earlier
+            # beside the plain launches than beside the walking kernel, and the step is 1.7 % slower.
+            wgrad(x, dsc, "scw", 1, 2, 0)
+            wgrad(x, dc1, "c1w", 3, 2, 1)
+            hybrid = ok = True
+            if fw:
+                if wait_next is not None:
+                    wait_next()
+                    wait_next = None
+                rc = lib.mft_block_entry_small_forward(
+                    ops._p(x_next), x_next.shape[-1], ops._p(params.c1w), params.c1w.shape[1] * params.c1w.shape[2], ops._p(params.scw),
+                    params.scw.shape[1] * params.scw.shape[2], ops._p(tn["c1"]), ops._p(tn["r1"]), ops._p(tn["sc"]), n, x_next.shape[1],
+                    x_next.shape[2], x_next.shape[-1], C, 2, ipg, ops._p(params.bn1g), ops._p(params.bn1b), C, ops._p(tn["m1"]),
+                    ops._p(tn["s1"]), ops.BN_EPS, ops._stream())
+                if rc == ops._lib.MFT_EINVAL:
+                    raise RuntimeError("block entry launch outside its domain after next_forward_ok accepted the shape")
+                ops._lib.check(rc, "mft_block_entry_small_forward")
+        if not hybrid:
+            if wait_next is not None:
+                wait_next()
+            ok = ops.wgrad_adam_next_forward(x, dsc, params.scw, m_.scw, v_.scw, 1, 1, 2, 0, st, ipg, x_next=x_next, mode=ops.WF_RAW,
+                                             raw=tn["sc"] if fw else None, **kw)
+            ok = ok and ops.wgrad_adam_next_forward(x, dc1, params.c1w, m_.c1w, v_.c1w, 3, 3, 2, 1, st, ipg, x_next=x_next,
+                                                    mode=ops.WF_ENTRY, raw=tn["c1"] if fw else None, act=tn["r1"] if fw else None,
+                                                    gamma=params.bn1g, beta=params.bn1b, gbs=C, mean=tn["m1"] if fw else None,
+                                                    rstd=tn["s1"] if fw else None, **kw)
         ok = ok and ops.wgrad_adam_next_forward(r1, dc2, params.c2w, m_.c2w, v_.c2w, 3, 3, 1, 1, st, ipg,
                                                 x_next=tn["r1"] if fw else None, mode=ops.WF_EXIT, raw=tn["c2"] if fw else None,
                                                 act=tn["out"] if fw else None, gamma=params.bn2g, beta=params.bn2b, gbs=C,
