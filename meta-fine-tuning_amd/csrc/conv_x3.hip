@@ -42,7 +42,7 @@ struct X3Args {
     unsigned in_plane_bytes;
     float* stats_ws;               // optional [tiles_m][2][Cout][2]: per-tile (sum x, sum x^2) of the two BatchNorm groups a tile can touch
     int rows_per_group;            // >= BM when stats_ws is set
-    int s1_rows;                   // conv_x3_s1_kernel: rows of the staged A image (BM + halo + one zero row per image-row boundary)
+    int s1_rows;                   // conv_x3_s1_kernel: rows of the staged A image (BM + 2 halo pixels + 16 all-zero rows)
     // conv_x3_s1_kernel<.., BNIN = true>: ``in`` is the RAW output of the previous convolution; its train-mode BatchNorm + ReLU is
     // applied by the loader, with the statistics merged from that convolution's per-tile partials in the workgroup prologue
     const float* bn_ws; const float* bn_gamma; const float* bn_beta;
@@ -730,10 +730,10 @@ __global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
 // The implicit-GEMM kernel above fetches, splits and stores the A tile of every tap separately, although the three kw taps of one
 // kernel row read the SAME pixels shifted by one: with OW == W the flat output index m is also the flat input pixel index, and tap
 // (kh, kw) of output m needs pixel m + (kh-1) W + (kw-1) -- or zero where ow + kw - 1 leaves the image row.  This form stages, per
-// (kh, 32-channel slice), ONE image of the BM pixels m0 .. m0+BM-1 shifted by (kh-1) rows, plus one halo pixel at each end and one
-// all-zero row at every image-row boundary inside the tile (LDS row of pixel m: (m - m0) + 1 + number of boundaries before it), and
-// the three kw taps read their fragments from it at row offsets -1 / 0 / +1: the zero rows ARE the horizontal padding, so no
-// per-lane masking is needed.  Global loads, bf16x3 splits and LDS stores of the A operand drop to a third; the weights (B) are
+// (kh, 32-channel slice), ONE image of the BM pixels m0 .. m0+BM-1 shifted by (kh-1) rows, plus one halo pixel at each end and
+// sixteen all-zero rows (LDS row of pixel m: (m - m0) + 1), and the three kw taps read their fragments from it at row offsets
+// -1 / 0 / +1 -- except that a lane whose output pixel is the first / last of its image row reads a zero row for kw = 0 / kw = 2:
+// that IS the horizontal padding (one address select per lane and tap, no masking of data).  Global loads, bf16x3 splits and LDS stores of the A operand drop to a third; the weights (B) are
 // staged per tap as before.  K is walked (kh, ci, kw) instead of (kh, kw, ci): the same products, summed in another order.
 // The launch is power-limited: the saving is in joules first, in issue slots second.
 // BNIN: the input is the raw output c of the previous 3x3 convolution and this kernel consumes relu(BatchNorm(c)) (SimpleBlock:
@@ -808,7 +808,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
         a_ok[j] = m < p.M;
         a_oh[j] = fr - (fr / H) * H;
         a_off[j] = ((a_ok[j] ? m : 0) * p.ldi + c4) * 4;           // (rows beyond M are never requested; keep the product in range)
-        a_lds[j] = (t + 1 + fr - fr0) * RS + c4;
+        a_lds[j] = (t + 1) * RS + c4;
         a_tab[j] = BNIN ? ((a_ok[j] ? m / p.rows_per_group - g0 : 0) * 2 * p.Cin + c4) : 0;
     }
     // halo pixels m0 - 1 and m0 + BM (threads 0-7 / 8-15): real only when they lie in the same image row as their neighbour
@@ -818,7 +818,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     const bool h_ok = tid < 16 && (hside ? (mh < p.M && mh - frh * W != 0) : (m0 > 0 && m0 - fr0 * W != 0));
     const int h_oh = frh - (frh / H) * H;
     const int h_off = ((h_ok ? mh : 0) * p.ldi + c4) * 4;
-    const int h_lds = (hside ? BM + 1 + (m0 + BM - 1) / W - fr0 : 0) * RS + c4;
+    const int h_lds = (hside ? BM + 1 : 0) * RS + c4;
     // a real halo pixel lies in the same image (hence the same group) as its neighbour inside the tile
     const int h_tab = BNIN ? (((hside && h_ok) ? (m0 + BM - 1) / p.rows_per_group - g0 : 0) * 2 * p.Cin + c4) : 0;
 
@@ -830,11 +830,21 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     const int plane_bytes = (int)(p.plane * 2);
 
     // fragment rows of this lane inside the staged image
-    int fa[TM];
+    // LDS row of pixel m0 + t is t + 1 (rows 0 and BM + 1: the halo pixels; rows BM + 2 .. BM + 17: zeros, never written after the
+    // fill).  A lane whose output pixel sits at the left / right end of its image row reads a ZERO row for the kw = 0 / kw = 2 tap --
+    // that is the horizontal padding -- namely the one of the sixteen that shares its banks with the row it replaces (rows 16 apart
+    // alias at the 80-byte pitch), so the 16 lanes of a ds_read_b128 still hit 64 distinct banks.  (Round 2's layout put one zero
+    // row at every image-row boundary INSIDE the image instead: the 16 lanes then spanned 17-19 LDS rows and 32 % of the LDS cycles
+    // of these kernels were bank conflicts -- PMC, profiles/r04_g_lds_conflicts.txt.)
+    int fa[TM], fl[TM], fr_[TM];
+    constexpr int Z0 = BM + 2;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int t = wm * (BM / 2) + i * 32 + r;
-        fa[i] = (t + 1 + (m0 + t) / W - fr0) * RS;
+        const int ow = (m0 + t) - ((m0 + t) / W) * W;
+        fa[i] = (t + 1) * RS;
+        fl[i] = ow == 0 ? (Z0 + ((t - Z0) & 15)) * RS : fa[i] - RS;              // replaces row t
+        fr_[i] = ow == W - 1 ? (Z0 + ((t + 2 - Z0) & 15)) * RS : fa[i] + RS;      // replaces row t + 2
     }
 
     f32x16 acc[NACC][TM][TN];
@@ -939,7 +949,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
+                        a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (kw == 0 ? fl[i] : (kw == 1 ? fa[i] : fr_[i])) + kk * 16 + h * 8);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -960,7 +970,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
-                        a[i][pl] = *(const f16x8*)(As + pl * A_PLANE + fa[i] + (kw - 1) * RS + kk * 16 + h * 8);
+                        a[i][pl] = *(const f16x8*)(As + pl * A_PLANE + (kw == 0 ? fl[i] : (kw == 1 ? fa[i] : fr_[i])) + kk * 16 + h * 8);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1194,7 +1204,8 @@ int g_x3_s1 = 1;           // 3x3 / stride 1 / pad 1 layers: A image staged once
 constexpr size_t X3_S1_LDS_3PER_CU = 160 * 1024 / 3;       // three workgroups per CU: the occupancy the trunk convolutions are tuned for
 
 inline size_t x3_s1_lds(int BM, int BN, int W, int bn_cin, int np = 3) {
-    return (size_t)np * (BM + 2 + (BM - 1) / W + 1 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
+    (void)W;
+    return (size_t)np * (BM + 18 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
 }
 
 template <int BM, int BN>
@@ -1203,7 +1214,7 @@ int launch_x3_s1(X3Args p, hipStream_t s, int np = 3) {
     p.tiles_n = p.Cout / BN;
     p.xcd_swizzle = g_x3_xcd;
     p.row_swz = g_x3_row_swz != 0;
-    p.s1_rows = BM + 2 + (BM - 1) / p.W + 1;
+    p.s1_rows = BM + 18;                             // BM pixels + two halo pixels + sixteen zero rows (one per bank phase)
     const size_t lds = x3_s1_lds(BM, BN, p.W, p.bn_ws ? p.Cin : 0, np);
     const dim3 grid((unsigned)(tiles_m * p.tiles_n));
     if (np == 2) {
@@ -1470,7 +1481,7 @@ static int x3_dispatch(const float* in, int ldi, const unsigned short* w3, long 
     if (bn_ws != nullptr && (in3 != nullptr || !bn_gamma || !bn_beta || rows_per_group < 128 || KH != 3 || KW != 3 || stride != 1 ||
                              pad != 1 || x3_s1_lds(128, 64, W, Cin, np) > X3_S1_LDS_3PER_CU ||
                              2 * mft_x3_stage_bytes_host(p.bn_max_tiles, Cin) >
-                                 (size_t)np * (128 + 2 + 127 / W + 1) * X3_RS * sizeof(unsigned short)))
+                                 (size_t)np * (128 + 18) * X3_RS * sizeof(unsigned short)))
         return MFT_EINVAL;                     // the loader-side BatchNorm exists in the shared-tap kernel only, at full occupancy
     p.in3 = in3;
     p.in_plane_bytes = 0;

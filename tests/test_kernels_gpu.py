@@ -984,7 +984,7 @@ def test_conv_x3_loader_side_batchnorm_is_bit_identical(Cin, Cout, H, ipg, G):
     (mft_conv2d_nhwc_x3_bnin_bnstats: statistics merged from C1's partials in the workgroup prologue) against the separate
     launches finalize -> mft_bn_apply -> mft_conv2d_nhwc_x3_bnstats: same arithmetic, so the convolution output and the
     statistics behind it must match bit for bit (tiles straddling groups, ragged last tile, image-row boundaries, negative
-    gammas).  256 channels on 6x6 maps do not fit the table at three workgroups per CU: refused."""
+    gammas).  A 512-channel table does not fit beside the tile at three workgroups per CU: refused (MFT_EINVAL -> None)."""
     from meta_fine_tuning_amd import _lib
     lib = _lib.lib()
     n = G * ipg
@@ -1012,11 +1012,11 @@ def test_conv_x3_loader_side_batchnorm_is_bit_identical(Cin, Cout, H, ipg, G):
     ws2b = torch.empty_like(ws2)
     m2b, s2b = torch.empty_like(m2), torch.empty_like(s2)
     r = ops.conv2d_x3_bnin_bnstats(c1b, ws1b, g1, b1, w2, Cout, ipg, out, ws2b, m2b, s2b)
-    if Cin == 256:
-        assert r is None                                             # the caller runs mft_bn_apply_x3ws + the plain convolution
-        r1b = ops.bn_apply_x3ws(c1b.view(-1, Cin), Cin, rows, G, ws1b, g1, b1, torch.empty((n * H * H, Cin), device=DEV), act=ops.ACT_RELU)
-        assert torch.equal(r1b.view_as(r1), r1)
-        return
+    # (256 channels on 6x6 maps were refused while the staged image carried a zero row per image-row boundary: 152 rows; with one
+    #  zero row -- 131 rows -- the (scale, shift) table fits beside the tile at three workgroups per CU.)  The stand-alone apply
+    #  from partials that a refusing shape falls back to is checked against the plain apply either way:
+    r1b = ops.bn_apply_x3ws(c1b.view(-1, Cin), Cin, rows, G, ws1b, g1, b1, torch.empty((n * H * H, Cin), device=DEV), act=ops.ACT_RELU)
+    assert torch.equal(r1b.view_as(r1), r1)
     assert r is not None
     assert torch.equal(out, ref)
     assert torch.equal(m2b, m2) and torch.equal(s2b, s2)
@@ -1028,6 +1028,13 @@ def test_conv_x3_loader_side_batchnorm_is_bit_identical(Cin, Cout, H, ipg, G):
     od = torch.nn.functional.conv2d(r1d.permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1)
     assert float((out.double().cpu() - od).abs().max()) < 2e-5 * max(1.0, float(od.abs().max()))
     del n_part
+    if Cin == 256:                                                       # outside the domain: the caller runs apply + plain convolution
+        xb = torch.zeros((8, 6, 6, 512), device=DEV)                      # groups of 4 images = 144 rows: inside the row domain
+        wsb = torch.zeros(int(lib.mft_conv2d_x3_stats_ws_floats(8, 6, 6, 512, 3, 3, 1, 1)), device=DEV)
+        wb = ops.split_weight_x3(ops.pack_conv_weight(torch.zeros((64, 512, 3, 3), device=DEV)))
+        gb = torch.ones(512, device=DEV)
+        assert ops.conv2d_x3_bnin_bnstats(xb, wsb, gb, gb, wb, 64, 4, torch.empty((8, 6, 6, 64), device=DEV),
+                                          torch.empty(int(lib.mft_conv2d_x3_stats_ws_floats(8, 6, 6, 64, 3, 3, 1, 1)), device=DEV)) is None
 
 
 @pytest.mark.parametrize("C,H,ipg,G,res", [(64, 21, 5, 6, "identity"), (128, 11, 5, 7, "bn"), (256, 6, 5, 5, "bn"), (64, 21, 3, 4, "none")])
