@@ -48,6 +48,13 @@ int mft_stream_destroy(void* stream);
  * (n a multiple of 1024) with no gradient operand -- the pure-stream rate of the memory system bench.py quotes beside the fused
  * weight-gradient + Adam kernel's.                                                                                          */
 int mft_stream_probe(float* w, float* m, float* v, long long n, void* stream);
+/* Measurement aid (no reference counterpart): hipEvent_t create / record on `stream` / elapsed milliseconds between two recorded
+ * events (synchronises on `stop`) / destroy.  _lib.LaunchTimer brackets every launcher call with a pair of these on the stream
+ * the launcher enqueues on: live per-kernel durations for bench.py's roofline objects on any stream of the engine.          */
+int mft_event_create(void** event_out);
+int mft_event_record(void* event, void* stream);
+int mft_event_elapsed_ms(void* start, void* stop, float* ms_out);
+int mft_event_destroy(void* event);
 int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles, void* stream);
 
 /* Device-side test-time views (datasets/EuroSAT_few_shot.py:145-170,240-276; data/additional_transforms.py:16-31): for every

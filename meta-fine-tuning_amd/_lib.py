@@ -22,6 +22,10 @@ SIGNATURES = {
     "mft_stream_destroy": [_P],
     "mft_stream_probe": [_P, _P, _P, _L, _P],
     "mft_probe_placement": [_P, _I, _I, _P],
+    "mft_event_create": [_P],
+    "mft_event_record": [_P, _P],
+    "mft_event_elapsed_ms": [_P, _P, _P],
+    "mft_event_destroy": [_P],
     "mft_augment_views": [_P, _I, _I, _I, _P, _I, _P, _L, _L, _I, _P, _P, _P],
     "mft_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _P],
     "mft_pack_oihw": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -172,3 +176,72 @@ MFT_EINVAL = -22
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed with code %d (hipError_t / MFT_EINVAL=-22)" % (what, rc))
+
+
+class LaunchTimer:
+    """Measurement aid: ``with LaunchTimer() as t: ...`` brackets EVERY launcher call made through ``lib()`` inside the block with
+    a pair of HIP events recorded on the stream the launcher enqueues on (its last argument), whichever stream that is -- the
+    engine's raw priority / CU-masked streams included, which torch.cuda.Event (current stream only) cannot see.
+    ``t.collect()`` -> {launcher name: [milliseconds per call, ...]} (synchronises).  A launcher that enqueues several kernels
+    is timed as one unit.  Not for use under stream capture (an event record would become a graph node); eager phases only."""
+
+    _SKIP = ("mft_event_", "mft_stream_", "mft_debug_", "mft_version", "mft_device_info", "mft_has_experiments",
+             "mft_wgrad_fwd_set_", "mft_probe_placement")
+
+    def __init__(self, only=None):
+        self.only = only                       # optional predicate(name) -> bool
+        self._pairs = []                       # (name, start, stop)
+        self._free = []
+        self._real = None
+
+    def _event(self):
+        if self._free:
+            return self._free.pop()
+        e = ctypes.c_void_p()
+        check(self._real.mft_event_create(ctypes.byref(e)), "mft_event_create")
+        return e
+
+    def __getattr__(self, name):               # stands in for the CDLL while the block runs
+        real = self.__dict__["_real"]
+        fn = getattr(real, name)
+        sig = SIGNATURES.get(name)
+        if (sig is None or not sig or sig[-1] is not _P or name.endswith("_ws_floats") or name.startswith(self._SKIP)
+                or (self.only is not None and not self.only(name))):
+            return fn
+
+        def timed(*args):
+            stream = args[-1]
+            a, b = self._event(), self._event()
+            real.mft_event_record(a, stream)
+            rc = fn(*args)
+            real.mft_event_record(b, stream)
+            self._pairs.append((name, a, b))
+            return rc
+        return timed
+
+    def __enter__(self):
+        global _lib
+        self._real = lib()
+        assert not isinstance(self._real, LaunchTimer), "LaunchTimer blocks do not nest"
+        _lib = self
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._real
+        return False
+
+    def collect(self):
+        out = {}
+        ms = ctypes.c_float()
+        for name, a, b in self._pairs:
+            check(self._real.mft_event_elapsed_ms(a, b, ctypes.byref(ms)), "mft_event_elapsed_ms")
+            out.setdefault(name, []).append(float(ms.value))
+            self._free += [a, b]
+        self._pairs = []
+        return out
+
+    def close(self):
+        for e in self._free:
+            self._real.mft_event_destroy(e)
+        self._free = []

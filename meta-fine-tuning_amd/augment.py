@@ -79,6 +79,27 @@ def sample_view_params(rs, n_img, Hs, Ws, size, num_aug):
     return P
 
 
+TRAIN_JITTER = (0.4, 0.4, 0.4)     # Brightness, Contrast, Color (datasets/miniImageNet_few_shot.py:108)
+
+
+def sample_train_view_params(rs, n_img, Hs, Ws, size, aug):
+    """Training-side transform of the reference's SetDataManager (datasets/miniImageNet_few_shot.py:109-141,178), ONE view per
+    image -> float32 [1, n_img, 10].  ``aug`` False: Resize([int(1.15 * size)] * 2) + CenterCrop(size) (the un-augmented box);
+    True (--train_aug): RandomResizedCrop(size) with torchvision's default scale (0.08, 1) and ratio (3/4, 4/3),
+    ImageJitter(Brightness .4, Contrast .4, Color .4), RandomHorizontalFlip (no vertical flip on this side)."""
+    P = np.zeros((1, n_img, NPARAM), dtype=np.float32)
+    P[0, :, 4:7] = 1.0
+    if not aug:
+        P[0, :, 0:4] = noaug_box(Hs, Ws, size)
+        return P
+    P[0, :, 0:4] = random_resized_crop_boxes(rs, n_img, Hs, Ws, scale=(0.08, 1.0))
+    u = rs.uniform(0.0, 1.0, size=(n_img, 3))
+    P[0, :, 4:7] = np.asarray(TRAIN_JITTER)[None] * (2.0 * u - 1.0) + 1.0
+    P[0, :, 7] = rs.uniform(0.0, 1.0, size=n_img) < 0.5
+    P[0, :, 9] = 1.0
+    return P
+
+
 def sample_view_params_torch(n_img, Hs, Ws, size, num_aug):
     """``sample_view_params`` on the REFERENCE's random stream: every draw comes from torch's global generator in the order
     the reference's loader consumes it -- image by image (SubDataset2.__getitem__, datasets/EuroSAT_few_shot.py:156-170), per

@@ -147,8 +147,11 @@ class _HeadFn(torch.autograd.Function):
 def resnet10_module_forward(mod, x):
     """backbone.ResNet.forward: x NCHW [n,3,H,W] on the GPU -> [n,512]."""
     _require_cuda(x, "ResNet10.forward")
-    x = x.contiguous().float()
-    xn = ops.nchw_to_nhwc(x)
+    if x.dim() == 4 and x.dtype == torch.float32 and x.permute(0, 2, 3, 1).is_contiguous():
+        xn = x.permute(0, 2, 3, 1)            # already NHWC in memory (train.ResidentEpisodeLoader: mft_augment_views writes NHWC)
+    else:
+        x = x.contiguous().float()
+        xn = ops.nchw_to_nhwc(x)
     params = list(mod.parameters())
     if not mod.training:
         # eval-mode BatchNorm (finetune(freeze_backbone=True), finetune.py:265-266): running statistics, no buffer updates

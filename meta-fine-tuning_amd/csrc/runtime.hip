@@ -93,3 +93,21 @@ extern "C" int mft_probe_placement(unsigned* out, int n_blocks, int spin_cycles,
     hipLaunchKernelGGL(probe_placement_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, out, spin_cycles);
     return mft_launch_status();
 }
+
+// Measurement aid (bench.py, tools/): HIP events recorded on the stream a launcher enqueues on, so that per-launch durations can be
+// measured live for ANY entry point of this library (meta_fine_tuning_amd._lib.LaunchTimer) -- torch.cuda.Event only sees torch's
+// current stream, and the engine runs on raw priority / CU-masked streams of its own.
+extern "C" int mft_event_create(void** event_out) {
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return (int)rc;
+    *event_out = (void*)e;
+    return 0;
+}
+extern "C" int mft_event_record(void* event, void* stream) { return (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream); }
+extern "C" int mft_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc != hipSuccess) return (int)rc;
+    return (int)hipEventElapsedTime(ms_out, (hipEvent_t)start, (hipEvent_t)stop);
+}
+extern "C" int mft_event_destroy(void* event) { return (int)hipEventDestroy((hipEvent_t)event); }

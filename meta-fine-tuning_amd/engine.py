@@ -17,9 +17,10 @@ import torch
 
 from . import functional as Fn
 from . import ops
+from . import settings
 
 
-_DEBUG_SKIP_TRUNK = os.environ.get("MFT_DEBUG_SKIP_TRUNK", "0") == "1"     # results are then WRONG; timing experiments only
+_DEBUG_SKIP_TRUNK = settings.current().debug_skip_trunk     # results are then WRONG; timing experiments only
 
 
 def pick_slab_buffers(rates, K):
@@ -149,6 +150,18 @@ def fuse_next_policy(setting, E, stem_cached, image_size, f16x2):
     return bool(E >= 32 and E % 32 == 0 and stem_cached and f16x2 and image_size <= 84)
 
 
+_WF_XCD_SET = False
+
+
+def _set_wgrad_fwd_xcd_once():
+    """MFT_WF_XCD (A/B hook: workgroup -> XCD order of the fused launch) is process-global kernel state: read ONCE per process,
+    not per engine -- an engine built later must not change the launch order of engines that already exist."""
+    global _WF_XCD_SET
+    if not _WF_XCD_SET:
+        ops._lib.lib().mft_wgrad_fwd_set_xcd(int(settings.current().wf_xcd))
+        _WF_XCD_SET = True
+
+
 class AdaptState:
     """Per-episode adaptable parameters + gradient + Adam moments (four tensor-major slabs)."""
 
@@ -172,8 +185,9 @@ class AdaptState:
         second weight slab of the deferred final pass; the gradient slab takes any other candidate, the rest goes back to the
         driver.  Placement does not touch any result.  MFT_SLAB_CANDIDATES=0 turns it off."""
         total = E * Fn.ADAPT_NUMEL
-        K = int(os.environ.get("MFT_SLAB_CANDIDATES", str(_SLAB_CANDIDATES)))
-        ballast_gb = min(float(os.environ.get("MFT_SLAB_BALLAST_GB", "12")), 6.4 * total * 4 / (1 << 30))
+        cfg = settings.current()
+        K = _SLAB_CANDIDATES if cfg.slab_candidates is None else cfg.slab_candidates
+        ballast_gb = min(cfg.slab_ballast_gb, 6.4 * total * 4 / (1 << 30))
         dev = torch.device(device)
         if K >= 5 and dev.type == "cuda" and total * 4 >= (64 << 20):
             free_b, _ = torch.cuda.mem_get_info(dev)
@@ -215,7 +229,7 @@ class AdaptState:
             # re-used when ONE probe of its two triples confirms the rates it promised (within 3 %); otherwise the full scan
             # runs (1.5 s at E = 128 -- a quarter of a 600-episode evaluation's fixed cost).  MFT_SLAB_HINTS=0 turns it off.
             hint_key = "%s|%d|%d|%.2f" % (torch.cuda.get_device_name(dev), total, K, ballast_gb)
-            hint = _placement_hint(hint_key, K=K) if os.environ.get("MFT_SLAB_HINTS", "1") == "1" else None
+            hint = _placement_hint(hint_key, K=K) if cfg.slab_hints else None
             best = rates = None
             if hint is not None:
                 w_, m_, v_, w2_ = hint["chosen"]
@@ -281,6 +295,7 @@ class FinetuneEngine:
         if self.use_graph:
             pipeline = False
         self._graphs = {}
+        self.fused_last_loop = False       # did the last inner_loop() run the fused weight-gradient + Adam + next-step-forward launches?
         self._dbg_x6 = {}
         self._alt = None
         self._pre = None            # ingest + stem cache of the NEXT batch, enqueued on their own stream (run_batch(prefetch=))
@@ -328,7 +343,9 @@ class FinetuneEngine:
         self.n_all = n_way * (n_support + n_query)
         fsd = {k[len("feature."):]: v for k, v in state.items()
                if k.startswith("feature.") and not k.startswith(("feature2.", "feature3."))}
-        self.W = Fn.ResNet10Weights(fsd, self.dev, x3=x3)
+        # the largest train-mode BatchNorm group this engine runs: the stem's, over the n_all images of the final pass (the inner
+        # loop's groups are `batch_size` images) -- the fp16 range proof of the f16x2 trunk is made for that size
+        self.W = Fn.ResNet10Weights(fsd, self.dev, x3=x3, max_rows=Fn.stem_rows_bound(max(self.n_all, batch_size), image_size))
         self.G = Fn.GnnHeadWeights(head_state if head_state is not None else state, self.dev, n_way) if mode == "gnn" else None
         if mode == "linear":
             self.cls = {k: torch.zeros((self.E, n_way, 512) if k.endswith("W") else (self.E, n_way), device=self.dev)
@@ -348,27 +365,29 @@ class FinetuneEngine:
         # (profiles/r04_b_fuse_next_*.txt): E = 128: 85.4 -> 87.1 episodes/s, E = 32: 59.4 -> 68.7, 20-shot E = 96: 20.3 -> 21.3;
         # but E = 120: 84.0 -> 80.3 (3.75 waves), 50-shot E = 128 (no stem cache): 7.93 -> 7.48, 224x224: 19.8 -> 19.6.
         # MFT_FUSE_NEXT = auto (default: that rule, fuse_next_policy, applied once the stem cache is decided) | 1 | 0.
-        self.fuse_next = os.environ.get("MFT_FUSE_NEXT", "auto")
-        ops._lib.lib().mft_wgrad_fwd_set_xcd(int(os.environ.get("MFT_WF_XCD", "1")))      # (A/B hook: workgroup -> XCD order of the fused launch)
+        cfg = settings.current()
+        self._fuse_next_setting = cfg.fuse_next      # "auto" | "1" | "0"; resolved to the boolean self.fuse_next below
+        self.fuse_next = False
+        _set_wgrad_fwd_xcd_once()
         # measured at E=128 (A/B in one session): steps per trunk launch set 1 / 2 / 4 / 8 -> 3.75 / 3.77 / 3.89 / 3.96 ms per
         # step: longer trunk launches disturb the HBM-bound stream more than they gain in efficiency; splitting one step's
         # trunk into 2 / 4 episode sub-batches gives 3.78 / 4.12: one step per launch set is the optimum
         # a single episode (the reference's per-episode finetune() call without the LookaheadLoader): the frozen trunk of 32 steps per
         # set of launches -- at E = 1 a trunk pass is 5 images and pure launch latency (5.4 -> 12.3 episodes/s, tools/small_e.py)
-        self.trunk_chunk = (int(os.environ.get("MFT_TRUNK_CHUNK", "32" if episodes_per_batch == 1 else "1")) if trunk_chunk is None
-                            else int(trunk_chunk))
+        self.trunk_chunk = (int(trunk_chunk) if trunk_chunk is not None else
+                            cfg.trunk_chunk if cfg.trunk_chunk is not None else (32 if episodes_per_batch == 1 else 1))
         # Queue priorities: the last-block stream is the critical path (its 8 launches per step are serial and HBM-bound), the
         # trunk stream only has to stay one step ahead.  A/B (one session, two runs each): last high / trunk normal 68.1, 68.1;
         # trunk high / last normal 67.4; both normal 67.2, 67.2 episodes/s.
         # (trunk at the device's least priority, below torch's range: 68.2 / 68.1 / 67.7 vs 67.8 / 68.0 / 67.5 at normal)
-        prio = int(os.environ.get("MFT_TRUNK_PRIORITY", "1"))
+        prio = cfg.trunk_priority
         self.s_trunk = None
         self._raw_last = None
         # CU partition (opt-in, MFT_TRUNK_CUS_PER_XCD = n): the frozen-trunk stream may use n of the 32 CUs of every XCD, the
         # last-block stream the other 32 - n (hipExtStreamCreateWithCUMask; mask bit i -> XCD i % 8, CU i // 8).  A 3-read /
         # 3-write stream keeps 93 % of its rate on 160 of the 256 CUs (tools/microbench/adam_cus.hip) while the matrix-bound
         # trunk scales with its CU count.
-        n_tr = int(os.environ.get("MFT_TRUNK_CUS_PER_XCD", "0"))
+        n_tr = cfg.trunk_cus_per_xcd
         if pipeline and 0 < n_tr < 32:
             def masked(bits):
                 words = (ctypes.c_uint * 8)()
@@ -380,7 +399,7 @@ class FinetuneEngine:
                 return out.value
             self._raw_stream = masked([i for i in range(256) if (i // 8) >= 32 - n_tr])
             self.s_trunk = torch.cuda.ExternalStream(self._raw_stream, device=self.dev)
-            if os.environ.get("MFT_TRUNK_CUS_ONLY", "0") != "1":      # (=1: only the trunk is confined; the last block may run anywhere)
+            if not cfg.trunk_cus_only:      # (=1: only the trunk is confined; the last block may run anywhere)
                 self._raw_last = masked([i for i in range(256) if (i // 8) < 32 - n_tr])
                 self.s_last = torch.cuda.ExternalStream(self._raw_last, device=self.dev)
         elif pipeline and prio > 0:              # below torch's range: a HIP stream at the device's least priority
@@ -392,7 +411,7 @@ class FinetuneEngine:
         elif pipeline:
             self.s_trunk = torch.cuda.Stream(device=self.dev, priority=prio)
         if self._raw_last is None:
-            self.s_last = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("MFT_LAST_PRIORITY", "-1"))) if pipeline else None
+            self.s_last = torch.cuda.Stream(device=self.dev, priority=cfg.last_priority) if pipeline else None
         px = image_size * image_size * 3
         self.Xs = torch.empty((self.E * self.n_total, px), device=self.dev)       # support store, NHWC rows
         self.Xall = torch.empty((self.E * self.n_all, image_size, image_size, 3), device=self.dev)
@@ -409,7 +428,7 @@ class FinetuneEngine:
         # (the opt-in pre-split-planes trunk reads the full-resolution cache; the default is the pooled (max, min) form)
         self._stem_pooled = False if Fn.X3_PLANES else None
         self.stem = Fn.StemCache(self.W, self.E * self.n_total, image_size, self.dev, pooled=self._stem_pooled) if stem_cache else None
-        self.fuse_next = fuse_next_policy(self.fuse_next, self.E, self.stem is not None, image_size, self.W.f16x2)
+        self.fuse_next = fuse_next_policy(self._fuse_next_setting, self.E, self.stem is not None, image_size, self.W.f16x2)
 
     # ------------------------------------------------------------------ ingest
     @_on_device
@@ -556,6 +575,7 @@ class FinetuneEngine:
         step stress different resources (MFMA vs HBM)."""
         if not tables:
             return
+        self.fused_last_loop = False
         dev = self.dev
         if len({t[0] for t in tables}) == 1:               # uniform mini-batches: two H2D copies for the whole loop
             idx_dev = torch.from_numpy(np.stack([t[1] for t in tables])).to(dev, non_blocking=True)
@@ -589,6 +609,9 @@ class FinetuneEngine:
         k0 = tables[0][0]
         H6 = (((((self.size + 6 - 7) // 2 + 1) + 2 - 3) // 2 + 1 + 1) // 2 + 1) // 2        # 84 -> 42 -> 21 -> 11 -> 6; 224 -> 14
         fuse = (self.fuse_next and uniform and self.fused_adam and not self.use_graph and Fn.next_forward_ok(k0, H6))
+        # what THIS loop runs (bench.py reports it; self.fuse_next is only the policy): the fused next-step forward needs uniform
+        # tables, the fused Adam launches, a shape the walking kernel covers and -- on the two-stream path -- one step per trunk launch
+        self.fused_last_loop = bool(fuse and (not self.pipeline or self.trunk_chunk == 1))
         if not self.pipeline:
             if fuse:
                 # step t's weight-gradient launches also produce step t+1's last-block forward: x6 of t+1 must exist before them
@@ -824,8 +847,8 @@ _ADAPT_STREAMS = {}
 _ADAPT_ARENAS = {}
 
 
-ADAPT_GRAPH = os.environ.get("MFT_ADAPT_GRAPH", "1") == "1"
-ADAPT_BATCHED_TRUNK = os.environ.get("MFT_ADAPT_BATCHED_TRUNK", "1") == "1"
+ADAPT_GRAPH = settings.current().adapt_graph
+ADAPT_BATCHED_TRUNK = settings.current().adapt_batched_trunk
 _ADAPT_GRAPHS = {}
 
 

@@ -25,6 +25,7 @@ import torch
 
 from . import engine as eng
 from . import parallel
+from . import settings
 from . import synthetic
 from .io_utils import model_dict, parse_args  # noqa: F401  (re-exported like the reference)
 
@@ -179,7 +180,8 @@ def _finetune(P, liz_x, y, model, state_in, save_it, linear=False, flatten=True,
         with torch.no_grad():
             out_all = feat(x0.cuda().reshape(-1, *x0.shape[2:])).view(n_way, n_support + n_query, -1)
             model.n_query = n_query
-            return torch.nn.functional.softmax(model.set_forward(out_all, is_feature=True), dim=1)
+            from . import ops
+            return ops.softmax_rows(model.set_forward(out_all, is_feature=True).float().contiguous())
     e = _engine_for(state_in, model, n_way, n_support, n_query, x0.size(-1), len(liz_x), P.fine_tune_epoch, 1,
                     fold50=getattr(model, "FOLD50", False))
     model.n_query = n_query                                          # finetune.py:312
@@ -231,7 +233,10 @@ def _finetune_linear_frozen(P, x0, state_in, n_way, n_support, n_query, classifi
     rc = ops._lib.lib().mft_linear_head_adam_run(ops._p(za), ops._p(y_dev), ops._p(table), 1, support_size, D, n_way, table.shape[0],
                                                  batch_size, ops._p(W), ops._p(b), 0.01, 0.9, 0.999, 1e-8, 0.001, ops._stream())
     ops._lib.check(rc, "mft_linear_head_adam_run")
-    return torch.nn.functional.softmax(zb @ W[0].t() + b[0], dim=1)
+    out = torch.empty((zb.shape[0], n_way), device=zb.device)      # softmax(zb @ W^T + b): one group of all query rows
+    rc = ops._lib.lib().mft_linear_head_scores(ops._p(zb), D, zb.shape[0], 1, n_way, D, ops._p(W), ops._p(b), ops._p(out), ops._stream())
+    ops._lib.check(rc, "mft_linear_head_scores")
+    return out
 
 
 def _finetune_linear(P, liz_x, y, state_in, save_it, linear=False, flatten=True, n_query=15, ds=False,
@@ -444,7 +449,7 @@ def short_job_candidates(n_batches):
 
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
              episodes_per_batch=32, verbose=True, method="gnnnet", state_b=None, freeze_backbone=False, rng_seed=None,
-             device_episodes=False, balance=False, timings=None, note=""):
+             device_episodes=False, balance=False, timings=None, note="", emulate_world=None, sampler=None):
     """The episode loop of finetune.py:599-682 on synthetic episodes; returns per-episode accuracies (all ranks' episodes, in
     episode order, on every rank).
 
@@ -456,13 +461,26 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
     The loop is software-pipelined (nothing of it changes a result): the episodes of batch b+2 are generated on a side stream
     while batch b adapts; for ``--method gnnnet`` batch b+1's ingest + stem cache run beside batch b's inner loop and batch b's
     final pass + GNN head beside batch b+1's first steps (FinetuneEngine.run_batch(defer_final=, prefetch=)); accuracies are
-    read from the device once, at the end.  ``balance``: equalise the batch sizes (``balanced_batch``)."""
+    read from the device once, at the end.  ``balance``: equalise the batch sizes (``balanced_batch``).
+    ``sampler``: an augment.EpisodeSampler over a uint8 dataset resident in HBM -- episode i is then ``sampler.episode(seed0 + i)``
+    (classes = randperm(n_classes)[:n_way], per class n_shot + n_query distinct random images, datasets/EuroSAT_few_shot.py:
+    75-124,329-351) and its 2 + gen_examples views are generated on the device (mft_augment_views) straight into the engine's
+    stores; without it the synthetic fp32 episodes of synthetic.test_episode(_device) are used.
+    ``emulate_world`` = (r, W) (measurement aid, single process only): run exactly rank r's share of a W-rank job -- the same
+    episodes, seeds, batch sizes and engine as that rank would -- and return ITS accuracies only (no gather)."""
     import time
     t_start = time.perf_counter()
     rank, W = parallel.world()
-    if W > 1 and rng_seed is None:
-        rng_seed = 10
-    mine = parallel.shard_indices(n_episodes, rank, W)
+    if emulate_world is not None:
+        assert W == 1, "emulate_world is a single-process measurement aid"
+        er, eW = emulate_world
+        if rng_seed is None:
+            rng_seed = 10
+        mine = parallel.shard_indices(n_episodes, er, eW)
+    else:
+        if W > 1 and rng_seed is None:
+            rng_seed = 10
+        mine = parallel.shard_indices(n_episodes, rank, W)
     if balance:
         episodes_per_batch = balanced_batch(len(mine), episodes_per_batch)
     y_query = np.repeat(range(n_way), n_query)
@@ -477,6 +495,22 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         if bi >= len(batches) or bi in gens:
             return
         ids = batches[bi]
+        if sampler is not None:
+            pipe = (method == "gnnnet" and not freeze_backbone and model is not None)
+            eps = []
+            for i in ids:
+                src, P, _ = sampler.episode(seed0 + i, size, gen_examples)
+                if pipe:
+                    eps.append((src, P))                  # the engine generates the views itself (run_batch(sources=True))
+                else:                                     # per-episode entry points take the list of NCHW views
+                    from . import augment
+                    v = augment.augment_views(src.view(-1, *src.shape[2:]), P, size)
+                    eps.append([v[k].view(n_way, n_shot + n_query, size, size, 3).permute(0, 1, 4, 2, 3).contiguous()
+                                for k in range(v.shape[0])])
+            ev = torch.cuda.Event()
+            ev.record()
+            gens[bi] = (eps, ev, torch.zeros((), dtype=torch.bool, device=dev))      # (views 0 and 1 share their parameters)
+            return
         if device_episodes:
             # the same synthetic distribution drawn with the device generator straight into HBM (a pure function of the seed as
             # well; not the numpy episodes): 600 19-view episodes are 96 GB of views -- minutes of host time, seconds on the GPU
@@ -498,6 +532,7 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         gens[bi] = (eps, ev, bad)
 
     pipelined = (method == "gnnnet" and not freeze_backbone and model is not None)
+    n_views = 2 + gen_examples
     engine = None
     flags, score_chunks = [], []
     marks = [] if timings is not None else None
@@ -541,17 +576,18 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         elif pipelined:
             if engine is None:
                 with eng.slab_candidates(short_job_candidates(len(batches))):        # a short job: the cheaper placement scan, or none
-                    engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, len(eps[0]), fine_tune_epoch,
+                    engine = _engine_for(state, model.cuda(), n_way, n_shot, n_query, size, n_views, fine_tune_epoch,
                                          episodes_per_batch, fold50=getattr(model, "FOLD50", False))
                 mark("engine built (host)")
                 if timings is not None:
                     torch.cuda.synchronize(dev)
                     timings["engine_ready_s"] = time.perf_counter() - t_start
                     mark("engine built + episodes generated (device)")
-            perms = [draw_episode_perms(method, n_way, n_shot, len(ep), fine_tune_epoch, np.random if rngs is None else rngs[k])[1]
+            perms = [draw_episode_perms(method, n_way, n_shot, n_views, fine_tune_epoch, np.random if rngs is None else rngs[k])[1]
                      for k, ep in enumerate(eps)]
             nxt = gens.get(bi + 1)
-            sc = engine.run_batch(eps, perms=perms, defer_final=True, prefetch=None if nxt is None else nxt[0])
+            sc = engine.run_batch(eps, perms=perms, defer_final=True, prefetch=None if nxt is None else nxt[0],
+                                  sources=sampler is not None)
         else:
             with eng.slab_candidates(short_job_candidates(len(batches))):            # (engines are built on the first batch)
                 sc = scores_batched(method, eps, model, state, state_b, fine_tune_epoch, n_way, n_shot, episodes_per_batch,
@@ -568,7 +604,7 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
         for p in pred:
             accs.append(float(np.mean(p == y_query)) * 100)
     gdev = "cuda" if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else "cpu"
-    accs = parallel.gather_episode_values(accs, n_episodes, device=gdev)
+    accs = np.asarray(accs) if emulate_world is not None else parallel.gather_episode_values(accs, n_episodes, device=gdev)
     if timings is not None:
         timings["total_s"] = time.perf_counter() - t_start
         timings["episodes_per_batch"] = episodes_per_batch
@@ -596,11 +632,11 @@ def _score_one(method, liz_x, model, state, state_b, n_way, n_shot, fine_tune_ep
 def _init_distributed():
     """Under torchrun (WORLD_SIZE > 1): one process per GPU, RCCL.  Must run before anything touches the GPU."""
     W = int(os.environ.get("WORLD_SIZE", "1"))
-    forced = os.environ.get("MFT_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ      # one rank, real collectives (tests)
+    forced = settings.current().force_collectives and "RANK" in os.environ      # one rank, real collectives (tests)
     if (W <= 1 and not forced) or torch.distributed.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if os.environ.get("MFT_ONE_DEVICE", "0") == "1":            # test hook: W ranks share device 0, gloo for the gather
+    if settings.current().one_device:            # test hook: W ranks share device 0, gloo for the gather
         torch.cuda.set_device(0)
         torch.distributed.init_process_group("gloo")
     else:
@@ -678,7 +714,7 @@ def standin_state(kind, n_way):
 def standin_allowed():
     """Stand-in weights are an explicit opt-in (``MFT_STANDIN_WEIGHTS=1``): a mis-pointed ``configs.save_dir`` must not print a
     plausible accuracy (the reference's torch.load raises on a missing file, finetune.py:498)."""
-    return os.environ.get("MFT_STANDIN_WEIGHTS", "0") == "1"
+    return settings.current().standin_weights
 
 
 def _resolve_state(kind, modelfile, n_way, explicit, verbose):
@@ -717,12 +753,13 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
     if params.method not in ('gnnnet', 'baseline', 'all'):
         raise NotImplementedError("--method %s: 'gnnnet', 'baseline' and 'all' are on the HIP hot path (protonet / relationnet / "
                                   "dampnet are out of scope, SURVEY.md §2.1)" % params.method)
-    size = int(os.environ.get("MFT_IMAGE_SIZE", "84"))
-    n_episodes = int(os.environ.get("MFT_EPISODES", n_episodes))
+    cfg = settings.current()
+    size = cfg.image_size
+    n_episodes = n_episodes if cfg.episodes is None else cfg.episodes
     if model_cls is None:
         model_cls = gnnnet_copy.GnnNet if params.n_shot == 50 else GnnNet
     if episodes_per_batch is None:
-        episodes_per_batch = int(os.environ.get("MFT_EPISODES_PER_BATCH", {5: 128, 20: 96, 50: 64}.get(params.n_shot, 32)))
+        episodes_per_batch = cfg.episodes_per_batch if cfg.episodes_per_batch is not None else {5: 128, 20: 96, 50: 64}.get(params.n_shot, 32)
     model = state = state_b = None
     f_gnn, f_b = checkpoint_files(params)
     main.loaded = {"gnnnet": None, "baseline": None}                 # what was actually read (tests, logs)
@@ -736,7 +773,7 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
         state_b, main.loaded["baseline"] = _resolve_state("baseline", f_b, params.test_n_way, params.save_iter != -1, rank == 0)
     used = [k for k in ("gnnnet", "baseline") if params.method in (k, "all")]
     print(params.freeze_backbone)                                    # finetune.py:591
-    tm = {} if os.environ.get("MFT_TIMINGS", "0") == "1" else None
+    tm = {} if cfg.timings else None
     if tm is not None:
         import time
         t_main = time.time()
@@ -745,10 +782,23 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
             print("[timings] process start -> evaluate: %.2f s" % (t_main - psutil.Process().create_time()), file=sys.stderr)
         except Exception:
             pass
+    sampler = None
+    if params.test_dataset:
+        # finetune.py:558-579: --test_dataset picks the novel-class loader.  Here: a dataset-SHAPED synthetic pool resident in HBM
+        # (synthetic.class_pool_u8; e.g. EuroSAT: 10 classes x 2700 images x 64x64 uint8) sampled per episode on the device
+        from . import augment
+        if params.test_dataset not in synthetic.DATASET_SHAPES or params.test_dataset == "miniImageNet":
+            raise ValueError('Unknown test dataset %r (the reference knows ISIC, EuroSAT, CropDisease, ChestX)' % params.test_dataset)
+        if rank == 0:
+            print("Loading %s" % params.test_dataset)                # finetune.py:559,565,571,577
+        pool = synthetic.class_pool_u8(params.test_dataset, torch.device("cuda", torch.cuda.current_device()), seed=1,
+                                       n_per_class=cfg.pool_per_class)
+        sampler = augment.EpisodeSampler(pool, params.test_n_way, params.n_shot + 15, seed=10)
     accs = evaluate(model, state, n_episodes, params.test_n_way, params.n_shot, 15, size, params.gen_examples,
                     params.fine_tune_epoch, method=params.method, state_b=state_b, freeze_backbone=params.freeze_backbone,
-                    episodes_per_batch=episodes_per_batch, device_episodes=os.environ.get("MFT_SYNTH_ON_HOST", "0") != "1",
-                    balance=os.environ.get("MFT_BALANCE_BATCHES", "1") == "1", timings=tm,
+                    sampler=sampler,
+                    episodes_per_batch=episodes_per_batch, device_episodes=not cfg.synth_on_host,
+                    balance=cfg.balance_batches, timings=tm,
                     note="" if all(main.loaded[k] is not None for k in used) else "   [SYNTHETIC stand-in weights, MFT_STANDIN_WEIGHTS=1]")
     if tm is not None:
         print("[timings] evaluate: %s" % tm, file=sys.stderr)

@@ -15,36 +15,48 @@ import numpy as np
 import torch
 
 from . import ops
+from . import settings
 
 # opt-in: data gradient of trunk.7.C2 from inside its weight-gradient + Adam launch (csrc/wgrad_dgrad.hip: one pass over the
 # weights instead of two).  Standalone 1.60-1.63 ms + 31 us (col2im + BN1 backward) vs 1.71-1.72 ms for the two passes, but with
 # 3 workgroups x 48 KB of w/m/v in flight per CU (8x fewer, longer workgroups) it loses more beside the trunk stream than the
 # 64x64-tile kernel does: 70.8 / 71.5 / 69.4 vs 71.0 / 71.4 / 71.1 episodes/s -- off by default.
-FUSED_DGRAD = os.environ.get("MFT_FUSED_DGRAD", "0") == "1"
-FUSED_LAST_BLOCK = os.environ.get("MFT_FUSED_LAST_BLOCK", "1") == "1"   # conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)
+FUSED_DGRAD = settings.current().fused_dgrad
+FUSED_LAST_BLOCK = settings.current().fused_last_block   # conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)
 # opt-in: trunk activations travel pre-split into bf16x3 planes between the x3 convolutions.  Bit-identical, but measured
 # SLOWER (66.5 vs 69.0 episodes/s): the convolutions are not bound by the in-loader split (161 vs 160 us standalone) while the
 # producers write 1.5x the bytes -- kept for the record (tests/test_engine_gpu.py::test_presplit_activation_planes_are_bit_identical)
-X3_PLANES = os.environ.get("MFT_X3_PLANES", "0") == "1"
-X3_FUSED_STATS = os.environ.get("MFT_X3_FUSED_STATS", "1") == "1"   # BatchNorm statistics from the bf16x3 convolution epilogue
+X3_PLANES = settings.current().x3_planes
+X3_FUSED_STATS = settings.current().x3_fused_stats   # BatchNorm statistics from the bf16x3 convolution epilogue
 # frozen trunk blocks without helper launches: statistics stay per-tile partials that each consumer merges itself, BN1 + ReLU is
 # applied by C2's loader, the stem's batch statistics are combined inside the pooled gather (12-13 launches per lockstep step
 # instead of 24; MFT_X3_FOLD_BN=0 restores the separate finalize / apply / combine launches)
-X3_FOLD_BN = os.environ.get("MFT_X3_FOLD_BN", "1") == "1"
+X3_FOLD_BN = settings.current().x3_fold_bn
 # frozen trunk.4-6 convolutions on two fp16 pieces per operand (three products, csrc/conv_x3.hip "f16x2") instead of three bf16
 # pieces (six products): half the matrix work at an error below an fp32-accumulating GEMM's.  Taken only when the state dict
 # passes ``f16x2_safe`` (every operand provably inside fp16's range); MFT_TRUNK_F16X2=0 keeps the bf16x3 kernels.
-TRUNK_F16X2 = os.environ.get("MFT_TRUNK_F16X2", "1") == "1"
+TRUNK_F16X2 = settings.current().trunk_f16x2
 # fused next-step forward (engine.fuse_next), opt-in variant: only trunk.7.C2's launch is the fused walking kernel, C1 / shortcut keep
 # the plain gradient + Adam launches + one entry launch (last_block_backward).  Alone that chain is 100 us shorter, in situ it is
 # slower: 87.2 vs 88.8-89.0 episodes/s (profiles/r04_d_fuse_c2_only_ab.txt) -- default 0 = all three layers fused
-FUSE_NEXT_C2_ONLY = os.environ.get("MFT_FUSE_NEXT_C2_ONLY", "0") == "1"
+FUSE_NEXT_C2_ONLY = settings.current().fuse_next_c2_only
 F16X2_BOUND = 3.0e4              # < 65504 with a factor 2 in hand
 F16X2_FLOOR = 2.0 ** -10          # typical operand magnitude that keeps the pieces normal fp16 numbers
 F16X2_MAX_ROWS = 1 << 20         # largest BatchNorm group (images x pixels) the bound is proven for (engine: 100 x 21 x 21 = 44,100)
 
 
-def f16x2_safe(sd, prefix=""):
+def stem_rows_bound(ipg, image_size):
+    """Upper bound of the largest BatchNorm group (the stem's: images x stem-output pixels) of a forward over ``ipg`` images per
+    group, in the form ResNet10Weights.planes() re-derives it from a block's input side (odd sides round up: 84 -> 42 -> 21 ->
+    11 gives 4 * 11 = 44 >= 42)."""
+    oh = (image_size + 6 - 7) // 2 + 1
+    ph = (oh + 2 - 3) // 2 + 1
+    h6 = (ph + 2 - 3) // 2 + 1
+    side = max(oh, 2 * ph, 4 * h6)
+    return int(ipg) * side * side
+
+
+def f16x2_safe(sd, prefix="", max_rows=None):
     """Can every operand of the frozen trunk.4-6 convolutions be split into fp16 pieces with full relative accuracy?
     Upper range -- weights: |w| < F16X2_BOUND; activations: each of these convolutions reads relu(BN(.)) or relu(BN(.) + BN(.)) /
     relu(BN(.) + x) (backbone.py:251-261), and a train-mode BatchNorm output over n rows is bounded by |gamma| sqrt(n - 1) + |beta|
@@ -54,6 +66,7 @@ def f16x2_safe(sd, prefix=""):
     harmless beside O(1) operands, so the TYPICAL magnitude of every operand tensor must be well inside the normal range: rms weight
     and median |gamma| >= 2^-10 (He-initialised 3x3 weights: 0.03-0.06)."""
     import math
+    max_rows = F16X2_MAX_ROWS if max_rows is None else int(max_rows)       # the largest BatchNorm group the caller will ever run
 
     def arr(key):              # numpy on purpose: the first torch CPU reduction of a process spins up the intra-op thread pool (1-2 s on a 256-core host)
         return np.abs(sd[prefix + key].detach().float().cpu().numpy())
@@ -62,7 +75,7 @@ def f16x2_safe(sd, prefix=""):
         w, b = arr(name + ".weight"), arr(name + ".bias")
         if not float(np.median(w)) >= F16X2_FLOOR:
             return float("inf")
-        return float(w.max()) * math.sqrt(F16X2_MAX_ROWS) + float(b.max())
+        return float(w.max()) * math.sqrt(max_rows) + float(b.max())
 
     try:
         x_in = g("trunk.1")                                     # stem BatchNorm -> ReLU -> max pool -> trunk.4
@@ -131,15 +144,19 @@ class Arena:
 class ResNet10Weights:
     """Packed device copy of a backbone.ResNet10 state dict (keys 'trunk.*' under ``prefix``)."""
 
-    def __init__(self, sd, device, prefix="", x3=False, f16x2=None):
+    def __init__(self, sd, device, prefix="", x3=False, f16x2=None, max_rows=None):
         """``x3``: also keep split planes of the frozen trunk.4-6 weights (csrc/conv_x3.hip: fp32-accurate convolution on the
         bf16 / fp16 matrix cores); used wherever these layers run with shared weights.  ``f16x2``: two fp16 planes (three
-        products) instead of three bf16 planes (six); None = TRUNK_F16X2 and f16x2_safe(sd)."""
+        products) instead of three bf16 planes (six); None = TRUNK_F16X2 and f16x2_safe(sd, max_rows).
+        ``max_rows``: the largest train-mode BatchNorm group (images x stem-output pixels) the caller will run through these
+        weights -- the fp16 range proof of f16x2_safe is made for THAT size (default F16X2_MAX_ROWS), and ``planes()`` hands the
+        fp16 planes out only to calls inside it."""
         self.device = device
         self.conv = {}
         self.conv3 = {}
+        self.f16x2_rows = F16X2_MAX_ROWS if max_rows is None else max(int(max_rows), 1)
         if f16x2 is None:
-            f16x2 = bool(x3) and TRUNK_F16X2 and not X3_PLANES and f16x2_safe(sd, prefix)
+            f16x2 = bool(x3) and TRUNK_F16X2 and not X3_PLANES and f16x2_safe(sd, prefix, self.f16x2_rows)
         self.f16x2 = bool(f16x2)
         split = ops.split_weight_h2 if self.f16x2 else ops.split_weight_x3
         self.bn = {}
@@ -167,6 +184,21 @@ class ResNet10Weights:
             conv(p + ".C1"); bn(p + ".BN1"); conv(p + ".C2"); bn(p + ".BN2")
             if cin != cout:
                 conv(p + ".shortcut"); bn(p + ".BNshortcut")
+
+    _STEM_SCALE = {"trunk.4": 2, "trunk.5": 2, "trunk.6": 4}      # block input side -> (at most) stem-output side
+
+    def planes(self, p, ipg, H, fixed=None, running=None):
+        """The split weight planes block ``p`` may use for a call with ``ipg`` images per BatchNorm group on H x H inputs: the
+        bf16x3 planes always (no range condition); the fp16 planes only where f16x2_safe's proof holds -- TRAIN-mode BatchNorm
+        in front of every convolution (a z-score over n rows is bounded by sqrt(n - 1); eval-mode ``fixed`` / ``running``
+        statistics bound nothing) and no BatchNorm group larger than the ``max_rows`` the proof was made for (the stem's group,
+        ipg x stem-output pixels, is the largest).  Otherwise {}: the caller's fp32-MFMA kernels."""
+        if not self.conv3 or not self.f16x2:
+            return self.conv3
+        if fixed is not None or running is not None:
+            return {}
+        side = self._STEM_SCALE.get(p, 8) * H
+        return self.conv3 if ipg * side * side <= self.f16x2_rows else {}
 
     def repack(self):
         """The source parameters changed in place (optimizer.step): refresh every packed convolution weight with ONE launch.
@@ -268,8 +300,9 @@ class StemCache:
         self.n_slots = n_slots
         self.OH = (H + 6 - 7) // 2 + 1
         self.PH = (self.OH + 2 - 3) // 2 + 1
-        self.pooled = (os.environ.get("MFT_STEM_POOLED", "1") == "1") if pooled is None else bool(pooled)
-        chunk = int(os.environ.get("MFT_STEM_CHUNK", chunk))
+        cfg = settings.current()
+        self.pooled = cfg.stem_pooled if pooled is None else bool(pooled)
+        chunk = chunk if cfg.stem_chunk is None else cfg.stem_chunk
         self.chunk = min(chunk, n_slots)
         self.mean = torch.empty((n_slots, 64), device=device)
         self.m2 = torch.empty((n_slots, 64), device=device)
@@ -428,7 +461,7 @@ def simple_block(W, p, x, arena, ipg, cin, cout, stride, running=None, tag="b", 
         g1, b1, g2, b2, gs, bs = slab.bn1g, slab.bn1b, slab.bn2g, slab.bn2b, slab.bnsg, slab.bnsb
         gbs = cout
     wipg = ipg if slab is not None else 0
-    w3 = W.conv3 if slab is None else {}
+    w3 = W.planes(p, ipg, H, fixed, running) if slab is None else {}
 
     def conv(name, inp, wpk, k, s, pd, out):
         if (p + name) in w3:
@@ -883,8 +916,8 @@ class GnnHeadWeights:
 
 
 _PAIR_IJ = {}
-FUSED_PAIR_MLP = os.environ.get("MFT_FUSED_PAIR_MLP", "1") == "1"
-PAIR_MLP_BYTES = int(float(os.environ.get("MFT_PAIR_MLP_GB", "6")) * (1 << 30))     # raw-activation budget per chunk of episodes
+FUSED_PAIR_MLP = settings.current().fused_pair_mlp
+PAIR_MLP_BYTES = int(settings.current().pair_mlp_gb * (1 << 30))     # raw-activation budget per chunk of episodes
 
 
 def pair_index_table(N, device):

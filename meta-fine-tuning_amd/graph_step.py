@@ -13,7 +13,9 @@ import warnings
 
 import torch
 
-ENABLED = os.environ.get("MFT_TRAIN_GRAPH", "1") == "1"
+from . import settings
+
+ENABLED = settings.current().train_graph
 
 
 class GraphedLossBackward:
@@ -38,10 +40,15 @@ class GraphedLossBackward:
         self.side = None
         self.failed = False
         self.rekeyed = 0
+        self._walk = None
 
     def _key(self, x):
-        ps = list(self.model.parameters())
-        mods = tuple((m.training, getattr(m, "momentum", None)) for m in self.model.modules())
+        # the module tree is walked ONCE (the model's structure does not change between steps): per step the key costs only the
+        # address / flag reads -- this is the replay path, which exists to remove host work
+        if self._walk is None:
+            self._walk = (list(self.model.parameters()), list(self.model.modules()))
+        ps, ms = self._walk
+        mods = tuple((m.training, getattr(m, "momentum", None)) for m in ms)
         return (tuple(x.shape), x.dtype, self.model.n_way, self.model.n_query, tuple((p.data_ptr(), p.requires_grad) for p in ps), mods)
 
     def _clear_foreign_grads(self, optimizer):

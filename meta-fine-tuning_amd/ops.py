@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from . import settings
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 BN_EPS = 1e-5
@@ -167,7 +168,7 @@ def conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=
     return out
 
 
-SMALL_GROUPS = int(os.environ.get("MFT_SMALL_GROUPS", "12"))     # up to this many per-episode weight sets take the K-sliced GEMM route
+SMALL_GROUPS = settings.current().small_groups     # up to this many per-episode weight sets take the K-sliced GEMM route
 _KSPLIT_WS = {}
 
 

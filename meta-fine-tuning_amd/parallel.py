@@ -62,8 +62,8 @@ def collectives_forced():
     """MFT_FORCE_COLLECTIVES=1 with an initialised process group: run the collectives even with ONE rank instead of taking the
     single-process shortcuts -- so that a one-GPU box executes the real RCCL calls (communicator set-up, all-reduce of the flat
     gradient bucket, all-gather, broadcast) on the tensors the multi-GPU drivers use (tests/test_drivers_gpu.py)."""
-    import os
-    return os.environ.get("MFT_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
+    from . import settings
+    return settings.current().force_collectives and dist.is_available() and dist.is_initialized()
 
 
 def shard_indices(n_items, rank, world_size):
@@ -114,18 +114,21 @@ class FlatGradBucket:
 
     def allreduce_mean(self):
         """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place).  With one rank nothing is exchanged
-        and the gradients stay where autograd put them."""
+        and the gradients stay where autograd put them.  A parameter whose ``.grad`` is None (frozen this step; every rank
+        freezes the same ones) contributes zeros to the sum and KEEPS ``grad = None``, so the optimiser skips it as
+        torch.optim.Adam does -- no per-step ``zeros_like`` allocation, and the addresses in optim.Adam's pointer table stay put
+        (ADVICE r04)."""
         _, W = world()
         if W == 1 and not collectives_forced():
-            for p in self.params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
             return
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in self.params]
-        torch._foreach_copy_(self.views, grads)                 # fused multi-tensor copies (104 tensors -> a few launches)
+        live = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(live) != len(self.params):
+            for v, p in zip(self.views, self.params):
+                if p.grad is None:
+                    v.zero_()
+        views, grads = [v for v, _ in live], [g for _, g in live]
+        if views:
+            torch._foreach_copy_(views, grads)                  # fused multi-tensor copies (104 tensors -> a few launches)
         if self.flat.is_cuda and dist.get_backend() == "gloo":   # CPU-test / one-device hook: stage through the host
             host = self.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -133,7 +136,8 @@ class FlatGradBucket:
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)     # "nccl" == RCCL over xGMI
         self.flat.div_(W)
-        torch._foreach_copy_(grads, self.views)
+        if views:
+            torch._foreach_copy_(grads, views)
 
 
 def broadcast_buffers(module, src=0):

@@ -183,3 +183,28 @@ def test_episode_device(seed, device, n_way=5, n_support=5, n_query=15, size=84,
             v = torch.flip(v, dims=[-1])
         views.append(v.contiguous())
     return views
+
+
+# dataset shapes: classes x images per class x source side.  miniImageNet: 64 base classes
+# (datasets/miniImageNet_few_shot.py:53) x 600 images, served downsampled to 84x84 (README.md:86-88); EuroSAT: 10 classes
+# (datasets/EuroSAT_few_shot.py:85) x 2700 images of 64x64.  The other test sets keep their class counts (cl_list lines of
+# datasets/{CropDisease,ISIC,Chest}_few_shot.py) on a 64x64 x 600 stand-in pool.
+DATASET_SHAPES = {"miniImageNet": (64, 600, 84), "EuroSAT": (10, 2700, 64), "CropDisease": (38, 600, 64), "ISIC": (7, 600, 64),
+                  "ChestX": (7, 600, 64)}
+
+
+def class_pool_u8(dataset, device, seed=0, n_per_class=None, noise=1.0):
+    """A dataset-SHAPED synthetic image pool resident in HBM: uint8 [n_classes, n_per_class, side, side, 3] (what an
+    ImageFolder of decoded images is once on the device).  Class c = a low-frequency template + per-image noise, drawn with the
+    device generator class by class (a pure function of (seed, dataset, device type)), mapped to pixels as 128 + 48 * x."""
+    n_classes, per, side = DATASET_SHAPES[dataset]
+    per = int(n_per_class or per)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) * 7919 + 13)
+    low = torch.randn((n_classes, 3, 7, 7), generator=g, device=device)
+    t = torch.nn.functional.interpolate(low, size=(side, side), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    pool = torch.empty((n_classes, per, side, side, 3), dtype=torch.uint8, device=device)
+    for c in range(n_classes):
+        x = t[c][None] + noise * torch.randn((per, side, side, 3), generator=g, device=device)
+        pool[c] = torch.clamp(torch.round(128.0 + 48.0 * x), 0, 255).to(torch.uint8)
+    return pool

