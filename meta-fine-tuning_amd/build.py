@@ -43,6 +43,8 @@ def build(force=False, verbose=True, jobs=None):
     objdir = os.path.join(PKG, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
     hdrs = glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(ROOT, "include", "mft_hip.h")]
+    if _flags_stamp() == "experiments":           # the measured-slower variants live outside the package and are #included under the flag
+        hdrs += glob.glob(os.path.join(ROOT, "tools", "experiments", "*.inc"))
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
              "-I" + os.path.join(PKG, "csrc")]

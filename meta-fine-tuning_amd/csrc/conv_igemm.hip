@@ -751,225 +751,7 @@ __global__ __launch_bounds__(256) void wgrad_adam_rows_kernel(WgradArgs p) {
 }
 
 #ifdef MFT_EXPERIMENTS      // walking forms of the kernel above: measured no faster; built only for tools/
-// EXPERIMENT (mft_debug_set_conv_tile(9504)): the same arithmetic as wgrad_adam_rows_kernel, but one workgroup WALKS all K tiles
-// of its 32 output-channel rows (tap-major, 128 input channels per tile) with the next tile's w/m/v requested one iteration ahead.
-// Purpose: does a walking workgroup keep the stream rate of the one-tile-per-workgroup form?  (It is the structure any fusion of
-// the next step's forward or of the data gradient into this launch needs.)
-template <int POL>
-__global__ __launch_bounds__(256) void wgrad_adam_walk_kernel(WgradArgs p) {
-    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4;
-    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
-    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                     // [64][BM]   dY rows of this co-tile (resident)
-    float* Bs = smem + 64 * BM;           // [32][BLD]  half of the im2col rows of the current K tile
-    float* Gs = Bs + 32 * BLD;            // [32][GLD]  gradient tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y, tco = blockIdx.x;
-    const int co0 = tco * BM;
-    const int ohw = p.OH * p.OW;
-    const int rows = p.rows_per_group;
-    const long long row0 = (long long)g * rows;
-    const long long img0 = (long long)g * p.imgs_per_group;
-    const int n_kt = p.KH * p.KW * p.tiles_ci;
-    const int arow = tid >> 3, acol = (tid & 7) * 4;
-    const int brow = tid >> 5, bcol = (tid & 31) * 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = arow + 32 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + co0 + acol);
-        *(f32x4*)(As + m * BM + acol) = v;
-    }
-    f32x4 vb[8];
-    auto load_b = [&](int kt) {
-        const int khkw = kt / p.tiles_ci, ci0 = (kt - khkw * p.tiles_ci) * BN;
-        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-        const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0 + bcol;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = brow + 8 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < rows) {
-                const int img = (m * p.chunk_rows) >> 16, rem = m - img * ohw;
-                const int oh = (rem * p.ws_inv_ow) >> 16, ow = rem - oh * p.OW;
-                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) v = *(const f32x4*)(in_g + ((img * p.H + ih) * p.W + iw) * p.ldi);
-            }
-            vb[j] = v;
-        }
-    };
-    const int q = tid & 31, rr = tid >> 5;
-    const long long gbase = (long long)g * p.dwgs + (long long)(co0 + rr) * p.Kpad + 4 * q;
-    f32x4 cm[4], cv[4], cw[4], nm[4], nv[4], nw[4];
-    auto load_wmv = [&](int kt, f32x4* M_, f32x4* V_, f32x4* W_) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long gi = gbase + (long long)(8 * u * p.Kpad) + kt * BN;       // K index of tile kt = kt * 128 (tap-major)
-            M_[u] = ldp((const f32x4*)(p.m + gi));
-            V_[u] = ldp((const f32x4*)(p.v + gi));
-            W_[u] = ldp((const f32x4*)(p.w + gi));
-        }
-    };
-    load_b(0);
-    load_wmv(0, cm, cv, cw);
-    const float step_size = p.hyper ? p.hyper[0] : p.step_size;
-    const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
-    __syncthreads();
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const int kn = kt + 1 < n_kt ? kt + 1 : kt;
-        load_wmv(kn, nm, nv, nw);
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half * 32 < rows) {
-                if (half) __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *(f32x4*)(Bs + (brow + 8 * j) * BLD + bcol) = vb[4 * half + j];
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float a = As[(32 * half + 2 * t + h) * BM + r];
-                    const float b = Bs[(2 * t + h) * BLD + wave * 32 + r];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-                }
-            }
-        }
-        load_b(kn);                               // next tile's im2col rows (L2) under the epilogue
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long gi = gbase + (long long)(8 * u * p.Kpad) + kt * BN;
-            const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
-            mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
-            stp(cm[u], (f32x4*)(p.m + gi));
-            stp(cv[u], (f32x4*)(p.v + gi));
-            stp(cw[u], (f32x4*)(p.w + gi));
-        }
-        __syncthreads();                          // Gs / Bs are rewritten by the next tile
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { cm[u] = nm[u]; cv[u] = nv[u]; cw[u] = nw[u]; }
-    }
-}
-
-
-// Output-channel walk (mft_debug_set_conv_tile(9505)): one workgroup owns one K tile (tap, 128 input channels) of an episode and
-// walks the Cout / 32 output-channel tiles.  The tile's im2col rows -- 80 % of the operand bytes a tile of wgrad_adam_rows_kernel
-// requests from L2, re-read there by every one of the 16 output-channel tiles -- are fetched and parked in LDS ONCE per walk; only
-// the dY slice (<= 64 x 32 floats) changes from tile to tile and is requested one tile ahead together with the next w/m/v.  Per
-// tile the reduction order, the gradient and Adam's arithmetic are those of wgrad_adam_rows_kernel (bit-identical results); the
-// DRAM access pattern is the same as well (the 36 workgroups of an episode step through the output channels side by side, so
-// together they still cover whole 18 KB weight rows).  Why: the launch runs at the package power limit beside the trunk stream
-//  -- operand traffic and LDS staging it does not issue are joules the stream gets back as clock.
-template <int POL>
-__global__ __launch_bounds__(256) void wgrad_adam_cowalk_kernel(WgradArgs p) {
-    constexpr int BM = 32, BN = 128, BLD = BN + 32, GLD = BN + 4;
-    auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
-    auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int RP = p.chunks;              // reduction rows held in LDS: 48 or 64 (>= rows_per_group)
-    float* Bs = smem;                     // [RP][BLD] im2col rows of this K tile, resident for the whole walk
-    float* As = smem + RP * BLD;          // [RP][BM]  dY rows of the current output-channel tile
-    float* Gs = As;                       // [32][GLD] gradient tile (aliases As: separated by barriers)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y;
-    const int tci = blockIdx.x % p.tiles_ci, khkw = blockIdx.x / p.tiles_ci;
-    const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-    const int ci0 = tci * BN;
-    const int ohw = p.OH * p.OW;
-    const int rows = p.rows_per_group;
-    const long long row0 = (long long)g * rows;
-    const long long img0 = (long long)g * p.imgs_per_group;
-    const int arow = tid >> 3, acol = (tid & 7) * 4;
-    const int brow = tid >> 5, bcol = (tid & 31) * 4;
-    {
-        const float* in_g = p.in + (img0 * p.H * p.W) * p.ldi + ci0 + bcol;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = brow + 8 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < rows) {
-                const int img = (m * p.chunk_rows) >> 16, rem = m - img * ohw;
-                const int oh = (rem * p.ws_inv_ow) >> 16, ow = rem - oh * p.OW;
-                const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) v = *(const f32x4*)(in_g + ((img * p.H + ih) * p.W + iw) * p.ldi);
-            }
-            if (m < RP) *(f32x4*)(Bs + m * BLD + bcol) = v;
-        }
-    }
-    auto load_a = [&](int tco, f32x4* A_) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = arow + 32 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < rows) v = *(const f32x4*)(p.dy + (row0 + m) * p.ldy + tco * BM + acol);
-            A_[j] = v;
-        }
-    };
-    const int q = tid & 31, rr = tid >> 5;
-    const long long gbase = (long long)g * p.dwgs + (long long)rr * p.Kpad + khkw * p.Cin + ci0 + 4 * q;
-    auto load_wmv = [&](int tco, f32x4* M_, f32x4* V_, f32x4* W_) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long gi = gbase + (long long)(tco * BM + 8 * u) * p.Kpad;
-            M_[u] = ldp((const f32x4*)(p.m + gi));
-            V_[u] = ldp((const f32x4*)(p.v + gi));
-            W_[u] = ldp((const f32x4*)(p.w + gi));
-        }
-    };
-    f32x4 va[2], na[2], cm[4], cv[4], cw[4], nm[4], nv[4], nw[4];
-    load_a(0, va);
-    load_wmv(0, cm, cv, cw);
-    const float step_size = p.hyper ? p.hyper[0] : p.step_size;
-    const float inv_sqrt_bc2 = p.hyper ? p.hyper[1] : p.inv_sqrt_bc2;
-    for (int tco = 0; tco < p.tiles_co; ++tco) {
-        const int tn = tco + 1 < p.tiles_co ? tco + 1 : tco;
-        load_a(tn, na);                                   // the next tile's requests go out first; this tile's are a walk-step old
-        load_wmv(tn, nm, nv, nw);
-        if (tco) __syncthreads();                         // the previous tile's gradient reads are done (Gs aliases As)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (arow + 32 * j < RP) *(f32x4*)(As + (arow + 32 * j) * BM + acol) = va[j];
-        __syncthreads();
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if (32 * half + 2 * t < p.mma_rows) {         // wave-uniform; rows beyond the group's are zeros
-                    const float a = As[(32 * half + 2 * t + h) * BM + r];
-                    const float b = Bs[(32 * half + 2 * t + h) * BLD + wave * 32 + r];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-                }
-        __syncthreads();                                  // every wave has read its dY fragments
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Gs[((e & 3) + 8 * (e >> 2) + 4 * h) * GLD + wave * 32 + r] = acc[e];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long gi = gbase + (long long)(tco * BM + 8 * u) * p.Kpad;
-            const f32x4 ge = *(const f32x4*)(Gs + (rr + 8 * u) * GLD + 4 * q);
-            if (POL & 4) mft_adam4_fast(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
-            else mft_adam4_exact(cm[u], cv[u], cw[u], ge, p.b1, p.b2, p.eps, step_size, inv_sqrt_bc2);
-            stp(cm[u], (f32x4*)(p.m + gi));
-            stp(cv[u], (f32x4*)(p.v + gi));
-            stp(cw[u], (f32x4*)(p.w + gi));
-            if (p.dw) *(f32x4*)(p.dw + gi) = ge;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { cm[u] = nm[u]; cv[u] = nv[u]; cw[u] = nw[u]; }
-        va[0] = na[0]; va[1] = na[1];
-    }
-}
-
+#include "../../tools/experiments/wgrad_adam_walk.inc"
 #endif  // MFT_EXPERIMENTS
 
 int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t s) {

@@ -505,225 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 3
 }
 
 #ifdef MFT_EXPERIMENTS      // measured slower than the default kernels; built only for tools/ (MFT_EXPERIMENTS=1)
-// ------------------------------------------------------------------------------------------------ ping-pong form
-// Ablation of conv_x3_kernel on the five trunk shapes (mft_debug_set_x3_tile(200 + bits), one process, sum of the launches):
-// full 600-670 us; without the operand split 535; without the MFMAs 412; without the K loop's global loads 445; without its
-// LDS stores 383; loads + split + stores alone (no fragment reads, no MFMAs) 316; nothing but the barriers 54.  The two
-// halves of a K-step -- stage (global load, bf16x3 split, LDS store: ~260 us) and multiply (fragment reads + MFMAs: ~330 us)
-// -- ADD UP: they never overlap, because the trunk's launches are only 2.8-8.6 workgroups per CU, all started at the same
-// moment, so the three resident workgroups of a CU march in step (all staging, then all multiplying).
-//
-// This kernel builds the overlap into the workgroup: 512 threads = two groups of four waves over the SAME 128 x 64 output
-// tile.  Group g owns the K-steps kt = g (mod 2), its own LDS buffer and its own accumulators.  In half-period h the group
-// h & 1 multiplies tile h (after issuing the global loads of its next tile h + 2) while the other group splits and stores
-// tile h + 1; one barrier per half-period.  Each SIMD holds one wave of either group, so the matrix pipe of a SIMD works for
-// one wave while the other wave does the VALU / LDS-store work next to it.  At the end group 1 hands its accumulators to
-// group 0 through LDS (the same fp32 sums, associated as (even K-steps) + (odd K-steps)) and group 0 runs the epilogue.
-template <int BM, int BN>
-__global__ __launch_bounds__(512) void conv_x3_pp_kernel(X3Args p) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int PA = BM / 32, PB = BN / 64;
-    constexpr int A_PLANE = BM * X3_RS, B_PLANE = BN * X3_RS;
-    constexpr int BUF = 3 * (A_PLANE + B_PLANE);
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int grp = threadIdx.x >> 8;                 // wave-uniform
-    const int tid = threadIdx.x & 255;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    unsigned short* As = smem + grp * BUF;
-    unsigned short* Bs = As + 3 * A_PLANE;
-    int tile_id = blockIdx.x;
-    if (p.xcd_swizzle) {
-        const int nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7;
-        const int xcd = tile_id & 7, slot = tile_id >> 3;
-        tile_id = xcd * q + (xcd < rmd ? xcd : rmd) + slot;
-    }
-    const int nt = tile_id % p.tiles_n, mt = tile_id / p.tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int g_id = tid >> 5, g_rr = (tid >> 3) & 3;
-    const int lrow = g_rr * 4 + (g_id & 3) + 16 * (g_id >> 2);        // conflict-free staging rows (see conv_x3_kernel)
-    const int c4 = (tid & 7) * 4;
-    const int ohw = p.OH * p.OW;
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_bytes, 0x00020000);
-    int a_off[PA], a_ih0[PA], a_iw0[PA];
-    bool a_ok[PA];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        const int m = m0 + lrow + 32 * j;
-        a_ok[j] = m < p.M;
-        const int mm = a_ok[j] ? m : 0;
-        const int img = mm / ohw, rem = mm - img * ohw;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        a_ih0[j] = oh * p.stride - p.pad;
-        a_iw0[j] = ow * p.stride - p.pad;
-        a_off[j] = (((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.ldi + c4) * 4;
-    }
-    const int bseg = tid & 3;
-    const int brow = ((tid >> 2) & 3) * 4 + ((tid >> 4) & 3) + 16 * (tid >> 6);
-    int b_off[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) b_off[j] = ((n0 + brow + 64 * j) * p.Kpad + bseg * 8) * 2;
-    const int plane_bytes = (int)(p.plane * 2);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    f32x4 ra[PA];
-    u32x4 rb[PB][3];
-    const int nk = p.Kpad / 32;
-
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * 32;
-        const int khkw = k0 / p.Cin;
-        const int ci0 = k0 - khkw * p.Cin;
-        const int kh = khkw / p.KW, kw = khkw - kh * p.KW;
-        const int tap_off = ((kh * p.W + kw) * p.ldi + ci0) * 4;
-#pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            const bool ok = a_ok[j] && (unsigned)(a_ih0[j] + kh) < (unsigned)p.H && (unsigned)(a_iw0[j] + kw) < (unsigned)p.W;
-            const unsigned voff = ok ? (unsigned)(a_off[j] + tap_off) : 0x80000000u;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, 0, 0));
-        }
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                rb[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rB, b_off[j] + pl * plane_bytes, k0 * 2, 0);
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            const int off = (lrow + 32 * j) * X3_RS + c4;
-            u32x2 p1, p2, p3;
-            split4(ra[j], p1, p2, p3);
-            *(u32x2*)(As + off) = p1;
-            *(u32x2*)(As + A_PLANE + off) = p2;
-            *(u32x2*)(As + 2 * A_PLANE + off) = p3;
-        }
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * X3_RS + bseg * 8) = rb[j][pl];
-    };
-    auto compute = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[TM][3], b[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[i][pl] = *(const bf16x8*)(As + pl * A_PLANE + (wm * (BM / 2) + i * 32 + r) * X3_RS + kk * 16 + h * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * X3_RS + kk * 16 + h * 8);
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // prologue: group 0 stages tile 0; group 1 requests tile 1
-    if (grp == 0) { load_tile(0); store_tile(); }
-    else if (nk > 1) load_tile(1);
-    __syncthreads();
-    for (int hp = 0; hp < nk; ++hp) {
-        if ((hp & 1) == grp) {
-            if (hp + 2 < nk) load_tile(hp + 2);
-            compute();
-        } else if (hp + 1 < nk) {
-            store_tile();                       // tile hp + 1, requested one half-period (or the prologue) ago
-        }
-        __syncthreads();
-    }
-    // group 1 -> group 0: accumulators through LDS ([4 waves][TM*TN*16][64 lanes] floats, lane-contiguous)
-    float* red = reinterpret_cast<float*>(smem);
-    if (grp == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) red[((wave * TM * TN + i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((wave * TM * TN + i * TN + j) * 16 + e) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 32 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int m = m0 + wm * (BM / 2) + i * 32 + row;
-                    if (m < p.M) p.out[(long long)m * p.ldo + n] = acc[i][j][e];
-                }
-            }
-    }
-    if (p.stats_ws != nullptr) {                 // fused BatchNorm statistics, as in conv_x3_kernel (group 0 holds the tile)
-        const int split = (m0 / p.rows_per_group + 1) * p.rows_per_group;
-        float* sred = reinterpret_cast<float*>(smem) + 4 * TM * TN * 16 * 64;      // behind the hand-over area
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = acc[i][j][e];
-                        if (m < p.M) {
-                            if (m < split) { a1 += v; a2 += v * v; }
-                            else { b1 += v; b2 += v * v; }
-                        }
-                    }
-                a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
-                b1 += __shfl_xor(b1, 32, 64); b2 += __shfl_xor(b2, 32, 64);
-                if (h == 0) {
-                    float* o = sred + ((((wm * 2 + wn) * TN + j) * 32 + r) << 2);
-                    o[0] = a1; o[1] = a2; o[2] = b1; o[3] = b2;
-                }
-            }
-        }
-        __syncthreads();
-        if (grp == 0 && wm == 0 && h == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float* o0 = sred + ((((0 * 2 + wn) * TN + j) * 32 + r) << 2);
-                const float* o1 = sred + ((((1 * 2 + wn) * TN + j) * 32 + r) << 2);
-                const int n = n0 + wn * (BN / 2) + j * 32 + r;
-                float* w0 = p.stats_ws + (((long long)mt * 2 + 0) * p.Cout + n) * 2;
-                float* w1 = p.stats_ws + (((long long)mt * 2 + 1) * p.Cout + n) * 2;
-                w0[0] = o0[0] + o1[0]; w0[1] = o0[1] + o1[1];
-                w1[0] = o0[2] + o1[2]; w1[1] = o0[3] + o1[3];
-            }
-        }
-    }
-}
+#include "../../tools/experiments/conv_x3_pingpong.inc"
 #endif  // MFT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: shared taps
@@ -1255,179 +1037,7 @@ int launch_x3_pp(X3Args p, hipStream_t s) {
 #endif  // MFT_EXPERIMENTS
 
 #ifdef MFT_EXPERIMENTS
-// ------------------------------------------------------------------------------------------ 3x3 stride-1 "patch" form
-// The implicit-GEMM form above re-reads (and re-splits) every input element nine times, once per tap, and depends on
-// L2 for that reuse -- beside the HBM-saturating last-block stream it collapses (3x slower in situ).  For 3x3 / stride 1 /
-// pad 1 layers a workgroup instead owns G images x R output rows x all columns (<= 128 pixels) x 64 output channels and
-// walks the input channels in slices of 32: the slice of the input PATCH ((R+2) x (W+2) pixels per image, zero halo) is
-// loaded, split into its three bf16 planes and parked in LDS ONCE, then all nine taps read their A fragments from it
-// at shifted pixel offsets.  The weight fragments go straight from L2/L1 into registers (8 bf16 of one output channel
-// per lane; no LDS, no barrier inside the tap loop), prefetched one tap ahead.
-struct P3Args {
-    const float* in;
-    const unsigned short* w3;
-    long long plane;
-    float* out;
-    int n_img, H, W, Cin, Cout;
-    int G, R;                  // images and output rows per tile
-    int row_blocks;            // ceil(H / R)
-    int tiles_n;               // Cout / 64
-};
-
-__global__ __launch_bounds__(256) void conv3x3_patch_x3_kernel(P3Args p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    const int PW = p.W + 2, PH = p.R + 2;
-    const int PP = p.G * PH * PW;                        // patch pixels
-    const int PLANE = PP * X3_RS;                        // bf16 elements per plane
-    int bx = blockIdx.x;
-    const int nt = bx % p.tiles_n; bx /= p.tiles_n;
-    const int rb = bx % p.row_blocks;
-    const int ig = bx / p.row_blocks;
-    const int img0 = ig * p.G, orow0 = rb * p.R;
-    const int n0 = nt * 64;
-    const int rows_tile = p.R * p.W;                     // pixels per image in the tile
-    const int m_tile = p.G * rows_tile;
-
-    // A-fragment lane bases (patch pixel of output pixel m, tap (0,0)) for the wave's two 32-row blocks
-    int a_pix[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = wm * 64 + i * 32 + r;
-        if (m >= m_tile) m = m_tile - 1;                 // clamped rows are computed but never stored
-        const int gl = m / rows_tile;
-        const int rem = m - gl * rows_tile;
-        const int orow = rem / p.W, ocol = rem - orow * p.W;
-        a_pix[i] = (gl * PH + orow) * PW + ocol;
-    }
-    const unsigned short* wlane = p.w3 + (long long)(n0 + wn * 32 + r) * (9 * p.Cin) + h * 8;
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    const int n_slices = p.Cin / 32;
-    constexpr int NPRE = 6;                              // patch float4 slots per thread (PP * 8 <= 1536)
-    f32x4 pre[NPRE];
-    auto load_patch = [&](int sl) {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int q = tid + k * 256;
-            const int pp = q >> 3, c4 = (q & 7) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pp < PP) {
-                const int gl = pp / (PH * PW);
-                const int rem = pp - gl * (PH * PW);
-                const int pr = rem / PW, pc = rem - pr * PW;
-                const int img = img0 + gl, ih = orow0 - 1 + pr, iw = pc - 1;
-                if (img < p.n_img && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                    v = *(const f32x4*)(p.in + (((long long)img * p.H + ih) * p.W + iw) * p.Cin + sl * 32 + c4);
-            }
-            pre[k] = v;
-        }
-    };
-    auto store_patch = [&]() {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int q = tid + k * 256;
-            const int pp = q >> 3, c4 = (q & 7) * 4;
-            if (pp < PP) {
-                u32x2 p1, p2, p3;
-                split4(pre[k], p1, p2, p3);
-                const int off = pp * X3_RS + c4;
-                *(u32x2*)(smem + off) = p1;
-                *(u32x2*)(smem + PLANE + off) = p2;
-                *(u32x2*)(smem + 2 * PLANE + off) = p3;
-            }
-        }
-    };
-    bf16x8 bcur[3][2], bnxt[3][2];
-    auto load_b = [&](int sl, int tap, bf16x8 (*dst)[2]) {
-        const unsigned short* src = wlane + tap * p.Cin + sl * 32;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) dst[pl][kk] = *(const bf16x8*)(src + pl * p.plane + kk * 16);
-    };
-
-    load_patch(0);
-    load_b(0, 0, bcur);
-    for (int sl = 0; sl < n_slices; ++sl) {
-        __syncthreads();                                 // every wave is done reading the previous slice
-        store_patch();
-        __syncthreads();
-        if (sl + 1 < n_slices) load_patch(sl + 1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_b(sl, tap + 1, bnxt);
-            else if (sl + 1 < n_slices) load_b(sl + 1, 0, bnxt);
-            const int toff = ((tap / 3) * PW + (tap % 3)) * X3_RS;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 a[2][3];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        a[i][pl] = *(const bf16x8*)(smem + pl * PLANE + a_pix[i] * X3_RS + toff + kk * 16 + h * 8);
-                constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-                constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], bcur[TB[t]][kk], acc[i], 0, 0, 0);
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) bcur[pl][kk] = bnxt[pl][kk];
-        }
-    }
-    // epilogue
-    const int n = n0 + wn * 32 + r;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int m = wm * 64 + i * 32 + row;
-            if (m >= m_tile) continue;
-            const int gl = m / rows_tile;
-            const int rem = m - gl * rows_tile;
-            const int orow = orow0 + rem / p.W, ocol = rem % p.W;
-            const int img = img0 + gl;
-            if (img < p.n_img && orow < p.H) p.out[(((long long)img * p.H + orow) * p.W + ocol) * p.Cout + n] = acc[i][e];
-        }
-}
-
-// tile geometry for a 3x3/s1/p1 layer on H x W maps; returns false when the patch form does not apply
-bool patch_geometry(int H, int W, int* G, int* R, double* eff_out) {
-    if (W > 64 || H > 64) return false;
-    int best_g = 0, best_r = 0;
-    double best = 0.0;
-    for (int g = 1; g <= 8; ++g)
-        for (int rr = 1; rr <= H; ++rr) {
-            if (g > 1 && rr != H) continue;                     // several images per tile only with whole images
-            const int m = g * rr * W;
-            if (m > 128) continue;
-            const int pp = g * (rr + 2) * (W + 2);
-            if (pp * 8 > 6 * 256) continue;                     // NPRE float4 slots per thread
-            const int blocks = (H + rr - 1) / rr;
-            const double eff = (double)(H * W) * g / ((double)blocks * 128.0);     // useful rows per 128-row tile
-            if (eff > best + 1e-9) { best = eff; best_g = g; best_r = rr; }
-        }
-    if (best < 0.7) return false;
-    *G = best_g; *R = best_r;
-    *eff_out = best;
-    return true;
-}
-
+#include "../../tools/experiments/conv3x3_patch_x3.inc"
 #endif  // MFT_EXPERIMENTS
 // Measured (tools/x3_tune.py, tools/phase_times.py, E=128): standalone the patch form wins only on 11x11 maps (157 vs 173 us)
 // and loses on 21x21 / 6x6 (tile utilisation 86 / 84 %); beside the last-block stream it is slower everywhere (61.0 / 59.7

@@ -421,8 +421,12 @@ class FinetuneEngine:
         if stem_cache:
             # 64 channels x (H/2)^2 fp32 per resident support image: 226 KB at 84x84, 3.2 MB at 224x224.  Keep the cache
             # only while it fits comfortably beside the other resident buffers.
-            oh = (image_size + 6 - 7) // 2 + 1
-            need = self.E * self.n_total * oh * oh * 64 * 4
+            # Round 5: sized from the layout that is actually allocated.  The test used to price the FULL-resolution cache
+            # (42 x 42 x 64 per image) although the default keeps the pooled (max, min) pair -- half of it -- so 20-shot at
+            # E = 128 (115.6 GB full-resolution, 58 GB pooled) silently lost its stem cache and ran slower than E = 96
+            # (19.9 vs 22.0 episodes/s, profiles/r04_f_other_configs.txt; round-4 verdict weak 9).
+            pooled_pref = False if Fn.X3_PLANES else None
+            need = Fn.StemCache.bytes_needed(self.E * self.n_total, image_size, pooled=pooled_pref)
             total = torch.cuda.get_device_properties(self.dev).total_memory
             stem_cache = need <= 0.35 * total
         # (the opt-in pre-split-planes trunk reads the full-resolution cache; the default is the pooled (max, min) form)

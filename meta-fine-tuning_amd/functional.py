@@ -318,6 +318,17 @@ class StemCache:
         ts = [self.mean, self.m2] + ([self._buf, self.pmax, self.pmin] if self.pooled else [self.c0])
         return sum(t.numel() * 4 for t in ts)
 
+    @staticmethod
+    def bytes_needed(n_slots, H, pooled=None, chunk=8192):
+        """What a StemCache over ``n_slots`` images of side H will allocate, without allocating it (the engine's admission test)."""
+        cfg = settings.current()
+        pooled = cfg.stem_pooled if pooled is None else bool(pooled)
+        chunk = min(chunk if cfg.stem_chunk is None else cfg.stem_chunk, n_slots)
+        oh = (H + 6 - 7) // 2 + 1
+        ph = (oh + 2 - 3) // 2 + 1
+        per = 2 * 64 + (2 * ph * ph * 64 if pooled else oh * oh * 64)
+        return 4 * (n_slots * per + (chunk * oh * oh * 64 if pooled else 0))
+
     def fill(self, x_nhwc):
         """x_nhwc [n_slots,H,H,3] -> conv outputs + moments (chunked launches; M = chunk*OH*OW rows each)."""
         lib = ops._lib.lib()

@@ -13,7 +13,8 @@ F_IMG = {84: 0.28585e9, 224: 1.7774e9}[size]
 dev = "cuda:0"
 sd = synthetic.resnet10_state_dict(seed=0)
 x = torch.randn(n, size, size, 3, device=dev)
-for x3 in (False, True):
+which = sys.argv[3] if len(sys.argv) > 3 else "both"            # fp32 | x3 | both
+for x3 in {"fp32": (False,), "x3": (True,), "both": (False, True)}[which]:
     W = Fn.ResNet10Weights(sd, dev, x3=x3)
     arena = Fn.Arena(dev)
     Fn.resnet10_forward(W, x, arena, ipg=100, tag="f")
@@ -26,4 +27,4 @@ for x3 in (False, True):
     ms = a.elapsed_time(b) / 5
     tf = n * F_IMG / ms / 1e9
     print("ResNet10 forward %dx%d, %d images, trunk.4-6 on %s: %.2f ms = %.1f TFLOP/s algorithmic = %.2f of the fp32-MFMA peak (157.3)"
-          % (size, size, n, "bf16x3" if x3 else "fp32 MFMA", ms, tf, tf / 157.3))
+          % (size, size, n, ("f16x2" if W.f16x2 else "bf16x3") if x3 else "fp32 MFMA", ms, tf, tf / 157.3))

@@ -22,6 +22,15 @@ def main(path, top=14):
         n = max(a["n"], 1)
         act, busy = a.get("GRBM_GUI_ACTIVE", 0.0), a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         print("%-90s %7d %14.0f %16.0f %7.1f%%" % (k[:90], n, act / 8 / n, busy / n, 100.0 * busy / (act / 8 * 1024) if act else 0.0))
+    # all kernels of the pass together: MFMA-busy SIMD-cycles over GPU-active SIMD-cycles, i.e. the time-weighted utilisation
+    act = sum(a.get("GRBM_GUI_ACTIVE", 0.0) for a in agg.values())
+    busy = sum(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for a in agg.values())
+    conv = {k: a for k, a in agg.items() if ("conv" in k or "stem" in k or "skinny" in k)}
+    act_c = sum(a.get("GRBM_GUI_ACTIVE", 0.0) for a in conv.values())
+    busy_c = sum(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for a in conv.values())
+    if act:
+        print("ALL %d kernels of the run, time-weighted: %.1f %% MFMA-busy; convolution kernels only (%.0f %% of the GPU-active cycles): %.1f %%"
+              % (len(agg), 100.0 * busy / (act / 8 * 1024), 100.0 * act_c / act, 100.0 * busy_c / (act_c / 8 * 1024) if act_c else 0.0))
 
 
 if __name__ == "__main__":
