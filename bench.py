@@ -514,7 +514,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--episodes-per-batch", type=int, default=int(os.environ.get("MFT_EPB", "128")))
+    ap.add_argument("--episodes-per-batch", type=int, default=None,
+                    help="lockstep batch E (default: 128; 96 at --n-shot 20 and 64 at --n-shot 50, where the stem cache fits: "
+                         "profiles/r05_c_other_configs.txt; the MFT_EPB environment variable overrides the default)")
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--gen-examples", type=int, default=17)
     ap.add_argument("--n-shot", type=int, default=5, help="5 = BASELINE configs[1] (the metric); 20 = configs[2]; 50 = configs[4] "
@@ -549,6 +551,8 @@ def main():
                          "warm-up one batch is run on the golden's numpy permutation stream and its per-episode accuracies are "
                          "compared with the reference's (0 = off)")
     args = ap.parse_args()
+    if args.episodes_per_batch is None:
+        args.episodes_per_batch = int(os.environ.get("MFT_EPB", {20: 96, 50: 64}.get(args.n_shot, 128)))
 
     if args.cpu_baseline_only:
         import meta_fine_tuning_amd  # noqa: F401
@@ -688,116 +692,52 @@ def main():
                               "(DESIGN.md section 6)" % validate}
     np.random.seed(10 + rank)
 
-    # ---- kernel timers: HIP events recorded on the stream each kernel is launched on (the engine runs the frozen
-    # trunk and the last-block half of a step on two different HIP streams).  Dominant kernel of the path = the fused
-    # weight-gradient + Adam kernel (HBM-bound: w, m, v of every episode are read and written once per step); the
-    # implicit-GEMM convolutions (MFMA-bound) are reported next to it.
-    conv_events, adam_events, x3_events = [], [], []
-    orig_conv2d, orig_wgrad_adam, orig_conv2d_x3 = ops.conv2d, ops.conv2d_wgrad_adam, ops.conv2d_x3
-    timing = {"on": False}
+    # ---- kernel timers: HIP events recorded on the stream each launcher enqueues on (the engine runs the frozen trunk and the
+    # last-block half of a step on two different HIP streams), taken at the C-ABI by _lib.LaunchTimer -- no patched functions;
+    # the algorithmic work of a launch is derived from the launcher's own arguments (include/mft_hip.h).  Dominant kernel of the
+    # path = the fused weight-gradient + Adam kernel (HBM-bound: w, m, v of every episode are read and written once per step);
+    # the implicit-GEMM convolutions (MFMA-bound) are reported next to it.
+    from meta_fine_tuning_amd import _lib as _L
 
-    def timed_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group=0, bias=None, out=None):
-        if not timing["on"]:
-            return orig_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group, bias, out)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        r = orig_conv2d(x, w_pk, Cout, KH, KW, stride, pad, imgs_per_group, bias, out)
-        b.record(s)
-        OH = r.shape[1]
-        conv_events.append((a, b, conv_flops(x.shape[0], OH, Cout, KH * KW * x.shape[3])))
-        return r
+    def _osz(h, k, s_, p_):
+        return (h + 2 * p_ - k) // s_ + 1
 
-    def timed_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group=0, **kw):
-        if not timing["on"]:
-            return orig_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group, **kw)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        orig_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group, **kw)
-        b.record(s)
-        adam_events.append((a, b, 6.0 * 4.0 * w.numel()))      # read w,m,v + write w,m,v; the gradient never reaches HBM
-        return None
+    def _adam_bytes(a, n=8, cin=11, cout=12, kh=13, kw=14, ipg=17):          # read w, m, v + write w, m, v; the gradient never reaches HBM
+        return 24.0 * (a[n] // a[ipg]) * a[cout] * a[kh] * a[kw] * a[cin]
 
-    def timed_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out=None):
-        if not timing["on"]:
-            return orig_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        r = orig_conv2d_x3(x, w3, Cout, KH, KW, stride, pad, out)
-        b.record(s)
-        x3_events.append((a, b, conv_flops(x.shape[0], r.shape[1], Cout, KH * KW * x.shape[3])))
-        return r
+    def _conv_fl(a, n, h, w_, cin, cout, kh, kw, st, pd):
+        return 2.0 * a[n] * _osz(a[h], a[kh], a[st], a[pd]) * _osz(a[w_], a[kw], a[st], a[pd]) * a[cout] * a[kh] * a[kw] * a[cin]
 
-    orig_x3_bn = ops.conv2d_x3_bnstats
+    WORK = {   # launcher -> (family, algorithmic bytes | flops of one call from its C-ABI arguments)
+        "mft_wgrad_adam_next_forward": ("adam", _adam_bytes),
+        "mft_conv2d_wgrad_adam_nhwc": ("adam", _adam_bytes),
+        "mft_conv2d_wgrad_adam_nhwc_dev": ("adam", _adam_bytes),
+        "mft_conv2d_wgrad_adam_dgrad_nhwc": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
+        "mft_conv2d_wgrad_adam_dgrad_nhwc_dev": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
+        "mft_conv2d_nhwc": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        "mft_conv2d_nhwc_ksplit": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        "mft_conv2d_nhwc_ksplit_grouped": ("f32", lambda a: _conv_fl(a, 5, 6, 7, 8, 9, 10, 11, 12, 13)),
+        "mft_conv2d_nhwc_x3": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        "mft_conv2d_nhwc_h2": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        "mft_conv2d_nhwc_x3_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        "mft_conv2d_nhwc_h2_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+        # C2 of trunk.4 / trunk.5 with BN1 + ReLU applied by its loader (3x3, stride 1, pad 1): the same convolution FLOPs
+        "mft_conv2d_nhwc_x3_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
+        "mft_conv2d_nhwc_h2_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
+    }
 
-    def timed_x3_bn(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, **kw):
-        if not timing["on"]:
-            return orig_x3_bn(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, **kw)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        r = orig_x3_bn(x, w3, Cout, KH, KW, stride, pad, imgs_per_group, out, ws, mean, rstd, **kw)
-        b.record(s)
-        if r is not None:                   # None: outside the fused form's domain, the caller falls back to conv2d_x3 + bn_stats
-            x3_events.append((a, b, conv_flops(x.shape[0], out.shape[1], Cout, KH * KW * x.shape[3])))
-        return r
-
-    orig_x3_bnin = ops.conv2d_x3_bnin_bnstats
-
-    def timed_x3_bnin(c_raw, in_ws, in_gamma, in_beta, w3, Cout, imgs_per_group, out, ws, mean=None, rstd=None, **kw):
-        # C2 of trunk.4 / trunk.5 with BN1 + ReLU applied by its loader: the same convolution FLOPs (the BatchNorm work rides along)
-        if not timing["on"]:
-            return orig_x3_bnin(c_raw, in_ws, in_gamma, in_beta, w3, Cout, imgs_per_group, out, ws, mean, rstd, **kw)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        r = orig_x3_bnin(c_raw, in_ws, in_gamma, in_beta, w3, Cout, imgs_per_group, out, ws, mean, rstd, **kw)
-        b.record(s)
-        if r is not None:
-            x3_events.append((a, b, conv_flops(c_raw.shape[0], out.shape[1], Cout, 9 * c_raw.shape[3])))
-        return r
-
-    orig_wgrad_adam_dgrad = ops.conv2d_wgrad_adam_dgrad
-
-    def timed_wgrad_adam_dgrad(x, dy, w, m, v, dxp, step, imgs_per_group, **kw):
-        # the one-pass form of the same launch (weight gradient + Adam that also leaves the data gradient): same 6 x 4 B per
-        # parameter of algorithmic traffic, counted with the dominant kernel
-        if not timing["on"]:
-            return orig_wgrad_adam_dgrad(x, dy, w, m, v, dxp, step, imgs_per_group, **kw)
-        s = torch.cuda.current_stream()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        ok = orig_wgrad_adam_dgrad(x, dy, w, m, v, dxp, step, imgs_per_group, **kw)
-        b.record(s)
-        if ok:
-            adam_events.append((a, b, 6.0 * 4.0 * w.numel()))
-        return ok
-
-    orig_wgrad_next = ops.wgrad_adam_next_forward
-
-    def timed_wgrad_next(x, dy, w, m, v, *a, **kw):
-        # the default form of the dominant launch (csrc/wgrad_fwd.hip): weight gradient + Adam that also computes the next inner
-        # step's convolution from the tiles it has just updated.  Algorithmic traffic as before: 6 x 4 B per parameter.
-        if not timing["on"]:
-            return orig_wgrad_next(x, dy, w, m, v, *a, **kw)
-        s = torch.cuda.current_stream()
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record(s)
-        ok = orig_wgrad_next(x, dy, w, m, v, *a, **kw)
-        eb.record(s)
-        if ok:
-            adam_events.append((ea, eb, 6.0 * 4.0 * w.numel()))
-        return ok
-
-    ops.wgrad_adam_next_forward = timed_wgrad_next
-    ops.conv2d_wgrad_adam_dgrad = timed_wgrad_adam_dgrad
-    ops.conv2d = timed_conv2d
-    ops.conv2d_wgrad_adam = timed_wgrad_adam
-    ops.conv2d_x3 = timed_conv2d_x3
-    ops.conv2d_x3_bnstats = timed_x3_bn
-    ops.conv2d_x3_bnin_bnstats = timed_x3_bnin
+    def timed_launches(fn):
+        """Run ``fn`` with an event pair around every launch of the families above -> {family: [(ms, work), ...]}."""
+        with _L.LaunchTimer(only=WORK.__contains__, keep_args=True) as lt:
+            fn()
+            torch.cuda.synchronize()
+            calls = lt.collect(calls=True)
+            lt.close()
+        fam = {"adam": [], "f32": [], "x3": []}
+        for name, ms, a in calls:
+            kind, work = WORK[name]
+            fam[kind].append((ms, float(work(a))))
+        return fam
 
     def sync_all():
         if dist is not None:
@@ -835,15 +775,13 @@ def main():
     # rocprofv3 kernel-trace of this same command (profiles/) must and does show the same averages.
     roof = roof_mfma = roof_x3 = None
     if rank == 0:
-        timing["on"] = True
-        one_batch()
-        torch.cuda.synchronize()
-        timing["on"] = False
-        a_ms = sum(a.elapsed_time(b) for a, b, _ in adam_events)
-        a_by = sum(f for _, _, f in adam_events)
+        fam = timed_launches(one_batch)
+        adam_events, conv_events, x3_events = fam["adam"], fam["f32"], fam["x3"]
+        a_ms = sum(t for t, _ in adam_events)
+        a_by = sum(f for _, f in adam_events)
         n_a = len(adam_events)
         ach = a_by / (a_ms * 1e-3) / 1e9
-        big = [(a.elapsed_time(b), f) for a, b, f in adam_events if f == max(x[2] for x in adam_events)]
+        big = [(t, f) for t, f in adam_events if f == max(x[1] for x in adam_events)]
         roof = {"bound": "hbm", "kernel": "wgrad_adam_fwd_kernel (trunk.7 weight gradient with torch.optim.Adam fused in the epilogue AND "
                                           "the next inner step's convolution from the weight tiles just updated; per-episode w,m,v "
                                           "streamed once per inner step and not read again by a forward launch; MFT_FUSE_NEXT=0: "
@@ -873,12 +811,12 @@ def main():
             # result of the run is already on the host, so they may be overwritten
             ws, ms_, vs_ = e.adapt.w.c2w, e.adapt.m.c2w, e.adapt.v.c2w
             ws.normal_(0.0, 0.02, generator=gen); ms_.zero_(); vs_.zero_()
-            orig_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 1, 5)
+            ops.conv2d_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 1, 5)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for it in range(5):
-                orig_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 2 + it, 5)
+                ops.conv2d_wgrad_adam(xs, dys, ws, ms_, vs_, 512, 3, 3, 1, 1, 2 + it, 5)
             e1.record()
             torch.cuda.synchronize()
             t_us = e0.elapsed_time(e1) * 1e3 / 5
@@ -894,7 +832,7 @@ def main():
                 ad_ = e.adapt.w
 
                 def fused_once(step_):
-                    orig_wgrad_next(xs, dys, ws, ms_, vs_, 3, 3, 1, 1, step_, 5, x_next=xs, mode=ops.WF_EXIT, raw=tn["c2"], act=tn["out"],
+                    ops.wgrad_adam_next_forward(xs, dys, ws, ms_, vs_, 3, 3, 1, 1, step_, 5, x_next=xs, mode=ops.WF_EXIT, raw=tn["c2"], act=tn["out"],
                                     gamma=ad_.bn2g, beta=ad_.bn2b, gbs=512, mean=st_["m2"], rstd=st_["s2"], sc_raw=tn["sc"],
                                     gamma_s=ad_.bnsg, beta_s=ad_.bnsb, mean_s=st_["ms"], rstd_s=st_["ss"], pooled=ft_)
                 fused_once(1)
@@ -913,7 +851,6 @@ def main():
         # what a pure w/m/v stream gets on THIS lease (the same binary measures 5.2-6.3 TB/s on different leases): an Adam-shaped
         # 3-read / 3-write pass over scratch arrays of the size of one parameter slab, no gradient operand, no matrix work
         try:
-            from meta_fine_tuning_amd import _lib as _L
             n_el = (E * 3673088) // 1024 * 1024
             sw, sm, sv = (torch.zeros(n_el, device=dev) for _ in range(3))
             st_ = ops._stream
@@ -946,13 +883,13 @@ def main():
             roof["stream_reference"]["on_engine_slabs"] = {"achieved": round(slab_gbs, 1), "dominant_kernel_in_situ_vs_this": round(ach / slab_gbs, 4)}
         except RuntimeError as ex:
             roof["stream_reference"] = {"error": str(ex)[:120]}
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
-        tot_fl = sum(f for _, _, f in conv_events)
+        tot_ms = sum(t for t, _ in conv_events)
+        tot_fl = sum(f for _, f in conv_events)
         n_launch = len(conv_events)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
         if x3_events:
-            x_ms = sum(a.elapsed_time(b) for a, b, _ in x3_events)
-            x_fl = sum(f for _, _, f in x3_events)
+            x_ms = sum(t for t, _ in x3_events)
+            x_fl = sum(f for _, f in x3_events)
             ach3 = x_fl / (x_ms * 1e-3) / 1e12
             n_prod = 3 if e.W.f16x2 else 6            # matrix-core flops executed per algorithmic flop
             roof_x3 = {"bound": "mfma", "kernel": ("conv_x3_kernel / conv_x3_s1_kernel / conv_x3_s1_bnin_kernel, NP = 2 (frozen trunk.4-6: fp32-accurate 3-term "
@@ -968,20 +905,13 @@ def main():
             if not args.no_standalone:
                 # the same convolutions with the GPU to themselves: six trunk steps on one stream, no last-block stream beside them
                 try:
-                    n0 = len(x3_events)
                     prs = [eng.draw_perms(e.n_total, e.epochs, np.random.RandomState(900 + i)) for i in range(E)]
                     tabs = [t_ for t_ in e.step_tables(prs, E) if t_[0] == e.bs][:7]
                     e.trunk_step(torch.from_numpy(tabs[0][1]).to(dev), e.bs, 0)
                     torch.cuda.synchronize()
-                    timing["on"] = True
-                    for t_ in tabs[1:]:
-                        e.trunk_step(torch.from_numpy(t_[1]).to(dev), e.bs, 0)
-                    torch.cuda.synchronize()
-                    timing["on"] = False
-                    alone = x3_events[n0:]
-                    s_ms = sum(a.elapsed_time(b) for a, b, _ in alone)
-                    s_fl = sum(f for _, _, f in alone)
-                    del x3_events[n0:]
+                    alone = timed_launches(lambda: [e.trunk_step(torch.from_numpy(t_[1]).to(dev), e.bs, 0) for t_ in tabs[1:]])["x3"]
+                    s_ms = sum(t for t, _ in alone)
+                    s_fl = sum(f for _, f in alone)
                     if alone and s_ms > 0:
                         sa = s_fl / (s_ms * 1e-3) / 1e12
                         roof_x3["standalone"] = {"what": "the same eight convolutions per step with no co-running last-block stream (6 trunk steps)",
@@ -989,7 +919,6 @@ def main():
                                                  "vs_fp32_mfma_peak": round(sa / (PEAK_F32_MFMA / 1e12), 3),
                                                  "avg_launch_us": round(s_ms * 1e3 / len(alone), 2)}
                 except Exception as ex:   # noqa: BLE001 -- an extra measurement must not cost the line
-                    timing["on"] = False
                     roof_x3["standalone"] = {"error": str(ex)[:120]}
         roof_mfma = {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_conv_kernel (fp32 MFMA implicit GEMM: stem, "
                                                 "weight-streaming per-episode trunk.7 launches, GNN GEMMs)",

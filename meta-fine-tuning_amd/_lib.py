@@ -188,9 +188,10 @@ class LaunchTimer:
     _SKIP = ("mft_event_", "mft_stream_", "mft_debug_", "mft_version", "mft_device_info", "mft_has_experiments",
              "mft_wgrad_fwd_set_", "mft_probe_placement")
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, keep_args=False):
         self.only = only                       # optional predicate(name) -> bool
-        self._pairs = []                       # (name, start, stop)
+        self.keep_args = keep_args             # also keep each call's C-ABI arguments (shapes: callers derive bytes / flops from them)
+        self._pairs = []                       # (name, start, stop, args | None)
         self._free = []
         self._real = None
 
@@ -214,8 +215,11 @@ class LaunchTimer:
             a, b = self._event(), self._event()
             real.mft_event_record(a, stream)
             rc = fn(*args)
+            if rc != 0:                        # refused (MFT_EINVAL: outside the launcher's domain, the host falls back) -- nothing ran
+                self._free += [a, b]
+                return rc
             real.mft_event_record(b, stream)
-            self._pairs.append((name, a, b))
+            self._pairs.append((name, a, b, args if self.keep_args else None))
             return rc
         return timed
 
@@ -231,15 +235,17 @@ class LaunchTimer:
         _lib = self._real
         return False
 
-    def collect(self):
-        out = {}
+    def collect(self, calls=False):
+        """-> {launcher: [ms per call, ...]}; ``calls=True``: the flat list [(launcher, ms, args | None), ...] in call order."""
+        out, flat = {}, []
         ms = ctypes.c_float()
-        for name, a, b in self._pairs:
+        for name, a, b, args in self._pairs:
             check(self._real.mft_event_elapsed_ms(a, b, ctypes.byref(ms)), "mft_event_elapsed_ms")
             out.setdefault(name, []).append(float(ms.value))
+            flat.append((name, float(ms.value), args))
             self._free += [a, b]
         self._pairs = []
-        return out
+        return flat if calls else out
 
     def close(self):
         for e in self._free:

@@ -513,3 +513,40 @@ def test_training_side_view_parameters():
     assert ratio.min() >= 0.70 and ratio.max() <= 1.40
     assert np.all(np.abs(P1[0, :, 4:7] - 1.0) <= 0.4 + 1e-6) and np.abs(P1[0, :, 4:7] - 1.0).max() > 0.3
     assert 0.4 < P1[0, :, 7].mean() < 0.6 and np.all(P1[0, :, 8] == 0.0) and np.all(P1[0, :, 9] == 1.0)
+
+
+def test_settings_object_is_the_single_typed_source_of_knobs(monkeypatch):
+    """settings.Settings: one typed field per MFT_* knob (KNOBS table == dataclass fields), parsed and validated in one place;
+    current() follows the environment (tests change variables), bad values raise with the variable's name, and no module of the
+    package parses an MFT_* variable on its own any more (build-time MFT_EXPERIMENTS / MFT_BUILD_JOBS excepted)."""
+    import dataclasses
+    from meta_fine_tuning_amd import settings
+    for v in [k[1] for k in settings.KNOBS]:
+        monkeypatch.delenv(v, raising=False)
+    s = settings.current()
+    assert dataclasses.is_dataclass(s) and s == settings.Settings()            # defaults ARE the product
+    assert [f.name for f in dataclasses.fields(s)] == [k[0] for k in settings.KNOBS]
+    assert len({k[1] for k in settings.KNOBS}) == len(settings.KNOBS)
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        s.fuse_next = "1"
+    monkeypatch.setenv("MFT_EPISODES", "7")
+    monkeypatch.setenv("MFT_TRUNK_F16X2", "0")
+    s2 = settings.current()
+    assert s2.episodes == 7 and s2.trunk_f16x2 is False and s2.fuse_next == "auto"
+    monkeypatch.setenv("MFT_FUSE_NEXT", "yes")
+    with pytest.raises(ValueError, match="MFT_FUSE_NEXT"):
+        settings.current()
+    monkeypatch.setenv("MFT_FUSE_NEXT", "0")
+    monkeypatch.setenv("MFT_SLAB_BALLAST_GB", "lots")
+    with pytest.raises(ValueError, match="MFT_SLAB_BALLAST_GB"):
+        settings.current()
+    # every knob is documented, and the package holds no stray parser
+    assert all(len(k[4]) > 10 for k in settings.KNOBS) and "MFT_FUSE_NEXT" in settings.describe()
+    pkg = os.path.dirname(os.path.abspath(settings.__file__))
+    stray = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f not in ("settings.py", "build.py"):
+                txt = open(os.path.join(root, f)).read()
+                stray += [(f, m) for m in re.findall(r"environ[^\n]*?(MFT_[A-Z0-9_]+)", txt)]
+    assert not stray, stray

@@ -1238,3 +1238,41 @@ def test_grouped_k_sliced_convolutions_match_float64(G, ipg, H, Cin, Cout, k, st
         gref = torch.cat([torch.nn.grad.conv2d_input((ipg, Cin, H, H), ws_[g].double(), dyd[g * ipg:(g + 1) * ipg], padding=pad)
                           for g in range(G)]).permute(0, 2, 3, 1)
         assert float((dx.double().cpu() - gref).abs().max()) < 1e-5 * float(gref.abs().max())
+
+
+def test_launch_timer_brackets_launchers_on_their_own_streams():
+    """_lib.LaunchTimer (bench.py's roofline source): every launcher call inside the block is timed by a pair of HIP events on the
+    stream it enqueues on -- a side stream included, which torch.cuda.Event on the current stream would not see --, refused calls
+    (MFT_EINVAL) are not counted, the C-ABI arguments are kept on request, and results are unchanged."""
+    from meta_fine_tuning_amd import _lib
+    x = torch.randn(64, 21, 21, 64, device=DEV)
+    w = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device=DEV) * 0.05)
+    ref = ops.conv2d(x, w, 64, 3, 3, 1, 1).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with _lib.LaunchTimer(keep_args=True) as lt:
+        assert _lib.lib() is lt
+        a = ops.conv2d(x, w, 64, 3, 3, 1, 1)
+        with torch.cuda.stream(side):
+            b = ops.conv2d(x, w, 64, 3, 3, 1, 1)
+            c = ops.softmax_rows(torch.randn(128, 5, device=DEV))
+        rc = _lib.lib().mft_stream_probe(ops._p(x), ops._p(x), ops._p(x), 100, ops._stream())      # n not a multiple of 1024: refused
+        assert rc == _lib.MFT_EINVAL
+        torch.cuda.synchronize()
+        calls = lt.collect(calls=True)
+        lt.close()
+    assert not isinstance(_lib.lib(), _lib.LaunchTimer)
+    names = [n for n, _, _ in calls]
+    assert len(names) == 3 and names[0] == names[1] and names[0] in ("mft_conv2d_nhwc", "mft_conv2d_nhwc_ksplit") and names[2] == "mft_softmax_rows"
+    assert all(0.0 < ms < 50.0 for _, ms, _ in calls)
+    args = calls[0][2]
+    assert (args[6], args[7], args[8], args[9], args[10], args[11], args[12]) == (64, 21, 21, 64, 64, 3, 3)      # n, H, W, Cin, Cout, KH, KW
+    assert torch.equal(a, ref) and torch.equal(b, ref) and c.shape == (128, 5)
+    only = _lib.LaunchTimer(only=lambda n: n == "mft_softmax_rows")
+    with only:
+        ops.conv2d(x, w, 64, 3, 3, 1, 1)
+        ops.softmax_rows(torch.randn(8, 5, device=DEV))
+        torch.cuda.synchronize()
+        got = only.collect()
+        only.close()
+    assert list(got) == ["mft_softmax_rows"] and len(got["mft_softmax_rows"]) == 1

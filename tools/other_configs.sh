@@ -16,7 +16,7 @@ PY
 }
 run "--n-shot 20 --episodes-per-batch 96 --steps 2 --warmup 1"
 run "--n-shot 20 --episodes-per-batch 128 --steps 2 --warmup 1"
-run "--n-shot 50 --episodes-per-batch 128 --steps 1 --warmup 1"
+run "--n-shot 50 --episodes-per-batch 64 --steps 1 --warmup 1"
 run "--image-size 224 --episodes-per-batch 32 --steps 2 --warmup 1"
 run "--episodes-per-batch 120 --steps 4 --warmup 1"
 run "--episodes-per-batch 64 --steps 6 --warmup 2"
