@@ -523,12 +523,13 @@ class FinetuneEngine:
         xb = ops.gather_rows(self.Xs, idx_dev, out=a.get("xb%d.%d" % (k, parity), (n, H * H * 3)))
         return Fn.resnet10_trunk(self.W, xb.view(n, H, H, 3), a, k, upto=7, tag="tr%d.%d" % (k, parity))
 
-    def last_step(self, x6, lab_dev, k, nxt=None, tape=None):
+    def last_step(self, x6, lab_dev, k, nxt=None, tape=None, before_next_read=None):
         """Adapted part: trunk.7 forward with per-episode weights, CE on the 512-d feature, last-block backward,
         Adam (finetune.py:286-299).
         ``nxt`` = (x6 of the NEXT step | None, its tape buffers | None): the weight-gradient + Adam launches also run the next
         step's trunk.7 forward (Fn.last_block_backward(nxt=)); ``tape``: this step's forward as left by the PREVIOUS step's
-        launches (None: run the forward here -- the first step of a loop)."""
+        launches (None: run the forward here -- the first step of a loop).  ``before_next_read``: the stream wait for the producer
+        of ``nxt``'s x6, run by last_block_backward right before the first launch that reads it."""
         E = self.E
         if tape is None:
             tape = {}
@@ -557,7 +558,8 @@ class FinetuneEngine:
                                    adam=(self.adapt.m, self.adapt.v, self.hyper, self.lr), ce=ce)
         elif self.fused_adam:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k,
-                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr), ce=ce, nxt=nxt)
+                                   adam=(self.adapt.m, self.adapt.v, self.adapt.step, self.lr), ce=ce, nxt=nxt,
+                                   before_next_read=before_next_read)
         else:
             Fn.last_block_backward(tape, dlogits, self.adapt.w, self.adapt.g, self.arena, ipg=k, tag="bw%d" % k, ce=ce)
             ops.adam_step(self.adapt.w.flat, self.adapt.g.flat, self.adapt.m.flat, self.adapt.v.flat, self.adapt.step,
@@ -668,7 +670,7 @@ class FinetuneEngine:
                         tn = self._next_tape(x6n, k0, (t + 1) & 1)
                         ev_next = ready[t + 1]
                         wait_next = (lambda ev=ev_next: self.s_last.wait_event(ev))
-                    self.last_step(x6s[t], lab_all[t], k0, nxt=(x6n, tn, wait_next), tape=tape)
+                    self.last_step(x6s[t], lab_all[t], k0, nxt=(x6n, tn), tape=tape, before_next_read=wait_next)
                     tape = tn
                     ev = torch.cuda.Event()
                     ev.record(self.s_last)

@@ -712,14 +712,17 @@ def next_step_tape(arena, tag, n, oh, ow, C, groups):
     return t
 
 
-def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None, nxt=None):
+def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=None, ce=None, nxt=None, before_next_read=None):
     """Backward of CE(feat) through avgpool + trunk.7 only (everything below is frozen: SURVEY §2.3 K13).
     ``params``/``grads``: LastBlockSlab (per-group).  Gradients are written in place into ``grads``.
     ``adam`` = (m_slab, v_slab, step, lr): fuse the Adam update of the three conv weights into the wgrad
     epilogues (their gradients are then not materialised) and update the BatchNorm affine tail separately.
-    ``nxt`` = (x_next | None, tape_next | None[, callable run right before the first launch that reads x_next]) (needs ``adam``): the three weight-gradient + Adam launches also run the NEXT inner
+    ``nxt`` = (x_next | None, tape_next | None) (needs ``adam``): the three weight-gradient + Adam launches also run the NEXT inner
     step's trunk.7 forward on ``x_next`` from the weight tiles they have just updated and fill ``tape_next`` (next_step_tape) --
-    no forward launch reads the updated weights back (csrc/wgrad_fwd.hip).  The BatchNorm-affine Adam tail then runs BEFORE them
+    no forward launch reads the updated weights back (csrc/wgrad_fwd.hip).
+    ``before_next_read``: a callable (the caller's stream wait for the producer of ``x_next``) that is run EXACTLY ONCE, right
+    before the first launch that reads ``x_next``; the function asserts that it ran whenever ``x_next`` was read, and refuses the
+    argument on paths that never read ``x_next`` (an unconsumed wait would be a silent race).  The BatchNorm-affine Adam tail then runs BEFORE them
     (their epilogues apply the updated gamma / beta), C1 and the shortcut before C2 (whose forward consumes r1 and sc of step
     t+1).  x_next None: the last inner step (update only)."""
     x, c1, r1, c2, sc, out = tape["x"], tape["c1"], tape["r1"], tape["c2"], tape["sc"], tape["out"]
@@ -804,15 +807,22 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
         ops.adam_step(params.flat[-nb:], grads.flat[-nb:], m.flat[-nb:], v.flat[-nb:], 1 if hyper is not None else step,
                       lr=lr, hyper=hyper)
 
+    if before_next_read is not None and (nxt is None or nxt[0] is None):
+        raise RuntimeError("before_next_read given, but this call never reads x_next")
     if nxt is not None:
         assert adam is not None and not done_c2
         x_next, tn = nxt[0], nxt[1]
+        waited = [before_next_read is None]
+
+        def wait_next_once():
+            if not waited[0]:
+                before_next_read()
+                waited[0] = True
         m_, v_, step, lr = adam
         hyper = step if torch.is_tensor(step) else None
         st = 1 if hyper is not None else step
         dc1 = _dgrad_c2_bn1(lib, tape, params, grads, arena, tag, dc2, c1, r1, n, oh, ow, C, ipg, bn_bwd)
         adam_tail()
-        wait_next = nxt[2] if len(nxt) > 2 else None      # the caller's stream wait for x_next, issued where x_next is first read
         kw = dict(lr=lr, hyper=hyper)
         fw = x_next is not None
         ok = hybrid = False
@@ -825,9 +835,7 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
             wgrad(x, dc1, "c1w", 3, 2, 1)
             hybrid = ok = True
             if fw:
-                if wait_next is not None:
-                    wait_next()
-                    wait_next = None
+                wait_next_once()
                 rc = lib.mft_block_entry_small_forward(
                     ops._p(x_next), x_next.shape[-1], ops._p(params.c1w), params.c1w.shape[1] * params.c1w.shape[2], ops._p(params.scw),
                     params.scw.shape[1] * params.scw.shape[2], ops._p(tn["c1"]), ops._p(tn["r1"]), ops._p(tn["sc"]), n, x_next.shape[1],
@@ -837,8 +845,8 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
                     raise RuntimeError("block entry launch outside its domain after next_forward_ok accepted the shape")
                 ops._lib.check(rc, "mft_block_entry_small_forward")
         if not hybrid:
-            if wait_next is not None:
-                wait_next()
+            if fw:
+                wait_next_once()
             ok = ops.wgrad_adam_next_forward(x, dsc, params.scw, m_.scw, v_.scw, 1, 1, 2, 0, st, ipg, x_next=x_next, mode=ops.WF_RAW,
                                              raw=tn["sc"] if fw else None, **kw)
             ok = ok and ops.wgrad_adam_next_forward(x, dc1, params.c1w, m_.c1w, v_.c1w, 3, 3, 2, 1, st, ipg, x_next=x_next,
@@ -854,6 +862,7 @@ def last_block_backward(tape, dfeat, params, grads, arena, ipg, tag="bw", adam=N
                                                 pooled=tn["feat"] if fw else None, **kw)
         if not ok:
             raise RuntimeError("wgrad_adam_next_forward: shape outside the fused kernel's domain (the caller checks next_forward_ok)")
+        assert waited[0] or not fw, "x_next was read without the caller's stream wait"
         if fw:
             tn["x"] = x_next
         return
