@@ -104,6 +104,12 @@ int mft_ce_pool_bn_backward2(const float* feat, const int* labels, int imgs_per_
  * 3x3/stride 2/pad 1 window of the RAW convolution output.  mft_bn_relu_pooled_gather: y[n] = ReLU(BN(pmax or pmin of image
  * src_idx[n])) with the statistics of the group of n (channels with gamma >= 0 take the maximum, the others the minimum):
  * bit-identical to mft_bn_relu_maxpool_gather on the full-resolution cache because the BatchNorm affine is monotone per channel. */
+/* The stem-cache fill in ONE launch (round 5, csrc/stem.hip: stem_cache_kernel): trunk.0 (backbone.py:408, 7x7 / stride 2) of n_img
+ * NHWC images + per-image per-channel (mean, M2) of its output [n_img, 64] + per 3x3 / stride-2 / pad-1 window the max and min of
+ * it [n_img, PH, PW, 64] -- what mft_conv2d_nhwc + mft_bn_image_moments + mft_pool_window_minmax produce, without the
+ * full-resolution output ever reaching HBM.  MFT_EINVAL outside the specialised shape (84 x 84): run the three launches.     */
+int mft_stem_cache_fill(const float* in, const float* w, int w_ld, int n_img, int H, int W, float* pmax, float* pmin,
+                        float* mean_img, float* m2_img, void* stream);
 int mft_pool_window_minmax(const float* x, float* ymax, float* ymin, long long n_img, int H, int W, int C, void* stream);
 int mft_bn_relu_pooled_gather(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH, int OW, int C,
                               int imgs_per_group, const float* mean, const float* rstd, const float* gamma, const float* beta,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mft_stream_create_priority": [_I, _P, _P],
     "mft_ce_pool_bn_backward2": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "mft_pool_window_minmax": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "mft_stem_cache_fill": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_conv2d_nhwc_x3_bnin_bnstats": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_split_f16x2": [_P, _P, _L, _P],
     "mft_conv2d_nhwc_h2": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

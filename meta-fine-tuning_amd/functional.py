@@ -306,9 +306,11 @@ class StemCache:
         self.chunk = min(chunk, n_slots)
         self.mean = torch.empty((n_slots, 64), device=device)
         self.m2 = torch.empty((n_slots, 64), device=device)
+        self.fused_fill = bool(self.pooled and cfg.stem_fused_fill and H == 84)      # (csrc/stem.hip: stem_cache_kernel<84>)
         if self.pooled:
             self.c0 = None
-            self._buf = torch.empty((self.chunk, self.OH, self.OH, 64), device=device)      # one chunk of raw stem output
+            # one chunk of raw stem output: only the three-launch fill needs it
+            self._buf = None if self.fused_fill else torch.empty((self.chunk, self.OH, self.OH, 64), device=device)
             self.pmax = torch.empty((n_slots, self.PH, self.PH, 64), device=device)
             self.pmin = torch.empty((n_slots, self.PH, self.PH, 64), device=device)
         else:
@@ -316,7 +318,7 @@ class StemCache:
 
     def nbytes(self):
         ts = [self.mean, self.m2] + ([self._buf, self.pmax, self.pmin] if self.pooled else [self.c0])
-        return sum(t.numel() * 4 for t in ts)
+        return sum(t.numel() * 4 for t in ts if t is not None)
 
     @staticmethod
     def bytes_needed(n_slots, H, pooled=None, chunk=8192):
@@ -327,13 +329,24 @@ class StemCache:
         oh = (H + 6 - 7) // 2 + 1
         ph = (oh + 2 - 3) // 2 + 1
         per = 2 * 64 + (2 * ph * ph * 64 if pooled else oh * oh * 64)
-        return 4 * (n_slots * per + (chunk * oh * oh * 64 if pooled else 0))
+        fused = bool(pooled and cfg.stem_fused_fill and H == 84)
+        return 4 * (n_slots * per + (chunk * oh * oh * 64 if (pooled and not fused) else 0))
 
     def fill(self, x_nhwc):
         """x_nhwc [n_slots,H,H,3] -> conv outputs + moments (chunked launches; M = chunk*OH*OW rows each)."""
         lib = ops._lib.lib()
         n = x_nhwc.shape[0]
         assert n == self.n_slots
+        if self.fused_fill:
+            # ONE launch: convolution + per-image moments + per-window (max, min); the full-resolution output never reaches HBM
+            wpk = self.W.conv["trunk.0"]
+            rc = lib.mft_stem_cache_fill(ops._p(x_nhwc), ops._p(wpk), wpk.shape[-1], n, x_nhwc.shape[1], x_nhwc.shape[2],
+                                         ops._p(self.pmax), ops._p(self.pmin), ops._p(self.mean), ops._p(self.m2), ops._stream())
+            if rc != ops._lib.MFT_EINVAL:
+                ops._lib.check(rc, "mft_stem_cache_fill")
+                return
+            self.fused_fill = False                                   # outside the kernel's domain: the three launches from now on
+            self._buf = torch.empty((self.chunk, self.OH, self.OH, 64), device=x_nhwc.device)
         for i in range(0, n, self.chunk):
             j = min(i + self.chunk, n)
             c0 = self._buf[:j - i] if self.pooled else self.c0[i:j]

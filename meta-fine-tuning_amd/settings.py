@@ -51,6 +51,7 @@ KNOBS = (
     ("trunk_f16x2", "MFT_TRUNK_F16X2", _flag, True, "frozen trunk.4-6 on two fp16 pieces per operand (0: three bf16 pieces)"),
     ("fuse_next_c2_only", "MFT_FUSE_NEXT_C2_ONLY", _flag, False, "only trunk.7.C2's launch fused (measured slower)"),
     ("stem_pooled", "MFT_STEM_POOLED", _flag, True, "stem cache keeps per-window (max, min) instead of the full-resolution output"),
+    ("stem_fused_fill", "MFT_STEM_FUSED_FILL", _flag, True, "stem cache filled by ONE launch (convolution + moments + window min/max; 0: three launches through a full-resolution buffer)"),
     ("stem_chunk", "MFT_STEM_CHUNK", _opt_int, None, "images per stem-cache fill launch (None: StemCache's default)"),
     ("fused_last_block", "MFT_FUSED_LAST_BLOCK", _flag, True, "conv + BatchNorm fusions of the adapted block (csrc/skinny.hip)"),
     ("small_groups", "MFT_SMALL_GROUPS", int, 12, "up to this many per-episode weight sets take the K-sliced GEMM route"),
@@ -96,6 +97,7 @@ class Settings:
     trunk_f16x2: bool = True
     fuse_next_c2_only: bool = False
     stem_pooled: bool = True
+    stem_fused_fill: bool = True
     stem_chunk: "int | None" = None
     fused_last_block: bool = True
     small_groups: int = 12

@@ -1276,3 +1276,38 @@ def test_launch_timer_brackets_launchers_on_their_own_streams():
         got = only.collect()
         only.close()
     assert list(got) == ["mft_softmax_rows"] and len(got["mft_softmax_rows"]) == 1
+
+
+@pytest.mark.parametrize("n", [1, 7, 600])
+def test_stem_cache_fused_fill_matches_the_three_launches(n, monkeypatch):
+    """mft_stem_cache_fill (csrc/stem.hip: stem_cache_kernel -- trunk.0 + per-image moments + per-window (max, min) in ONE launch, the
+    full-resolution output never written) against the three launches it replaces (mft_conv2d_nhwc + mft_bn_image_moments +
+    mft_pool_window_minmax): window extrema EQUAL (max / min of the same convolution results), moments to fp32 rounding, and both
+    against a float64 statement of the op."""
+    from meta_fine_tuning_amd import functional as Fn
+    sd = synthetic.resnet10_state_dict(seed=5)
+    W = Fn.ResNet10Weights(sd, DEV)
+    x = torch.randn(n, 84, 84, 3, device=DEV) * 1.7 + 0.3
+    monkeypatch.setenv("MFT_STEM_FUSED_FILL", "1")
+    a = Fn.StemCache(W, n, 84, DEV, pooled=True)
+    assert a.fused_fill and a._buf is None
+    a.fill(x)
+    monkeypatch.setenv("MFT_STEM_FUSED_FILL", "0")
+    b = Fn.StemCache(W, n, 84, DEV, pooled=True)
+    assert not b.fused_fill
+    b.fill(x)
+    torch.cuda.synchronize()
+    assert a.fused_fill                                                    # the launch was inside its domain
+    assert torch.equal(a.pmax, b.pmax) and torch.equal(a.pmin, b.pmin)
+    assert torch.allclose(a.mean, b.mean, rtol=0, atol=2e-6) and torch.allclose(a.m2, b.m2, rtol=2e-5, atol=1e-3)
+    # float64 reference of the whole op on a few images
+    k = min(n, 3)
+    w64 = sd["trunk.0.weight"].double().to(DEV)
+    c = torch.nn.functional.conv2d(x[:k].permute(0, 3, 1, 2).double(), w64, stride=2, padding=3)          # [k, 64, 42, 42]
+    assert torch.allclose(a.mean[:k].double(), c.mean(dim=(2, 3)), atol=1e-5)
+    assert torch.allclose(a.m2[:k].double(), ((c - c.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    mx = torch.nn.functional.max_pool2d(c, 3, 2, 1).permute(0, 2, 3, 1)
+    mn = -torch.nn.functional.max_pool2d(-c, 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.allclose(a.pmax[:k].double(), mx, atol=2e-5) and torch.allclose(a.pmin[:k].double(), mn, atol=2e-5)
+    # a 224 x 224 cache is outside the fused kernel's domain and says so
+    assert not Fn.StemCache(W, 2, 224, DEV, pooled=True).fused_fill
