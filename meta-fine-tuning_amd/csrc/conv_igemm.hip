@@ -1074,7 +1074,7 @@ extern "C" int mft_debug_reset(void) {
     mft_wgrad_fwd_set_xcd(1);
     g_dgrad_parity = 1; g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
     mft_skinny_set_lines(1); mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
-    mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(41);
+    mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(31); mft_debug_set_x3_tile(41);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(70); mft_debug_set_x3_tile(80); mft_debug_set_x3_tile(91); mft_debug_set_x3_tile(100); mft_debug_set_x3_tile(200);
     return 0;
 }

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 3
 // partials (bn_fold.h) into an LDS table of (scale, shift) per (group, channel).  The loader then applies one FMA + max per
 // element in front of the bf16x3 split; padding and zero rows stay exact zeros.  Removes BN1's finalize and apply launches and
 // the activation they wrote and re-read.
-template <int BM, int BN, bool BNIN, int NP = 3>
+template <int BM, int BN, bool BNIN, int NP = 3, bool BDB = true>
 __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     static_assert(NP == 3 || NP == 2, "3 bf16 pieces (six products) or 2 fp16 pieces (three products)");
     constexpr int NACC = NP == 3 ? 1 : 2;           // f16x2: leading products / cross products in separate accumulators
@@ -534,9 +534,13 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     constexpr int B_PLANE = BN * RS;
     const int A_PLANE = p.s1_rows * RS;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    // f16x2 (NP == 2): TWO weight-tile buffers, so that the next tap's tile is stored while slower waves still multiply the
+    // current one -- one barrier per tap instead of two (round 5); the bf16x3 form keeps one (a second would cost its third
+    // workgroup per CU)
+    constexpr int NBB = (NP == 2 && BDB) ? 2 : 1;        // (BDB = false: the single-buffer form, mft_debug_set_x3_tile(30), for A/B)
     unsigned short* As = smem;                       // [NP][s1_rows][RS]
-    unsigned short* Bs = smem + NP * A_PLANE;        // [NP][BN][RS]
-    float* bn_tab = reinterpret_cast<float*>(Bs + NP * B_PLANE);     // BNIN: [2 groups][scale | shift][Cin]
+    unsigned short* Bs = smem + NP * A_PLANE;        // [NBB][NP][BN][RS]
+    float* bn_tab = reinterpret_cast<float*>(Bs + NBB * NP * B_PLANE);     // BNIN: [2 groups][scale | shift][Cin]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -715,14 +719,15 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
             if (tid < 16) put_a(S.rh, h_lds);
         }
     };
-    auto store_b = [&](const Stage& S) {
+    auto store_b = [&](const Stage& S, int bb = 0) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                *(u32x4*)(Bs + pl * B_PLANE + (brow + 64 * j) * RS + bseg * 8) = S.rb[j][pl];
+                *(u32x4*)(Bs + (bb * NP + pl) * B_PLANE + (brow + 64 * j) * RS + bseg * 8) = S.rb[j][pl];
     };
-    auto compute = [&](int kw) {
+    auto compute = [&](int kw, int bb = 0) {
+        const unsigned short* const Bc = Bs + bb * NP * B_PLANE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if constexpr (NP == 3) {
@@ -736,7 +741,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        b[j][pl] = *(const bf16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
+                        b[j][pl] = *(const bf16x8*)(Bc + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
                 constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -757,7 +762,7 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
-                        b[j][pl] = *(const f16x8*)(Bs + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
+                        b[j][pl] = *(const f16x8*)(Bc + pl * B_PLANE + (wn * (BN / 2) + j * 32 + r) * RS + kk * 16 + h * 8);
                 // cross products first (hi x lo, lo x hi -> acc 1), leading product last (-> acc 0): neighbouring MFMAs of one
                 // (i, j) alternate between the two accumulators, so none waits for its predecessor's result
                 constexpr int TA[3] = {0, 1, 0};
@@ -782,25 +787,51 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     store_a(st, 0);
     store_b(st);
     __syncthreads();
-    for (int ms = 0; ms < n_ms; ++ms) {
-        const int msn = ms + 1 < n_ms ? ms + 1 : ms;      // branch-free body: the last image is simply requested twice
-        load_b(ms, 1, st);
-        compute(0);
-        __syncthreads();
-        store_b(st);
-        __syncthreads();
-        load_b(ms, 2, st);
-        compute(1);
-        __syncthreads();
-        store_b(st);
-        __syncthreads();
-        load_a(msn, st);
-        load_b(msn, 0, st);
-        compute(2);
-        __syncthreads();
-        store_a(st, msn);
-        store_b(st);
-        __syncthreads();
+    if constexpr (NBB == 2) {
+        // Tap s multiplies weight buffer s & 1 while tap s + 1's tile goes into the other one: that buffer was last read by tap
+        // s - 1, which every wave finished before the barrier that closed it.  The staged image A is single: its refill waits
+        // for the third tap of all waves (two barriers there) -- four barriers per (kh, channel slice) instead of six.
+        int cur = 0;
+        for (int ms = 0; ms < n_ms; ++ms) {
+            const int msn = ms + 1 < n_ms ? ms + 1 : ms;      // branch-free body: the last image is simply requested twice
+            load_b(ms, 1, st);
+            compute(0, cur);
+            store_b(st, cur ^ 1);
+            __syncthreads();
+            load_b(ms, 2, st);
+            compute(1, cur ^ 1);
+            store_b(st, cur);
+            __syncthreads();
+            load_a(msn, st);
+            load_b(msn, 0, st);
+            compute(2, cur);
+            store_b(st, cur ^ 1);
+            __syncthreads();
+            store_a(st, msn);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int ms = 0; ms < n_ms; ++ms) {
+            const int msn = ms + 1 < n_ms ? ms + 1 : ms;      // branch-free body: the last image is simply requested twice
+            load_b(ms, 1, st);
+            compute(0);
+            __syncthreads();
+            store_b(st);
+            __syncthreads();
+            load_b(ms, 2, st);
+            compute(1);
+            __syncthreads();
+            store_b(st);
+            __syncthreads();
+            load_a(msn, st);
+            load_b(msn, 0, st);
+            compute(2);
+            __syncthreads();
+            store_a(st, msn);
+            store_b(st);
+            __syncthreads();
+        }
     }
 
     // epilogue (as conv_x3_kernel): C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -858,15 +889,15 @@ __device__ __forceinline__ void conv_x3_s1_body(const X3Args& p) {
     }
 }
 
-template <int BM, int BN, int NP = 3>
+template <int BM, int BN, int NP = 3, bool BDB = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? 3 : 1))) void conv_x3_s1_kernel(X3Args p) {
-    conv_x3_s1_body<BM, BN, false, NP>(p);
+    conv_x3_s1_body<BM, BN, false, NP, BDB>(p);
 }
 
 // (three waves per SIMD is what the trunk is tuned for: the loader-side BatchNorm must fit the same 168 registers)
-template <int BM, int BN, int NP = 3>
+template <int BM, int BN, int NP = 3, bool BDB = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_x3_s1_bnin_kernel(X3Args p) {
-    conv_x3_s1_body<BM, BN, true, NP>(p);
+    conv_x3_s1_body<BM, BN, true, NP, BDB>(p);
 }
 
 // mean / rstd of every (group, channel) from the per-tile partials: tile t of BM rows overlaps group g in n_t rows;
@@ -985,9 +1016,11 @@ int g_x3_s1 = 1;           // 3x3 / stride 1 / pad 1 layers: A image staged once
 
 constexpr size_t X3_S1_LDS_3PER_CU = 160 * 1024 / 3;       // three workgroups per CU: the occupancy the trunk convolutions are tuned for
 
+int g_x3_bdb = 1;    // f16x2 shared-tap kernels: two weight-tile buffers / one barrier per tap (mft_debug_set_x3_tile(30 | 31); 0 = round 4's form)
+
 inline size_t x3_s1_lds(int BM, int BN, int W, int bn_cin, int np = 3) {
     (void)W;
-    return (size_t)np * (BM + 18 + BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
+    return (size_t)np * (BM + 18 + ((np == 2 && g_x3_bdb) ? 2 : 1) * BN) * X3_RS * sizeof(unsigned short) + (size_t)4 * bn_cin * sizeof(float);
 }
 
 template <int BM, int BN>
@@ -999,9 +1032,12 @@ int launch_x3_s1(X3Args p, hipStream_t s, int np = 3) {
     p.s1_rows = BM + 18;                             // BM pixels + two halo pixels + sixteen zero rows (one per bank phase)
     const size_t lds = x3_s1_lds(BM, BN, p.W, p.bn_ws ? p.Cin : 0, np);
     const dim3 grid((unsigned)(tiles_m * p.tiles_n));
-    if (np == 2) {
-        if (p.bn_ws) hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN, 2>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN, 2>), grid, dim3(256), lds, s, p);
+    if (np == 2 && g_x3_bdb) {
+        if (p.bn_ws) hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN, 2, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN, 2, true>), grid, dim3(256), lds, s, p);
+    } else if (np == 2) {
+        if (p.bn_ws) hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN, 2, false>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_x3_s1_kernel<BM, BN, 2, false>), grid, dim3(256), lds, s, p);
     } else if (p.bn_ws) {
         hipLaunchKernelGGL((conv_x3_s1_bnin_kernel<BM, BN>), grid, dim3(256), lds, s, p);
     } else {
@@ -1059,7 +1095,7 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
 extern "C" int mft_debug_set_x3_tile(int t) {
 #ifndef MFT_EXPERIMENTS
     // product build: only the knobs that select VALIDATED alternative paths exist (tile shape 0-3, XCD order 20/21, staging-row
-    // assignment 40/41, shared-tap vs per-tap kernel 90/91); the measured-slower experiment kernels are not compiled in
+    // assignment 40/41, one / two weight-tile buffers 30/31, shared-tap vs per-tap kernel 90/91); the measured-slower experiment kernels are not compiled in
     const bool off = (t == 10 || t == 60 || t == 70 || t == 80 || t == 100 || t == 200);      // "experiment off" codes are no-ops
     if (!off && ((t >= 10 && t < 20) || t == 42 || (t >= 60 && t < 90) || t >= 100)) return MFT_EINVAL;
 #endif
@@ -1070,6 +1106,7 @@ extern "C" int mft_debug_set_x3_tile(int t) {
     else if (t >= 70) g_x3_pp = t - 70;
     else if (t >= 60) g_x3_db = t - 60;
     else if (t >= 40) g_x3_row_swz = t - 40;
+    else if (t >= 30) g_x3_bdb = t - 30;
     else if (t >= 20) g_x3_xcd = t - 20;
     else if (t >= 10) g_x3_patch = t - 10;
     else g_x3_tile = t;

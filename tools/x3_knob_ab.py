@@ -26,7 +26,8 @@ knobs = [int(k) for k in sys.argv[1:]] or [41]
 data = []
 for (name, cin, cout, k, s, p, H) in LAYERS:
     x = torch.randn(n, H, H, cin, device="cuda")
-    w3 = ops.split_weight_x3(ops.pack_conv_weight(torch.randn(cout, cin, k, k, device="cuda") * 0.05))
+    split = ops.split_weight_h2 if os.environ.get("X3_H2", "1") == "1" else ops.split_weight_x3      # f16x2 (default) | bf16x3 planes
+    w3 = split(ops.pack_conv_weight(torch.randn(cout, cin, k, k, device="cuda") * 0.05))
     data.append((name, x, w3, cout, k, s, p, ops.conv2d_x3(x, w3, cout, k, k, s, p)))
 ref = [d[7].clone() for d in data]            # outputs under the default knobs
 for kn in knobs:
