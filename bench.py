@@ -80,6 +80,37 @@ def pmc_traffic(E, fused=False):
 G9_NOISE, G9_SEED_SD, G9_EP_SEED0 = 2.0, 31, 90000          # oracle/make_golden_g9.py
 
 
+# ---- algorithmic work of one launch, from the launcher's own C-ABI arguments (positions as declared in include/mft_hip.h;
+# tests/test_host_cpu.py::test_bench_work_table_matches_the_header checks every index against the header's parameter names)
+def _osz(h, k, s_, p_):
+    return (h + 2 * p_ - k) // s_ + 1
+
+def _adam_bytes(a, n=8, cin=11, cout=12, kh=13, kw=14, ipg=17):          # read w, m, v + write w, m, v; the gradient never reaches HBM
+    return 24.0 * (a[n] // a[ipg]) * a[cout] * a[kh] * a[kw] * a[cin]
+
+def _conv_fl(a, n, h, w_, cin, cout, kh, kw, st, pd):
+    return 2.0 * a[n] * _osz(a[h], a[kh], a[st], a[pd]) * _osz(a[w_], a[kw], a[st], a[pd]) * a[cout] * a[kh] * a[kw] * a[cin]
+
+LAUNCH_WORK = {   # launcher -> (family, algorithmic bytes | flops of one call from its C-ABI arguments)
+    "mft_wgrad_adam_next_forward": ("adam", _adam_bytes),
+    "mft_conv2d_wgrad_adam_nhwc": ("adam", _adam_bytes),
+    "mft_conv2d_wgrad_adam_nhwc_dev": ("adam", _adam_bytes),
+    "mft_conv2d_wgrad_adam_dgrad_nhwc": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
+    "mft_conv2d_wgrad_adam_dgrad_nhwc_dev": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
+    "mft_conv2d_nhwc": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    "mft_conv2d_nhwc_ksplit": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    "mft_conv2d_nhwc_ksplit_grouped": ("f32", lambda a: _conv_fl(a, 5, 6, 7, 8, 9, 10, 11, 12, 13)),
+    "mft_conv2d_nhwc_x3": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    "mft_conv2d_nhwc_h2": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    "mft_conv2d_nhwc_x3_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    "mft_conv2d_nhwc_h2_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
+    # C2 of trunk.4 / trunk.5 with BN1 + ReLU applied by its loader (3x3, stride 1, pad 1): the same convolution FLOPs
+    "mft_conv2d_nhwc_x3_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
+    "mft_conv2d_nhwc_h2_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
+}
+
+
+
 def g9_state():
     """The weights of the accuracy golden G9 (seeded backbone + the head meta-trained with the REFERENCE's set_forward_loss,
     tests/golden/g9_head.npz): with them the engine's accuracies are comparable with the reference's own finetune() run."""
@@ -699,43 +730,16 @@ def main():
     # the implicit-GEMM convolutions (MFMA-bound) are reported next to it.
     from meta_fine_tuning_amd import _lib as _L
 
-    def _osz(h, k, s_, p_):
-        return (h + 2 * p_ - k) // s_ + 1
-
-    def _adam_bytes(a, n=8, cin=11, cout=12, kh=13, kw=14, ipg=17):          # read w, m, v + write w, m, v; the gradient never reaches HBM
-        return 24.0 * (a[n] // a[ipg]) * a[cout] * a[kh] * a[kw] * a[cin]
-
-    def _conv_fl(a, n, h, w_, cin, cout, kh, kw, st, pd):
-        return 2.0 * a[n] * _osz(a[h], a[kh], a[st], a[pd]) * _osz(a[w_], a[kw], a[st], a[pd]) * a[cout] * a[kh] * a[kw] * a[cin]
-
-    WORK = {   # launcher -> (family, algorithmic bytes | flops of one call from its C-ABI arguments)
-        "mft_wgrad_adam_next_forward": ("adam", _adam_bytes),
-        "mft_conv2d_wgrad_adam_nhwc": ("adam", _adam_bytes),
-        "mft_conv2d_wgrad_adam_nhwc_dev": ("adam", _adam_bytes),
-        "mft_conv2d_wgrad_adam_dgrad_nhwc": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
-        "mft_conv2d_wgrad_adam_dgrad_nhwc_dev": ("adam", lambda a: 24.0 * (a[8] // a[13]) * a[12] * 9 * a[11]),
-        "mft_conv2d_nhwc": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        "mft_conv2d_nhwc_ksplit": ("f32", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        "mft_conv2d_nhwc_ksplit_grouped": ("f32", lambda a: _conv_fl(a, 5, 6, 7, 8, 9, 10, 11, 12, 13)),
-        "mft_conv2d_nhwc_x3": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        "mft_conv2d_nhwc_h2": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        "mft_conv2d_nhwc_x3_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        "mft_conv2d_nhwc_h2_bnstats": ("x3", lambda a: _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)),
-        # C2 of trunk.4 / trunk.5 with BN1 + ReLU applied by its loader (3x3, stride 1, pad 1): the same convolution FLOPs
-        "mft_conv2d_nhwc_x3_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
-        "mft_conv2d_nhwc_h2_bnin_bnstats": ("x3", lambda a: 2.0 * a[9] * a[10] * a[11] * a[13] * 9 * a[12]),
-    }
-
     def timed_launches(fn):
         """Run ``fn`` with an event pair around every launch of the families above -> {family: [(ms, work), ...]}."""
-        with _L.LaunchTimer(only=WORK.__contains__, keep_args=True) as lt:
+        with _L.LaunchTimer(only=LAUNCH_WORK.__contains__, keep_args=True) as lt:
             fn()
             torch.cuda.synchronize()
             calls = lt.collect(calls=True)
             lt.close()
         fam = {"adam": [], "f32": [], "x3": []}
         for name, ms, a in calls:
-            kind, work = WORK[name]
+            kind, work = LAUNCH_WORK[name]
             fam[kind].append((ms, float(work(a))))
         return fam
 

@@ -550,3 +550,30 @@ def test_settings_object_is_the_single_typed_source_of_knobs(monkeypatch):
                 txt = open(os.path.join(root, f)).read()
                 stray += [(f, m) for m in re.findall(r"environ[^\n]*?(MFT_[A-Z0-9_]+)", txt)]
     assert not stray, stray
+
+
+def test_bench_work_table_matches_the_header():
+    """bench.LAUNCH_WORK derives the algorithmic bytes / flops of a launch from the launcher's C-ABI arguments BY POSITION: every
+    launcher it names must exist in include/mft_hip.h, and evaluating its formula on arguments built from the header's parameter
+    NAMES must give the textbook figure -- a signature change cannot silently shift an index."""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(root, "include", "mft_hip.h")).read(), flags=re.S)
+    vals = {"n_img": 640, "H": 6, "W": 6, "Cin": 256, "Cout": 512, "KH": 3, "KW": 3, "stride": 2, "pad": 1, "imgs_per_group": 5}
+    for name, (family, work) in bench.LAUNCH_WORK.items():
+        m = re.search(r"\bint\s+%s\s*\(([^;]*?)\)\s*;" % re.escape(name), hdr, flags=re.S)
+        assert m, "launcher %s is not declared in include/mft_hip.h" % name
+        params = [re.sub(r"[\*\s]", " ", q).split()[-1] for q in m.group(1).split(",")]
+        v = dict(vals)
+        if "KH" not in params:                                  # the 3x3 / stride-1 / pad-1 (or fixed 3x3) forms carry no kernel geometry
+            v.update(KH=3, KW=3, stride=1, pad=1)
+        args = [v.get(q, 0) for q in params]
+        assert {"n_img", "Cin", "Cout"} <= set(params), (name, params)
+        got = work(args)
+        oh = (v["H"] + 2 * v["pad"] - v["KH"]) // v["stride"] + 1
+        if family == "adam":
+            want = 24.0 * (v["n_img"] // v["imgs_per_group"]) * v["Cout"] * v["KH"] * v["KW"] * v["Cin"]
+        else:
+            want = 2.0 * v["n_img"] * oh * oh * v["Cout"] * v["KH"] * v["KW"] * v["Cin"]
+        assert got == want, (name, params, got, want)
+    assert {f for f, _ in bench.LAUNCH_WORK.values()} == {"adam", "f32", "x3"}
