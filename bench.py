@@ -344,7 +344,8 @@ def strong_scaling_leg(n_episodes, state, rank, world, dev, e_max=128, emulate_w
         ft._ENGINES.clear()
         return {"what": "rank 0's share of the fixed %d-episode job at W = %d (episodes 0, %d, %d, ...: %d episodes) run ALONE on one GPU "
                         "through finetune.evaluate -- what each of the %d ranks does concurrently on its own GPU; the W-rank job's wall is "
-                        "this plus the accuracy all-gather (600 doubles) and rank skew, which a 1-GPU box cannot measure"
+                        "this plus the accuracy all-gather (600 doubles) and rank skew, which a 1-GPU box cannot measure; the ratio to the 1-GPU "
+                        "leg can exceed W because a single-batch share skips the slab-placement scan (engine ready after 0.2 s instead of 0.7-1.2 s)"
                         % (n_episodes, emulate_world, emulate_world, 2 * emulate_world, len(accs), emulate_world),
                 "emulated_world": emulate_world, "rank_share_episodes": int(len(accs)), "rank_wall_s": round(dt, 3),
                 "projected_episodes_per_s": round(n_episodes / dt, 2), "episodes_per_batch": tm.get("episodes_per_batch"),
