@@ -1,4 +1,5 @@
 #!/bin/bash
+# Smaller lockstep batches with each round-5 kernel change switched off in turn, and the fused next-step forward on / off: gpurun -- bash tools/small_batches_ab.sh
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/e64; mkdir -p $O; : > $O/out.txt
 COMMON="--no-cpu-baseline --strong-episodes 0 --no-standalone --validate-episodes 0"
