@@ -139,7 +139,9 @@ def _check_full_length(accs, ref, spread):
     k = len(spread)
     d_ref = np.abs(spread - ref[:k])
     assert d.mean() <= max(2.0 * d_ref.mean(), 1.4), (d.mean(), d_ref.mean())                     # 1.4 = one query of 75
-    assert d.max() <= max(2.0 * d_ref.max(), 8.0 + 1e-6), (d.max(), d_ref.max())
+    # (the spread list is shorter than the accuracy list, so its maximum under-estimates the tail: never below G9's hard cap of
+    #  twelve queries)
+    assert d.max() <= max(2.0 * d_ref.max(), 16.0 + 1e-6), (d.max(), d_ref.max())
 
 
 def test_g19_accuracy_20shot_full_length(golden_dir):

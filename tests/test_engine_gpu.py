@@ -670,28 +670,32 @@ def test_inner_loop_500_steps_teacher_forced_trajectory(golden_dir):
         e.close()
 
 
-def test_inner_loop_2000_steps_teacher_forced_trajectory_20shot(golden_dir):
-    """The inner loop at the 20-shot README length (BASELINE configs[2]: 5 epochs x 400 mini-batches = 2000 Adam steps) on the
-    index order of golden G4d: last-block weight norms after 500 and 2000 steps against the reference's fp64 run, inside the
-    envelope the reference's OWN fp32 variants span around it (default, 1 ATen thread, oneDNN off -- other summation orders of
-    the same arithmetic), probe features within 4x the reference's own fp32-vs-fp64 distance."""
+@pytest.mark.parametrize("ns,fname,ep_seed,marks", [(20, "g4d_inner_loop_2000.npz", 331, (500, 2000)),
+                                                    (50, "g4e_inner_loop_5000.npz", 332, (2000, 5000))])
+def test_inner_loop_full_length_teacher_forced_trajectory(golden_dir, ns, fname, ep_seed, marks):
+    """The inner loop at the README length of the 20-shot (BASELINE configs[2]: 5 epochs x 400 mini-batches = 2000 Adam steps) and
+    50-shot (configs[4], finetune_50.py:264-299: 5 x 1000 = 5000 steps) runs, on the index order of goldens G4d / G4e: last-block
+    weight norms at two marks against the reference's fp64 run, inside the envelope the reference's OWN fp32 variants span
+    around it (default, 1 ATen thread, oneDNN off -- other summation orders of the same arithmetic), probe features within 4x
+    the reference's own fp32-vs-fp64 distance."""
     import os
-    if not os.path.exists(os.path.join(golden_dir, "g4d_inner_loop_2000.npz")):
-        pytest.skip("golden g4d not generated")
-    g = _g(golden_dir, "g4d_inner_loop_2000.npz")
+    if not os.path.exists(os.path.join(golden_dir, fname)):
+        pytest.skip("golden %s not generated" % fname)
+    g = _g(golden_dir, fname)
     size = 84
     sd = synthetic.resnet10_state_dict(seed=9)
-    views = synthetic.test_episode(331, 5, 20, 15, size, gen_examples=17)
+    views = synthetic.test_episode(ep_seed, 5, ns, 15, size, gen_examples=17)
     full = {"feature." + k: v for k, v in sd.items()}
     full.update(synthetic.gnn_head_state_dict(seed=1))
     order = g["order"]
     fp32_variants = [v for v in g["variants"] if v != "f64"]
-    for tag in (500, 2000):
-        e = eng.FinetuneEngine(full, n_support=20, n_views=19, fine_tune_epoch=5, episodes_per_batch=1, device=DEV)
+    nt = 100 * ns                                            # 5 * ns supports x (19 + 1) views
+    for tag in marks:
+        e = eng.FinetuneEngine(full, n_support=ns, n_views=19, fine_tune_epoch=5, episodes_per_batch=1, device=DEV)
         e._ingest([views], False)
         e.adapt.reset(e.W)
         e.prepare_batch()
-        perms = [[order[ep * 2000:(ep + 1) * 2000] for ep in range(5)]]
+        perms = [[order[ep * nt:(ep + 1) * nt] for ep in range(5)]]
         e.inner_loop(e.step_tables(perms, 1)[:tag])
         torch.cuda.synchronize()
         w = e.adapt.w.export(0)
@@ -699,7 +703,7 @@ def test_inner_loop_2000_steps_teacher_forced_trajectory_20shot(golden_dir):
             n_hip, n64 = float(w[key].norm()), float(g["%s_s%d_f64" % (gk, tag)])
             spread = max(abs(float(g["%s_s%d_%s" % (gk, tag, v)]) - n64) for v in fp32_variants)
             assert abs(n_hip - n64) <= max(2.0 * spread, 0.02), (key, tag, n_hip, n64, spread)
-        xa = torch.cat([v[:, :20].contiguous().view(100, 3, size, size) for v in [views[0]] + views], 0)
+        xa = views[0][:, :ns].contiguous().view(5 * ns, 3, size, size)           # (the probe = the first five support images)
         feat = Fn.resnet10_forward(e.W, ops.nchw_to_nhwc(xa[:5].to(DEV)), Fn.Arena(DEV), ipg=5, slab=e.adapt.w).cpu().numpy()
         p64 = g["probe_s%d_f64" % tag]
         d_ref = max(np.percentile(np.abs(g["probe_s%d_%s" % (tag, v)] - p64), 99) for v in fp32_variants)
