@@ -482,7 +482,24 @@ def bench_metatrain(args, rank, world, dev, dist):
     model.n_query = 16
     opt = optim.Adam(model.parameters())
     bucket = parallel.FlatGradBucket(model.parameters())
-    eps = [synthetic.train_episode(5000 + 100 * rank + i, 5, 5, 16, 84).to(dev) for i in range(8)]
+    # Episode source (BASELINE configs[3]: "miniImageNet-shaped synthetic"): by default every step SAMPLES its episode inside the
+    # timed region from a miniImageNet-shaped uint8 pool resident in HBM -- randperm(64)[:5] classes, 21 distinct images per class,
+    # the training-side transform in one mft_augment_views launch (train.ResidentEpisodeLoader); the pool itself is generated
+    # before the clock starts.  --train-source fixed: eight pre-made fp32 episodes cycled (rounds 1-4).
+    if args.train_source == "pool":
+        from meta_fine_tuning_amd import train as _train
+        pool = synthetic.class_pool_u8("miniImageNet", torch.device(dev), seed=0)
+        loader = _train.ResidentEpisodeLoader(pool, 5, 5, 16, 84, n_episode=1 << 30, aug=args.train_aug, seed=100 + rank)
+
+        class _Eps:              # the loader's episodes, indexed like the fixed list
+            def __getitem__(self, i):
+                return loader.episode(0, i)
+
+            def __len__(self):
+                return 1 << 30
+        eps = _Eps()
+    else:
+        eps = [synthetic.train_episode(5000 + 100 * rank + i, 5, 5, 16, 84).to(dev) for i in range(8)]
 
     from meta_fine_tuning_amd import graph_step
     finetune = args.workload == "metafinetune"                        # train.py --fine_tune: set_forward_loss_finetune (gnnnet.py:106-231)
@@ -533,7 +550,11 @@ def bench_metatrain(args, rank, world, dev, dist):
             "config": {"workload": ("meta-fine-tuning training step (train.py --fine_tune, gnnnet.py:106-231: 105 inner Adam steps on trunk.7 per "
                                     "episode, then the outer step)" if finetune else "meta-training step (BASELINE configs[3])") +
                                    ": 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
-                                   "flat 21.2 MB gradient all-reduce + fused outer Adam", "parallelism": "episode-parallel x%d" % world},
+                                   "flat 21.2 MB gradient all-reduce + fused outer Adam",
+                       "episode_source": ("sampled per step inside the timed region from a miniImageNet-shaped resident uint8 pool "
+                                          "(64 x 600 x 84x84; %s transform on the device)" % ("--train_aug" if args.train_aug else "Resize + CenterCrop")
+                                          if args.train_source == "pool" else "eight pre-made fp32 episodes, cycled"),
+                       "parallelism": "episode-parallel x%d" % world},
             "last_loss": round(float(loss.detach().cpu()), 4), "graphed": graphed is not None and graphed.graph is not None,
             "roofline": roof, "cpu_baseline": cpu}))
     if dist is not None:
@@ -561,6 +582,11 @@ def main():
                          "rank per step (set_forward_loss -> full backward -> flat-bucket RCCL all-reduce -> fused outer Adam)")
     ap.add_argument("--image-size", type=int, default=84, help="84 = BASELINE configs (the metric); 224 = the reference's hard-coded "
                     "image_size (train.py:72, finetune.py:429) -- extra measurement, FLOP-derived fields then refer to 84")
+    ap.add_argument("--train-source", default="pool", choices=["pool", "fixed"],
+                    help="--workload metatrain / metafinetune: pool = sample every episode on the device from a miniImageNet-shaped "
+                         "resident uint8 pool inside the timed region (default); fixed = cycle eight pre-made fp32 episodes")
+    ap.add_argument("--train-aug", action="store_true", help="with --train-source pool: the --train_aug transform "
+                    "(RandomResizedCrop + ImageJitter + flip) instead of Resize + CenterCrop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-standalone", action="store_true", help="skip the extra standalone launches of the dominant kernel "
                     "(roofline.standalone); used for the PMC passes so that per-launch counter means cover the step mix only")

@@ -151,7 +151,10 @@ def augment_views(src_u8, params, size, out=None, view_stride=None, img_stride=N
     if not src_u8.is_cuda or src_u8.dtype != torch.uint8 or not src_u8.is_contiguous():
         raise RuntimeError("augment_views needs a contiguous uint8 CUDA (HIP) tensor [n_img, Hs, Ws, 3]")
     n_img, Hs, Ws, _ = src_u8.shape
-    p = torch.as_tensor(params, dtype=torch.float32).to(src_u8.device).contiguous()
+    if torch.is_tensor(params) and params.is_cuda and params.dtype == torch.float32:
+        p = params.contiguous()                  # already on the device (train.ResidentEpisodeLoader uploads a chunk of episodes at once)
+    else:
+        p = torch.as_tensor(params, dtype=torch.float32).to(src_u8.device).contiguous()
     n_views = p.shape[0]
     assert p.shape == (n_views, n_img, NPARAM)
     if out is None:
