@@ -247,18 +247,21 @@ def test_bench_helpers_and_pmc_provenance(tmp_path, monkeypatch):
     fl = bench.episode_flops(5, 5, 15, 19, 5)
     assert abs(fl / 1e12 - 1.0228) < 2e-3
     assert bench.episode_flops(5, 20, 15, 19, 5) > 3.9e12 and bench.episode_flops(5, 50, 15, 19, 5) > 9.9e12
-    sha = bench.kernel_source_sha()
-    assert len(sha) == 16
+    assert len(bench.kernel_source_sha()) == 16 and bench.kernel_source_sha(True) != bench.kernel_source_sha(False)
     # the refusal logic: a record is quoted only for its own episodes-per-step AND byte-identical kernel source.  Whether the
     # COMMITTED record is fresh is a profiling-job matter (any edit of the kernel file stales it until the PMC passes are re-run
     # on a GPU box): a stale record only warns here, and bench.py then reports traffic = null.
     with open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")) as f:
         rec = json.load(f)
+    fused = rec["kernel"].startswith("wgrad_adam_fwd_kernel")          # which of the two dominant-kernel forms the record was taken on
+    sha = bench.kernel_source_sha(fused)
     if rec["kernel_source_sha16"] != sha:
         import warnings
         warnings.warn("profiles/pmc_traffic.json was measured on other kernel source (%s, now %s): bench.py reports "
                       "roofline.traffic = null until tools/final_profiles.sh is re-run" % (rec["kernel_source_sha16"], sha))
-        assert bench.pmc_traffic(rec["episodes_per_step"]) is None
+        assert bench.pmc_traffic(rec["episodes_per_step"], fused) is None
+    else:
+        assert bench.pmc_traffic(rec["episodes_per_step"], fused) is not None      # the committed record belongs to THIS tree's kernel
     monkeypatch.setattr(bench, "kernel_source_sha", lambda fused=False: rec["kernel_source_sha16"])
     t = bench.pmc_traffic(rec["episodes_per_step"])
     assert t is not None and 1.0 <= t["mb_per_launch"] / t["algorithmic_mb_per_launch"] < 1.1
