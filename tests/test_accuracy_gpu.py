@@ -152,5 +152,5 @@ def test_g19_accuracy_20shot_full_length(golden_dir):
 
 def test_g19_accuracy_50shot_full_length(golden_dir):
     """BASELINE configs[4] (finetune_50.py + gnnnet_copy fold) at the README's length: 5000 Adam steps per episode, N = 130."""
-    accs, ref, spread = _run_g19(golden_dir, "g19_accuracy_50shot.npz", 50, 128, True)
+    accs, ref, spread = _run_g19(golden_dir, "g19_accuracy_50shot.npz", 50, 64, True)          # (E = 64: bench.py's 50-shot batch)
     _check_full_length(accs, ref, spread)

@@ -13,7 +13,7 @@ import test_accuracy_gpu as T
 
 gd = os.path.join(ROOT, "tests", "golden")
 for name, fname, ns, batch, fold in (("20-shot, 2000 steps/episode, E = 96", "g19_accuracy_20shot.npz", 20, 96, False),
-                                     ("50-shot, 5000 steps/episode, E = 40", "g19_accuracy_50shot.npz", 50, 128, True)):
+                                     ("50-shot, 5000 steps/episode, E = 64", "g19_accuracy_50shot.npz", 50, 64, True)):
     accs, ref, spread = T._run_g19(gd, fname, ns, batch, fold)
     d = np.abs(accs - ref)
     k = len(spread)
