@@ -442,9 +442,12 @@ def balanced_batch(n_mine, e_max):
 
 
 def short_job_candidates(n_batches):
-    """Slab-placement candidates for an evaluation of ``n_batches`` lockstep batches on this rank: the full scan (12) returns
-    1.4-2.2 % of a long job's time and costs 0.8 s; 8 candidates cost 0.3 s; a single batch (about a second of work) gets none."""
-    return 0 if n_batches <= 1 else (8 if n_batches <= 8 else None)
+    """Slab-placement candidates for an evaluation of ``n_batches`` lockstep batches on this rank (None = the engine's default,
+    12).  The scan returns 1.4-2.2 % of a long job's time and costs 0.3-0.8 s of allocation + probing on a good lease -- and
+    2.5-3.5 s on a lease whose allocations are slow (round 5, profiles/r05_j_fixed_job_marks.txt: the 5-batch 600-episode job
+    7.75 / 7.82 / 8.00 s without it, 7.89 / 8.11 / 8.56 s with the 8-candidate scan round 4 used here, 11.7-12.3 s on a slow
+    lease).  So only jobs of more than 8 batches (about 12 s of work) scan."""
+    return 0 if n_batches <= 8 else None
 
 
 def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_examples, fine_tune_epoch, seed0=0,
