@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const long long out_row0 = (long long)g * p.rows_per_group;
     if (p.ksplit > 1) {                    // partial tile of this K slice: ws[slice][all groups' rows][Cout]
-        float* part = p.ws + ((long long)blockIdx.z * gridDim.y * p.rows_per_group + out_row0) * p.Cout;
+        // (parity mode: one group, grid.y = class; a class's rows land at their dx pixel's row, so every row of a slice is written by
+        // exactly one class -- classes without taps write zeros -- and the slice sum below needs no parity logic)
+        float* part = p.ws + ((long long)blockIdx.z * (par ? 1 : (int)gridDim.y) * p.rows_per_group + out_row0) * p.Cout;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -295,7 +297,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m < p.rows_per_group) part[(long long)m * p.Cout + n] = acc[i][j][e];
+                    if (m >= rows) continue;
+                    long long orow = m;
+                    if (par) {
+                        const int img = m / ohw, rem = m - img * ohw;
+                        const int ii = rem / Wc, jj = rem - ii * Wc;
+                        orow = ((long long)img * p.OH + 2 * ii + ph) * p.OW + 2 * jj + pw;
+                    }
+                    part[orow * p.Cout + n] = acc[i][j][e];
                 }
             }
         return;
@@ -368,15 +377,15 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
             attr_once.mark();
         }
     }
-    if (p.ksplit > 1 && (p.ws == nullptr || p.parity)) return MFT_EINVAL;
+    if (p.ksplit > 1 && p.ws == nullptr) return MFT_EINVAL;
     if (p.parity) {
         if (!BT || groups != 1 || p.bt_stride != 2) return MFT_EINVAL;
         const int tm = cdiv(p.imgs_per_group * ((p.OH + 1) / 2) * ((p.OW + 1) / 2), BM);       // the largest class
-        hipLaunchKernelGGL(kern, dim3(tm * p.tiles_n, 4, 1), dim3(256), lds, s, p);
-        return mft_launch_status();
+        hipLaunchKernelGGL(kern, dim3(tm * p.tiles_n, 4, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, s, p);
+    } else {
+        dim3 grid(tiles_m * p.tiles_n, groups, p.ksplit > 1 ? p.ksplit : 1);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     }
-    dim3 grid(tiles_m * p.tiles_n, groups, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (p.ksplit > 1) {
         const long long total = (long long)groups * p.rows_per_group * (p.Cout / 4);
         long long blocks = (total + 255) / 256;
@@ -1110,9 +1119,18 @@ static int dgrad_impl(const float* dy, int ldy, const float* w, float* dx, int l
     a.tiles_n = 0;
     a.ksplit = 1; a.ws = nullptr;
     a.parity = (groups == 1 && stride == 2 && g_dgrad_parity) ? 1 : 0;
-    if (!a.parity && ws != nullptr && ldx % 4 == 0 && Cin % 64 == 0) {
-        a.ksplit = conv_ksplit(a.rows_per_group, Cin, a.Kpad, groups);
-        a.ws = ws;
+    if (ws != nullptr && ldx % 4 == 0 && Cin % 64 == 0) {
+        const int s_full = conv_ksplit(a.rows_per_group, Cin, a.Kpad, groups);      // what mft_conv_ksplit_ws_floats sized ws for
+        if (!a.parity) {
+            a.ksplit = s_full;
+            a.ws = ws;
+        } else if (s_full > 1) {
+            // parity classes: the class with the most taps walks ceil(KH/2) * ceil(KW/2) * Cout (trunk.7.C1's data gradient: 64
+            // K-steps on 240 tiles = 86 us of dependent steps, round 5); sliced like a four-group launch of the largest class
+            int sp = conv_ksplit((long long)imgs_per_group * ((H + 1) / 2) * ((W + 1) / 2), Cin, ((KH + 1) / 2) * ((KW + 1) / 2) * Cout, 4);
+            if (sp > s_full) sp = s_full;
+            if (sp > 1) { a.ksplit = sp; a.ws = ws; }
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     if (Cin % 64 == 0) return launch_conv<64, 64, 2, 2, false, true>(a, groups, s);
