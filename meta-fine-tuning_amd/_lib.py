@@ -234,6 +234,11 @@ class LaunchTimer:
     def __exit__(self, *exc):
         global _lib
         _lib = self._real
+        if exc and exc[0] is not None:         # the block raised: nobody will collect() -- do not leave the event pairs behind
+            for _, a, b, _ in self._pairs:
+                self._free += [a, b]
+            self._pairs = []
+            self.close()
         return False
 
     def collect(self, calls=False):
