@@ -412,17 +412,24 @@ def metatrain_roofline(model, opt, eps, step_s):
     """Roofline of the meta-training step (BASELINE configs[3]; round-4 verdict "missing 4"): three EAGER steps (the graphed step
     replays the same launches from one hipGraph, where nothing can be bracketed) with every C-ABI launcher call timed by a pair of
     HIP events on its own stream (_lib.LaunchTimer).  The step is a dense contraction (MFMA-bound): the
-    dominant class of launches is reported against the fp32-MFMA peak with its algorithmic FLOPs (backbone convolutions of 105
-    images of 84x84: forward 30.0, weight gradients 30.0, data gradients 26.5 GFLOP -- no data gradient for the stem); the other
-    classes are listed by their share of the eager step's kernel time."""
+    dominant class of launches is reported against the fp32-MFMA peak with its algorithmic FLOPs, summed per launch from the C-ABI
+    arguments (2 * output positions * Cout * KH * KW * Cin for every convolution / linear launch of the class: the backbone's 105
+    images of 84x84 AND the head's linear layers over 7,440 pair rows -- SURVEY.md section 8(d) counts conv + linear); the other
+    classes are listed by their share of the eager step's kernel time.  The four trunk.4 / trunk.5 forward launches and three
+    stride-1 data-gradient launches that run on the bf16x3 kernels (round 5) are counted with their class, at algorithmic FLOPs."""
     from meta_fine_tuning_amd import _lib
-    n_img, f_img = 105, 0.28585e9                                    # SURVEY.md section 8(d): F_img at 84x84
-    stem = 2.0 * 42 * 42 * 64 * 147
-    flops = {"forward convolutions": n_img * f_img, "weight gradients": n_img * f_img, "data gradients": n_img * (f_img - stem)}
 
-    def klass(name):
-        if name.startswith("mft_conv2d_dgrad"):
-            return "data gradients"
+    def conv_flops(name, a):
+        """Algorithmic FLOPs of one convolution-family launch from its C-ABI arguments (None: not one)."""
+        if name in ("mft_conv2d_nhwc", "mft_conv2d_nhwc_ksplit", "mft_conv2d_nhwc_x3"):
+            return _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)
+        if name.startswith(("mft_conv2d_dgrad_nhwc", "mft_conv2d_wgrad_nhwc", "mft_conv2d_wgrad_oihw")):
+            return _conv_fl(a, 5, 6, 7, 8, 9, 10, 11, 12, 13)       # (n, H, W = the forward input's; Cin, Cout the forward's)
+        return None
+
+    def klass(name, backward):
+        if name.startswith("mft_conv2d_dgrad") or (name == "mft_conv2d_nhwc_x3" and backward):
+            return "data gradients"                 # (stride-1 3x3 data gradients of the large layers run as bf16x3 convolutions)
         if name.startswith("mft_conv2d_wgrad"):
             return "weight gradients"
         if name.startswith("mft_conv2d_nhwc"):
@@ -431,36 +438,44 @@ def metatrain_roofline(model, opt, eps, step_s):
             return "pair-MLP (GNN Wcompute) forward + backward"
         if name.startswith("mft_bn_") or "bn_backward" in name:
             return "BatchNorm statistics / apply / backward"
-        if name.startswith(("mft_adam", "mft_pack_")):
-            return "outer Adam + weight repack"
+        if name.startswith(("mft_adam", "mft_pack_", "mft_split_")):
+            return "outer Adam + weight repack / plane refresh"
         return "other (pooling, losses, copies, GNN glue)"
 
     reps = 3
-    with _lib.LaunchTimer() as lt:
-        for i in range(reps):
+    per = {}
+    for i in range(reps):
+        with _lib.LaunchTimer(keep_args=True) as lt:
             opt.zero_grad()
             loss = model.set_forward_loss(eps[i % len(eps)])
             loss.backward()
             opt.step()
-        torch.cuda.synchronize()
-        times = lt.collect()
-        lt.close()
-    per = {}
-    for name, v in times.items():
-        c = per.setdefault(klass(name), {"ms_per_step": 0.0, "launches_per_step": 0})
-        c["ms_per_step"] += sum(v) / reps
-        c["launches_per_step"] += len(v) // reps
+            torch.cuda.synchronize()
+            calls = lt.collect(calls=True)
+            lt.close()
+        backward = False
+        for name, ms, a in calls:
+            backward = backward or ("backward" in name) or name.startswith(("mft_conv2d_dgrad", "mft_conv2d_wgrad"))
+            c = per.setdefault(klass(name, backward), {"ms_per_step": 0.0, "launches_per_step": 0, "gflop": 0.0})
+            c["ms_per_step"] += ms / reps
+            c["launches_per_step"] += 1
+            fl = conv_flops(name, a)
+            if fl is not None:
+                c["gflop"] += fl / reps / 1e9
     total = sum(c["ms_per_step"] for c in per.values())
     for c in per.values():
+        c["launches_per_step"] //= reps
         c["share"] = round(c["ms_per_step"] / total, 3)
         c["ms_per_step"] = round(c["ms_per_step"], 4)
+    flops = {k: v["gflop"] * 1e9 for k, v in per.items() if v["gflop"] > 0}
     dom = max(flops, key=lambda k: per.get(k, {"ms_per_step": 0.0})["ms_per_step"])
     ach = flops[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e12
     whole = 112e9 / step_s / 1e12               # 112 GFLOP per 84x84 meta-train episode
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": (PEAK_F32_MFMA / 1e12), "unit": "TFLOP/s", "frac": round(ach / (PEAK_F32_MFMA / 1e12), 4),
-            "traffic": None, "kernel": "%s (fp32 MFMA implicit GEMM; %.1f algorithmic GFLOP per step in %d launches)"
+            "traffic": None, "kernel": "%s (fp32 MFMA implicit GEMM; %.1f algorithmic GFLOP per step in %d launches, summed per launch from the C-ABI arguments)"
                                        % (dom, flops[dom] / 1e9, per[dom]["launches_per_step"]),
-            "classes": {k: dict(v, tflops=round(flops[k] / (v["ms_per_step"] * 1e-3) / 1e12, 2)) if k in flops else v
+            "classes": {k: (dict(v, gflop=round(v["gflop"], 2), tflops=round(flops[k] / (v["ms_per_step"] * 1e-3) / 1e12, 2)) if k in flops
+                            else {kk: vv for kk, vv in v.items() if kk != "gflop"})
                         for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "eager_kernel_ms_per_step": round(total, 3),
             "whole_step": {"algorithmic_gflop": 112.0, "tflops": round(whole, 2), "frac_of_f32_mfma_peak": round(whole / (PEAK_F32_MFMA / 1e12), 4),

@@ -169,6 +169,12 @@ int mft_conv2d_nhwc(const float* in, int ldi, const float* w, const float* bias,
  * a packed fp32 weight matrix [n] into three bf16 planes [3][n] once; mft_conv2d_nhwc_x3 consumes them (no bias, no groups;
  * Cin % 32 == 0, Cout % 64 == 0).  Replaces the same nn.Conv2d.forward call sites as mft_conv2d_nhwc for trunk.4-6.      */
 int mft_split_bf16x3(const float* w, unsigned short* planes, long long n, void* stream);
+/* The planes of SEVERAL weight matrices in one launch -- the per-step refresh of the meta-training path, where optimizer.step()
+ * (train.py:28, meta_template.py:87) changes every weight: jobs = n_jobs records of 8 x int64 in device memory {packed fp32 source
+ * [Cout][taps][Cin], planes [3][n], n = Cout*taps*Cin, Cout, Cin, taps, transposed, first element}, ordered by first element
+ * (the running sum of n).  transposed = 1 writes the planes of the stride-1 DATA-GRADIENT operand wt[ci][taps-1-tap][co] =
+ * w[co][tap][ci] (autograd of nn.Conv2d, loss.backward() at meta_template.py:86: dx = mft_conv2d_nhwc_x3(dy, wt), same padding). */
+int mft_split_bf16x3_multi(const void* jobs, int n_jobs, long long total_elements, void* stream);
 int mft_conv2d_nhwc_x3(const float* in, int ldi, const unsigned short* w3, long long plane_elems, float* out, int ldo,
                        int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* mft_conv2d_nhwc_x3 with the statistics of the train-mode BatchNorm that follows it (backbone.py:224-227) produced in the

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mft_debug_set_conv_tile": [_I],
     "mft_debug_reset": [],
     "mft_split_bf16x3": [_P, _P, _L, _P],
+    "mft_split_bf16x3_multi": [_P, _I, _L, _P],
     "mft_conv2d_nhwc_x3": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mft_debug_set_x3_tile": [_I],
     "mft_conv2d_x3_stats_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I],

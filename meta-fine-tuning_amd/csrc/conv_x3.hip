@@ -928,6 +928,40 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+// Several weight matrices split in ONE launch (meta-training: the weights change every step, so the planes of every layer that
+// runs on these kernels are refreshed per step; round 5).  Job = {packed fp32 source [Cout][taps][Cin], planes [3][n], n = Cout *
+// taps * Cin, Cout, Cin, taps, transposed, first element}; ``transposed``: the planes hold the DATA-GRADIENT operand of a stride-1
+// convolution, wt[ci][taps - 1 - tap][co] = w[co][tap][ci] (the tap-flipped, channel-swapped weights: dx = conv(dy, wt), same
+// padding) -- writes coalesced along co, reads strided (the matrices are L2-sized).  Same arithmetic as split_bf16x3_kernel.
+struct SplitJob { const float* src; unsigned short* dst; long long n, Cout, Cin, taps, transposed, start; };
+
+__global__ __launch_bounds__(256) void split_bf16x3_multi_kernel(const SplitJob* __restrict__ jobs, int n_jobs, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const SplitJob j = jobs[lo];
+        const long long l = i - j.start;
+        long long src = l;
+        if (j.transposed) {
+            const long long co = l % j.Cout, t = l / j.Cout;
+            const long long tp = t % j.taps, ci = t / j.taps;
+            src = (co * j.taps + (j.taps - 1 - tp)) * j.Cin + ci;
+        }
+        const float x = j.src[src];
+        const unsigned q1 = pk_bf16(x, 0.f) & 0xffffu;
+        const float r1 = x - __builtin_bit_cast(float, q1 << 16);
+        const unsigned q2 = pk_bf16(r1, 0.f) & 0xffffu;
+        const float r2 = r1 - __builtin_bit_cast(float, q2 << 16);
+        const unsigned q3 = pk_bf16(r2, 0.f) & 0xffffu;
+        j.dst[l] = (unsigned short)q1;
+        j.dst[j.n + l] = (unsigned short)q2;
+        j.dst[2 * j.n + l] = (unsigned short)q3;
+    }
+}
+
 // weights for the f16x2 kernels: [2][n] fp16 planes (hi, lo * 2^11), the same arithmetic as split4_h2
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -1089,6 +1123,15 @@ extern "C" int mft_split_bf16x3(const float* w, unsigned short* planes, long lon
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, planes, n);
+    return mft_launch_status();
+}
+
+extern "C" int mft_split_bf16x3_multi(const void* jobs, int n_jobs, long long total_elements, void* stream) {
+    if (n_jobs < 1 || total_elements < 1) return MFT_EINVAL;
+    long long blocks = (total_elements + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_bf16x3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const SplitJob*)jobs, n_jobs,
+                       total_elements);
     return mft_launch_status();
 }
 

@@ -36,6 +36,8 @@ X3_FOLD_BN = settings.current().x3_fold_bn
 # pieces (six products): half the matrix work at an error below an fp32-accumulating GEMM's.  Taken only when the state dict
 # passes ``f16x2_safe`` (every operand provably inside fp16's range); MFT_TRUNK_F16X2=0 keeps the bf16x3 kernels.
 TRUNK_F16X2 = settings.current().trunk_f16x2
+TRAIN_X3 = settings.current().train_x3            # meta-training: large 3x3 layers on the bf16x3 kernels (ResNet10Weights.train_planes)
+TRAIN_X3_MIN_ROWS = 8192
 # fused next-step forward (engine.fuse_next), opt-in variant: only trunk.7.C2's launch is the fused walking kernel, C1 / shortcut keep
 # the plain gradient + Adam launches + one entry launch (last_block_backward).  Alone that chain is 100 us shorter, in situ it is
 # slower: 87.2 vs 88.8-89.0 episodes/s (profiles/r04_d_fuse_c2_only_ab.txt) -- default 0 = all three layers fused
@@ -161,6 +163,8 @@ class ResNet10Weights:
         split = ops.split_weight_h2 if self.f16x2 else ops.split_weight_x3
         self.bn = {}
         self.plan = ops.PackPlan()          # sources that are live device tensors: repack() refreshes every packed copy in one launch
+        self.train3 = {}                    # meta-training: (layer, transposed) -> bf16x3 planes, registered on first use (train_planes)
+        self.tplan = ops.SplitPlan()
 
         def dev(t):
             return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -201,11 +205,33 @@ class ResNet10Weights:
         return self.conv3 if ipg * side * side <= self.f16x2_rows else {}
 
     def repack(self):
-        """The source parameters changed in place (optimizer.step): refresh every packed convolution weight with ONE launch.
+        """The source parameters changed in place (optimizer.step): refresh every packed convolution weight with ONE launch (and
+        the split planes of the layers the meta-training step runs on the split-precision kernels with a second one).
         BatchNorm weights / biases alias the parameters and need nothing.  Only valid when every convolution's source is a
         live device tensor (``can_repack``)."""
         assert self.can_repack()
         self.plan.run()
+        self.tplan.run()
+
+    def train_planes(self, name, cin, cout, k, stride, rows_out, transposed=False):
+        """Meta-training (weights change every step, one 105-image BatchNorm group, round 5): the bf16x3 planes of 3x3 layer
+        ``name`` -- of its tap-flipped / channel-swapped data-gradient operand with ``transposed`` -- if the layer is worth running
+        on the split-precision kernels, else None.  Worth it = enough output rows to fill the machine with 128-row tiles
+        (measured on 105 images of 84 x 84, profiles/r05_m_metatrain_x3.txt: 21 x 21 and 11 x 11 maps 1.4-1.7x the K-sliced fp32-MFMA
+        launch, 6 x 6 and 3 x 3 maps slower); bf16x3 has no range condition, so no proof about the changing weights is needed.
+        Planes are created at the first request and refreshed by ``repack()`` from then on."""
+        if not TRAIN_X3 or k != 3 or rows_out < TRAIN_X3_MIN_ROWS:
+            return None
+        ci, co = (cout, cin) if transposed else (cin, cout)          # the kernel's view: ci input channels -> co output channels
+        if ci % 32 != 0 or co % 64 != 0 or (transposed and stride != 1):
+            return None
+        key = (name, transposed)
+        pl = self.train3.get(key)
+        if pl is None:
+            if not self.can_repack():
+                return None
+            pl = self.train3[key] = self.tplan.add(self.conv[name], cout, cin, k * k, transposed)
+        return pl
 
     def can_repack(self):
         return len(self.plan.jobs) == len(self.conv) and not self.conv3

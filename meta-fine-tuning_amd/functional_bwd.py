@@ -71,6 +71,15 @@ def resnet10_forward_taped(W, x, running=None):
     def run(name):
         return None if running is None else running.get(name)
 
+    def conv3x3(name, inp, cin, cout, stride, rows_out):
+        w3 = W.train_planes(name, cin, cout, 3, stride, rows_out)
+        # the data-gradient operand's planes are registered HERE, on the caller's thread: the backward runs on autograd's device
+        # thread, where the host-to-device copy of a new job table aborts the process on this stack (measured, round 5)
+        W.train_planes(name, cin, cout, 3, stride, rows_out, transposed=True)
+        if w3 is not None:                       # bf16x3: fp32-accurate on the 16-bit matrix cores (planes refreshed by W.repack())
+            return ops.conv2d_x3(inp, w3, cout, 3, 3, stride, 1)
+        return ops.conv2d(inp, W.conv[name], cout, 3, 3, stride, 1)
+
     c0 = ops.conv2d(x, W.conv["trunk.0"], 64, 7, 7, 2, 3)
     H0 = c0.shape[1]
     m0, s0 = bn_stats(c0.view(-1, 64), 64, n * H0 * H0, run("trunk.1"))
@@ -90,11 +99,11 @@ def resnet10_forward_taped(W, x, running=None):
         OH = (H + 2 - 3) // stride + 1
         rows = n * OH * OH
         b = {"p": p, "x": a, "cin": cin, "cout": cout, "stride": stride, "rows": rows}
-        c1 = ops.conv2d(a, W.conv[p + ".C1"], cout, 3, 3, stride, 1)
+        c1 = conv3x3(p + ".C1", a, cin, cout, stride, rows)
         m1, s1 = bn_stats(c1.view(-1, cout), cout, rows, run(p + ".BN1"))
         g1, be1 = W.bn[p + ".BN1"]
         r1 = ops.bn_apply(c1.view(-1, cout), cout, rows, 1, m1, s1, g1, be1, act=RELU).view(n, OH, OH, cout)
-        c2 = ops.conv2d(r1, W.conv[p + ".C2"], cout, 3, 3, 1, 1)
+        c2 = conv3x3(p + ".C2", r1, cout, cout, 1, rows)
         m2, s2 = bn_stats(c2.view(-1, cout), cout, rows, run(p + ".BN2"))
         g2, be2 = W.bn[p + ".BN2"]
         if cin != cout:
@@ -120,6 +129,13 @@ def resnet10_backward(W, t, dfeat, need):
     n = t["n"]
     dev = dfeat.device
     grads = {}
+
+    def dgrad3x3(name, dy, cin, cout, stride, rows, H_in):
+        wt3 = W.train3.get((name, True))         # registered by the forward (resnet10_forward_taped.conv3x3); never created here
+        if wt3 is not None:                      # stride 1: dx = conv(dy, tap-flipped channel-swapped weights), same padding
+            return ops.conv2d_x3(dy, wt3, cin, 3, 3, 1, 1)
+        return ops.conv2d_dgrad(dy, W.conv[name], cin, 3, 3, 1, stride=stride, in_hw=(H_in, H_in))
+
     last = t["blocks"][-1]
     d_out = ops.avgpool_relu_backward(dfeat.contiguous(), last["out"])
     for b in reversed(t["blocks"]):
@@ -133,14 +149,14 @@ def resnet10_backward(W, t, dfeat, need):
         grads[p + ".BN2.weight"], grads[p + ".BN2.bias"] = dg, db
         dc2 = dc2.view(out.shape)
         grads[p + ".C2.weight"] = ops.conv2d_wgrad_oihw(b["r1"], dc2, cout, 3, 3, 1, 1)
-        dr1 = ops.conv2d_dgrad(dc2, W.conv[p + ".C2"], cout, 3, 3, 1)
+        dr1 = dgrad3x3(p + ".C2", dc2, cout, cout, 1, rows, out.shape[1])
         g1 = W.bn[p + ".BN1"][0]
         dc1, dg, db = bn_bwd(b["c1"].view(-1, cout), dr1.view(-1, cout), cout, rows, b["m1"], b["s1"], g1,
                              y_act=b["r1"].view(-1, cout), act=RELU)
         grads[p + ".BN1.weight"], grads[p + ".BN1.bias"] = dg, db
         dc1 = dc1.view(out.shape)
         grads[p + ".C1.weight"] = ops.conv2d_wgrad_oihw(x_in, dc1, cout, 3, 3, stride, 1)
-        dx = ops.conv2d_dgrad(dc1, W.conv[p + ".C1"], cin, 3, 3, 1, stride=stride, in_hw=(H_in, H_in))
+        dx = dgrad3x3(p + ".C1", dc1, cin, cout, stride, rows, H_in)
         if cin != cout:
             gs = W.bn[p + ".BNshortcut"][0]
             dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU)

@@ -110,6 +110,43 @@ class PackPlan:
         _lib.check(_lib.lib().mft_pack_oihw_multi(_p(self.table), len(self.jobs), self.total, _stream()), "mft_pack_oihw_multi")
 
 
+class SplitPlan:
+    """bf16x3 planes of several packed weight matrices refreshed by ONE launch (mft_split_bf16x3_multi): the per-step companion of
+    PackPlan for the meta-training layers that run on the split-precision kernels.  ``add(pk, Cout, Cin, taps, transposed)``
+    allocates the planes [3, rows, K] (rows, K = Cout, taps*Cin -- or Cin, taps*Cout for the transposed data-gradient operand),
+    fills them once and registers the job; ``run()`` refreshes every registered set from its (in-place updated) source."""
+
+    def __init__(self):
+        self.jobs, self.total, self.table, self.keep = [], 0, None, []
+
+    def add(self, pk, Cout, Cin, taps, transposed=False):
+        assert pk.is_cuda and pk.dtype == torch.float32 and pk.is_contiguous() and pk.shape == (Cout, taps * Cin) and (taps * Cin) % 32 == 0
+        n = pk.numel()
+        planes = torch.empty((3, Cin, taps * Cout) if transposed else (3, Cout, taps * Cin), device=pk.device, dtype=torch.int16)
+        self.jobs.append((pk.data_ptr(), planes.data_ptr(), n, Cout, Cin, taps, 1 if transposed else 0, self.total))
+        self.total += n
+        self.keep.append((pk, planes))
+        self.table = None
+        self._launch(len(self.jobs) - 1)
+        return planes
+
+    def _launch(self, only=None):
+        import numpy as np
+        if only is not None:                       # a job that has just been added: fill its planes now, alone
+            j = list(self.jobs[only])
+            j[7] = 0
+            tab = torch.from_numpy(np.asarray([j], dtype=np.int64)).to(self.keep[only][0].device)
+            _lib.check(_lib.lib().mft_split_bf16x3_multi(_p(tab), 1, j[2], _stream()), "mft_split_bf16x3_multi")
+            return
+        if self.table is None:
+            self.table = torch.from_numpy(np.asarray(self.jobs, dtype=np.int64)).to(self.keep[0][0].device)
+        _lib.check(_lib.lib().mft_split_bf16x3_multi(_p(self.table), len(self.jobs), self.total, _stream()), "mft_split_bf16x3_multi")
+
+    def run(self):
+        if self.jobs:
+            self._launch()
+
+
 def unpack_conv_weight(pk, shape):
     Cout, Cin, KH, KW = shape
     w = torch.empty(shape, device=pk.device, dtype=torch.float32)

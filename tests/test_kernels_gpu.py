@@ -1143,6 +1143,38 @@ def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride,
     assert float((dw.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
 
 
+@pytest.mark.parametrize("n,H,cin,cout", [(105, 21, 64, 64), (105, 11, 128, 128), (7, 11, 64, 128)])
+def test_split_plan_planes_and_data_gradient_on_the_split_kernels(n, H, cin, cout):
+    """ops.SplitPlan (mft_split_bf16x3_multi, the per-step plane refresh of the meta-training layers that run on the bf16x3 kernels):
+    its planes equal mft_split_bf16x3's bit for bit -- of the packed weights, and with ``transposed`` of the data-gradient operand
+    (mft_pack_dgrad's tap-flipped channel-swapped matrix) --, a refresh after an in-place weight update tracks the new values, and
+    the stride-1 data gradient computed as a convolution over the transposed planes agrees with the fp32 data-gradient launch and
+    with float64."""
+    w = rnd((cout, cin, 3, 3), 71, scale=(2.0 / (9 * cin)) ** 0.5).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    plan = ops.SplitPlan()
+    pf = plan.add(wp, cout, cin, 9, False)
+    pt = plan.add(wp, cout, cin, 9, True) if cin % 64 == 0 else None
+    assert bool((pf == ops.split_weight_x3(wp)).all())
+    if pt is not None:
+        wt = ops.pack_dgrad_weight(wp, cout, cin, 3, 3)[0].contiguous()
+        assert pt.shape == (3, cin, 9 * cout) and bool((pt == ops.split_weight_x3(wt)).all())
+    wp.mul_(1.5).add_(0.01)                                  # optimizer.step() + repack: same buffer, new values
+    plan.run()
+    assert bool((pf == ops.split_weight_x3(wp)).all())
+    if pt is None:
+        return
+    assert bool((pt == ops.split_weight_x3(ops.pack_dgrad_weight(wp, cout, cin, 3, 3)[0].contiguous())).all())
+    dy = nhwc(rnd((n, cout, H, H), 72)).to(DEV)
+    dx = ops.conv2d_x3(dy, pt, cin, 3, 3, 1, 1)
+    dx32 = ops.conv2d_dgrad(dy, wp, cin, 3, 3, 1)
+    w_now = ops.unpack_conv_weight(wp, (cout, cin, 3, 3))
+    ref = torch.nn.grad.conv2d_input((n, cin, H, H), w_now.double().cpu(), nchw(dy.cpu()).double(), stride=1, padding=1)
+    sc = float(ref.abs().max())
+    assert float((nchw(dx.cpu()).double() - ref).abs().max()) < 1e-5 * sc
+    assert float((dx - dx32).abs().max()) < 1e-5 * sc
+
+
 @pytest.mark.parametrize("n,H,Cin,Cout,k,stride,pad", [(105, 21, 64, 64, 3, 1, 1), (105, 6, 256, 512, 3, 2, 1), (21, 11, 128, 256, 1, 2, 0),
                                                        (4, 84, 3, 64, 7, 2, 3), (3, 6, 256, 256, 3, 1, 1)])
 def test_conv_wgrad_written_as_oihw(n, H, Cin, Cout, k, stride, pad):
