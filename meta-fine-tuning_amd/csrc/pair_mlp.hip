@@ -22,7 +22,6 @@
 // HBM traffic per pair row: raw h1..h4 written once and read once (2 x 2304 B) against 13 KB for the unfused sequence,
 // on half the rows.  Arithmetic is fp32 MFMA (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate) as in csrc/conv_igemm.hip.
 #include "mft_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -506,12 +505,6 @@ __global__ __launch_bounds__(256) void pair_dx_gather_kernel(const float* __rest
 
 }  // namespace
 
-static int g_pair_db = 0;     // 1: double-buffered LDS form (MFT_PAIR_DB=1 at load time; A/B measurements in DESIGN.md)
-__attribute__((constructor)) static void pair_env_init() {
-    const char* e = getenv("MFT_PAIR_DB");
-    if (e) g_pair_db = atoi(e);
-}
-
 extern "C" int mft_pair_mlp_tiles_m(int graphs_per_group, int N) {
     const long long P = (long long)N * (N + 1) / 2;
     return cdiv((long long)graphs_per_group * P, PM_BM);
@@ -535,23 +528,13 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
     p.slope = slope; p.ws_mean = ws_mean; p.ws_m2 = ws_m2; p.ws_n = ws_n;
     const long long nwg = (long long)p.tiles_m * p.tiles_n * n_groups;
     if (nwg > 0x7fffffffLL) return MFT_EINVAL;
+    // single-buffered form (32 KB of LDS, four workgroups per CU).  The double-buffered instantiation (DB = true: one barrier per
+    // K-step, 64.5 KB) measured the same on the batched final pass (rounds 2-3) and on the single-episode meta-training step
+    // (round 5: 3.73 / 3.77 vs 3.74 / 3.78 ms), so it is no longer launched.
     const size_t lds1 = (PM_BM + PM_BN) * PM_LD * sizeof(float);
-    static MftPerDeviceOnce attr_once;
-    if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)pair_mlp_layer_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
-        if (e != hipSuccess) return (int)e;
-        attr_once.mark();
-    }
     hipStream_t st = (hipStream_t)stream;
-    if (g_pair_db) {
-        if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 2 * lds1, st, p);
-        else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, true>), dim3((unsigned)nwg), dim3(256), 2 * lds1, st, p);
-    } else {
-        if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
-        else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
-    }
+    if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
+    else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
     return mft_launch_status();
 }
 
