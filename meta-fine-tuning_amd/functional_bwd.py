@@ -131,7 +131,8 @@ def resnet10_backward(W, t, dfeat, need):
     grads = {}
 
     def dgrad3x3(name, dy, cin, cout, stride, rows, H_in):
-        wt3 = W.train3.get((name, True))         # registered by the forward (resnet10_forward_taped.conv3x3); never created here
+        # registered by the forward (resnet10_forward_taped.conv3x3), never created here; the same size rule as the forward
+        wt3 = W.train3.get((name, True)) if (Fn.TRAIN_X3 and rows >= Fn.TRAIN_X3_MIN_ROWS) else None
         if wt3 is not None:                      # stride 1: dx = conv(dy, tap-flipped channel-swapped weights), same padding
             return ops.conv2d_x3(dy, wt3, cin, 3, 3, 1, 1)
         return ops.conv2d_dgrad(dy, W.conv[name], cin, 3, 3, 1, stride=stride, in_hw=(H_in, H_in))
