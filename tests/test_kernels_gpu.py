@@ -1308,6 +1308,15 @@ def test_launch_timer_brackets_launchers_on_their_own_streams():
         got = only.collect()
         only.close()
     assert list(got) == ["mft_softmax_rows"] and len(got["mft_softmax_rows"]) == 1
+    # a block that raises: the library handle is restored and the pending event pairs are released, not leaked
+    boom = _lib.LaunchTimer()
+    with pytest.raises(ZeroDivisionError):
+        with boom:
+            ops.conv2d(x, w, 64, 3, 3, 1, 1)
+            assert len(boom._pairs) == 1
+            1 / 0
+    assert not isinstance(_lib.lib(), _lib.LaunchTimer) and boom._pairs == [] and boom._free == []
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("n", [1, 7, 600])
