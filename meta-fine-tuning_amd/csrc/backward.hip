@@ -60,19 +60,21 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) {
 // phase 2: fixed-order sum of the partials -> dgamma, dbeta and the two group means used by phase 3
 // 256 threads = 16 channels x 16 chunk lanes; each lane sums every 16th partial, then a fixed xor tree over the 16 lanes
 // (a serial loop over up to ~340 partials per channel cost 50-250 us per BatchNorm in the meta-training step)
+// (LPC = 64: one group with >= 128 chunks -- a whole wave per channel, as in bn_stats_finalize)
+template <int LPC>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
-    const int kl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int kl = threadIdx.x % LPC;
+    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const int g = blockIdx.y;
     float s1 = 0.f, s2 = 0.f;
     if (c < p.C)
-        for (int k = kl; k < p.chunks; k += 16) {
+        for (int k = kl; k < p.chunks; k += LPC) {
             const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
             s1 += o[0];
             s2 += o[1];
         }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
+    for (int off = LPC / 2; off > 0; off >>= 1) {
         s1 += __shfl_xor(s1, off, 64);
         s2 += __shfl_xor(s2, off, 64);
     }
@@ -418,7 +420,10 @@ extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws; p.act = act; p.slope = slope;
     float* sums = ws + 2LL * n_groups * p.chunks * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.chunks, (C + 63) / 64, n_groups), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16, n_groups), dim3(256), 0, s, p, sums);
+    if (n_groups == 1 && p.chunks >= 128)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3((C + 3) / 4, 1), dim3(256), 0, s, p, sums);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16, n_groups), dim3(256), 0, s, p, sums);
     if (dx) {
         const long long total = (long long)n_groups * rows_per_group * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bgrid(total, 2048)), dim3(256), 0, s, p, (const float*)sums, n_groups);

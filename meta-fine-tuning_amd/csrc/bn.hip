@@ -58,23 +58,26 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
-// 256 threads = 16 channels x 16 chunk lanes (fixed xor tree over the lanes: deterministic)
+// 256 threads = (256 / LPC) channels x LPC chunk lanes (fixed xor tree over the lanes: deterministic).  LPC = 16 everywhere except
+// ONE group with >= 128 chunks (a single 105-image meta-training episode: 199-1024 partials per channel, which 16 lanes walk in
+// 13-64 dependent iterations -- 8-23 us per BatchNorm, round 5): there a whole wave sums one channel.
+template <int LPC>
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group,
                                                          int chunks, const float* __restrict__ ws, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* running_mean, float* running_var, float momentum) {
-    const int kl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int kl = threadIdx.x % LPC;
+    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const int g = blockIdx.y;
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
-        for (int k = kl; k < chunks; k += 16) {
+        for (int k = kl; k < chunks; k += LPC) {
             const float* o = ws + (((long long)g * chunks + k) * C + c) * 2;
             s1 += o[0];
             s2 += o[1];
         }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
+    for (int off = LPC / 2; off > 0; off >>= 1) {
         s1 += __shfl_xor(s1, off, 64);
         s2 += __shfl_xor(s2, off, 64);
     }
@@ -500,9 +503,12 @@ extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, 
     const int rpc = (rows_per_group + chunks - 1) / chunks;
     dim3 grid(chunks, (C + 63) / 64, n_groups);
     hipLaunchKernelGGL(bn_stats_partial, grid, dim3(256), 0, s, x, ldx, C, rows_per_group, rpc, chunks, ws);
-    dim3 g2((C + 15) / 16, n_groups, 1);
-    hipLaunchKernelGGL(bn_stats_finalize, g2, dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps, mean, rstd,
-                       running_mean, running_var, momentum);
+    if (n_groups == 1 && chunks >= 128)
+        hipLaunchKernelGGL(bn_stats_finalize<64>, dim3((C + 3) / 4, 1, 1), dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps,
+                           mean, rstd, running_mean, running_var, momentum);
+    else
+        hipLaunchKernelGGL(bn_stats_finalize<16>, dim3((C + 15) / 16, n_groups, 1), dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws,
+                           eps, mean, rstd, running_mean, running_var, momentum);
     return mft_launch_status();
 }
 
