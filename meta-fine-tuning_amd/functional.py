@@ -936,7 +936,7 @@ class GnnHeadWeights:
 
         def packed(src):
             w = dev(src)
-            pk = ops.pack_conv_weight(w)
+            pk = ops.pack_conv_weight(w, rows32=True)       # (48-, 5- and 1-row matrices: zero rows up to 32 for the data gradient)
             n_packed[0] += 1
             if w.data_ptr() == src.data_ptr():
                 self.plan.add(w, pk)

@@ -190,6 +190,9 @@ def _pad_rows32(w_pk):
     cp = ops.round_up(cout, 32)
     if cp == cout:
         return w_pk
+    buf = getattr(w_pk, "rows32", None)          # GnnHeadWeights packs into a row-padded buffer: nothing to build per step
+    if buf is not None and buf.shape == (cp, k) and buf.data_ptr() == w_pk.data_ptr():
+        return buf
     out = torch.zeros((cp, k), device=w_pk.device, dtype=torch.float32)
     out[:cout] = w_pk
     return out

@@ -70,14 +70,21 @@ def nchw_to_nhwc(x):
     return y
 
 
-def pack_conv_weight(w):
-    """OIHW (or [out,in] Linear) -> packed [Cout, roundup(KH*KW*Cin,32)]."""
+def pack_conv_weight(w, rows32=False):
+    """OIHW (or [out,in] Linear) -> packed [Cout, roundup(KH*KW*Cin,32)].  ``rows32``: the pack lives in a buffer whose row count is
+    rounded up to 32 with zero rows (``pk.rows32``: that buffer) -- the operand the data-gradient launch wants when Cout % 32 != 0
+    (the reduction runs over Cout); a refresh through PackPlan rewrites the Cout real rows only, the padding stays zero."""
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
     w = _f32c(w.detach())
     Cout, Cin, KH, KW = w.shape
     kpad = round_up(KH * KW * Cin, 32)
-    pk = torch.empty((Cout, kpad), device=w.device, dtype=torch.float32)
+    if rows32 and Cout % 32 != 0:
+        buf = torch.zeros((round_up(Cout, 32), kpad), device=w.device, dtype=torch.float32)
+        pk = buf[:Cout]
+        pk.rows32 = buf
+    else:
+        pk = torch.empty((Cout, kpad), device=w.device, dtype=torch.float32)
     _lib.check(_lib.lib().mft_pack_oihw(_p(w), _p(pk), Cout, Cin, KH, KW, kpad, _stream()), "mft_pack_oihw")
     return pk
 
