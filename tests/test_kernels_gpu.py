@@ -1143,6 +1143,20 @@ def test_conv_k_sliced_forms_match_plain_and_float64(n, H, Cin, Cout, k, stride,
     assert float((dw.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
 
 
+@pytest.mark.parametrize("rows,C,ld", [(7440, 192, 192), (7440, 96, 96), (7440, 32, 32), (2048, 64, 96), (480, 64, 64), (105, 128, 128), (33, 5, 8)])
+def test_colsum_matches_float64_and_is_deterministic(rows, C, ld):
+    """mft_colsum (bias gradients of nn.Linear / 1x1 nn.Conv2d, out[c] = sum_r x[r][c]): partial + final launches, float4 and
+    scalar forms, against float64; reruns are bit-identical (fixed summation order).  (A one-launch form -- 1024 row lanes + an
+    LDS tree -- was measured in round 5: 3.69-3.70 ms per meta-training step against 3.65-3.67 with the pair; not kept.)"""
+    from meta_fine_tuning_amd import functional_bwd as FB
+    x = rnd((rows, ld), 61).to(DEV)
+    got = FB.colsum(x, C)
+    ref = x.double().cpu()[:, :C].sum(0)
+    assert got.shape == (C,)
+    assert float((got.double().cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(got, FB.colsum(x, C))
+
+
 @pytest.mark.parametrize("n,H,cin,cout", [(105, 21, 64, 64), (105, 11, 128, 128), (7, 11, 64, 128)])
 def test_split_plan_planes_and_data_gradient_on_the_split_kernels(n, H, cin, cout):
     """ops.SplitPlan (mft_split_bf16x3_multi, the per-step plane refresh of the meta-training layers that run on the bf16x3 kernels):
