@@ -283,10 +283,13 @@ int mft_conv2d_wgrad_nhwc(const float* in, int ldi, const float* dy, int ldy, fl
                           int imgs_per_group, long long dw_group_stride, float* ws, void* stream);
 
 /* mft_conv2d_wgrad_nhwc for one weight set, gradient written as torch's [Cout][Cin][KH][KW] (Conv2d.weight.grad): the sum over
- * the split-M partials does the permutation (replaces wgrad + mft_unpack_oihw in the meta-training backward). */
+ * the split-M partials does the permutation (replaces wgrad + mft_unpack_oihw in the meta-training backward).
+ * cin_valid / cout_valid (0 = all): operands whose channel counts are zero-padded to the kernels' multiples (the GNN's 133 / 181 /
+ * 229 / 266 / 362 / 458 input features, its 48-, 5- and 1-row layers) hand back the [cout_valid][cin_valid][KH][KW] corner
+ * contiguously -- nn.Linear / 1x1 Conv2d .grad exactly, no slice + copy afterwards (gnn.py:38,64-76). */
 long long mft_conv2d_wgrad_oihw_ws_floats(int n_img, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, int ldy, float* dw_oihw, int n_img, int H, int W, int Cin,
-                          int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream);
+                          int Cout, int KH, int KW, int stride, int pad, int cin_valid, int cout_valid, float* ws, void* stream);
 
 /* conv weight gradient with torch.optim.Adam.step fused into the epilogue (finetune.py:293-299): the gradient tile stays
  * in MFMA accumulators; w, m, v (same packed layout / group stride as dw) are updated in place.  dw_or_null, when given,
@@ -328,12 +331,14 @@ void mft_wgrad_fwd_set_xcd(int on);
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */
 /* F.batch_norm(training=True) statistics (backbone.py:224,227,240,409; gnn.py:65-74; gnnnet.py:30):
  * per (group, channel) mean and 1/sqrt(biased var + eps) over rows_per_group rows.
- * ws: >= mft_bn_stats_ws_floats(...) floats.  running_mean/var (nullable, [C], n_groups must be 1
- * when given) get the momentum update with the unbiased variance.                          */
+ * ws: >= mft_bn_stats_ws_floats(...) floats.  running_mean/var (nullable, [C]) get the momentum update
+ * with the unbiased variance of GROUP 0 (one group in the reference's loops; with k episodes in lockstep
+ * group 0 plays rank 0 of an episode-parallel run); num_batches_tracked (nullable, int64
+ * scalar, only with running_mean) is incremented by the same launch (nn.BatchNorm2d's counter).     */
 long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups);
 int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
                  float* mean, float* rstd, float* ws,
-                 float* running_mean, float* running_var, float momentum, void* stream);
+                 float* running_mean, float* running_var, float momentum, long long* num_batches_tracked, void* stream);
 /* y = act( bn(x) [+ residual | + bn_r(residual)] ); gamma/beta [C] shared (gb_group_stride 0) or per group.
  * SimpleBlock.forward tail (backbone.py:251-261); F.leaky_relu(bn(.)) in Wcompute (gnn.py:84-102). */
 int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups,
@@ -398,6 +403,15 @@ int mft_avgpool_relu_backward(const float* dfeat, const float* out, float* dout,
  * rows of each group; loss[n_groups]; dlogits = (softmax - onehot)/rows_per_group (nullable).     */
 int mft_cross_entropy(const float* logits, int ld, const int* labels, int C, int rows_per_group, int n_groups,
                       float* loss, float* dlogits, void* stream);
+/* nn.CrossEntropyLoss(reduction='mean') on [rows, C] logits as the episode / pre-training loss modules call it
+ * (gnnnet.py:43,219-231: scores [80,5] vs repeat(range(5),16); baselinetrain.py:20,38-45): ONE launch each way.  labels:
+ * int64 (labels_i64 = 1, what torch passes) or int32; loss[0] = mean_r(logsumexp(x_r) - x_r[y_r]) summed in a fixed order;
+ * loss_sum (nullable, float64 device scalar) += loss: the running loss the episode loop prints (meta_template.py:91) without a
+ * host read-back per step;  backward: dlogits = (softmax - onehot) * grad_loss[0] / rows, grad_loss a DEVICE scalar (NULL = 1). */
+int mft_cross_entropy_mean(const float* logits, int ld, const void* labels, int labels_i64, int C, int rows, float* loss,
+                           double* loss_sum, void* stream);
+int mft_cross_entropy_mean_backward(const float* logits, int ld, const void* labels, int labels_i64, int C, int rows,
+                                    const float* grad_loss, float* dlogits, int ldd, void* stream);
 int mft_softmax_rows(const float* x, int ldx, float* y, int ldy, int C, int rows, void* stream);
 
 /* optimisers --------------------------------------------------------------------------- */
@@ -519,18 +533,22 @@ int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, int N, void
  * the gradient).  Nothing of shape [B*N*N, F] is formed.
  *  mft_pair_softmax_ut_backward: ds[r*ldds] = A_ij (dA_ij - <A_i, dA_i>) + A_ji (dA_ji - <A_j, dA_j>)  (rowdot_ws: n_graphs*N floats)
  *  mft_pair_bn_act_backward:     BatchNorm2d(train) + leaky_relu backward of one layer over merged rows.  g = dL/d(activation)
- *      [rows, ldg], z = the layer's RAW output [rows, C] (C = 96 | 192), scale / shift / mean / rstd as left by
- *      mft_pair_mlp_stats_finalize; sums[2*C] <- (sum u, sum u*xhat) = (d beta, d gamma); dz [rows, C] <- gamma rstd (u - cnt
- *      sum_u / n_tot - cnt xhat sum_ux / n_tot) with cnt = 1 on diagonal rows, 2 elsewhere, n_tot = n_graphs*N*N.
- *      ws: mft_pair_bwd_stats_ws_floats(rows, C) floats (fixed-order partial sums: deterministic).
+ *      [rows, ldg], z = the layer's RAW output [rows, C] (C = 96 | 192), rows = n_groups * rows_per_group (a group = the graphs
+ *      of one episode: its own BatchNorm statistics); scale / shift / mean / rstd [n_groups, C] as left by
+ *      mft_pair_mlp_stats_finalize; sums[n_groups][2*C] <- per group (sum u, sum u*xhat); dparams[2*C] (nullable) <- their sum over
+ *      the groups = (d beta | d gamma); dbias_zero[C] (nullable) <- 0, the gradient of the 1x1 convolution's bias in front of
+ *      the BatchNorm (identically zero); dz [rows, C] <- gamma rstd (u - cnt sum_u / n_tot - cnt xhat sum_ux / n_tot) with cnt = 1 on
+ *      diagonal rows, 2 elsewhere, n_tot = graphs_per_group*N*N.
+ *      ws: n_groups * mft_pair_bwd_stats_ws_floats(rows_per_group, C) floats (fixed-order partial sums: deterministic).
  *  mft_pair_absdiff_ut:          d[r - row0][:] = |x_i - x_j| for rows row0 .. row0 + nrows (layer 1's input, a bounded chunk)
  *  mft_pair_dx_gather:           dX[b, i, :F] += sum_j sign(x_i - x_j) * dd[p(i,j) - row0][:F] over the pairs inside the chunk     */
 int mft_pair_softmax_ut_backward(const float* A, const float* dA, const int* ij, float* rowdot_ws, float* ds, int ldds,
                                  int n_graphs, int N, void* stream);
-long long mft_pair_bwd_stats_ws_floats(long long rows, int C);
+long long mft_pair_bwd_stats_ws_floats(long long rows_per_group, int C);
 int mft_pair_bn_act_backward(const float* g, int ldg, const float* z, int C, const float* scale, const float* shift,
-                             const float* mean, const float* rstd, const float* gamma, const int* ij, int N, long long rows,
-                             long long n_tot, float slope, float* ws, float* sums, float* dz, void* stream);
+                             const float* mean, const float* rstd, const float* gamma, const int* ij, int N, long long rows_per_group,
+                             int n_groups, long long n_tot, float slope, float* ws, float* sums, float* dparams, float* dbias_zero,
+                             float* dz, void* stream);
 int mft_pair_absdiff_ut(const float* x, int ldx, const int* ij, float* d, int Kp, int F, int N, long long row0, long long nrows,
                         void* stream);
 int mft_pair_dx_gather(const float* x, int ldx, const float* dd, int lddd, float* dX, int lddx, int n_graphs, int N, int F,
@@ -557,12 +575,17 @@ int mft_gather_rows(const float* src, const int* idx, float* dst, int n_rows, lo
  * meta_template.py:76-109) --------------------------------------------------------------------------------------- */
 /* BatchNorm backward for any group size (three launches: chunked partial sums, fixed-order finalize, elementwise dx) with
  * the derivative of the activation that followed the BN fused in: dy_eff = dy * act'(y_act) (y_act = post-activation
- * output, NULL for none).  ws: mft_bn_backward_ws_floats floats.  dx may be NULL (parameter gradients only).          */
+ * output, NULL for none).  ws: mft_bn_backward_ws_floats floats.  dx may be NULL (parameter gradients only).
+ * dgamma / dbeta [n_groups, C] (nullable); dgamma_sum / dbeta_sum [C] (nullable): the same summed over the groups in group
+ * order by the finalize launch (k episodes in lockstep share one BatchNorm's affine parameters);  dbias_zero [C] (nullable):
+ * the gradient of a bias added in front of this BatchNorm (nn.Linear / Conv2d bias followed by train-mode BatchNorm: gnn.py:
+ * 43-56,64-76, gnnnet.py:30) -- identically zero, written as zeros by the same launch instead of a column-sum of rounding noise. */
 long long mft_bn_backward_ws_floats(int C, int rows_per_group, int n_groups);
 int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, const float* y_act, int ldya,
                         float* dx, int lddx, int C, int rows_per_group, int n_groups,
                         const float* mean, const float* rstd, const float* gamma, long long gb_group_stride,
-                        float* dgamma, float* dbeta, int act, float slope, float* ws, void* stream);
+                        float* dgamma, float* dbeta, int act, float slope, float* ws, float* dgamma_sum, float* dbeta_sum,
+                        float* dbias_zero, void* stream);
 /* dx (+)= dy * act'(y)  (ReLU / leaky-ReLU backward; GNN_nl's F.leaky_relu before the concat, gnn.py:160) */
 int mft_act_backward(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long long rows,
                      int act, float slope, int accumulate, void* stream);
@@ -580,9 +603,10 @@ int mft_masked_softmax_backward(const float* A, const float* dA, float* ds, int 
 /* |x_i - x_j| backward, accumulated into dx */
 int mft_pair_absdiff_backward(const float* x, int ldx, const float* dd, int ldd, float* dx, int lddx,
                               int n_graphs, int N, int F, void* stream);
-/* gmul backward: dx += dy[:, :F] + A^T dy[:, F:2F];  dA = dy[:, F:2F] x^T */
+/* gmul backward: dx[:, :F] (+)= dy[:, :F] + A^T dy[:, F:2F];  dA = dy[:, F:2F] x^T.  accumulate = 0: the first writer of a
+ * node-gradient buffer overwrites its F columns (no zero fill of the buffer beforehand) */
 int mft_graph_aggregate_backward(const float* A, const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
-                                 float* dA, int n_graphs, int N, int F, void* stream);
+                                 float* dA, int n_graphs, int N, int F, int accumulate, void* stream);
 int mft_build_graph_nodes_backward(const float* dnodes, int ld, float* dz, int zf, int n_episodes, int n_way,
                                    int n_support, int n_query, int fold, void* stream);
 int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,

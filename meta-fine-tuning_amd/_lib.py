@@ -49,14 +49,14 @@ SIGNATURES = {
     "mft_conv2d_nhwc_ksplit": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_dgrad_nhwc_ksplit": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_wgrad_oihw_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
-    "mft_conv2d_wgrad_oihw": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "mft_conv2d_wgrad_oihw": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,
                                    _F, _P],
     "mft_pair_softmax_ut_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "mft_pair_bwd_stats_ws_floats": [_L, _I],
-    "mft_pair_bn_act_backward": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _L, _L, _F, _P, _P, _P, _P],
+    "mft_pair_bn_act_backward": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _P, _P, _P, _P, _P],
     "mft_pair_absdiff_ut": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _P],
     "mft_pair_dx_gather": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _L, _L, _P],
     "mft_pack_oihw_multi": [_P, _I, _L, _P],
@@ -65,7 +65,7 @@ SIGNATURES = {
     "mft_wgrad_fwd_set_exact": [_I],
     "mft_wgrad_fwd_set_xcd": [_I],
     "mft_bn_stats_ws_floats": [_I, _I, _I],
-    "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P],
+    "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P],
     "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
     "mft_bn_relu_maxpool": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_relu_maxpool_gather": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -79,6 +79,8 @@ SIGNATURES = {
     "mft_avgpool_relu_backward": [_P, _P, _P, _I, _I, _I, _P],
     "mft_cross_entropy": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "mft_softmax_rows": [_P, _I, _P, _I, _I, _I, _P],
+    "mft_cross_entropy_mean": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
+    "mft_cross_entropy_mean_backward": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P],
     "mft_adam_step": [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "mft_sgd_step": [_P, _P, _P, _L, _I, _F, _F, _F, _F, _P],
     "mft_maml_delta": [_P, _P, _P, _L, _P],
@@ -131,14 +133,14 @@ SIGNATURES = {
     "mft_gather_rows": [_P, _P, _P, _I, _L, _P],
     "mft_var_to_rstd": [_P, _P, _I, _F, _P],
     "mft_bn_backward_ws_floats": [_I, _I, _I],
-    "mft_bn_backward_act": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P],
+    "mft_bn_backward_act": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "mft_act_backward": [_P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _I, _P],
     "mft_colsum": [_P, _I, _I, _L, _P, _P, _P],
     "mft_bn_relu_maxpool_arg": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_maxpool_relu_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mft_masked_softmax_backward": [_P, _P, _P, _I, _I, _I, _P],
     "mft_pair_absdiff_backward": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
-    "mft_graph_aggregate_backward": [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P],
+    "mft_graph_aggregate_backward": [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "mft_build_graph_nodes_backward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
 }

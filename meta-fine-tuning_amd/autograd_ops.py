@@ -46,10 +46,12 @@ def _same_storage(old_key, new_key):
 
 
 def _running(mod):
+    """name -> (running_mean, running_var, num_batches_tracked) of every tracking BatchNorm2d: the statistics launch of each layer
+    advances all three (mft_bn_stats), so a forward costs no counter launch of its own."""
     run = {}
     for name, m in mod.named_modules():
         if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats:
-            run[name] = (m.running_mean, m.running_var)
+            run[name] = (m.running_mean, m.running_var, m.num_batches_tracked)
     return run
 
 
@@ -107,9 +109,9 @@ class _ResNet10FullFn(torch.autograd.Function):
     train.py:28; meta_template.py:76-92)."""
 
     @staticmethod
-    def forward(ctx, mod, x_nhwc, *params):
+    def forward(ctx, mod, x_nhwc, groups, *params):
         W = module_weights(mod)
-        feat, tape = FB.resnet10_forward_taped(W, x_nhwc, running=_running(mod))
+        feat, tape = FB.resnet10_forward_taped(W, x_nhwc, running=_running(mod), groups=groups)
         ctx.tape, ctx.W, ctx.mod = tape, W, mod
         return feat
 
@@ -120,16 +122,16 @@ class _ResNet10FullFn(torch.autograd.Function):
         need = [p.requires_grad for p in mod.parameters()]
         g = FB.resnet10_backward(ctx.W, ctx.tape, dfeat.contiguous().float(), set(names))
         out = [g[nm] if r else None for nm, r in zip(names, need)]
-        return (None, None) + tuple(out)
+        return (None, None, None) + tuple(out)
 
 
 class _HeadFn(torch.autograd.Function):
     """GnnNet.fc + graph assembly + GNN_nl + score gather with a hand-written backward (gnnnet.py:76-87,210-217)."""
 
     @staticmethod
-    def forward(ctx, model, feats, n_support, n_query, fold, *params):
+    def forward(ctx, model, feats, n_support, n_query, fold, episodes, *params):
         G = head_weights(model.gnn, model.fc, model.n_way)
-        scores, tape = FB.head_forward_taped(G, feats.contiguous().float(), model.n_way, n_support, n_query, fold)
+        scores, tape = FB.head_forward_taped(G, feats.contiguous().float(), model.n_way, n_support, n_query, fold, episodes)
         ctx.tape, ctx.G, ctx.model = tape, G, model
         ctx.feats_need = feats.requires_grad
         return scores
@@ -141,12 +143,74 @@ class _HeadFn(torch.autograd.Function):
         names = ["fc." + n for n, _ in model.fc.named_parameters()] + ["gnn." + n for n, _ in model.gnn.named_parameters()]
         plist = list(model.fc.parameters()) + list(model.gnn.parameters())
         out = [g[nm].view_as(p) if p.requires_grad else None for nm, p in zip(names, plist)]
-        return (None, dfeats if ctx.feats_need else None, None, None, None) + tuple(out)
+        return (None, dfeats if ctx.feats_need else None, None, None, None, None) + tuple(out)
 
 
-def resnet10_module_forward(mod, x):
-    """backbone.ResNet.forward: x NCHW [n,3,H,W] on the GPU -> [n,512]."""
+class _CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(scores, y) = mean_r(logsumexp(scores_r) - scores_r[y_r]) with ONE launch each way
+    (mft_cross_entropy_mean / _backward; gnnnet.py:219-231, baselinetrain.py:38-45).  Labels are read as given (int64 or int32)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, loss_sum):
+        rows, C = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        lib = ops._lib.lib()
+        ops._lib.check(lib.mft_cross_entropy_mean(ops._p(logits), logits.stride(0), ops._p(target), 1 if target.dtype == torch.int64 else 0,
+                                                  C, rows, ops._p(loss), ops._p(loss_sum), ops._stream()), "mft_cross_entropy_mean")
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        rows, C = logits.shape
+        d = torch.empty((rows, C), device=logits.device, dtype=torch.float32)
+        g = g.contiguous().float()
+        lib = ops._lib.lib()
+        ops._lib.check(lib.mft_cross_entropy_mean_backward(ops._p(logits), logits.stride(0), ops._p(target),
+                                                           1 if target.dtype == torch.int64 else 0, C, rows, ops._p(g), ops._p(d), C,
+                                                           ops._stream()), "mft_cross_entropy_mean_backward")
+        return d, None, None
+
+
+class CrossEntropyLoss(torch.nn.CrossEntropyLoss):
+    """``nn.CrossEntropyLoss()`` as the episode / pre-training losses use it (gnnnet.py:43, baselinetrain.py:20: default arguments,
+    [rows, C] float scores against [rows] class indices), computed by the HIP library.  Same class hierarchy and attributes as
+    torch's module; anything outside that use (class weights, label smoothing, probabilities as targets, a CPU tensor) raises --
+    there is no torch fallback on the product path."""
+
+    def forward(self, input, target):
+        if (self.weight is not None or self.reduction != "mean" or self.label_smoothing != 0.0 or input.dim() != 2 or target.dim() != 1
+                or target.dtype not in (torch.int64, torch.int32) or target.shape[0] != input.shape[0]):
+            raise NotImplementedError("CrossEntropyLoss on the HIP path: default options, [rows, C] scores, [rows] int64 / int32 labels")
+        _require_cuda(input, "CrossEntropyLoss")
+        if not target.is_cuda:
+            raise RuntimeError("CrossEntropyLoss: labels are on the CPU -- the MI355X path has no CPU fallback; call .cuda() first")
+        if input.dtype != torch.float32 or input.stride(1) != 1:
+            input = input.float().contiguous()
+        return _CrossEntropyFn.apply(input, target.contiguous(), self.loss_sum(input.device))
+
+    def loss_sum(self, device=None):
+        """float64 device scalar that every forward of this module adds its loss to (one per device, never re-created: a recorded
+        hipGraph keeps writing it).  The episode loops print running means from differences of it -- one read-back per printed
+        line instead of one per step (meta_template.py:91-93)."""
+        sums = self.__dict__.setdefault("_mft_loss_sums", {})
+        if device is None:
+            return next(iter(sums.values()), None)
+        key = torch.device(device).index
+        t = sums.get(key)
+        if t is None:
+            t = sums[key] = torch.zeros((), device=device, dtype=torch.float64)
+        return t
+
+
+def resnet10_module_forward(mod, x, groups=1):
+    """backbone.ResNet.forward: x NCHW [n,3,H,W] on the GPU -> [n,512].  ``groups`` > 1 (meta-training only): the n images are
+    ``groups`` episodes one after the other, each a BatchNorm mini-batch of its own (GnnNet.set_forward_loss_lockstep)."""
     _require_cuda(x, "ResNet10.forward")
+    if groups != 1 and not (mod.training and torch.is_grad_enabled() and all(p.requires_grad for p in mod.parameters())):
+        raise NotImplementedError("several BatchNorm groups per call exist on the meta-training path only (train mode, every "
+                                  "backbone parameter trainable)")
     if x.dim() == 4 and x.dtype == torch.float32 and x.permute(0, 2, 3, 1).is_contiguous():
         xn = x.permute(0, 2, 3, 1)            # already NHWC in memory (train.ResidentEpisodeLoader: mft_augment_views writes NHWC)
     else:
@@ -163,17 +227,14 @@ def resnet10_module_forward(mod, x):
         return Fn.resnet10_forward(W, xn, arena_for(xn.device), ipg=n, fixed=_eval_weights(mod, W), tag="evl%d" % n).clone()
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         if any(p.requires_grad for p in params[:-9]):
-            out = _ResNet10FullFn.apply(mod, xn, *params)       # meta-training: gradients for the whole backbone
+            out = _ResNet10FullFn.apply(mod, xn, groups, *params)       # meta-training: gradients for the whole backbone
         else:
             out = _ResNet10Fn.apply(mod, xn, *params)           # inner loop: last block only
     else:
         W = module_weights(mod)
         n = xn.shape[0]
         out = Fn.resnet10_forward(W, xn, arena_for(xn.device), ipg=n, running=_running(mod), tag="mod%d" % n).clone()
-    nbt = [m.num_batches_tracked for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats]
-    if nbt:
-        torch._foreach_add_(nbt, 1)                   # one launch for all 12 counters
-    return out
+    return out            # (every BatchNorm's num_batches_tracked was advanced by its own statistics launch: _running)
 
 
 # ---------------------------------------------------------------------------------------------- packing
@@ -258,13 +319,13 @@ def touch(mod):
             m.__dict__["_mft_pack"] = (tuple((k[0], -1) for k in c[0]), c[1])
 
 
-def gnnnet_head(model, feats, n_support, n_query, fold=False):
-    """GnnNet.fc + z_stack + forward_gnn for one episode (gnnnet.py:76-87,210-217): feats [n_way*(S+n_query), 512]
-    -> scores [n_way*n_query, n_way].  Differentiable (hand-written backward) when autograd is recording."""
+def gnnnet_head(model, feats, n_support, n_query, fold=False, episodes=1):
+    """GnnNet.fc + z_stack + forward_gnn (gnnnet.py:76-87,210-217): feats [episodes*n_way*(S+n_query), 512] (one episode after
+    the other) -> scores [episodes*n_way*n_query, n_way].  Differentiable (hand-written backward) when autograd is recording."""
     _require_cuda(feats, "GnnNet head")
     plist = list(model.fc.parameters()) + list(model.gnn.parameters())
     if torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in plist)):
-        return _HeadFn.apply(model, feats, n_support, n_query, fold, *plist)
+        return _HeadFn.apply(model, feats, n_support, n_query, fold, episodes, *plist)
     G = head_weights(model.gnn, model.fc, model.n_way)
     f = feats.detach().contiguous().float()
-    return Fn.gnnnet_scores(G, f, 1, model.n_way, n_support, n_query, arena_for(f.device), fold=fold, tag="head1").clone()
+    return Fn.gnnnet_scores(G, f, episodes, model.n_way, n_support, n_query, arena_for(f.device), fold=fold, tag="head%d" % episodes).clone()

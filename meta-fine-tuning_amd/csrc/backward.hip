@@ -18,6 +18,10 @@ struct BnBwdArgs {
     int ldx, lddy, ldya, lddx, C, rows_per_group, rows_per_chunk, chunks;
     const float* mean; const float* rstd; const float* gamma; long long gbs;
     float* dgamma; float* dbeta; float* ws; int act; float slope;
+    // meta-training extras (all nullable): the gradients summed over the groups in group order ([C] each: k episodes in lockstep
+    // share one set of affine parameters), and the gradient of a bias added in FRONT of this BatchNorm, which is identically zero
+    // (a per-channel shift of the input leaves a train-mode BatchNorm's output unchanged): written as exact zeros
+    float* dgamma_sum; float* dbeta_sum; float* dbias_zero; int n_groups;
 };
 
 // phase 1: per (chunk, 64-channel tile, group) partial sums of dy_eff and dy_eff * xhat
@@ -65,24 +69,35 @@ template <int LPC>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
     const int kl = threadIdx.x % LPC;
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
-    const int g = blockIdx.y;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < p.C)
-        for (int k = kl; k < p.chunks; k += LPC) {
-            const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
-            s1 += o[0];
-            s2 += o[1];
-        }
+    // one block row per group -- or, when the sums over the groups are wanted, ONE block row that walks the groups in order
+    const bool walk = p.dgamma_sum != nullptr || p.dbeta_sum != nullptr;
+    const int g0 = walk ? 0 : blockIdx.y, g1 = walk ? p.n_groups : g0 + 1;
+    float t1 = 0.f, t2 = 0.f;
+    for (int g = g0; g < g1; ++g) {
+        float s1 = 0.f, s2 = 0.f;
+        if (c < p.C)
+            for (int k = kl; k < p.chunks; k += LPC) {
+                const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
+                s1 += o[0];
+                s2 += o[1];
+            }
 #pragma unroll
-    for (int off = LPC / 2; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
+        for (int off = LPC / 2; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        if (c >= p.C || kl != 0) continue;
+        if (p.dbeta) p.dbeta[(long long)g * p.C + c] = s1;
+        if (p.dgamma) p.dgamma[(long long)g * p.C + c] = s2;
+        sums[((long long)g * p.C + c) * 2] = s1 / (float)p.rows_per_group;
+        sums[((long long)g * p.C + c) * 2 + 1] = s2 / (float)p.rows_per_group;
+        t1 += s1;
+        t2 += s2;
     }
     if (c >= p.C || kl != 0) return;
-    if (p.dbeta) p.dbeta[(long long)g * p.C + c] = s1;
-    if (p.dgamma) p.dgamma[(long long)g * p.C + c] = s2;
-    sums[((long long)g * p.C + c) * 2] = s1 / (float)p.rows_per_group;
-    sums[((long long)g * p.C + c) * 2 + 1] = s2 / (float)p.rows_per_group;
+    if (p.dbeta_sum) p.dbeta_sum[c] = t1;
+    if (p.dgamma_sum) p.dgamma_sum[c] = t2;
+    if (p.dbias_zero && g0 == 0) p.dbias_zero[c] = 0.f;
 }
 
 // phase 3: dx = gamma * rstd * (dy_eff - mean(dy_eff) - xhat * mean(dy_eff * xhat))
@@ -318,14 +333,15 @@ __global__ __launch_bounds__(256) void graph_aggregate_bwd_kernel(const float* _
                                                                   const float* __restrict__ x, int ldx,
                                                                   const float* __restrict__ dy, int lddy,
                                                                   float* __restrict__ dx, int lddx,
-                                                                  float* __restrict__ dA, int n_graphs, int N, int F) {
+                                                                  float* __restrict__ dA, int n_graphs, int N, int F,
+                                                                  int accumulate) {
     const long long row = blockIdx.x;     // (b, i)
     const long long b = row / N;
     const int i = (int)(row % N);
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         float s = dy[row * lddy + f];
         for (int j = 0; j < N; ++j) s += A[(b * N + j) * N + i] * dy[(b * N + j) * lddy + F + f];
-        dx[row * lddx + f] += s;
+        dx[row * lddx + f] = accumulate ? dx[row * lddx + f] + s : s;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int j = wv; j < N; j += 4) {
@@ -408,7 +424,8 @@ extern "C" long long mft_bn_backward_ws_floats(int C, int rows_per_group, int n_
 extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, const float* y_act, int ldya,
                                    float* dx, int lddx, int C, int rows_per_group, int n_groups, const float* mean,
                                    const float* rstd, const float* gamma, long long gb_group_stride, float* dgamma,
-                                   float* dbeta, int act, float slope, float* ws, void* stream) {
+                                   float* dbeta, int act, float slope, float* ws, float* dgamma_sum, float* dbeta_sum,
+                                   float* dbias_zero, void* stream) {
     if (C % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0 || (dx && lddx % 4 != 0) || (y_act && ldya % 4 != 0)) return MFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     BnBwdArgs p;
@@ -418,12 +435,14 @@ extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int
     p.rows_per_chunk = (rows_per_group + p.chunks - 1) / p.chunks;
     p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.gbs = gb_group_stride;
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws; p.act = act; p.slope = slope;
+    p.dgamma_sum = dgamma_sum; p.dbeta_sum = dbeta_sum; p.dbias_zero = dbias_zero; p.n_groups = n_groups;
+    const bool walk = dgamma_sum != nullptr || dbeta_sum != nullptr;
     float* sums = ws + 2LL * n_groups * p.chunks * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.chunks, (C + 63) / 64, n_groups), dim3(256), 0, s, p);
     if (n_groups == 1 && p.chunks >= 128)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3((C + 3) / 4, 1), dim3(256), 0, s, p, sums);
     else
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16, n_groups), dim3(256), 0, s, p, sums);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16, walk ? 1 : n_groups), dim3(256), 0, s, p, sums);
     if (dx) {
         const long long total = (long long)n_groups * rows_per_group * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bgrid(total, 2048)), dim3(256), 0, s, p, (const float*)sums, n_groups);
@@ -490,9 +509,9 @@ extern "C" int mft_pair_absdiff_backward(const float* x, int ldx, const float* d
 }
 
 extern "C" int mft_graph_aggregate_backward(const float* A, const float* x, int ldx, const float* dy, int lddy, float* dx,
-                                            int lddx, float* dA, int n_graphs, int N, int F, void* stream) {
+                                            int lddx, float* dA, int n_graphs, int N, int F, int accumulate, void* stream) {
     hipLaunchKernelGGL(graph_aggregate_bwd_kernel, dim3(n_graphs * N), dim3(256), 0, (hipStream_t)stream, A, x, ldx, dy,
-                       lddy, dx, lddx, dA, n_graphs, N, F);
+                       lddy, dx, lddx, dA, n_graphs, N, F, accumulate);
     return mft_launch_status();
 }
 

@@ -65,7 +65,8 @@ template <int LPC>
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group,
                                                          int chunks, const float* __restrict__ ws, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
-                                                         float* running_mean, float* running_var, float momentum) {
+                                                         float* running_mean, float* running_var, float momentum,
+                                                         long long* num_batches_tracked) {
     const int kl = threadIdx.x % LPC;
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     const int g = blockIdx.y;
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
     var = fmaxf(var, 0.f);
     mean[(long long)g * C + c] = m;
     rstd[(long long)g * C + c] = 1.0f / sqrtf(var + eps);
-    if (running_mean) {
-        const float unb = var * ((float)rows_per_group / (float)max(rows_per_group - 1, 1));
+    if (running_mean && g == 0) {          // several groups (k episodes in lockstep): group 0's statistics advance the buffers, as rank 0's
+        const float unb = var * ((float)rows_per_group / (float)max(rows_per_group - 1, 1));   // do in an episode-parallel run
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        if (num_batches_tracked && c == 0 && g == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (one thread of the launch)
     }
 }
 
@@ -495,9 +497,9 @@ extern "C" long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_gro
 
 extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
                             float* mean, float* rstd, float* ws, float* running_mean, float* running_var,
-                            float momentum, void* stream) {
+                            float momentum, long long* num_batches_tracked, void* stream) {
     if (C % 4 != 0 || ldx % 4 != 0 || rows_per_group <= 0 || n_groups <= 0) return MFT_EINVAL;
-    if (running_mean && n_groups != 1) return MFT_EINVAL;
+    if (num_batches_tracked && !running_mean) return MFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int chunks = stats_chunks(rows_per_group, n_groups, C);
     const int rpc = (rows_per_group + chunks - 1) / chunks;
@@ -505,10 +507,10 @@ extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, 
     hipLaunchKernelGGL(bn_stats_partial, grid, dim3(256), 0, s, x, ldx, C, rows_per_group, rpc, chunks, ws);
     if (n_groups == 1 && chunks >= 128)
         hipLaunchKernelGGL(bn_stats_finalize<64>, dim3((C + 3) / 4, 1, 1), dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws, eps,
-                           mean, rstd, running_mean, running_var, momentum);
+                           mean, rstd, running_mean, running_var, momentum, num_batches_tracked);
     else
         hipLaunchKernelGGL(bn_stats_finalize<16>, dim3((C + 15) / 16, n_groups, 1), dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws,
-                           eps, mean, rstd, running_mean, running_var, momentum);
+                           eps, mean, rstd, running_mean, running_var, momentum, num_batches_tracked);
     return mft_launch_status();
 }
 

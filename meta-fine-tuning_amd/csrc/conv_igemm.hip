@@ -418,6 +418,7 @@ struct WgradArgs {
     int oihw;            // plain weight gradient: partials always go through ws and the chunk sum writes torch's [Cout][Cin][KH][KW] layout
     int ws_inv_ow;       // wgrad_adam_rows_kernel: ceil(65536 / OW) (chunk_rows then holds ceil(65536 / (OH*OW)))
     int mma_rows;        // wgrad_adam_rows_kernel: reduction rows that get matrix instructions (rows_per_group, or 64 = the padded form)
+    int cin_out, cout_out;   // oihw: the gradient handed back is the first cout_out x cin_out of the Cout x Cin computed (0 = all)
 };
 
 // dw[co][(kh,kw,ci)] = sum_m dy[m][co] * in[pix(m,kh,kw)][ci]; reduction index m is the slow memory
@@ -815,7 +816,7 @@ int launch_wgrad_adam_rows(const WgradArgs& a, int taps, int groups, hipStream_t
 // dependent loads (one thread per element walked all chunks serially: 14-60 us per call for 30-250 chunks).
 template <bool OIHW>
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int chunks,
-                                                            long long dwgs, int Cin, int taps, int Kpad) {
+                                                            long long dwgs, int Cin, int taps, int Kpad, int cin_out, int cout_out) {
     __shared__ f32x4 red[8][33];
     const int g = blockIdx.y;
     const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
@@ -834,14 +835,14 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
             if constexpr (!OIHW) {
                 *(f32x4*)(dw + (long long)g * dwgs + i * 4) = t;
             } else {                                               // packed [Cout][(tap, ci)] -> torch's [Cout][Cin][KH][KW]
-                const long long e0 = i * 4;
+                const long long e0 = i * 4;                        // (the first cout_out x cin_out of it: zero-padded operand rows / columns)
                 const int co = (int)(e0 / Kpad), k0 = (int)(e0 - (long long)co * Kpad);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = k0 + e;
-                    if (k < taps * Cin) {
+                    if (k < taps * Cin && co < cout_out) {
                         const int tap = k / Cin, ci = k - tap * Cin;
-                        dw[((long long)co * Cin + ci) * taps + tap] = t[e];
+                        if (ci < cin_out) dw[((long long)co * cin_out + ci) * taps + tap] = t[e];
                     }
                 }
             }
@@ -877,10 +878,10 @@ int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
         if (blocks > 4096) blocks = 4096;
         if (p.oihw)
             hipLaunchKernelGGL(reduce_chunks_kernel<true>, dim3(blocks, 1), dim3(256), 0, s, (const float*)p.ws, p.dw, n, p.chunks, p.dwgs,
-                               a.Cin, a.KH * a.KW, a.Kpad);
+                               a.Cin, a.KH * a.KW, a.Kpad, a.cin_out > 0 ? a.cin_out : a.Cin, a.cout_out > 0 ? a.cout_out : a.Cout);
         else
             hipLaunchKernelGGL(reduce_chunks_kernel<false>, dim3(blocks, groups), dim3(256), 0, s, (const float*)p.ws, p.dw, n, p.chunks,
-                               p.dwgs, a.Cin, a.KH * a.KW, a.Kpad);
+                               p.dwgs, a.Cin, a.KH * a.KW, a.Kpad, a.Cin, a.Cout);
     }
     return mft_launch_status();
 }
@@ -1190,12 +1191,14 @@ extern "C" long long mft_conv2d_wgrad_oihw_ws_floats(int n_img, int H, int W, in
 }
 
 extern "C" int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, int ldy, float* dw_oihw, int n_img, int H, int W,
-                                     int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws, void* stream) {
-    if (ws == nullptr) return MFT_EINVAL;
+                                     int Cin, int Cout, int KH, int KW, int stride, int pad, int cin_valid, int cout_valid, float* ws,
+                                     void* stream) {
+    if (ws == nullptr || cin_valid < 0 || cin_valid > Cin || cout_valid < 0 || cout_valid > Cout) return MFT_EINVAL;
     WgradArgs a = {};
     a.in = in; a.dy = dy; a.dw = dw_oihw; a.ldi = ldi; a.ldy = ldy;
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.oihw = 1;
+    a.cin_out = cin_valid; a.cout_out = cout_valid;
     a.dwgs = (long long)Cout * ((KH * KW * Cin + 31) / 32 * 32);
     return wgrad_dispatch(a, n_img, 0, false, ws, (hipStream_t)stream);
 }

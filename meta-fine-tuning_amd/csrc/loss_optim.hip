@@ -139,6 +139,79 @@ extern "C" int mft_cross_entropy(const float* logits, int ld, const int* labels,
     return mft_launch_status();
 }
 
+// ---- nn.CrossEntropyLoss(reduction='mean') of the meta-training / pre-training losses (gnnnet.py:219-231: [80,5] scores;
+// baselinetrain.py:38-45: [16, num_class]) as ONE launch forward and ONE backward: labels are read as torch hands them over
+// (int64, or int32), the mean is formed in a fixed order inside one workgroup (rerun- and replay-identical), and the backward
+// takes the upstream gradient as a DEVICE scalar (what autograd passes; a hipGraph replay cannot bake a host value in).
+namespace {
+__device__ __forceinline__ long long ce_label(const void* labels, int i64, long long row) {
+    return i64 ? ((const long long*)labels)[row] : (long long)((const int*)labels)[row];
+}
+
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ logits, int ld, const void* __restrict__ labels,
+                                                      int i64, int C, int rows, float* __restrict__ loss, double* loss_sum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float part[4];
+    float acc = 0.f;                                  // lane 0 of each wave: the sum of its rows (row = wave, wave + 4, ...)
+    for (int row = wave; row < rows; row += 4) {
+        const float* x = logits + (long long)row * ld;
+        float mx = -3.4e38f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+        se = wave_sum(se);
+        const long long y = ce_label(labels, i64, row);
+        const float xy = (y >= 0 && y < C) ? x[y] : __builtin_nanf("");      // an out-of-range label poisons the loss (torch asserts)
+        acc += (mx + __logf(se)) - xy;
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = (((part[0] + part[1]) + part[2]) + part[3]) / (float)rows;
+        loss[0] = l;
+        if (loss_sum) *loss_sum += (double)l;         // the episode loop's running loss (meta_template.py:91: avg_loss + loss.item())
+    }
+}
+
+// dlogits[row, c] = (softmax(row)[c] - [c == y]) * gout / rows; one wave per row
+__global__ __launch_bounds__(256) void ce_mean_bwd_kernel(const float* __restrict__ logits, int ld, const void* __restrict__ labels,
+                                                          int i64, int C, int rows, const float* __restrict__ gout,
+                                                          float* __restrict__ dlogits, int ldd) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + row * ld;
+    float mx = -3.4e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += __expf(x[c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    const long long y = ce_label(labels, i64, row);
+    const float sc = (gout ? gout[0] : 1.f) / (float)rows;
+    float* d = dlogits + row * ldd;
+    for (int c = lane; c < C; c += 64) d[c] = (__expf(x[c] - lse) - (c == y ? 1.f : 0.f)) * sc;
+}
+}  // namespace
+
+extern "C" int mft_cross_entropy_mean(const float* logits, int ld, const void* labels, int labels_i64, int C, int rows, float* loss,
+                                      double* loss_sum, void* stream) {
+    if (rows < 1 || C < 1 || ld < C) return MFT_EINVAL;
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, labels_i64, C, rows, loss,
+                       loss_sum);
+    return mft_launch_status();
+}
+
+extern "C" int mft_cross_entropy_mean_backward(const float* logits, int ld, const void* labels, int labels_i64, int C, int rows,
+                                               const float* grad_loss, float* dlogits, int ldd, void* stream) {
+    if (rows < 1 || C < 1 || ld < C || ldd < C) return MFT_EINVAL;
+    hipLaunchKernelGGL(ce_mean_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, labels_i64, C,
+                       rows, grad_loss, dlogits, ldd);
+    return mft_launch_status();
+}
+
 extern "C" int mft_softmax_rows(const float* x, int ldx, float* y, int ldy, int C, int rows, void* stream) {
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, C,
                        rows);

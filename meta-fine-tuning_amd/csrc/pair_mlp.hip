@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void softmax_ut_backward_kernel(const float* _
 }
 
 // BatchNorm + leaky_relu backward over merged rows, phase 1: per-channel sums of u = g * lrelu'(y) and u * xhat, y = z * scale +
-// shift, xhat = (z - mean) * rstd.  One block per contiguous range of rows; fixed-order partials (block, then row lane).
+// shift, xhat = (z - mean) * rstd.  One block per contiguous range of rows of ONE group (grid.y = group = episode: k episodes in
+// lockstep have their own BatchNorm statistics, gnn.py:65-102 runs once per episode); fixed-order partials (block, then row lane).
 __global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ z, int C,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -383,14 +384,17 @@ __global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __rest
     __shared__ float red[2][10][192];
     const int q = C / 4, rp = 256 / q;                // float4 per row; rows per pass (5 at C = 192, 10 at C = 96)
     const int c4 = (threadIdx.x % q) * 4, rl = threadIdx.x / q;
+    const int grp = blockIdx.y;
+    const long long gro = (long long)grp * rows;      // first row of the group
     f32x4 su = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
     if (rl < rp) {
-        const f32x4 sc = *(const f32x4*)(scale + c4), sh = *(const f32x4*)(shift + c4);
-        const f32x4 mu = *(const f32x4*)(mean + c4), rs = *(const f32x4*)(rstd + c4);
+        const long long go = (long long)grp * C;
+        const f32x4 sc = *(const f32x4*)(scale + go + c4), sh = *(const f32x4*)(shift + go + c4);
+        const f32x4 mu = *(const f32x4*)(mean + go + c4), rs = *(const f32x4*)(rstd + go + c4);
         const long long r0 = (long long)blockIdx.x * rows_per_block;
         const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         for (long long r = r0 + rl; r < r1; r += rp) {
-            const f32x4 gv = *(const f32x4*)(g + r * ldg + c4), zv = *(const f32x4*)(z + r * C + c4);
+            const f32x4 gv = *(const f32x4*)(g + (gro + r) * ldg + c4), zv = *(const f32x4*)(z + (gro + r) * C + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y = zv[e] * sc[e] + sh[e];
@@ -407,44 +411,59 @@ __global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __rest
         const int k = i / C, c = i - k * C;
         float s = 0.f;
         for (int l = 0; l < rp; ++l) s += red[k][l][c];
-        ws[((long long)blockIdx.x * 2 + k) * C + c] = s;
+        ws[(((long long)grp * gridDim.x + blockIdx.x) * 2 + k) * C + c] = s;
     }
 }
 
 // 16 (sum kind, channel) entries per block, 16 lanes per entry over the block partials (lane l takes partials l, l+16, ...),
 // combined in lane order: fixed summation order, and chains of ~8 dependent loads instead of one of ~120 (the serial form took
-// 28 us per call -- 12 calls per meta-training step -- for 178 KB of partials)
-__global__ __launch_bounds__(256) void pair_bwd_stats_final_kernel(const float* __restrict__ ws, int nblk, int C, float* __restrict__ sums) {
+// 28 us per call -- 12 calls per meta-training step -- for 178 KB of partials).  The groups are walked in order: sums[g][2C] per
+// group (what phase 2 subtracts), dparams[2C] = their sum over the groups = (d beta | d gamma) of the shared affine parameters;
+// dbias_zero [C] (nullable): the gradient of the 1x1 convolution's bias in front of this BatchNorm -- identically zero.
+__global__ __launch_bounds__(256) void pair_bwd_stats_final_kernel(const float* __restrict__ ws, int nblk, int C, int n_groups,
+                                                                   float* __restrict__ sums, float* __restrict__ dparams,
+                                                                   float* __restrict__ dbias_zero) {
     __shared__ float red[16][17];
     const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + e;                 // over 2 * C
-    float s = 0.f;
-    if (i < 2 * C) {
-        const int k = i / C, c = i - k * C;
-        for (int b = l; b < nblk; b += 16) s += ws[((long long)b * 2 + k) * C + c];
-    }
-    red[l][e] = s;
-    __syncthreads();
-    if (l == 0 && i < 2 * C) {
-        float t = red[0][e];
+    float tot = 0.f;
+    for (int grp = 0; grp < n_groups; ++grp) {
+        float s = 0.f;
+        if (i < 2 * C) {
+            const int k = i / C, c = i - k * C;
+            for (int b = l; b < nblk; b += 16) s += ws[(((long long)grp * nblk + b) * 2 + k) * C + c];
+        }
+        red[l][e] = s;
+        __syncthreads();
+        if (l == 0 && i < 2 * C) {
+            float t = red[0][e];
 #pragma unroll
-        for (int j = 1; j < 16; ++j) t += red[j][e];
-        sums[i] = t;
+            for (int j = 1; j < 16; ++j) t += red[j][e];
+            sums[(long long)grp * 2 * C + i] = t;
+            tot += t;
+        }
+        __syncthreads();
+    }
+    if (l == 0 && i < 2 * C) {
+        if (dparams) dparams[i] = tot;
+        if (dbias_zero && i < C) dbias_zero[i] = 0.f;
     }
 }
 
 // phase 2: dz = gamma * rstd * (u - cnt * sum_u / n_tot - cnt * xhat * sum_ux / n_tot), cnt = 1 on diagonal rows, 2 elsewhere
+// (sums, scale, shift, mean, rstd of the row's group; n_tot = positions of ONE group)
 __global__ __launch_bounds__(256) void pair_bwd_dz_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ z, int C,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
                                                           const int* __restrict__ ij, int P, float inv_n_tot, float slope,
-                                                          long long rows, float* __restrict__ dz) {
+                                                          long long rows, long long rows_per_group, float* __restrict__ dz) {
     const int q = C / 4;
     const long long total = rows * q;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const long long r = t / q;
         const int c4 = (int)(t - r * q) * 4;
+        const long long go = (r / rows_per_group) * C;
         const int pk = ij[r % P];
         const float cnt = ((pk >> 16) == (pk & 0xffff)) ? 1.f : 2.f;
         const f32x4 gv = *(const f32x4*)(g + r * ldg + c4), zv = *(const f32x4*)(z + r * C + c4);
@@ -452,10 +471,10 @@ __global__ __launch_bounds__(256) void pair_bwd_dz_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = c4 + e;
-            const float y = zv[e] * scale[c] + shift[c];
+            const float y = zv[e] * scale[go + c] + shift[go + c];
             const float u = y > 0.f ? gv[e] : gv[e] * slope;
-            const float xh = (zv[e] - mean[c]) * rstd[c];
-            o[e] = gamma[c] * rstd[c] * (u - cnt * (sums[c] * inv_n_tot) - cnt * xh * (sums[C + c] * inv_n_tot));
+            const float xh = (zv[e] - mean[go + c]) * rstd[go + c];
+            o[e] = gamma[c] * rstd[go + c] * (u - cnt * (sums[2 * go + c] * inv_n_tot) - cnt * xh * (sums[2 * go + C + c] * inv_n_tot));
         }
         *(f32x4*)(dz + r * C + c4) = o;
     }
@@ -581,27 +600,33 @@ extern "C" int mft_pair_softmax_ut_backward(const float* A, const float* dA, con
     return mft_launch_status();
 }
 
-extern "C" long long mft_pair_bwd_stats_ws_floats(long long rows, int C) {
-    long long nblk = (rows + 63) / 64;
+extern "C" long long mft_pair_bwd_stats_ws_floats(long long rows_per_group, int C) {
+    long long nblk = (rows_per_group + 63) / 64;
     if (nblk > 1024) nblk = 1024;
-    return nblk * 2 * C;
+    return nblk * 2 * C;                           // per group
 }
 
 extern "C" int mft_pair_bn_act_backward(const float* g, int ldg, const float* z, int C, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, const float* gamma, const int* ij, int N,
-                                        long long rows, long long n_tot, float slope, float* ws, float* sums, float* dz, void* stream) {
-    if ((C != 96 && C != 192) || ldg < C || ldg % 4 != 0 || rows < 1 || n_tot < rows) return MFT_EINVAL;
-    long long nblk = (rows + 63) / 64;            // ~64 rows per block: enough blocks to fill the CUs at the 5-shot graph size too
+                                        long long rows_per_group, int n_groups, long long n_tot, float slope, float* ws, float* sums,
+                                        float* dparams, float* dbias_zero, float* dz, void* stream) {
+    if ((C != 96 && C != 192) || ldg < C || ldg % 4 != 0 || rows_per_group < 1 || n_groups < 1 || n_groups > 65535 || n_tot < rows_per_group)
+        return MFT_EINVAL;
+    const long long P = (long long)N * (N + 1) / 2;
+    if (rows_per_group % P != 0) return MFT_EINVAL;         // a group is whole graphs
+    long long nblk = (rows_per_group + 63) / 64;   // ~64 rows per block: enough blocks to fill the CUs at the 5-shot graph size too
     if (nblk > 1024) nblk = 1024;
-    const long long rpb = (rows + nblk - 1) / nblk;
+    const long long rpb = (rows_per_group + nblk - 1) / nblk;
+    const long long rows = rows_per_group * n_groups;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pair_bwd_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean, rstd, slope, rows,
-                       rpb, ws);
-    hipLaunchKernelGGL(pair_bwd_stats_final_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)nblk, C, sums);
+    hipLaunchKernelGGL(pair_bwd_stats_kernel, dim3((unsigned)nblk, (unsigned)n_groups), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean,
+                       rstd, slope, rows_per_group, rpb, ws);
+    hipLaunchKernelGGL(pair_bwd_stats_final_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)nblk, C, n_groups, sums,
+                       dparams, dbias_zero);
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(pair_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean, rstd, gamma,
-                       (const float*)sums, ij, N * (N + 1) / 2, 1.0f / (float)n_tot, slope, rows, dz);
+                       (const float*)sums, ij, (int)P, 1.0f / (float)n_tot, slope, rows, rows_per_group, dz);
     return mft_launch_status();
 }
 

@@ -431,14 +431,27 @@ class SyntheticNovelLoader:
             yield [(v, y) for v in views]
 
 
-def balanced_batch(n_mine, e_max):
+FUSED_GAIN = 1.12      # steady-state rate of the fused next-step-forward inner loop over the unfused one (89.5 vs 79-80 episodes/s at E = 120 / 128)
+
+
+def balanced_batch(n_mine, e_max, fused=False):
     """Episodes per lockstep batch for a rank that owns ``n_mine`` episodes: the engine always runs full batches (a short one is
     padded with copies of its last episode), so 600 episodes at 128 per batch would pay for 640.  Same number of batches, equal
-    sizes: 600 -> 5 x 120."""
+    sizes: 600 -> 5 x 120.
+
+    ``fused``: the engine's fused inner loop (engine.fuse_next_policy: whole waves of its walking kernel need E % 32 == 0) is
+    available at this configuration.  Then the equal size is rounded up to the next multiple of 32 when the padded episodes cost
+    less than the unfused path would (600 -> 5 x 128 = 640 slots at 1.12x the rate beats 600 unfused slots: the README-shaped
+    600-episode job ran wholly unfused in round 5; 75 -> 96 does not pay and stays 75)."""
     if n_mine <= 0:
         return max(1, e_max)
     nb = (n_mine + e_max - 1) // e_max
-    return (n_mine + nb - 1) // nb
+    e = (n_mine + nb - 1) // nb
+    if fused and e >= 32 and e % 32 != 0:
+        e32 = (e + 31) // 32 * 32
+        if e32 <= e_max and nb * e32 < FUSED_GAIN * nb * e:
+            return e32
+    return e
 
 
 def short_job_candidates(n_batches):
@@ -485,7 +498,9 @@ def evaluate(model, state, n_episodes, n_way, n_shot, n_query, size, gen_example
             rng_seed = 10
         mine = parallel.shard_indices(n_episodes, rank, W)
     if balance:
-        episodes_per_batch = balanced_batch(len(mine), episodes_per_batch)
+        # (the fused inner loop exists for --method gnnnet / all at 84 x 84 with the stem cache: engine.fuse_next_policy)
+        episodes_per_batch = balanced_batch(len(mine), episodes_per_batch,
+                                            fused=(size <= 84 and not freeze_backbone and settings.current().fuse_next != "0"))
     y_query = np.repeat(range(n_way), n_query)
     batches = [mine[c:c + episodes_per_batch] for c in range(0, len(mine), episodes_per_batch)]
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -302,11 +302,11 @@ def _bn_stats4(arena, tag, x, ipg, groups, running=None, fixed=None):
     rows = ipg * H * W
     nws = max(int(ops._lib.lib().mft_bn_stats_ws_floats(C, rows, groups)), 1)
     ws = arena.get("bn.ws", (max(nws, 1 << 16),)) if nws <= (1 << 16) else arena.get(tag + ".ws", (nws,))
-    rm = rv = None
+    rm = rv = nbt = None
     if running is not None:
-        rm, rv = running
+        rm, rv, nbt = running if len(running) == 3 else (running + (None,))
     rc = ops._lib.lib().mft_bn_stats(ops._p(x), C, C, rows, groups, ops.BN_EPS, ops._p(mean), ops._p(rstd), ops._p(ws),
-                                     ops._p(rm), ops._p(rv), 0.1, ops._stream())
+                                     ops._p(rm), ops._p(rv), 0.1, ops._p(nbt), ops._stream())
     ops._lib.check(rc, "mft_bn_stats")
     return mean, rstd
 

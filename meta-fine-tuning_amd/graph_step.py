@@ -18,6 +18,14 @@ from . import settings
 ENABLED = settings.current().train_graph
 
 
+def bump_versions(tensors):
+    """Advance autograd's version counter of every tensor by one WITHOUT a device launch: parameters were (or are about to be)
+    written through raw pointers, and the weight-pack caches of autograd_ops key on ``p._version``."""
+    tensors = tuple(tensors)
+    if tensors:
+        torch._C._autograd._unsafe_set_version_counter(tensors, tuple(t._version + 1 for t in tensors))
+
+
 class GraphedLossBackward:
     """``loss = step(x, optimizer)`` leaves the loss in a static tensor and the gradients in ``p.grad`` exactly as
     ``optimizer.zero_grad(); loss = loss_fn(x); loss.backward()`` would.  The caller must not drop the gradients between
@@ -81,8 +89,8 @@ class GraphedLossBackward:
     def _capture(self, x):
         from . import autograd_ops as AG  # noqa: F401  (packed weight copies are refreshed inside the captured forward)
         self.static_x = x.detach().to("cuda", copy=True)
-        with torch.no_grad():
-            torch._foreach_mul_(self.params, 1.0)       # bump every version counter: the captured forward must contain the repack launches
+        self._one = torch.ones((), device=self.static_x.device, dtype=torch.float32)
+        bump_versions(self.params)                      # the captured forward must contain the repack launches
         for p in self.params:
             p.grad = None
         g = torch.cuda.CUDAGraph()
@@ -90,7 +98,7 @@ class GraphedLossBackward:
             warnings.simplefilter("ignore")
             with torch.cuda.graph(g):
                 self.static_loss = self.loss_fn(self.static_x)
-                self.static_loss.backward()
+                self.static_loss.backward(self._one)     # (autograd's implicit ones_like(loss) would be a fill launch in every replay)
         self.graph = g
 
     def __call__(self, x, optimizer=None):

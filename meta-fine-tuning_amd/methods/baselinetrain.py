@@ -5,6 +5,7 @@ HIP forward / full backward (autograd_ops), the classifier through the same GEMM
 import torch
 import torch.nn as nn
 
+from .. import autograd_ops as AG
 from .. import functional_bwd as FB
 from .. import ops
 
@@ -58,7 +59,7 @@ class BaselineTrain(nn.Module):
         self.classifier.bias.data.fill_(0)                               # baselinetrain.py:17
         self.loss_type = loss_type
         self.num_class = num_class
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = AG.CrossEntropyLoss()                             # nn.CrossEntropyLoss() (baselinetrain.py:20), HIP launches
         self.top1 = AverageMeter()
 
     def forward(self, x):

@@ -1,7 +1,7 @@
 """GnnNet: ResNet10 features -> Linear+BN projector -> GNN over (support + one query) graphs
 (mirror of methods/gnnnet.py:20-231), with the reference's attributes, asserts and state_dict keys.
 
-All arithmetic runs in libmft_hip.so.  ``set_forward`` batches the n_query graphs of an episode in one
+All arithmetic runs in libmft_hip.so (the loss included: autograd_ops.CrossEntropyLoss).  ``set_forward`` batches the n_query graphs of an episode in one
 grouped launch sequence; ``set_forward_finetune`` runs the first-order-MAML inner loop (15 epochs of
 4-image Adam steps on the last ResNet block, gnnnet.py:153-177) on device-resident per-episode state.
 """
@@ -40,7 +40,7 @@ class GnnNet(MetaTemplate):
         super().__init__(model_func, n_way, n_support)
         if self.maml:
             raise NotImplementedError("gnnnet_maml fast-weight layers are off the hot path (SURVEY.md §2.1)")
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = AG.CrossEntropyLoss()                         # nn.CrossEntropyLoss() (gnnnet.py:43) on mft_cross_entropy_mean
         self.first = True
         self.fc = nn.Sequential(nn.Linear(self.feat_dim, 128), nn.BatchNorm1d(128, track_running_stats=False))
         self.gnn = GNN_nl(128 + self.n_way, 96, self.n_way)
@@ -97,6 +97,29 @@ class GnnNet(MetaTemplate):
         y_query = self._y_query()
         scores = self.set_forward(x)
         return self.loss_fn(scores, y_query)
+
+    # ------------------------------------------------------------------ k episodes in lockstep (opt-in, train.py --episodes_per_rank k)
+    def set_forward_lockstep(self, xs):
+        """xs [k, n_way, n_support+n_query, 3,H,W]: k episodes through ONE sequence of launches -- every BatchNorm of the backbone
+        and of the head keeps per-episode statistics (a group per episode), convolutions / linear layers see k times the rows.
+        Scores [k*n_way*n_query, n_way], episode after episode, each exactly what ``set_forward`` gives for that episode."""
+        xs = xs.cuda()
+        k = xs.size(0)
+        feats = AG.resnet10_module_forward(self.feature, xs.reshape(-1, *xs.size()[3:]), groups=k)
+        return AG.gnnnet_head(self, feats, self._graph_support(), self.n_query, fold=self.FOLD50, episodes=k)
+
+    def set_forward_loss_lockstep(self, xs):
+        """mean over the k episodes of ``set_forward_loss`` (gnnnet.py:219-224): its backward leaves the AVERAGE of the k episodes'
+        gradients taken at the same parameters -- the step a k-rank episode-parallel run takes after its all-reduce
+        (parallel.FlatGradBucket), here on one GPU with k times the work per launch."""
+        k = xs.size(0)
+        key = ("lockstep", self.n_way, self.n_query, k, torch.cuda.current_device())
+        if not hasattr(self, "_yq_cache"):
+            self._yq_cache = {}
+        y = self._yq_cache.get(key)
+        if y is None:
+            y = self._yq_cache[key] = torch.from_numpy(np.tile(np.repeat(range(self.n_way), self.n_query), k)).cuda()
+        return self.loss_fn(self.set_forward_lockstep(xs), y)
 
     def set_forward_loss_finetune(self, x):
         y_query = self._y_query()

@@ -60,6 +60,11 @@ class MetaTemplate(nn.Module):
         avg_loss = 0
         graphed = graph_step.for_loop(self, loss_fn)      # forward + backward as one hipGraph replay (plain set_forward_loss only)
         avg_dev = None
+        # the running sum the reference keeps in a Python float (= double): the loss module adds every step's loss to a float64
+        # device scalar inside its own launch (AG.CrossEntropyLoss.loss_sum) -- no extra launch and no host sync per step
+        acc = getattr(getattr(self, "loss_fn", None), "loss_sum", None)
+        acc = acc(next(self.parameters()).device) if (acc is not None and graphed is not None) else None
+        base = acc.item() if acc is not None else 0.0
         for i, (x, _) in enumerate(train_loader):
             self.n_query = x.size(1) - (self.n_support if n_support_images is None else n_support_images)
             if self.change_way:
@@ -67,10 +72,11 @@ class MetaTemplate(nn.Module):
             if graphed is not None:
                 loss = graphed(x, optimizer)     # (grads of parameters outside the recorded step are dropped as zero_grad() would)
                 optimizer.step()
-                # the running sum the reference keeps in a Python float (= double), kept on the device: no host sync per step
-                avg_dev = loss.detach().double() if avg_dev is None else avg_dev + loss.detach().double()
+                if acc is None:                  # (a loss module that is not ours: keep the sum on the device the slow way)
+                    avg_dev = loss.detach().double() if avg_dev is None else avg_dev + loss.detach().double()
                 if i % print_freq == 0:
-                    print('Epoch {:d} | Batch {:d}/{:d} | Loss {:f}'.format(epoch, i, len(train_loader), avg_dev.item() / float(i + 1)))
+                    tot = (acc.item() - base) if acc is not None else avg_dev.item()
+                    print('Epoch {:d} | Batch {:d}/{:d} | Loss {:f}'.format(epoch, i, len(train_loader), tot / float(i + 1)))
                 continue
             optimizer.zero_grad()
             loss = loss_fn(x)

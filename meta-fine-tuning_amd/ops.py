@@ -389,16 +389,18 @@ def conv2d_wgrad(x, dy, Cout, KH, KW, stride, pad, imgs_per_group=0, out=None, l
     return out
 
 
-def conv2d_wgrad_oihw(x, dy, Cout, KH, KW, stride, pad):
-    """Weight gradient of a shared-weight convolution as torch lays Conv2d.weight.grad out: [Cout, Cin, KH, KW]."""
+def conv2d_wgrad_oihw(x, dy, Cout, KH, KW, stride, pad, cin_valid=0, cout_valid=0, out=None):
+    """Weight gradient of a shared-weight convolution as torch lays Conv2d.weight.grad out: [Cout, Cin, KH, KW].
+    ``cin_valid`` / ``cout_valid``: the operands carry zero-padded channels; only that corner is written (contiguously)."""
     _f32c(x)
     _f32c(dy)
     n, H, W, Cin = x.shape
-    out = torch.empty((Cout, Cin, KH, KW), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((cout_valid or Cout, cin_valid or Cin, KH, KW), device=x.device, dtype=torch.float32)
     ws = torch.empty((int(_lib.lib().mft_conv2d_wgrad_oihw_ws_floats(n, H, W, Cin, Cout, KH, KW, stride, pad)),), device=x.device,
                      dtype=torch.float32)
-    rc = _lib.lib().mft_conv2d_wgrad_oihw(_p(x), Cin, _p(dy), dy.shape[-1], _p(out), n, H, W, Cin, Cout, KH, KW, stride, pad, _p(ws),
-                                          _stream())
+    rc = _lib.lib().mft_conv2d_wgrad_oihw(_p(x), Cin, _p(dy), dy.shape[-1], _p(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
+                                          cin_valid, cout_valid, _p(ws), _stream())
     _lib.check(rc, "mft_conv2d_wgrad_oihw")
     return out
 
@@ -466,8 +468,10 @@ def conv2d_wgrad_adam_dgrad(x, dy, w, m, v, dxp, step, imgs_per_group, lr=0.01, 
 
 # ------------------------------------------------------------------------------------ batch norm
 
-def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=None, momentum=0.1, eps=BN_EPS):
-    """x2d [rows, ld] -> mean, rstd [n_groups, C]."""
+def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=None, momentum=0.1, eps=BN_EPS,
+             num_batches_tracked=None):
+    """x2d [rows, ld] -> mean, rstd [n_groups, C].  ``num_batches_tracked`` (int64 scalar tensor, with running statistics only):
+    incremented by the same launch."""
     _f32c(x2d)
     ld = x2d.shape[-1]
     mean = torch.empty((n_groups, C), device=x2d.device, dtype=torch.float32)
@@ -475,7 +479,7 @@ def bn_stats(x2d, C, rows_per_group, n_groups, running_mean=None, running_var=No
     nws = _lib.lib().mft_bn_stats_ws_floats(C, rows_per_group, n_groups)
     ws = torch.empty((max(int(nws), 1),), device=x2d.device, dtype=torch.float32)
     rc = _lib.lib().mft_bn_stats(_p(x2d), ld, C, rows_per_group, n_groups, eps, _p(mean), _p(rstd), _p(ws),
-                                 _p(running_mean), _p(running_var), momentum, _stream())
+                                 _p(running_mean), _p(running_var), momentum, _p(num_batches_tracked), _stream())
     _lib.check(rc, "mft_bn_stats")
     return mean, rstd
 

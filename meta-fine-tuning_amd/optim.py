@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .graph_step import bump_versions
 
 
 CHUNK = 16384          # elements per workgroup of the multi-tensor launch (multiple of 4: chunks stay 16-byte aligned)
@@ -62,8 +63,7 @@ class Adam(torch.optim.Optimizer):
                     st = self.state[p]
                     ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"], beta1=b1,
                                   beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"])
-            # parameters were updated through raw pointers: bump autograd's version counters (the weight-pack caches of
-            # autograd_ops key on ``p._version``) with one fused no-op write ON THE PARAMETERS THEMSELVES -- an in-place op on
-            # ``p.data`` does not touch the parameter's counter (step() runs under no_grad, so this is legal on leaves)
-            torch._foreach_add_(ps, 0)
+            # parameters were updated through raw pointers: bump autograd's version counters ON THE PARAMETERS THEMSELVES (the
+            # weight-pack caches of autograd_ops key on ``p._version``) -- host-side, no launch
+            bump_versions(ps)
         return loss

@@ -384,6 +384,12 @@ def test_checkpoint_lookup_mirrors_the_reference(tmp_path, monkeypatch):
 def test_balanced_batches_and_lookahead_guard():
     from meta_fine_tuning_amd import finetune as ft
     assert [ft.balanced_batch(n, 128) for n in (600, 300, 150, 75, 128, 129, 1)] == [120, 100, 75, 75, 128, 65, 1]
+    # where the engine's fused inner loop applies (it wants E % 32 == 0): round the equal size up to a multiple of 32 when the padded
+    # slots cost less than running unfused -- 600 -> 5 x 128, 300 -> 3 x 100 stays (128 would pad 28 %), 75 stays, 250 -> 2 x 128
+    assert [ft.balanced_batch(n, 128, fused=True) for n in (600, 300, 150, 75, 128, 129, 250, 1)] == [128, 100, 75, 75, 128, 65, 128, 1]
+    for n in range(1, 700, 37):
+        e = ft.balanced_batch(n, 128, fused=True)
+        assert e <= 128 and e * ((n + 127) // 128) >= n
     for n in range(1, 700, 37):
         e = ft.balanced_batch(n, 128)
         nb = (n + 127) // 128

@@ -1366,3 +1366,22 @@ def test_stem_cache_fused_fill_matches_the_three_launches(n, monkeypatch):
     assert torch.allclose(a.pmax[:k].double(), mx, atol=2e-5) and torch.allclose(a.pmin[:k].double(), mn, atol=2e-5)
     # a 224 x 224 cache is outside the fused kernel's domain and says so
     assert not Fn.StemCache(W, 2, 224, DEV, pooled=True).fused_fill
+
+
+@pytest.mark.parametrize("rows,K,kv,cp,cv", [(7440, 160, 133, 192, 192), (480, 288, 266, 64, 48), (480, 480, 458, 32, 5), (7440, 96, 96, 32, 1),
+                                             (300, 256, 229, 192, 0)])
+def test_conv_wgrad_oihw_valid_corner(rows, K, kv, cp, cv):
+    """mft_conv2d_wgrad_oihw(cin_valid, cout_valid): the GNN's linear layers carry zero-padded input features / output rows; the
+    launch hands back the [cout_valid, cin_valid] corner contiguously -- equal, bit for bit, to slicing the full gradient
+    (gnn.py:38,64-76: nn.Linear / 1x1 Conv2d .grad)."""
+    x = rnd((rows, K), 301).to(DEV)
+    x[:, kv:] = 0
+    dy = rnd((rows, cp), 302).to(DEV)
+    if cv:
+        dy[:, cv:] = 0
+    full = ops.conv2d_wgrad_oihw(x.view(rows, 1, 1, K), dy.view(rows, 1, 1, cp), cp, 1, 1, 1, 0).view(cp, K)
+    got = ops.conv2d_wgrad_oihw(x.view(rows, 1, 1, K), dy.view(rows, 1, 1, cp), cp, 1, 1, 1, 0, cin_valid=kv, cout_valid=cv)
+    assert got.shape == (cv or cp, kv, 1, 1) and got.is_contiguous()
+    assert torch.equal(got.view(cv or cp, kv), full[:cv or cp, :kv])
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    assert float((got.view(cv or cp, kv).double().cpu() - ref[:cv or cp, :kv]).abs().max()) < 2e-5 * float(ref.abs().max())

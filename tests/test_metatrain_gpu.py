@@ -675,3 +675,62 @@ def test_graphed_meta_finetune_loop_is_bit_identical(capsys, monkeypatch):
     assert any(k.startswith("feature3.") for k in sd_e) and sd_e.keys() == sd_g.keys()
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ round 6: the loss is a HIP launch
+@pytest.mark.parametrize("rows,C,dtype", [(80, 5, torch.int64), (16, 64, torch.int64), (33, 200, torch.int32), (7, 3, torch.int64)])
+def test_cross_entropy_module_matches_torch(rows, C, dtype):
+    """AG.CrossEntropyLoss (mft_cross_entropy_mean / _backward: gnnnet.py:43,219-231; baselinetrain.py:20,38-45) against
+    nn.CrossEntropyLoss in float64: loss, d(scores) under a non-unit upstream gradient, and the float64 running sum."""
+    from meta_fine_tuning_amd import autograd_ops as AG
+    g = torch.Generator().manual_seed(rows * 131 + C)
+    s = (torch.randn(rows, C, generator=g) * 3.0)
+    y = torch.randint(0, C, (rows,), generator=g)
+    crit = AG.CrossEntropyLoss()
+    assert isinstance(crit, torch.nn.CrossEntropyLoss)
+    sg = s.cuda().requires_grad_(True)
+    loss = crit(sg, y.to(dtype).cuda())
+    (loss * 0.37).backward()
+    sd = s.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(sd, y)
+    (ref * 0.37).backward()
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert float((sg.grad.cpu().double() - sd.grad).abs().max()) < 1e-7
+    loss2 = crit(sg.detach(), y.to(dtype).cuda())
+    assert abs(float(crit.loss_sum(sg.device)) - (float(loss) + float(loss2))) < 1e-6
+    with pytest.raises(RuntimeError):
+        crit(s, y)                                        # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        AG.CrossEntropyLoss(label_smoothing=0.1)(sg, y.cuda())
+
+
+def test_meta_training_step_issues_no_torch_device_ops():
+    """One eager meta-training step (zero_grad, set_forward_loss, backward with an explicit upstream gradient, optimizer.step) is
+    C-ABI launches only: the torch profiler sees no aten fill / copy / arithmetic kernel on the device (round-5 verdict, row a7:
+    25 ATen kernels per step).  The only device-side torch work left is what autograd itself adds around the functions (none for
+    this graph) -- asserted by name."""
+    from torch.profiler import ProfilerActivity, profile
+    from meta_fine_tuning_amd import optim
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+    model.load_state_dict(synthetic.gnnnet_state_dict(seed=0))
+    model.train()
+    model.n_query = 16
+    opt = optim.Adam(model.parameters())
+    x = synthetic.train_episode(5, 5, 5, 16, 84).cuda()
+    one = torch.ones((), device="cuda")
+    for _ in range(2):
+        opt.zero_grad()
+        model.set_forward_loss(x).backward(one)
+        opt.step()
+    torch.cuda.synchronize()
+    nbt0 = int(model.feature.trunk[1].num_batches_tracked)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        opt.zero_grad()
+        model.set_forward_loss(x).backward(one)
+        opt.step()
+        torch.cuda.synchronize()
+    dev_kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    aten = sorted({n for n in dev_kernels if "at::native" in n or n.startswith("void at::")})
+    assert dev_kernels, "the profiler recorded no device kernels"
+    assert not aten, aten
+    assert int(model.feature.trunk[1].num_batches_tracked) == nbt0 + 1 == int(model.feature.trunk[7].BN2.num_batches_tracked)

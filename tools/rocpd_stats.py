@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(path, top=40):
+def main(path, top=0):
     con = sqlite3.connect(path)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -23,9 +23,9 @@ def main(path, top=40):
     span = max(r[2] for r in rows) - min(r[1] for r in rows)
     print("# %d dispatches, sum of kernel time %.3f ms, first-start..last-end span %.3f ms" % (len(rows), tot / 1e6, span / 1e6))
     print("%-110s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"))
-    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top or None]:      # (top = 0: every kernel -- a trace kept under profiles/ is never cut)
         print("%-110s %8d %12.3f %10.2f %10.2f %10.2f %6.2f" % (name[:110], a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / tot))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
