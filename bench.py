@@ -416,6 +416,9 @@ OTHER_CONFIGS = (
      ["--n-shot", "50", "--steps", "1", "--warmup", "1"], 420),
     ("configs3_metatrain", "configs[3]: meta-training step (set_forward_loss + full backward + flat-bucket all-reduce + fused outer Adam), "
      "one 105-image episode per rank per step, hipGraph replay", ["--workload", "metatrain", "--steps", "300", "--warmup", "10"], 300),
+    ("configs3_metatrain_lockstep4", "configs[3] with the opt-in --episodes_per_rank 4: four episodes per optimizer step in lockstep on the one GPU "
+     "(per-episode BatchNorm statistics, gradients averaged over them = the update of a 4-rank episode-parallel run; value counts 4 episodes "
+     "per step)", ["--workload", "metatrain", "--episodes-per-rank", "4", "--steps", "200", "--warmup", "10"], 300),
     ("reference_224", "the reference's own image_size 224 (finetune.py:429; train.py:72) at configs[1]'s 5-way 5-shot, 500 inner steps",
      ["--image-size", "224", "--episodes-per-batch", "32", "--steps", "2", "--warmup", "1"], 420),
 )
@@ -466,7 +469,7 @@ def other_configs_children(args):
     return out
 
 
-def metatrain_roofline(model, opt, eps, step_s):
+def metatrain_roofline(model, opt, eps, step_s, loss_fn=None, k=1):
     """Roofline of the meta-training step (BASELINE configs[3]; round-4 verdict "missing 4"): three EAGER steps (the graphed step
     replays the same launches from one hipGraph, where nothing can be bracketed) with every C-ABI launcher call timed by a pair of
     HIP events on its own stream (_lib.LaunchTimer).  The step is a dense contraction (MFMA-bound): the
@@ -481,6 +484,9 @@ def metatrain_roofline(model, opt, eps, step_s):
         """Algorithmic FLOPs of one convolution-family launch from its C-ABI arguments (None: not one)."""
         if name in ("mft_conv2d_nhwc", "mft_conv2d_nhwc_ksplit", "mft_conv2d_nhwc_x3"):
             return _conv_fl(a, 6, 7, 8, 9, 10, 11, 12, 13, 14)
+        if name == "mft_conv2d_wgrad_oihw_multi":                   # (the job array itself is the first argument: ops.WgradBatch.flush)
+            return sum(2.0 * j.n_img * _osz(j.H, j.KH, j.stride, j.pad) * _osz(j.W, j.KW, j.stride, j.pad) * j.Cout * j.KH * j.KW * j.Cin
+                       for j in a[0])
         if name.startswith(("mft_conv2d_dgrad_nhwc", "mft_conv2d_wgrad_nhwc", "mft_conv2d_wgrad_oihw")):
             return _conv_fl(a, 5, 6, 7, 8, 9, 10, 11, 12, 13)       # (n, H, W = the forward input's; Cin, Cout the forward's)
         return None
@@ -505,7 +511,7 @@ def metatrain_roofline(model, opt, eps, step_s):
     for i in range(reps):
         with _lib.LaunchTimer(keep_args=True) as lt:
             opt.zero_grad()
-            loss = model.set_forward_loss(eps[i % len(eps)])
+            loss = (loss_fn or model.set_forward_loss)(eps[i % len(eps)])
             loss.backward()
             opt.step()
             torch.cuda.synchronize()
@@ -528,7 +534,7 @@ def metatrain_roofline(model, opt, eps, step_s):
     flops = {k: v["gflop"] * 1e9 for k, v in per.items() if v["gflop"] > 0}
     dom = max(flops, key=lambda k: per.get(k, {"ms_per_step": 0.0})["ms_per_step"])
     ach = flops[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e12
-    whole = 112e9 / step_s / 1e12               # 112 GFLOP per 84x84 meta-train episode
+    whole = k * 112e9 / step_s / 1e12           # 112 GFLOP per 84x84 meta-train episode (k episodes per step)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": (PEAK_F32_MFMA / 1e12), "unit": "TFLOP/s", "frac": round(ach / (PEAK_F32_MFMA / 1e12), 4),
             "traffic": None, "kernel": "%s (fp32 MFMA implicit GEMM; %.1f algorithmic GFLOP per step in %d launches, summed per launch from the C-ABI arguments)"
                                        % (dom, flops[dom] / 1e9, per[dom]["launches_per_step"]),
@@ -536,7 +542,7 @@ def metatrain_roofline(model, opt, eps, step_s):
                             else {kk: vv for kk, vv in v.items() if kk != "gflop"})
                         for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "eager_kernel_ms_per_step": round(total, 3),
-            "whole_step": {"algorithmic_gflop": 112.0, "tflops": round(whole, 2), "frac_of_f32_mfma_peak": round(whole / (PEAK_F32_MFMA / 1e12), 4),
+            "whole_step": {"algorithmic_gflop": 112.0 * k, "tflops": round(whole, 2), "frac_of_f32_mfma_peak": round(whole / (PEAK_F32_MFMA / 1e12), 4),
                            "ms_per_step_graphed": round(step_s * 1e3, 3)},
             "method": "HIP events around every launcher call of three eager steps, each on the launcher's own stream (_lib.LaunchTimer); "
                       "kernel-trace cross-check: profiles/r05_metatrain_kernel_trace.txt"}
@@ -576,7 +582,12 @@ def bench_metatrain(args, rank, world, dev, dist):
 
     from meta_fine_tuning_amd import graph_step
     finetune = args.workload == "metafinetune"                        # train.py --fine_tune: set_forward_loss_finetune (gnnnet.py:106-231)
-    loss_fn = model.set_forward_loss_finetune if finetune else model.set_forward_loss
+    kk = max(1, args.episodes_per_rank)
+    if kk > 1:
+        assert not finetune and args.train_source == "fixed"
+        base = eps
+        eps = [torch.stack([base[(i + j) % len(base)] for j in range(kk)]) for i in range(len(base))]      # k pre-made episodes per step
+    loss_fn = model.set_forward_loss_finetune if finetune else (model.set_forward_loss_lockstep if kk > 1 else model.set_forward_loss)
     graphed = graph_step.for_loop(model, loss_fn)                      # the episode loop's own path (MetaTemplate._episode_loop)
     if finetune:
         np.random.seed(10 + rank)
@@ -611,19 +622,20 @@ def bench_metatrain(args, rank, world, dev, dist):
         dt = float(t.item())
     roof = cpu = None
     if rank == 0 and not finetune:
-        roof = metatrain_roofline(model, opt, eps, dt / args.steps)
+        roof = metatrain_roofline(model, opt, eps, dt / args.steps, loss_fn, kk)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline_subprocess(args.gen_examples, workload="metatrain")
     if rank == 0:
         print(json.dumps({
-            "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node", "value": round(world * args.steps / dt, 3),
+            "metric": "episodes/sec at 5-way N-shot (ResNet10+GNN) per GPU and 1/2/4/8-GPU node", "value": round(world * kk * args.steps / dt, 3),
             "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("meta-fine-tuning training step (train.py --fine_tune, gnnnet.py:106-231: 105 inner Adam steps on trunk.7 per "
                                     "episode, then the outer step)" if finetune else "meta-training step (BASELINE configs[3])") +
-                                   ": 5-way 5-shot, 16 queries, 84x84, one episode per rank, "
-                                   "flat 21.2 MB gradient all-reduce + fused outer Adam",
+                                   ": 5-way 5-shot, 16 queries, 84x84, %s per rank and step, "
+                                   "flat 21.2 MB gradient all-reduce + fused outer Adam" % ("one episode" if kk == 1 else "%d episodes in lockstep (opt-in --episodes-per-rank: per-episode BatchNorm statistics, gradients averaged over them: the update of a %d-rank episode-parallel run)" % (kk, kk * world)),
+                       "episodes_per_step": kk * world,
                        "episode_source": ("sampled per step inside the timed region from a miniImageNet-shaped resident uint8 pool "
                                           "(64 x 600 x 84x84; %s transform on the device)" % ("--train_aug" if args.train_aug else "Resize + CenterCrop")
                                           if args.train_source == "pool" else "eight pre-made fp32 episodes, cycled"),
@@ -659,6 +671,10 @@ def main():
                     help="--workload metatrain / metafinetune: fixed = cycle eight pre-made fp32 episodes resident in HBM (default: synthetic "
                          "data generation excluded, SURVEY section 8(d), as the headline workload does); pool = sample every episode on the "
                          "device from a miniImageNet-shaped resident uint8 pool INSIDE the timed region (4.00 vs 3.87 ms per step)")
+    ap.add_argument("--episodes-per-rank", type=int, default=1,
+                    help="--workload metatrain: k episodes per optimizer step in lockstep on each GPU (GnnNet.set_forward_loss_lockstep: "
+                         "per-episode BatchNorm statistics, gradients averaged over the k episodes = the update of a k-rank "
+                         "episode-parallel run); value counts k episodes per step.  Opt-in, its own line; 1 = the reference's loop")
     ap.add_argument("--train-aug", action="store_true", help="with --train-source pool: the --train_aug transform "
                     "(RandomResizedCrop + ImageJitter + flip) instead of Resize + CenterCrop")
     ap.add_argument("--no-cpu-baseline", action="store_true")

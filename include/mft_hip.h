@@ -291,6 +291,17 @@ long long mft_conv2d_wgrad_oihw_ws_floats(int n_img, int H, int W, int Cin, int 
 int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, int ldy, float* dw_oihw, int n_img, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad, int cin_valid, int cout_valid, float* ws, void* stream);
 
+/* Several independent mft_conv2d_wgrad_oihw problems in ONE pair of launches (up to 16 per pair; a Cin == 3 stem job keeps its own):
+ * the meta-training backward (meta_template.py:76-92: loss.backward() over 31 convolution / linear layers) defers every weight
+ * gradient to the end of its pass -- nothing downstream reads them -- and runs them together.  jobs: HOST array; each job means
+ * what the same-named arguments of mft_conv2d_wgrad_oihw mean (ws: mft_conv2d_wgrad_oihw_ws_floats floats per job); every job's
+ * result is bit-identical to its own mft_conv2d_wgrad_oihw launch (same tiles, chunking and summation order). */
+typedef struct MftWgradJob {
+    const float* in; const float* dy; float* dw_oihw; float* ws;
+    int ldi, ldy, n_img, H, W, Cin, Cout, KH, KW, stride, pad, cin_valid, cout_valid, reserved;
+} MftWgradJob;
+int mft_conv2d_wgrad_oihw_multi(const MftWgradJob* jobs, int n_jobs, void* stream);
+
 /* conv weight gradient with torch.optim.Adam.step fused into the epilogue (finetune.py:293-299): the gradient tile stays
  * in MFMA accumulators; w, m, v (same packed layout / group stride as dw) are updated in place.  dw_or_null, when given,
  * also receives the gradient.  Same Adam form as mft_adam_step (no weight decay).                                    */
@@ -531,7 +542,8 @@ int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, int N, void
 /* loss.backward() through gnn.Wcompute (gnn.py:78-132 under autograd, meta_template.py:76-92) on the forward's upper-triangle pair
  * rows p(i, j), i <= j: a merged row carries the sum of the reference's (i, j) and (j, i) gradients (every operator is linear in
  * the gradient).  Nothing of shape [B*N*N, F] is formed.
- *  mft_pair_softmax_ut_backward: ds[r*ldds] = A_ij (dA_ij - <A_i, dA_i>) + A_ji (dA_ji - <A_j, dA_j>)  (rowdot_ws: n_graphs*N floats)
+ *  mft_pair_softmax_ut_backward: ds[r*ldds] = A_ij (dA_ij - <A_i, dA_i>) + A_ji (dA_ji - <A_j, dA_j>)  (rowdot_ws: n_graphs*N floats;
+ *      dbias_zero, nullable: one float <- 0 = the gradient of conv2d_last's bias, identically zero under the row softmax)
  *  mft_pair_bn_act_backward:     BatchNorm2d(train) + leaky_relu backward of one layer over merged rows.  g = dL/d(activation)
  *      [rows, ldg], z = the layer's RAW output [rows, C] (C = 96 | 192), rows = n_groups * rows_per_group (a group = the graphs
  *      of one episode: its own BatchNorm statistics); scale / shift / mean / rstd [n_groups, C] as left by
@@ -543,7 +555,7 @@ int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, int N, void
  *  mft_pair_absdiff_ut:          d[r - row0][:] = |x_i - x_j| for rows row0 .. row0 + nrows (layer 1's input, a bounded chunk)
  *  mft_pair_dx_gather:           dX[b, i, :F] += sum_j sign(x_i - x_j) * dd[p(i,j) - row0][:F] over the pairs inside the chunk     */
 int mft_pair_softmax_ut_backward(const float* A, const float* dA, const int* ij, float* rowdot_ws, float* ds, int ldds,
-                                 int n_graphs, int N, void* stream);
+                                 int n_graphs, int N, float* dbias_zero, void* stream);
 long long mft_pair_bwd_stats_ws_floats(long long rows_per_group, int C);
 int mft_pair_bn_act_backward(const float* g, int ldg, const float* z, int C, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const int* ij, int N, long long rows_per_group,

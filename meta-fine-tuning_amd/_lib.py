@@ -50,11 +50,12 @@ SIGNATURES = {
     "mft_conv2d_dgrad_nhwc_ksplit": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mft_conv2d_wgrad_oihw_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_wgrad_oihw": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "mft_conv2d_wgrad_oihw_multi": [_P, _I, _P],
     "mft_conv2d_wgrad_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_wgrad_nhwc": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P],
     "mft_conv2d_wgrad_adam_nhwc": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _F, _F, _F,
                                    _F, _P],
-    "mft_pair_softmax_ut_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "mft_pair_softmax_ut_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "mft_pair_bwd_stats_ws_floats": [_L, _I],
     "mft_pair_bn_act_backward": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _L, _I, _L, _F, _P, _P, _P, _P, _P, _P],
     "mft_pair_absdiff_ut": [_P, _I, _P, _P, _I, _I, _I, _L, _L, _P],

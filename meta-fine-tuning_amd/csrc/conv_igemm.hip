@@ -430,7 +430,7 @@ struct WgradArgs {
 // STEMW: the 7x7x3 stem (Cin == 3): the "ci" axis of the tile is the flattened k = (kh*KW+kw)*3+ci (147 -> 160).
 // POL: cache policy of the w/m/v stream (bit 0: nontemporal loads, bit 1: nontemporal stores); 3 is the default
 template <int BM, int BN, bool ADAM, bool STEMW, bool EARLYT = false, int POL = 3>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+__device__ __forceinline__ void conv_wgrad_tile(const WgradArgs& p, const int bid_x, const int bid_y, const int bid_z) {
     auto ldp = [](const f32x4* q) { return (POL & 1) ? __builtin_nontemporal_load(q) : *q; };
     auto stp = [](const f32x4 v, f32x4* q) { if (POL & 2) __builtin_nontemporal_store(v, q); else *q = v; };
     constexpr int TM = BM / 64, TN = BN / 64;   // waves 2 x 2, wave tile (BM/2) x (BN/2)
@@ -448,9 +448,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y;
+    const int g = bid_y;
 
-    int bx = blockIdx.x;
+    int bx = bid_x;
     const int tci = bx % p.tiles_ci;
     bx /= p.tiles_ci;
     const int tco = bx % p.tiles_co;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             e_w[u] = ldp((const f32x4*)(p.w + e_gi[u]));
         }
     }
-    const int m_begin = blockIdx.z * p.chunk_rows;
+    const int m_begin = bid_z * p.chunk_rows;
     const int m_end = min(m_begin + p.chunk_rows, p.rows_per_group);
     const bool a_col_ok = (co0 + acol) < p.Cout;
     const bool b_col_ok = STEMW ? true : (ci0 + bcol) < p.Cin;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
     if (!ADAM) {
-        float* dwg = (p.chunks > 1 || p.oihw) ? p.ws + ((long long)g * p.chunks + blockIdx.z) * p.dwgs
+        float* dwg = (p.chunks > 1 || p.oihw) ? p.ws + ((long long)g * p.chunks + bid_z) * p.dwgs
                                               : p.dw + (long long)g * p.dwgs;
         const int ci_lim = STEMW ? p.Kpad : p.Cin;
 #pragma unroll
@@ -619,6 +619,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             }
         }
     }
+}
+
+template <int BM, int BN, bool ADAM, bool STEMW, bool EARLYT = false, int POL = 3>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    conv_wgrad_tile<BM, BN, ADAM, STEMW, EARLYT, POL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent weight-gradient problems in ONE launch (mft_conv2d_wgrad_oihw_multi): the meta-training backward defers every
+// layer's weight gradient to the end of its pass (nothing downstream reads them) and runs them together -- 31 launches + 31 partial
+// sums per step become 2 + 2 (a dependent kernel costs >= 4.7 us in a replayed step whatever it does).  Workgroup b belongs to the
+// job j with start[j] <= b < start[j + 1]; inside a job the numbering is the single launch's (x = tile and tap, z = row chunk), so
+// every job computes bit for bit what its own launch would.
+constexpr int WG_MULTI = 16;
+struct WgradMultiArgs {
+    WgradArgs job[WG_MULTI];
+    int start[WG_MULTI + 1];
+    int nx[WG_MULTI];          // grid.x of the job's own launch
+    int n;
+};
+
+static_assert(sizeof(WgradMultiArgs) <= 4000, "kernel arguments are passed by value: keep them inside the 4 KB kernarg segment");
+
+__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradMultiArgs a) {
+    const int b = blockIdx.x;
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && b >= a.start[j + 1]) ++j;
+    const WgradArgs p = a.job[j];
+    const int local = b - a.start[j];
+    conv_wgrad_tile<64, 64, false, false, false, 3>(p, local % a.nx[j], 0, local / a.nx[j]);
 }
 
 // ---------------------------------------------------------------------------- weight gradient + Adam, <= 64 reduction rows
@@ -844,6 +874,55 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
                         const int tap = k / Cin, ci = k - tap * Cin;
                         if (ci < cin_out) dw[((long long)co * cin_out + ci) * taps + tap] = t[e];
                     }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct ReduceMultiArgs {
+    const float* ws[WG_MULTI]; float* dw[WG_MULTI];
+    long long n[WG_MULTI], dwgs[WG_MULTI];
+    int chunks[WG_MULTI], Cin[WG_MULTI], taps[WG_MULTI], Kpad[WG_MULTI], cin_out[WG_MULTI], cout_out[WG_MULTI];
+    int start[WG_MULTI + 1];
+    int cnt;
+};
+
+static_assert(sizeof(ReduceMultiArgs) <= 4000, "kernarg segment");
+
+// reduce_chunks_kernel<true> of several jobs in one launch (same lanes, same summation order per element as the single launch)
+__global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceMultiArgs a) {
+    __shared__ f32x4 red[8][33];
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.cnt && (int)blockIdx.x >= a.start[j + 1]) ++j;
+    const float* __restrict__ ws = a.ws[j];
+    float* __restrict__ dw = a.dw[j];
+    const long long n = a.n[j], dwgs = a.dwgs[j];
+    const int chunks = a.chunks[j], Cin = a.Cin[j], taps = a.taps[j], Kpad = a.Kpad[j], cin_out = a.cin_out[j], cout_out = a.cout_out[j];
+    const int lb = blockIdx.x - a.start[j], nb = a.start[j + 1] - a.start[j];
+    const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const long long nq = n >> 2;
+    for (long long i0 = (long long)lb * 32; i0 < nq; i0 += (long long)nb * 32) {
+        const long long i = i0 + q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < nq)
+            for (int c = l; c < chunks; c += 8) s += *(const f32x4*)(ws + (long long)c * dwgs + i * 4);
+        red[l][q] = s;
+        __syncthreads();
+        if (l == 0 && i < nq) {
+            f32x4 t = red[0][q];
+#pragma unroll
+            for (int jj = 1; jj < 8; ++jj) t += red[jj][q];
+            const long long e0 = i * 4;
+            const int co = (int)(e0 / Kpad), k0 = (int)(e0 - (long long)co * Kpad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                if (k < taps * Cin && co < cout_out) {
+                    const int tap = k / Cin, ci = k - tap * Cin;
+                    if (ci < cin_out) dw[((long long)co * cin_out + ci) * taps + tap] = t[e];
                 }
             }
         }
@@ -1201,6 +1280,61 @@ extern "C" int mft_conv2d_wgrad_oihw(const float* in, int ldi, const float* dy, 
     a.cin_out = cin_valid; a.cout_out = cout_valid;
     a.dwgs = (long long)Cout * ((KH * KW * Cin + 31) / 32 * 32);
     return wgrad_dispatch(a, n_img, 0, false, ws, (hipStream_t)stream);
+}
+
+// Host side of the multi-problem launch: each job is prepared exactly as mft_conv2d_wgrad_oihw prepares it (same chunking, same
+// workspace layout), then up to WG_MULTI jobs share a launch; the stem (Cin == 3: its own K-major kernel) keeps its own launch.
+extern "C" int mft_conv2d_wgrad_oihw_multi(const MftWgradJob* jobs, int n_jobs, void* stream) {
+    if (jobs == nullptr || n_jobs < 1) return MFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n_jobs;) {
+        WgradMultiArgs wa = {};
+        ReduceMultiArgs ra = {};
+        int cnt = 0, wgs = 0, rblocks = 0;
+        for (; j0 < n_jobs && cnt < WG_MULTI; ++j0) {
+            const MftWgradJob& jb = jobs[j0];
+            if (jb.ws == nullptr || jb.cin_valid < 0 || jb.cin_valid > jb.Cin || jb.cout_valid < 0 || jb.cout_valid > jb.Cout) return MFT_EINVAL;
+            if (jb.Cin == 3) {                                        // the stem: single launch (STEMW kernel)
+                int rc = mft_conv2d_wgrad_oihw(jb.in, jb.ldi, jb.dy, jb.ldy, jb.dw_oihw, jb.n_img, jb.H, jb.W, jb.Cin, jb.Cout, jb.KH, jb.KW,
+                                               jb.stride, jb.pad, jb.cin_valid, jb.cout_valid, jb.ws, stream);
+                if (rc != 0) return rc;
+                continue;
+            }
+            if (jb.Cin % 4 != 0 || jb.Cout % 4 != 0 || jb.ldi % 4 != 0 || jb.ldy % 4 != 0 || jb.n_img < 1) return MFT_EINVAL;
+            WgradArgs a = {};
+            a.in = jb.in; a.dy = jb.dy; a.dw = jb.dw_oihw; a.ldi = jb.ldi; a.ldy = jb.ldy;
+            a.H = jb.H; a.W = jb.W; a.Cin = jb.Cin; a.Cout = jb.Cout; a.KH = jb.KH; a.KW = jb.KW; a.stride = jb.stride; a.pad = jb.pad;
+            a.oihw = 1; a.cin_out = jb.cin_valid; a.cout_out = jb.cout_valid;
+            a.OH = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
+            a.OW = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
+            a.Kpad = (a.KH * a.KW * a.Cin + 31) / 32 * 32;
+            a.dwgs = (long long)a.Cout * a.Kpad;
+            a.imgs_per_group = jb.n_img;
+            a.rows_per_group = jb.n_img * a.OH * a.OW;
+            a.ws = jb.ws;
+            wgrad_chunking(a.rows_per_group, wgrad_wgs_per_chunk(a.Cin, a.Cout, a.KH, a.KW, 1), &a.chunk_rows, &a.chunks);
+            a.tiles_ci = (a.Cin + 63) / 64;
+            a.tiles_co = (a.Cout + 63) / 64;
+            const int nx = a.tiles_ci * a.tiles_co * a.KH * a.KW;
+            wa.job[cnt] = a; wa.start[cnt] = wgs; wa.nx[cnt] = nx;
+            wgs += nx * a.chunks;
+            const long long n = (long long)a.Cout * a.Kpad;
+            int blocks = (int)((n / 4 + 31) / 32);
+            if (blocks > 4096) blocks = 4096;
+            ra.ws[cnt] = a.ws; ra.dw[cnt] = a.dw; ra.n[cnt] = n; ra.dwgs[cnt] = a.dwgs; ra.chunks[cnt] = a.chunks; ra.Cin[cnt] = a.Cin;
+            ra.taps[cnt] = a.KH * a.KW; ra.Kpad[cnt] = a.Kpad; ra.cin_out[cnt] = a.cin_out > 0 ? a.cin_out : a.Cin;
+            ra.cout_out[cnt] = a.cout_out > 0 ? a.cout_out : a.Cout; ra.start[cnt] = rblocks;
+            rblocks += blocks;
+            ++cnt;
+        }
+        if (cnt == 0) continue;
+        wa.start[cnt] = wgs; wa.n = cnt;
+        ra.start[cnt] = rblocks; ra.cnt = cnt;
+        constexpr int lds = 32 * (64 + 64) * 4;
+        hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3(wgs), dim3(256), lds, s, wa);
+        hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(rblocks), dim3(256), 0, s, ra);
+    }
+    return mft_launch_status();
 }
 
 static int wgrad_adam_impl(const float* in, int ldi, const float* dy, int ldy, float* w, float* m, float* v,

@@ -359,16 +359,31 @@ __global__ __launch_bounds__(256) void softmax_rowdot_kernel(const float* __rest
 }
 
 // ds_ut[b, p(i,j)] = A_ij (dA_ij - rd_i) + A_ji (dA_ji - rd_j)  (i < j);  diagonal: A_ii (dA_ii - rd_i) (= 0: the masked logit)
+// INLINE_RD (small graphs, N <= 64): every thread forms the two row dots <A_i, dA_i>, <A_j, dA_j> itself (2 N multiply-adds out of
+// L1 / L2) -- no softmax_rowdot launch in front.  dbias_zero (nullable, one float): the gradient of conv2d_last's bias, which is
+// identically zero (the bias shifts every logit of a softmax row alike): written as 0 here instead of a column sum of rounding noise.
+template <bool INLINE_RD>
 __global__ __launch_bounds__(256) void softmax_ut_backward_kernel(const float* __restrict__ A, const float* __restrict__ dA,
                                                                   const float* __restrict__ rd, const int* __restrict__ ij,
-                                                                  float* __restrict__ ds, int ldds, int n_graphs, int N, int P) {
+                                                                  float* __restrict__ ds, int ldds, int n_graphs, int N, int P,
+                                                                  float* __restrict__ dbias_zero) {
     const long long total = (long long)n_graphs * P;
+    if (dbias_zero && blockIdx.x == 0 && threadIdx.x == 0) dbias_zero[0] = 0.f;
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(r / P), pk = ij[r % P];
         const int i = pk >> 16, j = pk & 0xffff;
         const long long base = (long long)b * N * N, rb = (long long)b * N;
-        float v = A[base + (long long)i * N + j] * (dA[base + (long long)i * N + j] - rd[rb + i]);
-        if (i != j) v += A[base + (long long)j * N + i] * (dA[base + (long long)j * N + i] - rd[rb + j]);
+        float rdi, rdj;
+        if (INLINE_RD) {
+            rdi = 0.f; rdj = 0.f;
+            const float* Ai = A + base + (long long)i * N; const float* dAi = dA + base + (long long)i * N;
+            const float* Aj = A + base + (long long)j * N; const float* dAj = dA + base + (long long)j * N;
+            for (int k = 0; k < N; ++k) { rdi += Ai[k] * dAi[k]; rdj += Aj[k] * dAj[k]; }
+        } else {
+            rdi = rd[rb + i]; rdj = rd[rb + j];
+        }
+        float v = A[base + (long long)i * N + j] * (dA[base + (long long)i * N + j] - rdi);
+        if (i != j) v += A[base + (long long)j * N + i] * (dA[base + (long long)j * N + i] - rdj);
         ds[r * ldds] = v;
     }
 }
@@ -587,16 +602,21 @@ extern "C" int mft_masked_softmax_ut(const float* s_ut, float* A, int n_graphs, 
 
 /* ---- backward over upper-triangle rows (see the kernels' comments) ---- */
 extern "C" int mft_pair_softmax_ut_backward(const float* A, const float* dA, const int* ij, float* rowdot_ws, float* ds, int ldds,
-                                            int n_graphs, int N, void* stream) {
+                                            int n_graphs, int N, float* dbias_zero, void* stream) {
     if (n_graphs < 1 || N < 1 || ldds < 1) return MFT_EINVAL;
     const long long rows = (long long)n_graphs * N;
     const int P = N * (N + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, dA, rowdot_ws, rows, N);
     long long blocks = ((long long)n_graphs * P + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(softmax_ut_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, dA, (const float*)rowdot_ws, ij, ds, ldds,
-                       n_graphs, N, P);
+    if (N <= 64) {                 // 5-shot graphs (N = 30): one launch, the row dots formed in place
+        hipLaunchKernelGGL(softmax_ut_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, A, dA, (const float*)nullptr, ij, ds,
+                           ldds, n_graphs, N, P, dbias_zero);
+        return mft_launch_status();
+    }
+    hipLaunchKernelGGL(softmax_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, dA, rowdot_ws, rows, N);
+    hipLaunchKernelGGL(softmax_ut_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, A, dA, (const float*)rowdot_ws, ij, ds,
+                       ldds, n_graphs, N, P, dbias_zero);
     return mft_launch_status();
 }
 

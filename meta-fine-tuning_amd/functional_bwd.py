@@ -10,9 +10,11 @@ import torch
 
 from . import functional as Fn
 from . import ops
+from . import settings
 
 L = ops._lib
 RELU, LRELU, NONE = ops.ACT_RELU, ops.ACT_LRELU, ops.ACT_NONE
+WGRAD_BATCH = settings.current().wgrad_batch      # deferred multi-problem weight gradients (ops.WgradBatch)
 
 
 def _zeros(shape, dev):
@@ -173,6 +175,7 @@ def resnet10_backward(W, t, dfeat, need):
     n, groups = t["n"], t.get("groups", 1)
     dev = dfeat.device
     grads = {}
+    wb = ops.WgradBatch(WGRAD_BATCH)            # every layer's weight gradient is registered as the pass goes and run at its end
 
     def dgrad3x3(name, dy, cin, cout, stride, rows, H_in):
         # registered by the forward (resnet10_forward_taped.conv3x3), never created here; the same size rule as the forward
@@ -193,21 +196,21 @@ def resnet10_backward(W, t, dfeat, need):
         dc2, dg, db = bn_bwd(b["c2"].view(-1, cout), d2, cout, rows, b["m2"], b["s2"], g2, y_act=o2, act=RELU, groups=groups)
         grads[p + ".BN2.weight"], grads[p + ".BN2.bias"] = dg, db
         dc2 = dc2.view(out.shape)
-        grads[p + ".C2.weight"] = ops.conv2d_wgrad_oihw(b["r1"], dc2, cout, 3, 3, 1, 1)
+        grads[p + ".C2.weight"] = wb.add(b["r1"], dc2, cout, 3, 3, 1, 1)
         dr1 = dgrad3x3(p + ".C2", dc2, cout, cout, 1, rows, out.shape[1])
         g1 = W.bn[p + ".BN1"][0]
         dc1, dg, db = bn_bwd(b["c1"].view(-1, cout), dr1.view(-1, cout), cout, rows, b["m1"], b["s1"], g1,
                              y_act=b["r1"].view(-1, cout), act=RELU, groups=groups)
         grads[p + ".BN1.weight"], grads[p + ".BN1.bias"] = dg, db
         dc1 = dc1.view(out.shape)
-        grads[p + ".C1.weight"] = ops.conv2d_wgrad_oihw(x_in, dc1, cout, 3, 3, stride, 1)
+        grads[p + ".C1.weight"] = wb.add(x_in, dc1, cout, 3, 3, stride, 1)
         dx = dgrad3x3(p + ".C1", dc1, cin, cout, stride, rows, H_in)
         if cin != cout:
             gs = W.bn[p + ".BNshortcut"][0]
             dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU, groups=groups)
             grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dg, db
             dsc = dsc.view(out.shape)
-            grads[p + ".shortcut.weight"] = ops.conv2d_wgrad_oihw(x_in, dsc, cout, 1, 1, stride, 0)
+            grads[p + ".shortcut.weight"] = wb.add(x_in, dsc, cout, 1, 1, stride, 0)
             dxs = ops.conv2d_dgrad(dsc, W.conv[p + ".shortcut"], cin, 1, 1, 0, stride=stride, in_hw=(H_in, H_in))
             act_backward(dxs.view(-1, cin), dxs.view(-1, cin), dx.view(-1, cin), cin, NONE, True)
         else:
@@ -222,7 +225,8 @@ def resnet10_backward(W, t, dfeat, need):
     g0 = W.bn["trunk.1"][0]
     dc0, dg, db = bn_bwd(c0.view(-1, 64), d_bn0.view(-1, 64), 64, n * H0 * H0, t["m0"], t["s0"], g0, groups=groups)
     grads["trunk.1.weight"], grads["trunk.1.bias"] = dg, db
-    grads["trunk.0.weight"] = ops.conv2d_wgrad_oihw(t["x"], dc0.view(c0.shape), 64, 7, 7, 2, 3)
+    grads["trunk.0.weight"] = wb.add(t["x"], dc0.view(c0.shape), 64, 7, 7, 2, 3)
+    wb.flush()
     return grads
 
 
@@ -254,14 +258,15 @@ def _linear_fwd(h, K, w, b, cout, lease=None):
     return o
 
 
-def _linear_bwd(h, K, w, d_o, cout, need_dx=True, k_valid=0, db=None):
+def _linear_bwd(h, K, w, d_o, cout, need_dx=True, k_valid=0, db=None, wb=None):
     """-> (dx [rows,K] or None, dW [cout, k_valid or K] in nn.Linear's layout, db [cout]).  d_o [rows, roundup(cout,32)] with zero
     padding columns; ``k_valid``: the input features that are real (the rest of K is zero padding of the operand); ``db``: the bias
     gradient when the caller already has it (a bias in front of a BatchNorm: exact zeros from the BatchNorm-backward launch)."""
     rows = h.shape[0]
     cp = d_o.shape[1]
     hin = h.view(rows, 1, 1, K) if h.shape[1] == K else _narrow(h, K)
-    dW = ops.conv2d_wgrad_oihw(hin, d_o.view(rows, 1, 1, cp), cp, 1, 1, 1, 0, cin_valid=k_valid, cout_valid=cout).view(cout, k_valid or K)
+    wg = ops.conv2d_wgrad_oihw if wb is None else wb.add        # (wb: deferred to the end of the pass, ops.WgradBatch)
+    dW = wg(hin, d_o.view(rows, 1, 1, cp), cp, 1, 1, 1, 0, cin_valid=k_valid, cout_valid=cout).view(cout, k_valid or K)
     if db is None:
         db = colsum(d_o, cp)[:cout]
     dx = None
@@ -275,8 +280,8 @@ def _narrow(h, K):
     return h[:, :K].contiguous().view(h.shape[0], 1, 1, K)
 
 
-PAIR_CHUNK_ROWS = 32768         # pair rows whose |x_i - x_j| exist at one time in the backward of layer 1 (<= 33 MB at F = 229: one
-                                # chunk for up to four 5-shot episodes in lockstep, three for one 20-shot episode)
+PAIR_CHUNK_ROWS = 16384         # pair rows whose |x_i - x_j| exist at one time in the backward of layer 1 (<= 16 MB at F = 229: one
+                                # chunk for two 5-shot episodes in lockstep, two for four)
 
 
 def wcompute_taped(G, name, x, F, n_graphs, N, groups=1):
@@ -327,7 +332,7 @@ def _pair_activation(t, li, layers, rows):
     return ops.bn_apply(z, cout, rows // groups, groups, m, s, gam, beta, act=LRELU, out=_empty(z.shape, z.device))
 
 
-def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
+def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix, wb=None):
     """Accumulates d(x) into dX[:, :F]; writes parameter gradients into ``grads`` under ``prefix``.  Works on the forward's
     upper-triangle rows: a merged row carries the sum of the reference's (i, j) and (j, i) gradients (csrc/pair_mlp.hip, backward
     section); layer 1's input |x_i - x_j| is produced for PAIR_CHUNK_ROWS rows at a time."""
@@ -340,13 +345,14 @@ def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
     ij, F, Kp = t["ij"], t["F"], t["Kp"]
     ds = t["lease"].take((rows, 32), dev)              # column 0: gradient of the compact symmetric score (columns 1..31 stay 0)
     rd = _empty((n_graphs * N,), dev)
+    db5 = _empty((1,), dev)                    # conv2d_last.bias shifts every logit of a softmax row alike: zero gradient, from this launch
     L.check(lib.mft_pair_softmax_ut_backward(ops._p(t["A"]), ops._p(dA), ops._p(ij), ops._p(rd), ops._p(ds), 32, n_graphs, N,
-                                             ops._stream()), "mft_pair_softmax_ut_backward")
+                                             ops._p(db5), ops._stream()), "mft_pair_softmax_ut_backward")
     h4 = _pair_activation(t, 3, layers, rows)
-    dh, dW, db = _linear_bwd(h4, 96, w5, ds, 1)
+    dh, dW, _ = _linear_bwd(h4, 96, w5, ds, 1, db=db5, wb=wb)
     del h4
     grads[prefix + ".conv2d_last.weight"] = dW.view(1, 96, 1, 1)
-    grads[prefix + ".conv2d_last.bias"] = db
+    grads[prefix + ".conv2d_last.bias"] = db5
     for li in (3, 2, 1, 0):
         w, b, gam, beta, cout = layers[li]
         sc, sh, m, s = t["bn"][li]
@@ -365,7 +371,7 @@ def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
         if li > 0:
             K = layers[li - 1][4]
             hin = _pair_activation(t, li - 1, layers, rows)
-            dh, dW, _ = _linear_bwd(hin, K, w, dz, cout, db=dbz)
+            dh, dW, _ = _linear_bwd(hin, K, w, dz, cout, db=dbz, wb=wb)
             del hin
             grads[prefix + ".conv2d_%d.weight" % (li + 1)] = dW.view(cout, K, 1, 1)
         else:
@@ -378,11 +384,14 @@ def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix):
                 L.check(lib.mft_pair_absdiff_ut(ops._p(x), x.shape[1], ops._p(ij), ops._p(d), Kp, F, N, r0, nr, ops._stream()),
                         "mft_pair_absdiff_ut")
                 dzc = dz[r0:r0 + nr]
-                part = ops.conv2d_wgrad_oihw(d.view(nr, 1, 1, Kp), dzc.view(nr, 1, 1, cout), cout, 1, 1, 1, 0, cin_valid=F).view(cout, F)
+                wg = ops.conv2d_wgrad_oihw if wb is None else wb.add
+                part = wg(d.view(nr, 1, 1, Kp), dzc.view(nr, 1, 1, cout), cout, 1, 1, 1, 0, cin_valid=F).view(cout, F)
                 if dW is None:
                     dW = part
-                else:                                    # (more than PAIR_CHUNK_ROWS pair rows: N > 30) dW += part, on the device
+                elif wb is None:                         # (more than PAIR_CHUNK_ROWS pair rows) dW += part, on the device
                     act_backward(part, part, dW, F, NONE, True)
+                else:                                    # ... once the deferred launch has produced both
+                    wb.then(lambda part=part, dW=dW: act_backward(part, part, dW, F, NONE, True))
                 dd = ops.conv2d_dgrad(dzc.view(nr, 1, 1, cout), wp, Kp, 1, 1, 0).view(nr, Kp)
                 L.check(lib.mft_pair_dx_gather(ops._p(x), x.shape[1], ops._p(dd), Kp, ops._p(dX), dX.shape[1], n_graphs, N, F, r0, nr,
                                                ops._stream()), "mft_pair_dx_gather")
@@ -404,7 +413,7 @@ def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1):
     return o, t
 
 
-def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix, first=False):
+def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix, first=False, wb=None):
     """d_o: gradient w.r.t. the Gconv output (after its BatchNorm when present), [rows, roundup(cout,32)].
     Accumulates into dX[:, :F] (``first``: overwrites them -- dX is not zero-filled); returns dA."""
     w, b, g, beta, cout = G.gc[t["name"]]
@@ -416,7 +425,7 @@ def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix, first=False):
         dbz = _empty((cout,), x.device)          # fc.bias sits in front of the BatchNorm1d: zero gradient, written by its backward
         d_o, dg, dbt = bn_bwd(t["raw"], d_o, cout, rows, m, s, g, lease=t.get("lease"), groups=t.get("groups", 1), dbias_zero=dbz)
         grads[prefix + ".bn.weight"], grads[prefix + ".bn.bias"] = dg, dbt
-    dy, dW, db = _linear_bwd(t["y"], t["y"].shape[1], w, d_o, cout, k_valid=2 * F, db=dbz)
+    dy, dW, db = _linear_bwd(t["y"], t["y"].shape[1], w, d_o, cout, k_valid=2 * F, db=dbz, wb=wb)
     grads[prefix + ".fc.weight"] = dW
     grads[prefix + ".fc.bias"] = db
     dA = _empty((n_graphs, N, N), x.device)
@@ -472,14 +481,15 @@ def head_backward(G, t, dscores):
     d_out = _empty((rows, 32), dev)
     L.check(L.lib().mft_gather_query_scores_backward(ops._p(dscores.contiguous()), ops._p(d_out), 32, k, n_way, ns, nq,
                                                      ops._stream()), "mft_gather_query_scores_backward")
-    dA = gconv_backward(G, t["gc"][2], d_out, x, dX, n_graphs, N, grads, "gnn.layer_last", first=True)
-    wcompute_backward(G, t["wc"][2], dA, x, dX, n_graphs, N, grads, "gnn.w_comp_last")
+    wb = ops.WgradBatch(WGRAD_BATCH)            # the head's 16 weight gradients: registered as the pass goes, run together at its end
+    dA = gconv_backward(G, t["gc"][2], d_out, x, dX, n_graphs, N, grads, "gnn.layer_last", first=True, wb=wb)
+    wcompute_backward(G, t["wc"][2], dA, x, dX, n_graphs, N, grads, "gnn.w_comp_last", wb=wb)
     for i in (1, 0):
         F = t["Fs"][i]
         d_ob = lease.take((rows, 64), dev)                   # 48 outputs padded to 64 (dgrad reduction width; the padding stays 0)
         act_backward(dX, x, d_ob, 48, LRELU, False, dy_off=F, y_off=F)
-        dA = gconv_backward(G, t["gc"][i], d_ob, x, dX, n_graphs, N, grads, "gnn.layer_l%d" % i)
-        wcompute_backward(G, t["wc"][i], dA, x, dX, n_graphs, N, grads, "gnn.layer_w%d" % i)
+        dA = gconv_backward(G, t["gc"][i], d_ob, x, dX, n_graphs, N, grads, "gnn.layer_l%d" % i, wb=wb)
+        wcompute_backward(G, t["wc"][i], dA, x, dX, n_graphs, N, grads, "gnn.layer_w%d" % i, wb=wb)
     per = n_way * ((2 * ns if fold else ns) + nq)
     dz = _empty((k * per, 128), dev)
     L.check(L.lib().mft_build_graph_nodes_backward(ops._p(dX), 256, ops._p(dz), 128, k, n_way, ns, nq, 1 if fold else 0,
@@ -487,6 +497,7 @@ def head_backward(G, t, dscores):
     dbz = _empty((128,), dev)                  # fc.0.bias sits in front of fc.1 (BatchNorm1d): zero gradient, from its backward launch
     dzr, dg, db = bn_bwd(t["z_raw"], dz, 128, k * per, t["mz"], t["sz"], G.fc_g, groups=k, dbias_zero=dbz)
     grads["fc.1.weight"], grads["fc.1.bias"] = dg, db
-    dfeats, dW, dbias = _linear_bwd(t["feats"], 512, G.fc_w, dzr, 128, db=dbz)
+    dfeats, dW, dbias = _linear_bwd(t["feats"], 512, G.fc_w, dzr, 128, db=dbz, wb=wb)
     grads["fc.0.weight"], grads["fc.0.bias"] = dW, dbias
+    wb.flush()
     return dfeats, grads

@@ -163,11 +163,12 @@ def for_loop(model, loss_fn):
         return None
     fn = getattr(loss_fn, "__func__", None)
     cache = model.__dict__.setdefault("_mft_graph_steps", {})
-    if fn is not None and fn is getattr(type(model), "set_forward_loss", None):
-        st = cache.get("set_forward_loss")
-        if st is None:
-            st = cache["set_forward_loss"] = GraphedLossBackward(model, loss_fn)
-        return st
+    for name in ("set_forward_loss", "set_forward_loss_lockstep"):         # (lockstep: k episodes per step; the input shape is part of the key)
+        if fn is not None and fn is getattr(type(model), name, None):
+            st = cache.get(name)
+            if st is None:
+                st = cache[name] = GraphedLossBackward(model, loss_fn)
+            return st
     if (fn is not None and fn is getattr(type(model), "set_forward_loss_finetune", None)
             and hasattr(model, "_finetune_prepare") and hasattr(model, "set_forward_loss_finetune_prepared")):
         st = cache.get("set_forward_loss_finetune")

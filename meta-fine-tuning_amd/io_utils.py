@@ -35,6 +35,8 @@ _PER_SCRIPT = {
         ("--save_freq", dict(default=50, type=int, help="Save frequency")),
         ("--start_epoch", dict(default=0, type=int, help="Starting epoch")),
         ("--stop_epoch", dict(default=400, type=int, help="Stopping epoch")),
+        # (not in the reference: k episodes per optimizer step in lockstep on one GPU = the update of a k-rank episode-parallel run)
+        ("--episodes_per_rank", dict(default=1, type=int, help="gnnnet without --fine_tune: episodes per optimizer step (lockstep)")),
     ],
     "save_features": [("--split", dict(default="novel", help="base/val/novel"))],
     "test": [

@@ -54,8 +54,9 @@ class MetaTemplate(nn.Module):
         return float(np.sum(pred[:, 0] == y_query)), len(y_query)
 
     # ------------------------------------------------------------------ episode loops
-    def _episode_loop(self, epoch, train_loader, optimizer, loss_fn, support_from_x=True, n_support_images=None):
-        """``n_support_images``: support images per class in x when that is not ``self.n_support`` (gnnnet_copy's literal 50)."""
+    def _episode_loop(self, epoch, train_loader, optimizer, loss_fn, support_from_x=True, n_support_images=None, lockstep=False):
+        """``n_support_images``: support images per class in x when that is not ``self.n_support`` (gnnnet_copy's literal 50).
+        ``lockstep``: x carries k episodes [k, n_way, n_support + n_query, ...] (train_loop_lockstep)."""
         print_freq = 10
         avg_loss = 0
         graphed = graph_step.for_loop(self, loss_fn)      # forward + backward as one hipGraph replay (plain set_forward_loss only)
@@ -66,9 +67,10 @@ class MetaTemplate(nn.Module):
         acc = acc(next(self.parameters()).device) if (acc is not None and graphed is not None) else None
         base = acc.item() if acc is not None else 0.0
         for i, (x, _) in enumerate(train_loader):
-            self.n_query = x.size(1) - (self.n_support if n_support_images is None else n_support_images)
+            ep = 1 if lockstep else 0                    # (dimension of x that counts the classes)
+            self.n_query = x.size(ep + 1) - (self.n_support if n_support_images is None else n_support_images)
             if self.change_way:
-                self.n_way = x.size(0)
+                self.n_way = x.size(ep)
             if graphed is not None:
                 loss = graphed(x, optimizer)     # (grads of parameters outside the recorded step are dropped as zero_grad() would)
                 optimizer.step()
@@ -91,6 +93,13 @@ class MetaTemplate(nn.Module):
 
     def train_loop2(self, epoch, train_loader, optimizer):
         self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss)
+
+    def train_loop_lockstep(self, epoch, train_loader, optimizer, k):
+        """Opt-in (train.py --episodes_per_rank k; not in the reference): ONE optimizer step per k consecutive episodes of the
+        loader, on the mean of their losses -- the update a k-rank episode-parallel run makes after its gradient all-reduce
+        (SURVEY.md section 8(e)), with the k episodes running in lockstep through one sequence of launches (per-episode BatchNorm
+        statistics).  The printed running loss is the mean over steps of the k-episode mean."""
+        self._episode_loop(epoch, LockstepLoader(train_loader, k), optimizer, self.set_forward_loss_lockstep, lockstep=True)
 
     def train_loop_finetune(self, epoch, train_loader, optimizer):
         self._episode_loop(epoch, train_loader, optimizer, self.set_forward_loss_finetune)
@@ -125,6 +134,26 @@ class MetaTemplate(nn.Module):
         linear_clf = nn.Linear(self.feat_dim, self.n_way).cuda()       # same torch-RNG draw as the reference
         return linear_head_adapt(z_support, y_support, z_query, linear_clf.weight.data, linear_clf.bias.data,
                                  self.n_way, self.n_support)
+
+
+class LockstepLoader:
+    """k consecutive episodes of an episode loader as one batch [k, n_way, n_support + n_query, 3, H, W] (a trailing group of fewer
+    than k episodes is not drawn: every step has the same shape, and every rank of a multi-GPU run the same number of steps)."""
+
+    def __init__(self, loader, k):
+        self.loader, self.k = loader, int(k)
+        assert self.k >= 1
+
+    def __len__(self):
+        return len(self.loader) // self.k
+
+    def __iter__(self):
+        buf = []
+        for x, y in self.loader:
+            buf.append(x)
+            if len(buf) == self.k:
+                yield torch.stack(buf), None
+                buf = []
 
 
 def linear_head_adapt(z_support, y_support, z_query, w, b, n_way, n_support, epochs=100, batch_size=4):

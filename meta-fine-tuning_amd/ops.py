@@ -405,6 +405,56 @@ def conv2d_wgrad_oihw(x, dy, Cout, KH, KW, stride, pad, cin_valid=0, cout_valid=
     return out
 
 
+class _WgradJob(ctypes.Structure):
+    """MftWgradJob (include/mft_hip.h)"""
+    _fields_ = [("inp", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("ws", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int) for n in ("ldi", "ldy", "n_img", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "cin_valid",
+                                            "cout_valid", "reserved")]
+
+
+class WgradBatch:
+    """Weight gradients of one backward pass, DEFERRED: ``add`` takes the same arguments as ``conv2d_wgrad_oihw`` and returns the
+    output tensor at once -- its contents exist after ``flush()``, which runs all registered problems in ONE pair of launches per
+    16 jobs (mft_conv2d_wgrad_oihw_multi).  Nothing downstream of a layer reads its weight gradient, so the meta-training backward
+    registers every layer's as it goes and flushes at the end: 31 + 31 launches per step become 2 + 2 (+ the stem's own), each job
+    bit-identical to its own launch.  The operands are kept alive (and must not be overwritten) until the flush.
+    ``MFT_WGRAD_BATCH=0``: every ``add`` launches immediately (A/B and bit-identity reference)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.jobs, self.keep, self.after = [], [], []
+
+    def add(self, x, dy, Cout, KH, KW, stride, pad, cin_valid=0, cout_valid=0):
+        if not self.enabled:
+            return conv2d_wgrad_oihw(x, dy, Cout, KH, KW, stride, pad, cin_valid, cout_valid)
+        _f32c(x)
+        _f32c(dy)
+        n, H, W, Cin = x.shape
+        out = torch.empty((cout_valid or Cout, cin_valid or Cin, KH, KW), device=x.device, dtype=torch.float32)
+        ws = torch.empty((int(_lib.lib().mft_conv2d_wgrad_oihw_ws_floats(n, H, W, Cin, Cout, KH, KW, stride, pad)),), device=x.device,
+                         dtype=torch.float32)
+        self.jobs.append((x.data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), Cin, dy.shape[-1], n, H, W, Cin, Cout, KH, KW, stride,
+                          pad, cin_valid, cout_valid, 0))
+        self.keep.append((x, dy, out, ws))
+        return out
+
+    def then(self, fn):
+        """Run ``fn()`` right after the flush (work that reads a deferred gradient, e.g. the sum over row chunks)."""
+        if not self.enabled:
+            fn()
+        else:
+            self.after.append(fn)
+
+    def flush(self):
+        if self.jobs:
+            arr = (_WgradJob * len(self.jobs))(*[_WgradJob(*j) for j in self.jobs])
+            dev = self.keep[0][0].device
+            _lib.check(_lib.lib().mft_conv2d_wgrad_oihw_multi(arr, len(self.jobs), _stream(dev)), "mft_conv2d_wgrad_oihw_multi")
+        for fn in self.after:
+            fn()
+        self.jobs, self.keep, self.after = [], [], []
+
+
 def conv2d_wgrad_adam(x, dy, w, m, v, Cout, KH, KW, stride, pad, step, imgs_per_group=0, lr=0.01, beta1=0.9,
                       beta2=0.999, eps=1e-8, dw=None, hyper=None):
     """Weight gradient of a conv with the Adam update of (w, m, v) [groups, Cout, KH*KW*Cin] fused in the epilogue.

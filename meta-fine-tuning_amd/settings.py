@@ -60,6 +60,7 @@ KNOBS = (
     # ---- training path
     ("train_graph", "MFT_TRAIN_GRAPH", _flag, True, "MetaTemplate episode loop: loss + backward replayed from one hipGraph"),
     ("train_x3", "MFT_TRAIN_X3", _flag, True, "meta-training: 3x3 layers with >= 8192 output rows on the bf16x3 kernels, forward and stride-1 data gradient (0: fp32 MFMA everywhere)"),
+    ("wgrad_batch", "MFT_WGRAD_BATCH", _flag, True, "meta-training backward: every layer's weight gradient deferred to the end of the pass and run in one multi-problem launch pair per 16 layers (0: one launch pair per layer, as round 5; bit-identical)"),
     ("train_source", "MFT_TRAIN_SOURCE", str, "pool", "train.main --dataset miniImageNet: 'pool' = resident uint8 class pool, 'synthetic' = host fp32 episodes"),
     # ---- drivers (finetune.main / train.main)
     ("standin_weights", "MFT_STANDIN_WEIGHTS", _flag, False, "allow synthetic stand-in weights when no checkpoint is found (explicit opt-in)"),
@@ -106,6 +107,7 @@ class Settings:
     pair_mlp_gb: float = 6.0
     train_graph: bool = True
     train_x3: bool = True
+    wgrad_batch: bool = True
     train_source: str = "pool"
     standin_weights: bool = False
     image_size: int = 84

@@ -183,6 +183,10 @@ def train(base_loader, model, optimization, start_epoch, stop_epoch, params, var
         model.train()
         if params.method == 'baseline':
             model.train_loop(epoch, base_loader, optimizer)              # train.py:41-42: every other method -> train_loop
+        elif not params.fine_tune and getattr(params, "episodes_per_rank", 1) > 1:
+            if fifty:
+                raise NotImplementedError("--episodes_per_rank with the 50-shot loops")
+            model.train_loop_lockstep(epoch, base_loader, optimizer, params.episodes_per_rank)
         elif not params.fine_tune:
             (model.train_loop50 if fifty else model.train_loop2)(epoch, base_loader, optimizer)
         else:

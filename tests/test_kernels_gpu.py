@@ -1385,3 +1385,33 @@ def test_conv_wgrad_oihw_valid_corner(rows, K, kv, cp, cv):
     assert torch.equal(got.view(cv or cp, kv), full[:cv or cp, :kv])
     ref = dy.double().cpu().t() @ x.double().cpu()
     assert float((got.view(cv or cp, kv).double().cpu() - ref[:cv or cp, :kv]).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_conv_wgrad_multi_is_bit_identical_to_single_launches():
+    """mft_conv2d_wgrad_oihw_multi (ops.WgradBatch: every weight gradient of a backward pass in one pair of launches per 16 jobs, the
+    stem on its own) against the same problems launched one by one: bit for bit, for 3x3 / 1x1 / strided / stem / zero-padded linear
+    jobs in one batch of 19 (two multi launches)."""
+    jobs = [(105, 21, 64, 64, 3, 1, 1, 0, 0), (105, 21, 64, 128, 3, 2, 1, 0, 0), (105, 21, 64, 128, 1, 2, 0, 0, 0), (105, 6, 256, 512, 3, 2, 1, 0, 0),
+            (105, 3, 512, 512, 3, 1, 1, 0, 0), (4, 84, 3, 64, 7, 2, 3, 0, 0), (7440, 1, 160, 192, 1, 1, 0, 133, 0), (7440, 1, 192, 192, 1, 1, 0, 0, 0),
+            (7440, 1, 96, 32, 1, 1, 0, 0, 1), (480, 1, 288, 64, 1, 1, 0, 266, 48), (480, 1, 480, 32, 1, 1, 0, 458, 5), (105, 1, 512, 128, 1, 1, 0, 0, 0)]
+    jobs = jobs + jobs[:7]
+    wb = ops.WgradBatch(True)
+    outs, refs = [], []
+    for i, (n, H, Cin, Cout, k, stride, pad, cv, ov) in enumerate(jobs):
+        x = nhwc(rnd((n, Cin, H, H), 400 + i)).to(DEV)
+        OH = (H + 2 * pad - k) // stride + 1
+        dy = nhwc(rnd((n, Cout, OH, OH), 500 + i)).to(DEV)
+        if cv:
+            x[..., cv:] = 0
+        if ov:
+            dy[..., ov:] = 0
+        outs.append(wb.add(x, dy, Cout, k, k, stride, pad, cv, ov))
+        refs.append(ops.conv2d_wgrad_oihw(x, dy, Cout, k, k, stride, pad, cv, ov))
+    wb.flush()
+    torch.cuda.synchronize()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert o.shape == r.shape and torch.equal(o, r), (i, jobs[i])
+    off = ops.WgradBatch(False)                            # disabled: add() launches at once
+    x = nhwc(rnd((5, 64, 6, 6), 7)).to(DEV)
+    dy = nhwc(rnd((5, 64, 6, 6), 8)).to(DEV)
+    assert torch.equal(off.add(x, dy, 64, 3, 3, 1, 1), ops.conv2d_wgrad_oihw(x, dy, 64, 3, 3, 1, 1))

@@ -17,4 +17,5 @@ prof() {   # key, args...
 prof configs2_20shot --n-shot 20 --steps 1 --warmup 1
 prof configs4_50shot --n-shot 50 --steps 1 --warmup 1
 prof configs3_metatrain --workload metatrain --steps 300 --warmup 10
+prof configs3_metatrain_lockstep4 --workload metatrain --episodes-per-rank 4 --steps 200 --warmup 10
 prof reference_224 --image-size 224 --episodes-per-batch 32 --steps 2 --warmup 1
