@@ -232,16 +232,11 @@ int mft_bn_apply_x3ws_fits(int C, int rows_per_group, int with_res_bn);  /* 1 wh
 int mft_bn_relu_pooled_gather_moments(const float* pmax, const float* pmin, const int* src_idx, float* y, int n_img, int OH, int OW,
                                       int C, int imgs_per_group, const float* mean_img, const float* m2_img, int rows_per_img,
                                       float eps, const float* gamma, const float* beta, float* mean, float* rstd, void* stream);
-int mft_debug_set_x3_tile(int tile);          /* tuning aid: 0 auto, 1: 128x64, 2: 128x128 */
 
-/* tuning aid: force the forward tile of mft_conv2d_nhwc (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 128x32; 0: automatic) */
 /* 1 when the library was built with -DMFT_EXPERIMENTS (MFT_EXPERIMENTS=1 python -m meta_fine_tuning_amd.build): the kernel
- * variants DESIGN.md records as measured slower and the timing / power ablation aids exist only then (tools/); in the product
- * build their mft_debug_set_* codes return MFT_EINVAL.                                                                       */
+ * variants DESIGN.md records as measured slower and the timing / power ablation aids exist only then (tools/).
+ * (The form-selection hooks the tests and A/B tools use are NOT part of this header: include/mft_hip_testing.h.)            */
 int mft_has_experiments(void);
-int mft_debug_set_conv_tile(int tile);
-/* All tuning knobs (mft_debug_set_conv_tile / mft_debug_set_x3_tile) back to their defaults. */
-int mft_debug_reset(void);
 
 /* conv data gradient (autograd of nn.Conv2d / nn.Linear inputs in loss.backward(), finetune.py:293; meta_template.py:86):
  * dx[h][w][ci] = sum_{kh,kw,co} dy[(h+pad-kh)/s][(w+pad-kw)/s][co] * w[g][co][kh][kw][ci] (divisible offsets only), reading
@@ -331,12 +326,8 @@ int mft_wgrad_adam_next_forward(const float* x, int ldx, const float* dy, int ld
                                 const float* gamma, const float* beta, long long gb_group_stride, float* mean, float* rstd,
                                 const float* sc_raw, const float* gamma_s, const float* beta_s, float* mean_s, float* rstd_s,
                                 float* pooled, float bn_eps, void* stream);
-/* 1: correctly rounded division / square root in that launch's Adam epilogue (default 0: v_rcp_f32 / v_sqrt_f32, as
- * mft_conv2d_wgrad_adam_nhwc's default).                                                                                   */
-void mft_wgrad_fwd_set_exact(int on);
-/* 1 (default): the Cout / 32 workgroups of an episode are placed on ONE XCD (they re-read the same activation rows through that
- * XCD's L2); 0: natural workgroup order.  Placement only: no result changes.  Takes effect when the group count is a multiple of 8. */
-void mft_wgrad_fwd_set_xcd(int on);
+/* (its Adam epilogue: v_rcp_f32 / v_sqrt_f32 as mft_conv2d_wgrad_adam_nhwc's default -- DESIGN.md section 6, deviations; an episode's
+ * Cout / 32 workgroups are placed on ONE XCD; the correctly rounded form and the natural order are test hooks, mft_hip_testing.h) */
 
 
 /* BatchNorm (train mode, batch statistics) --------------------------------------------- */
@@ -350,6 +341,15 @@ long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups);
 int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
                  float* mean, float* rstd, float* ws,
                  float* running_mean, float* running_var, float momentum, long long* num_batches_tracked, void* stream);
+/* Several independent BatchNorm-apply problems (no residual) in ONE launch: the meta-training backward re-creates the twelve pair-MLP
+ * activations h_l = leaky_relu(BatchNorm(z_l)) (gnn.py:87-102; the forward keeps only the raw z_l) in front of its weight-gradient
+ * launches -- all twelve depend on the forward's tape only.  jobs: HOST array, up to 16 per launch; each job = mft_bn_apply's
+ * arguments of the same names (gamma / beta shared by the groups), bit-identical to its own launch. */
+typedef struct MftBnApplyJob {
+    const float* x; float* y; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int ldx, ldy, C, rows_per_group, n_groups, act; float slope; int reserved;
+} MftBnApplyJob;
+int mft_bn_apply_multi(const MftBnApplyJob* jobs, int n_jobs, void* stream);
 /* y = act( bn(x) [+ residual | + bn_r(residual)] ); gamma/beta [C] shared (gb_group_stride 0) or per group.
  * SimpleBlock.forward tail (backbone.py:251-261); F.leaky_relu(bn(.)) in Wcompute (gnn.py:84-102). */
 int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, int rows_per_group, int n_groups,
@@ -480,9 +480,11 @@ int mft_linear_head_adam_run(const float* z_support, const int* y_support, const
                              float eps, float weight_decay, void* stream);
 
 /* torch.optim.Adam.step over many tensors in one launch (train.py:28, meta_template.py:87): chunk_table is a DEVICE array of
- * n_chunks records {float* p; const float* g; float* m; float* v; long long n;} (40 bytes each, n <= 65536 elements; 16-byte aligned chunks take the float4 path).        */
+ * n_chunks records {float* p; const float* g; float* m; float* v; long long n;} (40 bytes each, n <= 65536 elements; 16-byte aligned chunks take the float4 path).
+ * grad_scale multiplies every gradient as it is read (1 = torch's step; 1 / world size when g is the all-reduced SUM of the ranks'
+ * gradients: the division of the episode-parallel step without a launch of its own).        */
 int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, void* stream);
+                   float weight_decay, float grad_scale, void* stream);
 
 /* hipGraph support: kernel arguments are frozen when a graph is captured, so Adam's bias corrections must come from device
  * memory.  mft_adam_hyper_advance does t = ++(*step) and writes hyper = {lr/(1-beta1^t), 1/sqrt(1-beta2^t)} (double precision,
@@ -621,8 +623,9 @@ int mft_graph_aggregate_backward(const float* A, const float* x, int ldx, const 
                                  float* dA, int n_graphs, int N, int F, int accumulate, void* stream);
 int mft_build_graph_nodes_backward(const float* dnodes, int ld, float* dz, int zf, int n_episodes, int n_way,
                                    int n_support, int n_query, int fold, void* stream);
+/* (dbias, nullable [n_way]: column sums of dscores = the gradient of the bias of the layer that produced `out`, gnn.layer_last.fc) */
 int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,
-                                     int n_support, int n_query, void* stream);
+                                     int n_support, int n_query, float* dbias, void* stream);
 
 #ifdef __cplusplus
 }

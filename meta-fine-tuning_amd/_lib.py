@@ -33,12 +33,9 @@ SIGNATURES = {
     "mft_pack_dgrad": [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P],
     "mft_conv2d_nhwc": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "mft_has_experiments": [],
-    "mft_debug_set_conv_tile": [_I],
-    "mft_debug_reset": [],
     "mft_split_bf16x3": [_P, _P, _L, _P],
     "mft_split_bf16x3_multi": [_P, _I, _L, _P],
     "mft_conv2d_nhwc_x3": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mft_debug_set_x3_tile": [_I],
     "mft_conv2d_x3_stats_ws_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
     "mft_conv2d_nhwc_x3_bnstats": [_P, _I, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "mft_conv2d_dgrad_nhwc": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
@@ -63,11 +60,10 @@ SIGNATURES = {
     "mft_pack_oihw_multi": [_P, _I, _L, _P],
     "mft_wgrad_adam_next_forward": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _F, _F, _F,
                                     _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P],
-    "mft_wgrad_fwd_set_exact": [_I],
-    "mft_wgrad_fwd_set_xcd": [_I],
     "mft_bn_stats_ws_floats": [_I, _I, _I],
     "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P],
     "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
+    "mft_bn_apply_multi": [_P, _I, _P],
     "mft_bn_relu_maxpool": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_relu_maxpool_gather": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_image_moments": [_P, _I, _I, _I, _L, _P, _P, _P],
@@ -113,7 +109,7 @@ SIGNATURES = {
                                            _P, _P, _P],
     "mft_linear_head_sgd_run": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _P],
     "mft_linear_head_adam_run": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _F, _P],
-    "mft_adam_multi": [_P, _I, _I, _F, _F, _F, _F, _F, _P],
+    "mft_adam_multi": [_P, _I, _I, _F, _F, _F, _F, _F, _F, _P],
     "mft_adam_hyper_advance": [_P, _P, _F, _F, _F, _P],
     "mft_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
     "mft_conv2d_wgrad_adam_nhwc_dev": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P, _F, _F,
@@ -143,7 +139,15 @@ SIGNATURES = {
     "mft_pair_absdiff_backward": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "mft_graph_aggregate_backward": [_P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "mft_build_graph_nodes_backward": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mft_gather_query_scores_backward": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+}
+# test / A-B hooks (include/mft_hip_testing.h): form selection for tests/ and tools/, never called by the product path
+TESTING_SIGNATURES = {
+    "mft_debug_set_conv_tile": [_I],
+    "mft_debug_set_x3_tile": [_I],
+    "mft_debug_reset": [],
+    "mft_wgrad_fwd_set_exact": [_I],
+    "mft_wgrad_fwd_set_xcd": [_I],
 }
 _RESTYPE = {"mft_conv2d_x3_stats_ws_floats": _L, "mft_bn_stats_ws_floats": _L, "mft_conv2d_wgrad_ws_floats": _L, "mft_bn_backward_ws_floats": _L,
             "mft_conv2d_wgrad_adam_dgrad_ws_floats": _L, "mft_pair_bwd_stats_ws_floats": _L, "mft_conv_ksplit_ws_floats": _L, "mft_conv2d_wgrad_oihw_ws_floats": _L, "mft_conv_ksplit_grouped_ws_floats": _L}
@@ -167,7 +171,7 @@ def lib():
             torch.cuda.init()
             torch.empty(1, device="cuda")
         h = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in list(SIGNATURES.items()) + list(TESTING_SIGNATURES.items()):
             fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, _I)

@@ -382,9 +382,18 @@ __global__ __launch_bounds__(256) void build_nodes_bwd_kernel(const float* __res
 
 // dout[node(e,q,c,last), k] = dscores[e, c*nq+q, k]; zero elsewhere
 __global__ __launch_bounds__(256) void gather_scores_bwd_kernel(const float* __restrict__ dscores, float* __restrict__ dout,
-                                                                int ldo, int n_ep, int n_way, int ns, int nq) {
+                                                                int ldo, int n_ep, int n_way, int ns, int nq, float* __restrict__ dbias) {
     const long long rows = (long long)n_ep * nq * n_way * (ns + 1);
     const long long total = rows * ldo;
+    // dbias[k] (nullable) = column sums of d(out) = of dscores (every other row of d(out) is zero): the gradient of layer_last's
+    // fc.bias (gnn.py:43-56; no BatchNorm behind it), summed in row order by the first n_way threads of block 0 -- the two
+    // column-sum launches the backward otherwise spends on it
+    if (dbias && blockIdx.x == 0 && (int)threadIdx.x < n_way) {
+        const long long nr = (long long)n_ep * n_way * nq;
+        float acc = 0.f;
+        for (long long r = 0; r < nr; ++r) acc += dscores[r * n_way + threadIdx.x];
+        dbias[threadIdx.x] = acc;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i % ldo);
@@ -524,9 +533,9 @@ extern "C" int mft_build_graph_nodes_backward(const float* dnodes, int ld, float
 }
 
 extern "C" int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,
-                                                int n_support, int n_query, void* stream) {
+                                                int n_support, int n_query, float* dbias, void* stream) {
     const long long total = (long long)n_episodes * n_query * n_way * (n_support + 1) * ldo;
     hipLaunchKernelGGL(gather_scores_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dscores, dout, ldo,
-                       n_episodes, n_way, n_support, n_query);
+                       n_episodes, n_way, n_support, n_query, dbias);
     return mft_launch_status();
 }

@@ -115,11 +115,11 @@ __device__ __forceinline__ float act_f(float v, int act, float slope) {
 }
 
 template <bool PLANES>
-__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
+__device__ __forceinline__ void bn_apply_blocks(const ApplyArgs& p, const int block, const int n_blocks) {
     const int cq = p.C >> 2;
     const long long total = (long long)p.n_groups * p.rows_per_group * cq;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)block * blockDim.x + threadIdx.x; i < total;
+         i += (long long)n_blocks * blockDim.x) {
         const long long row = i / cq;
         const int c = (int)(i - row * cq) * 4;
         const int g = (int)(row / p.rows_per_group);
@@ -165,6 +165,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
             *(mft_u32x2*)(q + 2 * p.plane_stride) = p3;
         }
     }
+}
+
+template <bool PLANES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(ApplyArgs p) {
+    bn_apply_blocks<PLANES>(p, blockIdx.x, gridDim.x);
+}
+
+// several apply problems in one launch (mft_bn_apply_multi): block b works for the job j with start[j] <= b < start[j + 1], as block
+// b - start[j] of that job's own launch
+constexpr int BA_MULTI = 16;
+struct ApplyMultiArgs {
+    ApplyArgs job[BA_MULTI];
+    int start[BA_MULTI + 1];
+    int n;
+};
+static_assert(sizeof(ApplyMultiArgs) <= 4000, "kernarg segment");
+
+__global__ __launch_bounds__(256) void bn_apply_multi_kernel(ApplyMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start[j + 1]) ++j;
+    const ApplyArgs p = a.job[j];
+    bn_apply_blocks<false>(p, blockIdx.x - a.start[j], a.start[j + 1] - a.start[j]);
 }
 
 // The same apply for the outputs of bf16x3 trunk convolutions whose statistics are still per-tile partials (csrc/conv_x3.hip):
@@ -524,6 +547,26 @@ extern "C" int mft_bn_apply(const float* x, int ldx, float* y, int ldy, int C, i
                 res, ldr, res_mean, res_rstd, res_gamma, res_beta, act, slope, nullptr, 0};
     const long long total = (long long)n_groups * rows_per_group * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_apply_multi(const MftBnApplyJob* jobs, int n_jobs, void* stream) {
+    if (jobs == nullptr || n_jobs < 1) return MFT_EINVAL;
+    for (int j0 = 0; j0 < n_jobs;) {
+        ApplyMultiArgs a = {};
+        int cnt = 0, blocks = 0;
+        for (; j0 < n_jobs && cnt < BA_MULTI; ++j0, ++cnt) {
+            const MftBnApplyJob& jb = jobs[j0];
+            if (jb.C % 4 != 0 || jb.ldx % 4 != 0 || jb.ldy % 4 != 0 || jb.rows_per_group < 1 || jb.n_groups < 1) return MFT_EINVAL;
+            a.job[cnt] = ApplyArgs{jb.x, jb.y, jb.ldx, jb.ldy, jb.C, jb.rows_per_group, jb.n_groups, jb.mean, jb.rstd, jb.gamma, jb.beta, 0,
+                                   nullptr, 0, nullptr, nullptr, nullptr, nullptr, jb.act, jb.slope, nullptr, 0};
+            a.start[cnt] = blocks;
+            blocks += grid_for((long long)jb.n_groups * jb.rows_per_group * (jb.C / 4));
+        }
+        a.start[cnt] = blocks;
+        a.n = cnt;
+        hipLaunchKernelGGL(bn_apply_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return mft_launch_status();
 }
 

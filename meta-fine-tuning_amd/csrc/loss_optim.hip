@@ -506,7 +506,7 @@ namespace {
 struct AdamChunk { float* p; const float* g; float* m; float* v; long long n; };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __restrict__ table, float step_size,
-                                                         float inv_sqrt_bc2, float b1, float b2, float eps, float wd) {
+                                                         float inv_sqrt_bc2, float b1, float b2, float eps, float wd, float gs) {
     const AdamChunk c = table[blockIdx.x];
     const bool vec = ((((unsigned long long)c.p | (unsigned long long)c.g | (unsigned long long)c.m | (unsigned long long)c.v) & 15ull) == 0);
     const long long n4 = vec ? (c.n >> 2) : 0;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __rest
         f32x4 mm = ((const f32x4*)c.m)[i], vv = ((const f32x4*)c.v)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ge = gg[e] + wd * pp[e];
+            const float ge = gg[e] * gs + wd * pp[e];         // gs: 1 / world size when the bucket holds the all-reduced SUM (exact at 1)
             mm[e] = b1 * mm[e] + (1.f - b1) * ge;
             vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
             pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps));
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __rest
     }
     for (long long i = 4 * n4 + threadIdx.x; i < c.n; i += 256) {
         const float pp = c.p[i];
-        const float ge = c.g[i] + wd * pp;
+        const float ge = c.g[i] * gs + wd * pp;
         const float mm = b1 * c.m[i] + (1.f - b1) * ge;
         const float vv = b2 * c.v[i] + (1.f - b2) * ge * ge;
         c.m[i] = mm;
@@ -538,12 +538,12 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk* __rest
 }  // namespace
 
 extern "C" int mft_adam_multi(const void* chunk_table, int n_chunks, int step, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, void* stream) {
+                              float weight_decay, float grad_scale, void* stream) {
     if (step < 1 || n_chunks < 1) return MFT_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunk_table,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
     return mft_launch_status();
 }
 

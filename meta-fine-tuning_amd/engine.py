@@ -158,7 +158,8 @@ def _set_wgrad_fwd_xcd_once():
     not per engine -- an engine built later must not change the launch order of engines that already exist."""
     global _WF_XCD_SET
     if not _WF_XCD_SET:
-        ops._lib.lib().mft_wgrad_fwd_set_xcd(int(settings.current().wf_xcd))
+        if not settings.current().wf_xcd:       # the default (one XCD per episode) is the library's own: the product path never touches
+            ops._lib.lib().mft_wgrad_fwd_set_xcd(0)      # the hook (include/mft_hip_testing.h); only the A/B value does
         _WF_XCD_SET = True
 
 

@@ -323,8 +323,28 @@ def wcompute_taped(G, name, x, F, n_graphs, N, groups=1):
     return A, t
 
 
+def pair_activations(G, tapes, rows):
+    """h_l = leaky_relu(BatchNorm(z_l)) of EVERY pair-MLP layer of the given Wcompute tapes in one launch (the forward keeps only the
+    raw z_l; the backward needs h_l as the weight-gradient operand of layer l + 1): twelve problems that depend on the tape only,
+    so they run together in front of the head's backward chain instead of one launch each inside it.  Leaves ``t["act"]``."""
+    jobs = []
+    for t in tapes:
+        layers = G.wc[t["name"]][0]
+        groups = t.get("groups", 1)
+        for li in range(4):
+            _, _, gam, beta, cout = layers[li]
+            _, _, m, s = t["bn"][li]
+            z = t["z"][li]
+            jobs.append((z, cout, rows // groups, groups, m, s, gam, beta, LRELU, _empty(z.shape, z.device)))
+    outs = ops.bn_apply_multi(jobs)
+    for i, t in enumerate(tapes):
+        t["act"] = outs[4 * i:4 * i + 4]
+
+
 def _pair_activation(t, li, layers, rows):
     """h_l = leaky_relu(BatchNorm(z_l)) of layer li as a [rows, C] operand of the generic GEMM launches (a transient)."""
+    if "act" in t:
+        return t["act"][li]
     _, _, gam, beta, cout = layers[li]
     _, _, m, s = t["bn"][li]
     z = t["z"][li]
@@ -413,13 +433,13 @@ def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1):
     return o, t
 
 
-def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix, first=False, wb=None):
+def gconv_backward(G, t, d_o, x, dX, n_graphs, N, grads, prefix, first=False, wb=None, db=None):
     """d_o: gradient w.r.t. the Gconv output (after its BatchNorm when present), [rows, roundup(cout,32)].
     Accumulates into dX[:, :F] (``first``: overwrites them -- dX is not zero-filled); returns dA."""
     w, b, g, beta, cout = G.gc[t["name"]]
     rows = n_graphs * N
     F = t["F"]
-    dbz = None
+    dbz = db                                      # (a caller that already holds the bias gradient: layer_last)
     if g is not None:
         m, s = t["stats"]
         dbz = _empty((cout,), x.device)          # fc.bias sits in front of the BatchNorm1d: zero gradient, written by its backward
@@ -479,10 +499,13 @@ def head_backward(G, t, dscores):
     lease = t["lease"]
     dX = _empty((rows, 256), dev)              # first written (all 229 feature columns) by layer_last's aggregate backward: no zero fill
     d_out = _empty((rows, 32), dev)
+    db_last = _empty((n_way,), dev)            # layer_last.fc.bias: the column sums of dscores, from the same launch
     L.check(L.lib().mft_gather_query_scores_backward(ops._p(dscores.contiguous()), ops._p(d_out), 32, k, n_way, ns, nq,
-                                                     ops._stream()), "mft_gather_query_scores_backward")
+                                                     ops._p(db_last), ops._stream()), "mft_gather_query_scores_backward")
     wb = ops.WgradBatch(WGRAD_BATCH)            # the head's 16 weight gradients: registered as the pass goes, run together at its end
-    dA = gconv_backward(G, t["gc"][2], d_out, x, dX, n_graphs, N, grads, "gnn.layer_last", first=True, wb=wb)
+    if WGRAD_BATCH:
+        pair_activations(G, t["wc"], n_graphs * (N * (N + 1) // 2))
+    dA = gconv_backward(G, t["gc"][2], d_out, x, dX, n_graphs, N, grads, "gnn.layer_last", first=True, wb=wb, db=db_last)
     wcompute_backward(G, t["wc"][2], dA, x, dX, n_graphs, N, grads, "gnn.w_comp_last", wb=wb)
     for i in (1, 0):
         F = t["Fs"][i]

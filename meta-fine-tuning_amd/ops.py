@@ -567,6 +567,26 @@ def bn_apply(x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act=ACT_
     return out
 
 
+class _BnApplyJob(ctypes.Structure):
+    """MftBnApplyJob (include/mft_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "y", "mean", "rstd", "gamma", "beta")] + \
+               [(n, ctypes.c_int) for n in ("ldx", "ldy", "C", "rows_per_group", "n_groups", "act")] + [("slope", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+def bn_apply_multi(jobs):
+    """``jobs``: list of (x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act, out) -- bn_apply of each (no residual) in ONE
+    launch per 16 jobs (mft_bn_apply_multi); returns the list of outputs."""
+    if not jobs:
+        return []
+    arr = (_BnApplyJob * len(jobs))()
+    for a, (x, C, rpg, ng, mean, rstd, gamma, beta, act, out) in zip(arr, jobs):
+        _f32c(x)
+        a.x, a.y, a.mean, a.rstd, a.gamma, a.beta = (t.data_ptr() for t in (x, out, mean, rstd, gamma, beta))
+        a.ldx, a.ldy, a.C, a.rows_per_group, a.n_groups, a.act, a.slope = x.shape[-1], out.shape[-1], C, rpg, ng, act, LRELU_SLOPE
+    _lib.check(_lib.lib().mft_bn_apply_multi(arr, len(jobs), _stream(jobs[0][0].device)), "mft_bn_apply_multi")
+    return [j[-1] for j in jobs]
+
+
 def bn_relu_maxpool(x, mean, rstd, gamma, beta, imgs_per_group=0):
     _f32c(x)
     n, H, W, C = x.shape

@@ -14,6 +14,8 @@ CHUNK = 16384          # elements per workgroup of the multi-tensor launch (mult
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = 1.0        # every gradient is multiplied by this as the update reads it (train.AllReduceAdam: 1 / world size
+                                     # when .grad holds the all-reduced SUM -- the mean without a division launch)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -56,11 +58,13 @@ class Adam(torch.optim.Optimizer):
                     cached = tables[id(group)] = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(ps[0].device))
                 table = cached[1]
                 rc = ops._lib.lib().mft_adam_multi(ops._p(table), len(rows), step, group["lr"], b1, b2, group["eps"],
-                                                   group["weight_decay"], ops._stream())
+                                                   group["weight_decay"], float(self.grad_scale), ops._stream())
                 ops._lib.check(rc, "mft_adam_multi")
             else:
                 for p in ps:
                     st = self.state[p]
+                    if self.grad_scale != 1.0:
+                        raise RuntimeError("grad_scale needs the multi-tensor launch (all parameters on the GPU, equal step counts)")
                     ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"], beta1=b1,
                                   beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"])
             # parameters were updated through raw pointers: bump autograd's version counters ON THE PARAMETERS THEMSELVES (the

@@ -112,7 +112,12 @@ class FlatGradBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def allreduce_mean(self):
+    def allreduce_sum(self):
+        """``allreduce_mean`` without the division: ``.grad`` holds the SUM over the ranks afterwards and the caller's optimiser
+        applies 1 / W as it reads the gradients (optim.Adam.grad_scale) -- one launch less per step.  Returns W."""
+        return self.allreduce_mean(divide=False)
+
+    def allreduce_mean(self, divide=True):
         """Pack grads -> all-reduce(SUM) -> divide by W -> unpack into .grad (in place).  With one rank nothing is exchanged
         and the gradients stay where autograd put them.  A parameter whose ``.grad`` is None (frozen this step; every rank
         freezes the same ones) contributes zeros to the sum and KEEPS ``grad = None``, so the optimiser skips it as
@@ -120,7 +125,7 @@ class FlatGradBucket:
         (ADVICE r04)."""
         _, W = world()
         if W == 1 and not collectives_forced():
-            return
+            return W
         live = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         if len(live) != len(self.params):
             for v, p in zip(self.views, self.params):
@@ -135,9 +140,11 @@ class FlatGradBucket:
             self.flat.copy_(host)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)     # "nccl" == RCCL over xGMI
-        self.flat.div_(W)
+        if divide:
+            self.flat.div_(W)
         if views:
             torch._foreach_copy_(grads, views)
+        return W
 
 
 def broadcast_buffers(module, src=0):

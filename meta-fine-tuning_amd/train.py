@@ -168,7 +168,8 @@ class AllReduceAdam:
 
     def step(self, closure=None):
         if self.bucket is not None:
-            self.bucket.allreduce_mean()
+            W = self.bucket.allreduce_sum()          # .grad = SUM over the ranks; the fused Adam launch reads it times 1 / W
+            self.opt.grad_scale = 1.0 / W
         return self.opt.step(closure)
 
 

@@ -61,8 +61,15 @@ def _worker(rank, world_size, port, out):
         p.grad = gi.clone()
     bucket = parallel.FlatGradBucket(params)
     assert bucket.numel == sum(p.numel() for p in params)
+    # the SUM form (the drivers' path: 1 / W is applied inside the fused Adam launch, optim.Adam.grad_scale) on a copy
+    params2 = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    for p2, gi in zip(params2, g):
+        p2.grad = gi.clone()
+    assert parallel.FlatGradBucket(params2).allreduce_sum() == world_size
     bucket.allreduce_mean()
     avg_grads = {k: p.grad.detach().clone() for k, p in zip(keys, params)}
+    for p2, p in zip(params2, params):
+        assert torch.equal(p2.grad, p.grad * world_size)           # (exact: W = 2)
     opt = torch.optim.Adam(params)
     opt.step()
     if rank == 0:

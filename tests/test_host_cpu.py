@@ -24,6 +24,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), "libmft_hip.so lacks %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert h.mft_version() >= 100
+    # the product header declares launchers only: the form-selection hooks of tests/ and tools/ live in their own header
+    assert not [n for n in declared if n.startswith("mft_debug_") or n.endswith(("_set_exact", "_set_xcd"))]
+    hooks = set(re.findall(r"\b(mft_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "mft_hip_testing.h")).read()))
+    assert hooks == set(_lib.TESTING_SIGNATURES) and all(hasattr(h, n) for n in hooks)
 
 
 def test_state_dict_contract():
