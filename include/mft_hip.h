@@ -525,6 +525,9 @@ int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, 
  *     group.  Writes the raw output `out` [n_groups*graphs_per_group*P, Cout] (bias added) and, per (group, 128-row tile),
  *     the weighted per-channel (mean, M2) and weight sum (off-diagonal rows count twice) into ws_mean / ws_m2 [n_groups *
  *     tiles_m, Cout] and ws_n [n_groups * tiles_m]; tiles_m = mft_pair_mlp_tiles_m(graphs_per_group, N).
+ *     f16x2 = 0: fp32 MFMA (exact products); 1: both operands split into two fp16 pieces by the loader, three products on the
+ *     fp16 matrix cores, fp32 accumulation (fp32-accurate; operands must lie inside fp16's range, |x| < 65504, else the output
+ *     is NaN: the caller checks weights / BatchNorm bounds where they are frozen, functional.pair_f16x2_safe).
  *   mft_pair_mlp_stats_finalize: merges a group's tiles (Chan, tile order) into the next layer's affine scale = gamma *
  *     rstd, shift = beta - mean * scale (biased variance over graphs_per_group*N*N positions; mean_out / rstd_out optional).
  *   mft_pair_mlp_score: conv2d_last (C -> 1) on BatchNorm + leaky_relu of the last raw layer -> compact symmetric scores
@@ -533,7 +536,7 @@ int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, 
 int mft_pair_mlp_tiles_m(int graphs_per_group, int N);
 int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
                        const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
-                       int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n, void* stream);
+                       int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n, int f16x2, void* stream);
 int mft_pair_mlp_stats_finalize(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m, int C,
                                 const float* gamma, const float* beta, float eps, float* scale, float* shift,
                                 float* mean_out, float* rstd_out, void* stream);

@@ -14,6 +14,7 @@
 // conflict-free.  Each lane reads 16 contiguous k of its row; MFMA step t pairs k=t (lanes 0-31)
 // with k=16+t (lanes 32-63) -- a fixed permutation of the reduction order shared by A and B.
 #include "mft_common.h"
+#include "mft_hip_testing.h"      // the form-selection hooks defined at the end of this file (tests / A-B tools only)
 
 int mft_stem_conv_dispatch(const float* in, const float* w, float* out, int n_img, int H, int W, int w_ld,
                            hipStream_t s);   // csrc/stem.hip

@@ -5,7 +5,6 @@
 #include <mutex>
 #include <stdint.h>
 #include "mft_hip.h"
-#include "mft_hip_testing.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -25,10 +25,25 @@
 
 namespace {
 
+typedef _Float16 pm_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pm_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pm_u32x2 __attribute__((ext_vector_type(2)));
+
+// "f16x2" (csrc/conv_x3.hip): x = hi + 2^-11 lo, hi = fp16(x), lo = fp16((x - hi) * 2^11): |x - (hi + 2^-11 lo)| <= 2^-22 |x|;
+// a b = a_hi b_hi + 2^-11 (a_hi b_lo + a_lo b_hi) + O(2^-22 a b): three fp16 MFMAs, leading / cross terms in two fp32 accumulators.
+__device__ __forceinline__ void pm_split4_h2(const f32x4 x, pm_u32x2& p1, pm_u32x2& p2) {
+    const pm_f16x4 hi = __builtin_convertvector(x, pm_f16x4);
+    const f32x4 r = (x - __builtin_convertvector(hi, f32x4)) * 2048.f;
+    const pm_f16x4 lo = __builtin_convertvector(r, pm_f16x4);
+    p1 = __builtin_bit_cast(pm_u32x2, hi);
+    p2 = __builtin_bit_cast(pm_u32x2, lo);
+}
+
 constexpr int PM_BM = 128;     // pair rows per tile
 constexpr int PM_BN = 96;      // output channels per tile (192 = 2 tiles, 96 = 1)
 constexpr int PM_BK = 32;
 constexpr int PM_LD = 36;      // LDS row stride in floats (conflict-free ds_read_b128 fragment reads)
+constexpr int PM_RS = 40;      // H2: LDS row stride in fp16 elements (32 + 8: 80-byte rows, 16-byte aligned fragments, as conv_x3's X3_RS)
 
 struct PairArgs {
     const float* in;           // PAIR: node features x [n_graphs*N, ld_in]; BNACT: previous raw layer output [rows, ld_in]
@@ -49,9 +64,16 @@ struct PairArgs {
 // MODE 0: PAIR loader (layer 1), MODE 1: BNACT loader (layers 2-4).  DB: double-buffered LDS (one barrier per K-step, 64.5 KB:
 // two workgroups per CU) or single-buffered (two barriers per K-step, 32 KB: four workgroups per CU -- a tile is only 3-8
 // K-steps long, so its load / compute / store phases overlap across workgroups rather than inside one).
-template <int MODE, bool DB>
+// H2: both operands are split into two fp16 pieces by the loader (A: |x_i - x_j| or the BatchNorm'd activation, as computed above in
+// fp32; B: the fp32 weight rows -- no pre-split planes, the weights change every meta-training step) and the tile runs on the fp16
+// matrix cores as three products per K-step with fp32 accumulation: fp32-accurate (error vs float64 below the fp32-MFMA form's,
+// tests/test_kernels_gpu.py::test_pair_mlp_f16x2_is_fp32_accurate), 18 MFMA issues of 32x32x16 per K-step instead of 48 of 32x32x2.
+// Operands beyond fp16's range (|x| >= 65504) become infinities: the result is NaN, loudly.
+template <int MODE, bool DB, bool H2 = false>
 __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
+    static_assert(!(H2 && DB), "f16x2: the single-buffer form only");
     constexpr int BM = PM_BM, BN = PM_BN, BK = PM_BK, LD = PM_LD;
+    constexpr int RS = PM_RS, A_PLANE = BM * RS, B_PLANE = BN * RS;
     constexpr int PA = BM / 32;        // 4 A passes of 32 rows
     constexpr int PB = BN / 32;        // 3 B passes
     constexpr int TN = BN / 32;        // 3 MFMA blocks per wave (wave = 32 rows x 96 channels)
@@ -116,10 +138,15 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     const float* sh_ptr = MODE == 1 ? p.shift_in + (long long)g * p.K + c4 : nullptr;
 
     f32x16 acc[TN];
+    f32x16 acx[H2 ? TN : 1];           // H2: the cross products a_hi b_lo + a_lo b_hi (weight 2^-11)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (H2 ? TN : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acx[j][e] = 0.f;
 
     f32x4 ra[PA], rb[PB];
     const int nk = p.Kpad / BK;
@@ -159,6 +186,25 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
         for (int j = 0; j < PB; ++j) rb[j] = *(const f32x4*)(b_ptr[j] + k0);
     };
     auto store_tile = [&](int buf) {
+        if constexpr (H2) {
+            unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);        // [2][BM][RS] then [2][BN][RS]
+            unsigned short* Bh = Ah + 2 * A_PLANE;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                pm_u32x2 p1, p2;
+                pm_split4_h2(ra[j], p1, p2);
+                *(pm_u32x2*)(Ah + (lrow + 32 * j) * RS + c4) = p1;
+                *(pm_u32x2*)(Ah + A_PLANE + (lrow + 32 * j) * RS + c4) = p2;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                pm_u32x2 p1, p2;
+                pm_split4_h2(rb[j], p1, p2);
+                *(pm_u32x2*)(Bh + (lrow + 32 * j) * RS + c4) = p1;
+                *(pm_u32x2*)(Bh + B_PLANE + (lrow + 32 * j) * RS + c4) = p2;
+            }
+            return;
+        }
         float* As = smem + (DB ? buf : 0) * (BM + BN) * LD;
         float* Bs = As + BM * LD;
 #pragma unroll
@@ -173,6 +219,30 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
+        if constexpr (H2) {
+            const unsigned short* Ah = reinterpret_cast<const unsigned short*>(smem);
+            const unsigned short* Bh = Ah + 2 * A_PLANE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {                       // two 16-wide halves of the K-step
+                pm_f16x8 a[2], b[TN][2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[pl] = *(const pm_f16x8*)(Ah + pl * A_PLANE + (wave * 32 + r) * RS + kk * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) b[j][pl] = *(const pm_f16x8*)(Bh + pl * B_PLANE + (j * 32 + r) * RS + kk * 16 + h * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[j][1], acx[j], 0, 0, 0);
+                    acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[j][0], acx[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[j][0], acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (kt + 1 < nk) store_tile(0);
+            __syncthreads();
+            continue;
+        }
         const float* As = smem + (DB ? buf : 0) * (BM + BN) * LD;
         const float* Bs = As + BM * LD;
         f32x4 av[4], bv[TN][4];
@@ -201,6 +271,12 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     // Statistics in one pass around the bias as pivot: S1 = sum w*(v - bias), S2 = sum w*(v - bias)^2 are sums of the bare
     // accumulators; tile mean = bias + S1/W, M2 = S2 - S1^2/W (cancellation only inside one 128-row tile; tiles are merged with
     // Chan's formula by the finalize launch).
+    if constexpr (H2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = __builtin_fmaf(acx[j][e], 1.0f / 2048.f, acc[j][e]);
+    }
     const long long out_row0 = (long long)g * p.rows_per_group;
     float wr[16];
 #pragma unroll
@@ -547,7 +623,7 @@ extern "C" int mft_pair_mlp_tiles_m(int graphs_per_group, int N) {
 extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
                                   const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
                                   int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n,
-                                  void* stream) {
+                                  int f16x2, void* stream) {
     if (Cout % PM_BN != 0 || Kpad % PM_BK != 0 || K > Kpad || ld_in % 4 != 0 || N < 1 || N > 65535 || n_groups < 1 ||
         (mode != 0 && mode != 1) || (mode == 1 && (K != Kpad || !scale_in || !shift_in)) || (mode == 0 && ld_in < Kpad))
         return MFT_EINVAL;
@@ -567,6 +643,12 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
     // (round 5: 3.73 / 3.77 vs 3.74 / 3.78 ms), so it is no longer launched.
     const size_t lds1 = (PM_BM + PM_BN) * PM_LD * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    if (f16x2) {                   // split-precision form: 35.8 KB of LDS (two fp16 planes per operand, 80-byte rows)
+        const size_t ldsh = 2 * (PM_BM + PM_BN) * PM_RS * sizeof(unsigned short);
+        if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, false, true>), dim3((unsigned)nwg), dim3(256), ldsh, st, p);
+        else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, false, true>), dim3((unsigned)nwg), dim3(256), ldsh, st, p);
+        return mft_launch_status();
+    }
     if (mode == 0) hipLaunchKernelGGL((pair_mlp_layer_kernel<0, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
     else hipLaunchKernelGGL((pair_mlp_layer_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds1, st, p);
     return mft_launch_status();

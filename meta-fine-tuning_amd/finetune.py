@@ -808,7 +808,9 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
         if params.test_dataset not in synthetic.DATASET_SHAPES or params.test_dataset == "miniImageNet":
             raise ValueError('Unknown test dataset %r (the reference knows ISIC, EuroSAT, CropDisease, ChestX)' % params.test_dataset)
         if rank == 0:
-            print("Loading %s" % params.test_dataset)                # finetune.py:559,565,571,577
+            # (the reference prints "Loading <dataset>" and reads an ImageFolder, finetune.py:559-577; there is no ImageFolder path
+            # here -- the pool below is SYNTHETIC and only dataset-SHAPED, and both printed lines say so: ADVICE r05)
+            print("Loading %s   [SYNTHETIC %s-shaped pool resident in HBM: no image files are read]" % (params.test_dataset, params.test_dataset))
         pool = synthetic.class_pool_u8(params.test_dataset, torch.device("cuda", torch.cuda.current_device()), seed=1,
                                        n_per_class=cfg.pool_per_class)
         sampler = augment.EpisodeSampler(pool, params.test_n_way, params.n_shot + 15, seed=10)
@@ -817,7 +819,8 @@ def main(argv=None, model_cls=None, n_episodes=600, episodes_per_batch=None):
                     sampler=sampler,
                     episodes_per_batch=episodes_per_batch, device_episodes=not cfg.synth_on_host,
                     balance=cfg.balance_batches, timings=tm,
-                    note="" if all(main.loaded[k] is not None for k in used) else "   [SYNTHETIC stand-in weights, MFT_STANDIN_WEIGHTS=1]")
+                    note=("" if all(main.loaded[k] is not None for k in used) else "   [SYNTHETIC stand-in weights, MFT_STANDIN_WEIGHTS=1]") +
+                         ("   [SYNTHETIC %s-shaped pool]" % params.test_dataset if params.test_dataset else ""))
     if tm is not None:
         print("[timings] evaluate: %s" % tm, file=sys.stderr)
     if torch.distributed.is_initialized():

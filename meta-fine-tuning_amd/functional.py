@@ -976,6 +976,7 @@ class GnnHeadWeights:
 
 _PAIR_IJ = {}
 FUSED_PAIR_MLP = settings.current().fused_pair_mlp
+PAIR_F16X2 = settings.current().pair_f16x2           # pair-MLP layers on the fp16 matrix cores as fp32-accurate two-piece products
 PAIR_MLP_BYTES = int(settings.current().pair_mlp_gb * (1 << 30))     # raw-activation budget per chunk of episodes
 
 
@@ -1033,7 +1034,7 @@ def wcompute(G, name, x, F, n_graphs, N, n_groups, arena, tag="wc"):
             ops._lib.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij),
                                                   ops._p(scale[li - 1]) if li else None, ops._p(shift[li - 1]) if li else None,
                                                   ops._p(w), K, Kpad, ops._p(b), ops._p(outs[li]), cout, ng, gpg, N,
-                                                  ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), st()),
+                                                  ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), 1 if PAIR_F16X2 else 0, st()),
                            "mft_pair_mlp_layer")
             ops._lib.check(lib.mft_pair_mlp_stats_finalize(ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), ng, tiles_m, cout,
                                                            ops._p(gam), ops._p(beta), ops.BN_EPS, ops._p(scale[li]),

@@ -308,7 +308,7 @@ def wcompute_taped(G, name, x, F, n_graphs, N, groups=1):
         sc, sh, m, s = (_empty((groups, cout), dev) for _ in range(4))
         L.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij), ops._p(sc_prev), ops._p(sh_prev), ops._p(w), K,
                                        Kpad, ops._p(b), ops._p(z), cout, groups, gpg, N, ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2),
-                                       ops._p(ws_n), ops._stream()), "mft_pair_mlp_layer")
+                                       ops._p(ws_n), 1 if Fn.PAIR_F16X2 else 0, ops._stream()), "mft_pair_mlp_layer")
         L.check(lib.mft_pair_mlp_stats_finalize(ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), groups, tiles_m, cout, ops._p(gam), ops._p(beta),
                                                 ops.BN_EPS, ops._p(sc), ops._p(sh), ops._p(m), ops._p(s), ops._stream()),
                 "mft_pair_mlp_stats_finalize")

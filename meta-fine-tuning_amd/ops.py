@@ -125,15 +125,23 @@ class SplitPlan:
 
     def __init__(self):
         self.jobs, self.total, self.table, self.keep = [], 0, None, []
+        self.retired = []          # job tables an earlier recording may still read: kept alive for good
 
     def add(self, pk, Cout, Cin, taps, transposed=False):
         assert pk.is_cuda and pk.dtype == torch.float32 and pk.is_contiguous() and pk.shape == (Cout, taps * Cin) and (taps * Cin) % 32 == 0
+        if torch.cuda.is_current_stream_capturing():
+            # a new job uploads a table (a synchronous host-to-device copy) and fills planes outside any recording: the episode
+            # loops run three eager steps before they record, so every layer's job exists by then
+            raise RuntimeError("SplitPlan.add() under stream capture: run one eager step first (the planes of every layer are "
+                               "registered by the first forward)")
         n = pk.numel()
         planes = torch.empty((3, Cin, taps * Cout) if transposed else (3, Cout, taps * Cin), device=pk.device, dtype=torch.int16)
         self.jobs.append((pk.data_ptr(), planes.data_ptr(), n, Cout, Cin, taps, 1 if transposed else 0, self.total))
         self.total += n
         self.keep.append((pk, planes))
-        self.table = None
+        if self.table is not None:
+            self.retired.append(self.table)      # a hipGraph recorded before this job existed replays run() with the OLD table: it must
+        self.table = None                        # stay valid (it refreshes the jobs that recording uses; the next run() builds the new one)
         self._launch(len(self.jobs) - 1)
         return planes
 

@@ -105,7 +105,12 @@ class FlatGradBucket:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        # (+ one float per parameter behind the gradients: 1 where this rank holds a gradient -- summed with them, so that ranks
+        # that disagree about WHICH parameters have one are caught instead of silently applying different updates: ADVICE r05)
+        self.flat_all = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=p0.device)
+        self.flat = self.flat_all[:self.numel]
+        self.has = self.flat_all[self.numel:]
+        self.calls = 0
         self.views = []
         off = 0
         for p in self.params:
@@ -127,6 +132,11 @@ class FlatGradBucket:
         if W == 1 and not collectives_forced():
             return W
         live = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        # every rank checks on the same schedule (the first two calls, then every 64th): the collective's size must agree across ranks
+        check = self.calls < 2 or self.calls % 64 == 0
+        self.calls += 1
+        if check:
+            self.has.copy_(torch.tensor([p.grad is not None for p in self.params], dtype=torch.float32))
         if len(live) != len(self.params):
             for v, p in zip(self.views, self.params):
                 if p.grad is None:
@@ -134,12 +144,20 @@ class FlatGradBucket:
         views, grads = [v for v, _ in live], [g for _, g in live]
         if views:
             torch._foreach_copy_(views, grads)                  # fused multi-tensor copies (104 tensors -> a few launches)
-        if self.flat.is_cuda and dist.get_backend() == "gloo":   # CPU-test / one-device hook: stage through the host
-            host = self.flat.cpu()
+        buf = self.flat_all if check else self.flat               # (check steps: the has-gradient floats ride behind the gradients)
+        if buf.is_cuda and dist.get_backend() == "gloo":          # CPU-test / one-device hook: stage through the host
+            host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            self.flat.copy_(host)
+            buf.copy_(host)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)     # "nccl" == RCCL over xGMI
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)            # "nccl" == RCCL over xGMI
+        if check:
+            got = self.has.cpu()
+            bad = [i for i, v in enumerate(got.tolist()) if v not in (0.0, float(W))]
+            if bad:
+                raise RuntimeError("FlatGradBucket: the ranks disagree about which parameters have a gradient (parameter indices %s: "
+                                   "%s of %d ranks hold one) -- a rank-dependent frozen / unused parameter would make the ranks apply "
+                                   "different updates" % (bad[:8], [int(got[i]) for i in bad[:8]], W))
         if divide:
             self.flat.div_(W)
         if views:

@@ -2,7 +2,9 @@
 
 ``Settings`` is a frozen dataclass: one field per knob, with its type, default, environment variable and meaning in ONE table
 (``KNOBS``).  ``current()`` returns the Settings for the present environment -- parsed and validated once per distinct set of
-``MFT_*`` values (tests that change a variable get a fresh object, everything else gets the cached one).  No module of the
+``MFT_*`` values (tests that change a variable get a fresh object, everything else gets the cached one) -- but note
+``IMPORT_TIME``: the knobs listed there are frozen into module constants at first import, the rest are read where they are used.
+A value that does not parse raises a ValueError naming its variable; boolean knobs take 0 / 1 / true / false / yes / no / on / off.  No module of the
 package parses an ``MFT_*`` variable itself any more; process-rank variables set by the launcher (RANK, LOCAL_RANK, WORLD_SIZE,
 MASTER_ADDR, OMP_NUM_THREADS) and the build's HIPCC are not knobs and stay where they are used.
 
@@ -12,9 +14,12 @@ import os
 
 
 def _flag(v):
-    if v not in ("0", "1"):
-        raise ValueError("expected 0 or 1, got %r" % (v,))
-    return v == "1"
+    lv = v.strip().lower()
+    if lv in ("1", "true", "yes", "on"):
+        return True
+    if lv in ("0", "false", "no", "off"):
+        return False
+    raise ValueError("expected 0 / 1 (or true / false), got %r" % (v,))
 
 
 def _opt_int(v):
@@ -61,6 +66,7 @@ KNOBS = (
     ("train_graph", "MFT_TRAIN_GRAPH", _flag, True, "MetaTemplate episode loop: loss + backward replayed from one hipGraph"),
     ("train_x3", "MFT_TRAIN_X3", _flag, True, "meta-training: 3x3 layers with >= 8192 output rows on the bf16x3 kernels, forward and stride-1 data gradient (0: fp32 MFMA everywhere)"),
     ("wgrad_batch", "MFT_WGRAD_BATCH", _flag, True, "meta-training backward: every layer's weight gradient deferred to the end of the pass and run in one multi-problem launch pair per 16 layers (0: one launch pair per layer, as round 5; bit-identical)"),
+    ("pair_f16x2", "MFT_PAIR_F16X2", _flag, False, "GNN pair-MLP layers (Wcompute) as f16x2 products on the fp16 matrix cores (fp32-accurate; 0: fp32 MFMA)"),
     ("train_source", "MFT_TRAIN_SOURCE", str, "pool", "train.main --dataset miniImageNet: 'pool' = resident uint8 class pool, 'synthetic' = host fp32 episodes"),
     # ---- drivers (finetune.main / train.main)
     ("standin_weights", "MFT_STANDIN_WEIGHTS", _flag, False, "allow synthetic stand-in weights when no checkpoint is found (explicit opt-in)"),
@@ -108,6 +114,7 @@ class Settings:
     train_graph: bool = True
     train_x3: bool = True
     wgrad_batch: bool = True
+    pair_f16x2: bool = False
     train_source: str = "pool"
     standin_weights: bool = False
     image_size: int = 84
@@ -155,6 +162,17 @@ def current():
     return _cache[1]
 
 
+# Knobs that modules freeze into module-level constants when they are first imported (a later change of the variable has no effect
+# in that process); every other knob is read live through ``current()`` at the point of use.
+IMPORT_TIME = frozenset((
+    "debug_skip_trunk", "adapt_graph", "adapt_batched_trunk", "fused_dgrad", "fused_last_block", "x3_planes", "x3_fused_stats",
+    "x3_fold_bn", "trunk_f16x2", "train_x3", "fuse_next_c2_only", "fused_pair_mlp", "pair_f16x2", "pair_mlp_gb", "wgrad_batch",
+    "train_graph", "small_groups", "wf_xcd",
+))
+assert IMPORT_TIME <= set(k[0] for k in KNOBS), IMPORT_TIME - set(k[0] for k in KNOBS)
+
+
 def describe():
-    """The knob table as text (README / --help material)."""
-    return "\n".join("%-26s %-22s default %-8r %s" % (var, field, default, doc) for field, var, _, default, doc in KNOBS)
+    """The knob table as text (README / --help material): variable, field, when it is read, default, meaning."""
+    return "\n".join("%-26s %-22s %-7s default %-8r %s" % (var, field, "import" if field in IMPORT_TIME else "live", default, doc)
+                     for field, var, _, default, doc in KNOBS)

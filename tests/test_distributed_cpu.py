@@ -74,6 +74,16 @@ def _worker(rank, world_size, port, out):
     opt.step()
     if rank == 0:
         torch.save({"params": {k: p.detach() for k, p in zip(keys, params)}, "grads": avg_grads}, out)
+    # ranks that disagree about WHICH parameters have a gradient are caught (every rank raises), not silently desynchronised
+    params3 = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    for i, (p3, gi) in enumerate(zip(params3, g)):
+        p3.grad = None if (i == 1 and rank == 1) else gi.clone()
+    try:
+        parallel.FlatGradBucket(params3).allreduce_mean()
+        raised = False
+    except RuntimeError as ex:
+        raised = "disagree" in str(ex)
+    assert raised
     # all ranks must hold identical parameters
     flat = torch.cat([p.detach().flatten() for p in params])
     ref = flat.clone()

@@ -173,6 +173,12 @@ def test_fused_pair_mlp_equals_materialised_wcompute(N, F, monkeypatch):
     assert e_f < 2e-5 and e_f <= 3.0 * e_u + 2e-6, (e_f, e_u)
     np.testing.assert_allclose(a_f.sum(2).cpu().numpy(), 1.0, atol=1e-5)
     assert float(a_f.diagonal(dim1=1, dim2=2).abs().max()) == 0.0    # masked diagonal (gnn.py:105-107)
+    # the same layers as f16x2 products on the fp16 matrix cores (round 6): fp32-accurate -- held to the fp32-MFMA form's own bound
+    monkeypatch.setattr(Fn, "PAIR_F16X2", not Fn.PAIR_F16X2)
+    a_h = Fn.wcompute(G, name, xd, F, B, N, groups, Fn.Arena(DEV)).clone()
+    e_h = np.abs(a_h.cpu().numpy() - ref).max()
+    assert e_h < 2e-5 and e_h <= 3.0 * e_u + 2e-6, (e_h, e_f, e_u)
+    np.testing.assert_allclose(a_h.sum(2).cpu().numpy(), 1.0, atol=1e-5)
 
 
 def test_gnnnet_scores_50shot_fold(golden_dir):
