@@ -341,6 +341,14 @@ long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups);
 int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,
                  float* mean, float* rstd, float* ws,
                  float* running_mean, float* running_var, float momentum, long long* num_batches_tracked, void* stream);
+/* Several independent mft_bn_stats problems (up to 8) in ONE launch pair -- SimpleBlock's BN2 and BNshortcut normalise two tensors
+ * that exist together (backbone.py:256-259).  jobs: HOST array; a job = mft_bn_stats's arguments of the same names; results are
+ * bit-identical to its own launches. */
+typedef struct MftBnStatsJob {
+    const float* x; float* mean; float* rstd; float* ws; float* running_mean; float* running_var; long long* num_batches_tracked;
+    int ldx, C, rows_per_group, n_groups; float eps, momentum;
+} MftBnStatsJob;
+int mft_bn_stats_multi(const MftBnStatsJob* jobs, int n_jobs, void* stream);
 /* Several independent BatchNorm-apply problems (no residual) in ONE launch: the meta-training backward re-creates the twelve pair-MLP
  * activations h_l = leaky_relu(BatchNorm(z_l)) (gnn.py:87-102; the forward keeps only the raw z_l) in front of its weight-gradient
  * launches -- all twelve depend on the forward's tape only.  jobs: HOST array, up to 16 per launch; each job = mft_bn_apply's
@@ -603,6 +611,15 @@ int mft_bn_backward_act(const float* x, int ldx, const float* dy, int lddy, cons
                         const float* mean, const float* rstd, const float* gamma, long long gb_group_stride,
                         float* dgamma, float* dbeta, int act, float slope, float* ws, float* dgamma_sum, float* dbeta_sum,
                         float* dbias_zero, void* stream);
+/* Several independent mft_bn_backward_act problems (up to 8; each with a dx) in ONE launch triple: the backward of SimpleBlock's BN2
+ * and BNshortcut reads the same upstream gradient and ReLU output (backbone.py:256-260).  jobs: HOST array; a job = the same-named
+ * arguments of mft_bn_backward_act (gamma shared by the groups); bit-identical to its own launches. */
+typedef struct MftBnBwdJob {
+    const float* x; const float* dy; const float* y_act; float* dx; const float* mean; const float* rstd; const float* gamma;
+    float* dgamma; float* dbeta; float* ws; float* dgamma_sum; float* dbeta_sum; float* dbias_zero;
+    int ldx, lddy, ldya, lddx, C, rows_per_group, n_groups, act; float slope; int reserved;
+} MftBnBwdJob;
+int mft_bn_backward_act_multi(const MftBnBwdJob* jobs, int n_jobs, void* stream);
 /* dx (+)= dy * act'(y)  (ReLU / leaky-ReLU backward; GNN_nl's F.leaky_relu before the concat, gnn.py:160) */
 int mft_act_backward(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int C, long long rows,
                      int act, float slope, int accumulate, void* stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mft_bn_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P],
     "mft_bn_apply": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _I, _F, _P],
     "mft_bn_apply_multi": [_P, _I, _P],
+    "mft_bn_stats_multi": [_P, _I, _P],
     "mft_bn_relu_maxpool": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_relu_maxpool_gather": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mft_bn_image_moments": [_P, _I, _I, _I, _L, _P, _P, _P],
@@ -131,6 +132,7 @@ SIGNATURES = {
     "mft_var_to_rstd": [_P, _P, _I, _F, _P],
     "mft_bn_backward_ws_floats": [_I, _I, _I],
     "mft_bn_backward_act": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _I, _F, _P, _P, _P, _P, _P],
+    "mft_bn_backward_act_multi": [_P, _I, _P],
     "mft_act_backward": [_P, _I, _P, _I, _P, _I, _I, _L, _I, _F, _I, _P],
     "mft_colsum": [_P, _I, _I, _L, _P, _P, _P],
     "mft_bn_relu_maxpool_arg": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],

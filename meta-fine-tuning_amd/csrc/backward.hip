@@ -25,10 +25,10 @@ struct BnBwdArgs {
 };
 
 // phase 1: per (chunk, 64-channel tile, group) partial sums of dy_eff and dy_eff * xhat
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) {
+__device__ __forceinline__ void bn_bwd_partial_body(const BnBwdArgs& p, const int bx, const int by, const int bz) {
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 64 + cq * 4;
-    const int g = blockIdx.z, chunk = blockIdx.x;
+    const int c = by * 64 + cq * 4;
+    const int g = bz, chunk = bx;
     const long long row0 = (long long)g * p.rows_per_group;
     __shared__ f32x4 red1[16][16];
     __shared__ f32x4 red2[16][16];
@@ -61,17 +61,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(BnBwdArgs p) { bn_bwd_partial_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+
 // phase 2: fixed-order sum of the partials -> dgamma, dbeta and the two group means used by phase 3
 // 256 threads = 16 channels x 16 chunk lanes; each lane sums every 16th partial, then a fixed xor tree over the 16 lanes
 // (a serial loop over up to ~340 partials per channel cost 50-250 us per BatchNorm in the meta-training step)
 // (LPC = 64: one group with >= 128 chunks -- a whole wave per channel, as in bn_stats_finalize)
 template <int LPC>
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdArgs& p, float* sums, const int bx, const int by) {
     const int kl = threadIdx.x % LPC;
-    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
+    const int c = bx * (256 / LPC) + threadIdx.x / LPC;
     // one block row per group -- or, when the sums over the groups are wanted, ONE block row that walks the groups in order
     const bool walk = p.dgamma_sum != nullptr || p.dbeta_sum != nullptr;
-    const int g0 = walk ? 0 : blockIdx.y, g1 = walk ? p.n_groups : g0 + 1;
+    const int g0 = walk ? 0 : by, g1 = walk ? p.n_groups : g0 + 1;
     float t1 = 0.f, t2 = 0.f;
     for (int g = g0; g < g1; ++g) {
         float s1 = 0.f, s2 = 0.f;
@@ -100,12 +102,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float
     if (p.dbias_zero && g0 == 0) p.dbias_zero[c] = 0.f;
 }
 
+template <int LPC>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs p, float* sums) {
+    bn_bwd_finalize_body<LPC>(p, sums, blockIdx.x, blockIdx.y);
+}
+
 // phase 3: dx = gamma * rstd * (dy_eff - mean(dy_eff) - xhat * mean(dy_eff * xhat))
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p, const float* sums, int n_groups) {
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBwdArgs& p, const float* sums, int n_groups, const int block, const int n_blocks) {
     const int cq = p.C >> 2;
     const long long total = (long long)n_groups * p.rows_per_group * cq;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)block * blockDim.x + threadIdx.x; i < total;
+         i += (long long)n_blocks * blockDim.x) {
         const long long row = i / cq;
         const int c = (int)(i - row * cq) * 4;
         const int g = (int)(row / p.rows_per_group);
@@ -127,6 +134,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p, const fl
         }
         *(f32x4*)(p.dx + row * p.lddx + c) = o;
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p, const float* sums, int n_groups) {
+    bn_bwd_apply_body(p, sums, n_groups, blockIdx.x, gridDim.x);
+}
+
+// Several independent BatchNorm backward problems in one launch triple (mft_bn_backward_act_multi): the backward of SimpleBlock's
+// BN2 and BNshortcut reads the same upstream gradient and ReLU output (backbone.py:256-260) -- three launches for both instead of
+// six.  Block -> job by start tables; inside a job the numbering of its own launches: bit-identical results.
+constexpr int BB_MULTI = 8;
+struct BnBwdMultiArgs {
+    BnBwdArgs job[BB_MULTI];
+    float* sums[BB_MULTI];
+    int lpc64[BB_MULTI];
+    int start_p[BB_MULTI + 1], start_f[BB_MULTI + 1], start_a[BB_MULTI + 1];
+    int n;
+};
+static_assert(sizeof(BnBwdMultiArgs) <= 4000, "kernarg segment");
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_multi_kernel(BnBwdMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start_p[j + 1]) ++j;
+    const BnBwdArgs p = a.job[j];
+    const int local = blockIdx.x - a.start_p[j], cy = (p.C + 63) / 64;
+    bn_bwd_partial_body(p, local % p.chunks, (local / p.chunks) % cy, local / (p.chunks * cy));
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_multi_kernel(BnBwdMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start_f[j + 1]) ++j;
+    const BnBwdArgs p = a.job[j];
+    const int local = blockIdx.x - a.start_f[j];
+    if (a.lpc64[j]) {
+        bn_bwd_finalize_body<64>(p, a.sums[j], local, 0);
+    } else {
+        const int fx = (p.C + 15) / 16;
+        bn_bwd_finalize_body<16>(p, a.sums[j], local % fx, local / fx);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnBwdMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start_a[j + 1]) ++j;
+    const BnBwdArgs p = a.job[j];
+    bn_bwd_apply_body(p, a.sums[j], p.n_groups, blockIdx.x - a.start_a[j], a.start_a[j + 1] - a.start_a[j]);
 }
 
 // ---------------------------------------------------------------------------------- elementwise helpers
@@ -456,6 +511,39 @@ extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int
         const long long total = (long long)n_groups * rows_per_group * (C / 4);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bgrid(total, 2048)), dim3(256), 0, s, p, (const float*)sums, n_groups);
     }
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_backward_act_multi(const MftBnBwdJob* jobs, int n_jobs, void* stream) {
+    if (jobs == nullptr || n_jobs < 1 || n_jobs > BB_MULTI) return MFT_EINVAL;
+    BnBwdMultiArgs a = {};
+    int bp = 0, bf = 0, ba = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const MftBnBwdJob& jb = jobs[j];
+        if (jb.C % 4 != 0 || jb.ldx % 4 != 0 || jb.lddy % 4 != 0 || jb.dx == nullptr || jb.lddx % 4 != 0 || (jb.y_act && jb.ldya % 4 != 0) ||
+            jb.rows_per_group < 1 || jb.n_groups < 1 || jb.ws == nullptr)
+            return MFT_EINVAL;
+        BnBwdArgs& p = a.job[j];
+        p.x = jb.x; p.dy = jb.dy; p.y_act = jb.y_act; p.dx = jb.dx;
+        p.ldx = jb.ldx; p.lddy = jb.lddy; p.ldya = jb.ldya; p.lddx = jb.lddx; p.C = jb.C; p.rows_per_group = jb.rows_per_group;
+        p.chunks = bwd_chunks(jb.rows_per_group, jb.n_groups, jb.C);
+        p.rows_per_chunk = (jb.rows_per_group + p.chunks - 1) / p.chunks;
+        p.mean = jb.mean; p.rstd = jb.rstd; p.gamma = jb.gamma; p.gbs = 0;
+        p.dgamma = jb.dgamma; p.dbeta = jb.dbeta; p.ws = jb.ws; p.act = jb.act; p.slope = jb.slope;
+        p.dgamma_sum = jb.dgamma_sum; p.dbeta_sum = jb.dbeta_sum; p.dbias_zero = jb.dbias_zero; p.n_groups = jb.n_groups;
+        const bool walk = jb.dgamma_sum != nullptr || jb.dbeta_sum != nullptr;
+        a.sums[j] = jb.ws + 2LL * jb.n_groups * p.chunks * jb.C;
+        a.lpc64[j] = (jb.n_groups == 1 && p.chunks >= 128) ? 1 : 0;
+        a.start_p[j] = bp; a.start_f[j] = bf; a.start_a[j] = ba;
+        bp += p.chunks * ((jb.C + 63) / 64) * jb.n_groups;
+        bf += a.lpc64[j] ? (jb.C + 3) / 4 : ((jb.C + 15) / 16) * (walk ? 1 : jb.n_groups);
+        ba += bgrid((long long)jb.n_groups * jb.rows_per_group * (jb.C / 4), 2048);
+    }
+    a.start_p[n_jobs] = bp; a.start_f[n_jobs] = bf; a.start_a[n_jobs] = ba; a.n = n_jobs;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_partial_multi_kernel, dim3(bp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(bf), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(ba), dim3(256), 0, s, a);
     return mft_launch_status();
 }
 

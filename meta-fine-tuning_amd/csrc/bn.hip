@@ -17,14 +17,14 @@ namespace {
 // grid (chunks, C/64 tiles... ) : block = 256 threads = 16 channel-quads (64 channels) x 16 row lanes.
 constexpr int ST_ROWS = 16;
 
-__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int ldx, int C,
-                                                        int rows_per_group, int rows_per_chunk, int chunks,
-                                                        float* __restrict__ ws) {
+__device__ __forceinline__ void bn_stats_partial_body(const float* __restrict__ x, int ldx, int C,
+                                                      int rows_per_group, int rows_per_chunk, int chunks,
+                                                      float* __restrict__ ws, const int bx, const int by, const int bz) {
     const int cq = threadIdx.x & 15;          // channel quad within the 64-channel tile
     const int rl = threadIdx.x >> 4;          // row lane 0..15
-    const int c = blockIdx.y * 64 + cq * 4;
-    const int g = blockIdx.z;
-    const int chunk = blockIdx.x;
+    const int c = by * 64 + cq * 4;
+    const int g = bz;
+    const int chunk = bx;
     const long long row0 = (long long)g * rows_per_group;
     __shared__ f32x4 red1[ST_ROWS][16];
     __shared__ f32x4 red2[ST_ROWS][16];
@@ -61,15 +61,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 // 256 threads = (256 / LPC) channels x LPC chunk lanes (fixed xor tree over the lanes: deterministic).  LPC = 16 everywhere except
 // ONE group with >= 128 chunks (a single 105-image meta-training episode: 199-1024 partials per channel, which 16 lanes walk in
 // 13-64 dependent iterations -- 8-23 us per BatchNorm, round 5): there a whole wave sums one channel.
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int ldx, int C,
+                                                        int rows_per_group, int rows_per_chunk, int chunks,
+                                                        float* __restrict__ ws) {
+    bn_stats_partial_body(x, ldx, C, rows_per_group, rows_per_chunk, chunks, ws, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 template <int LPC>
-__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group,
-                                                         int chunks, const float* __restrict__ ws, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                                         float* running_mean, float* running_var, float momentum,
-                                                         long long* num_batches_tracked) {
+__device__ __forceinline__ void bn_stats_finalize_body(const float* __restrict__ x, int ldx, int C, int rows_per_group,
+                                                       int chunks, const float* __restrict__ ws, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                       float* running_mean, float* running_var, float momentum,
+                                                       long long* num_batches_tracked, const int bx, const int by) {
     const int kl = threadIdx.x % LPC;
-    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
-    const int g = blockIdx.y;
+    const int c = bx * (256 / LPC) + threadIdx.x / LPC;
+    const int g = by;
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
         for (int k = kl; k < chunks; k += LPC) {
@@ -96,6 +102,58 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
         if (num_batches_tracked && c == 0 && g == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (one thread of the launch)
+    }
+}
+
+template <int LPC>
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ x, int ldx, int C, int rows_per_group,
+                                                         int chunks, const float* __restrict__ ws, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* running_mean, float* running_var, float momentum,
+                                                         long long* num_batches_tracked) {
+    bn_stats_finalize_body<LPC>(x, ldx, C, rows_per_group, chunks, ws, eps, mean, rstd, running_mean, running_var, momentum,
+                                num_batches_tracked, blockIdx.x, blockIdx.y);
+}
+
+// Several independent statistics problems in one launch pair (mft_bn_stats_multi): SimpleBlock's BN2 and BNshortcut see two
+// tensors that exist at the same time (backbone.py:256-259) -- one partial launch and one finalize launch for both instead of two
+// each (a dependent launch costs >= 4.7 us in the replayed meta-training step whatever it does).  Block b works for job j with
+// start[j] <= b < start[j + 1], numbered inside the job as its own launch would number it: bit-identical results.
+constexpr int BS_MULTI = 8;
+struct StatsJob {
+    const float* x; float* mean; float* rstd; float* ws; float* running_mean; float* running_var; long long* nbt;
+    int ldx, C, rows_per_group, rows_per_chunk, chunks, n_groups, lpc64;
+    float eps, momentum;
+};
+struct StatsMultiArgs {
+    StatsJob job[BS_MULTI];
+    int start_p[BS_MULTI + 1], start_f[BS_MULTI + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void bn_stats_partial_multi(StatsMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start_p[j + 1]) ++j;
+    const StatsJob p = a.job[j];
+    const int local = blockIdx.x - a.start_p[j], cy = (p.C + 63) / 64;
+    bn_stats_partial_body(p.x, p.ldx, p.C, p.rows_per_group, p.rows_per_chunk, p.chunks, p.ws, local % p.chunks, (local / p.chunks) % cy,
+                          local / (p.chunks * cy));
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_multi(StatsMultiArgs a) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < a.n && (int)blockIdx.x >= a.start_f[j + 1]) ++j;
+    const StatsJob p = a.job[j];
+    const int local = blockIdx.x - a.start_f[j];
+    if (p.lpc64) {
+        bn_stats_finalize_body<64>(p.x, p.ldx, p.C, p.rows_per_group, p.chunks, p.ws, p.eps, p.mean, p.rstd, p.running_mean, p.running_var,
+                                   p.momentum, p.nbt, local, 0);
+    } else {
+        const int fx = (p.C + 15) / 16;
+        bn_stats_finalize_body<16>(p.x, p.ldx, p.C, p.rows_per_group, p.chunks, p.ws, p.eps, p.mean, p.rstd, p.running_mean, p.running_var,
+                                   p.momentum, p.nbt, local % fx, local / fx);
     }
 }
 
@@ -534,6 +592,32 @@ extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, 
     else
         hipLaunchKernelGGL(bn_stats_finalize<16>, dim3((C + 15) / 16, n_groups, 1), dim3(256), 0, s, x, ldx, C, rows_per_group, chunks, ws,
                            eps, mean, rstd, running_mean, running_var, momentum, num_batches_tracked);
+    return mft_launch_status();
+}
+
+extern "C" int mft_bn_stats_multi(const MftBnStatsJob* jobs, int n_jobs, void* stream) {
+    if (jobs == nullptr || n_jobs < 1 || n_jobs > BS_MULTI) return MFT_EINVAL;
+    StatsMultiArgs a = {};
+    int bp = 0, bf = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const MftBnStatsJob& jb = jobs[j];
+        if (jb.C % 4 != 0 || jb.ldx % 4 != 0 || jb.rows_per_group <= 0 || jb.n_groups <= 0 || jb.ws == nullptr) return MFT_EINVAL;
+        if (jb.num_batches_tracked && !jb.running_mean) return MFT_EINVAL;
+        StatsJob& p = a.job[j];
+        p.x = jb.x; p.mean = jb.mean; p.rstd = jb.rstd; p.ws = jb.ws; p.running_mean = jb.running_mean; p.running_var = jb.running_var;
+        p.nbt = jb.num_batches_tracked; p.ldx = jb.ldx; p.C = jb.C; p.rows_per_group = jb.rows_per_group; p.n_groups = jb.n_groups;
+        p.eps = jb.eps; p.momentum = jb.momentum;
+        p.chunks = stats_chunks(jb.rows_per_group, jb.n_groups, jb.C);
+        p.rows_per_chunk = (jb.rows_per_group + p.chunks - 1) / p.chunks;
+        p.lpc64 = (jb.n_groups == 1 && p.chunks >= 128) ? 1 : 0;
+        a.start_p[j] = bp; a.start_f[j] = bf;
+        bp += p.chunks * ((jb.C + 63) / 64) * jb.n_groups;
+        bf += p.lpc64 ? (jb.C + 3) / 4 : ((jb.C + 15) / 16) * jb.n_groups;
+    }
+    a.start_p[n_jobs] = bp; a.start_f[n_jobs] = bf; a.n = n_jobs;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_multi, dim3(bp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_stats_finalize_multi, dim3(bf), dim3(256), 0, s, a);
     return mft_launch_status();
 }
 

@@ -150,8 +150,21 @@ def resnet10_forward_taped(W, x, running=None, groups=1):
         g1, be1 = W.bn[p + ".BN1"]
         r1 = ops.bn_apply(c1.view(-1, cout), cout, rows // groups, groups, m1, s1, g1, be1, act=RELU).view(n, OH, OH, cout)
         c2 = conv3x3(p + ".C2", r1, cout, cout, 1, rows)
-        m2, s2 = bn_stats(c2.view(-1, cout), cout, rows, run(p + ".BN2"), groups)
         g2, be2 = W.bn[p + ".BN2"]
+        if cin != cout and WGRAD_BATCH:
+            # BN2 and BNshortcut normalise two tensors that exist together: ONE statistics launch pair for both (mft_bn_stats_multi)
+            sc = ops.conv2d(a, W.conv[p + ".shortcut"], cout, 1, 1, stride, 0)
+            (m2, s2), (ms, ss) = ops.bn_stats_multi([(c2.view(-1, cout), cout, rows // groups, groups) + (run(p + ".BN2") or (None, None, None)),
+                                                     (sc.view(-1, cout), cout, rows // groups, groups) + (run(p + ".BNshortcut") or (None, None, None))])
+            gs, bs = W.bn[p + ".BNshortcut"]
+            out = ops.bn_apply(c2.view(-1, cout), cout, rows // groups, groups, m2, s2, g2, be2, act=RELU, res=sc.view(-1, cout),
+                               res_bn=(ms, ss, gs, bs)).view(n, OH, OH, cout)
+            b.update(sc=sc, ms=ms, ss=ss)
+            b.update(c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, out=out)
+            blocks.append(b)
+            a = out
+            continue
+        m2, s2 = bn_stats(c2.view(-1, cout), cout, rows, run(p + ".BN2"), groups)
         if cin != cout:
             sc = ops.conv2d(a, W.conv[p + ".shortcut"], cout, 1, 1, stride, 0)
             ms, ss = bn_stats(sc.view(-1, cout), cout, rows, run(p + ".BNshortcut"), groups)
@@ -193,7 +206,16 @@ def resnet10_backward(W, t, dfeat, need):
         o2 = out.view(-1, cout)
         d2 = d_out.view(-1, cout)
         g2 = W.bn[p + ".BN2"][0]
-        dc2, dg, db = bn_bwd(b["c2"].view(-1, cout), d2, cout, rows, b["m2"], b["s2"], g2, y_act=o2, act=RELU, groups=groups)
+        dsc = None
+        if cin != cout and WGRAD_BATCH:
+            # the backward of BN2 and of BNshortcut read the same d2 / o2: ONE launch triple for both (mft_bn_backward_act_multi)
+            gs = W.bn[p + ".BNshortcut"][0]
+            (dc2, dg, db), (dsc, dgs, dbs) = ops.bn_backward_multi([
+                (b["c2"].view(-1, cout), d2, o2, cout, rows, groups, b["m2"], b["s2"], g2, RELU),
+                (b["sc"].view(-1, cout), d2, o2, cout, rows, groups, b["ms"], b["ss"], gs, RELU)])
+            grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dgs, dbs
+        else:
+            dc2, dg, db = bn_bwd(b["c2"].view(-1, cout), d2, cout, rows, b["m2"], b["s2"], g2, y_act=o2, act=RELU, groups=groups)
         grads[p + ".BN2.weight"], grads[p + ".BN2.bias"] = dg, db
         dc2 = dc2.view(out.shape)
         grads[p + ".C2.weight"] = wb.add(b["r1"], dc2, cout, 3, 3, 1, 1)
@@ -206,9 +228,10 @@ def resnet10_backward(W, t, dfeat, need):
         grads[p + ".C1.weight"] = wb.add(x_in, dc1, cout, 3, 3, stride, 1)
         dx = dgrad3x3(p + ".C1", dc1, cin, cout, stride, rows, H_in)
         if cin != cout:
-            gs = W.bn[p + ".BNshortcut"][0]
-            dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU, groups=groups)
-            grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dg, db
+            if dsc is None:
+                gs = W.bn[p + ".BNshortcut"][0]
+                dsc, dg, db = bn_bwd(b["sc"].view(-1, cout), d2, cout, rows, b["ms"], b["ss"], gs, y_act=o2, act=RELU, groups=groups)
+                grads[p + ".BNshortcut.weight"], grads[p + ".BNshortcut.bias"] = dg, db
             dsc = dsc.view(out.shape)
             grads[p + ".shortcut.weight"] = wb.add(x_in, dsc, cout, 1, 1, stride, 0)
             dxs = ops.conv2d_dgrad(dsc, W.conv[p + ".shortcut"], cin, 1, 1, 0, stride=stride, in_hw=(H_in, H_in))

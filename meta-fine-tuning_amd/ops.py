@@ -575,6 +575,69 @@ def bn_apply(x2d, C, rows_per_group, n_groups, mean, rstd, gamma, beta, act=ACT_
     return out
 
 
+class _BnStatsJob(ctypes.Structure):
+    """MftBnStatsJob (include/mft_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "mean", "rstd", "ws", "running_mean", "running_var", "nbt")] + \
+               [(n, ctypes.c_int) for n in ("ldx", "C", "rows_per_group", "n_groups")] + [("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
+def bn_stats_multi(jobs, momentum=0.1, eps=BN_EPS):
+    """``jobs``: list of (x2d, C, rows_per_group, n_groups, running_mean | None, running_var | None, num_batches_tracked | None) --
+    bn_stats of each in ONE launch pair (mft_bn_stats_multi, up to 8 jobs); returns [(mean, rstd), ...]."""
+    arr = (_BnStatsJob * len(jobs))()
+    out, keep = [], []
+    for a, (x, C, rpg, ng, rm, rv, nbt) in zip(arr, jobs):
+        _f32c(x)
+        mean = torch.empty((ng, C), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty((max(int(_lib.lib().mft_bn_stats_ws_floats(C, rpg, ng)), 1),), device=x.device, dtype=torch.float32)
+        a.x, a.mean, a.rstd, a.ws = x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr()
+        a.running_mean = None if rm is None else rm.data_ptr()
+        a.running_var = None if rv is None else rv.data_ptr()
+        a.nbt = None if nbt is None else nbt.data_ptr()
+        a.ldx, a.C, a.rows_per_group, a.n_groups, a.eps, a.momentum = x.shape[-1], C, rpg, ng, eps, momentum
+        out.append((mean, rstd))
+        keep.append(ws)
+    _lib.check(_lib.lib().mft_bn_stats_multi(arr, len(jobs), _stream(jobs[0][0].device)), "mft_bn_stats_multi")
+    return out
+
+
+class _BnBwdJob(ctypes.Structure):
+    """MftBnBwdJob (include/mft_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "y_act", "dx", "mean", "rstd", "gamma", "dgamma", "dbeta", "ws", "dgamma_sum",
+                                                "dbeta_sum", "dbias_zero")] + \
+               [(n, ctypes.c_int) for n in ("ldx", "lddy", "ldya", "lddx", "C", "rows_per_group", "n_groups", "act")] + \
+               [("slope", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+def bn_backward_multi(jobs):
+    """``jobs``: list of (x2d, dy2d, y_act | None, C, rows, groups, mean, rstd, gamma, act) -- BatchNorm backward (+ activation
+    derivative) of each in ONE launch triple (mft_bn_backward_act_multi); returns [(dx, dgamma [C], dbeta [C]), ...] with the
+    parameter gradients summed over the groups."""
+    arr = (_BnBwdJob * len(jobs))()
+    out, keep = [], []
+    for a, (x, dy, ya, C, rows, groups, mean, rstd, gamma, act) in zip(arr, jobs):
+        _f32c(x)
+        _f32c(dy)
+        dev = x.device
+        rpg = rows // groups
+        dx = torch.empty_like(x)
+        dg, db = torch.empty((C,), device=dev, dtype=torch.float32), torch.empty((C,), device=dev, dtype=torch.float32)
+        ws = torch.empty((int(_lib.lib().mft_bn_backward_ws_floats(C, rpg, groups)),), device=dev, dtype=torch.float32)
+        a.x, a.dy, a.dx, a.mean, a.rstd, a.gamma, a.ws = (t.data_ptr() for t in (x, dy, dx, mean, rstd, gamma, ws))
+        a.y_act = None if ya is None else ya.data_ptr()
+        one = groups == 1
+        a.dgamma, a.dbeta = (dg.data_ptr(), db.data_ptr()) if one else (None, None)
+        a.dgamma_sum, a.dbeta_sum = (None, None) if one else (dg.data_ptr(), db.data_ptr())
+        a.dbias_zero = None
+        a.ldx, a.lddy, a.ldya, a.lddx = x.shape[-1], dy.shape[-1], 0 if ya is None else ya.shape[-1], dx.shape[-1]
+        a.C, a.rows_per_group, a.n_groups, a.act, a.slope = C, rpg, groups, act, LRELU_SLOPE
+        out.append((dx, dg, db))
+        keep.append(ws)
+    _lib.check(_lib.lib().mft_bn_backward_act_multi(arr, len(jobs), _stream(jobs[0][0].device)), "mft_bn_backward_act_multi")
+    return out
+
+
 class _BnApplyJob(ctypes.Structure):
     """MftBnApplyJob (include/mft_hip.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "y", "mean", "rstd", "gamma", "beta")] + \

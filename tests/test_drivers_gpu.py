@@ -531,6 +531,31 @@ def test_train_main_samples_episodes_from_the_resident_pool(tmp_path, monkeypatc
         assert all(torch.isfinite(p).all() for p in m.parameters())
 
 
+def test_train_main_episodes_per_rank_lockstep(tmp_path, monkeypatch, capsys):
+    """`train.py --episodes_per_rank 2` (round 6, not in the reference): six episodes of the resident pool become three optimizer
+    steps of two episodes in lockstep; the checkpoint is written as usual, the loss lines count steps, parameters stay finite and
+    move, and the run equals the same driver with the hipGraph replay off (eager lockstep steps)."""
+    from meta_fine_tuning_amd import configs, graph_step, train
+    outs = []
+    for graphed in (True, False):
+        monkeypatch.setattr(graph_step, "ENABLED", graphed)
+        monkeypatch.setattr(configs, "save_dir", str(tmp_path / ("g%d" % graphed)))
+        np.random.seed(10)
+        torch.manual_seed(0)
+        m = train.main(["--dataset", "miniImageNet", "--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1",
+                        "--episodes_per_rank", "2"], n_episode=10, size=84, pool_images_per_class=25)
+        d = tmp_path / ("g%d" % graphed) / "checkpoints" / "miniImageNet" / "ResNet10_gnnnet_5way_5shot"
+        assert (d / "0.tar").is_file()
+        out = capsys.readouterr().out
+        assert "Epoch 0 | Batch 0/5 | Loss" in out and "nan" not in out.lower()
+        outs.append(({k: v.clone() for k, v in m.state_dict().items()}, out))
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+    (a, pa), (b, pb) = outs
+    assert pa == pb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_finetune_main_test_dataset_uses_the_resident_sampler(monkeypatch, capsys):
     """`finetune.py --test_dataset EuroSAT` (finetune.py:558-579; BASELINE configs[4] is EuroSAT-shaped): episodes are sampled
     from a EuroSAT-shaped uint8 pool in HBM (10 classes, 64x64) and their 2 + G views are generated on the device by the engine

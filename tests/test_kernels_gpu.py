@@ -1415,3 +1415,29 @@ def test_conv_wgrad_multi_is_bit_identical_to_single_launches():
     x = nhwc(rnd((5, 64, 6, 6), 7)).to(DEV)
     dy = nhwc(rnd((5, 64, 6, 6), 8)).to(DEV)
     assert torch.equal(off.add(x, dy, 64, 3, 3, 1, 1), ops.conv2d_wgrad_oihw(x, dy, 64, 3, 3, 1, 1))
+
+
+@pytest.mark.parametrize("rows,C,groups", [(945, 512, 1), (3780, 256, 1), (12705, 128, 1), (4 * 945, 512, 4), (46305, 64, 1)])
+def test_bn_stats_and_backward_multi_are_bit_identical_to_single_launches(rows, C, groups):
+    """mft_bn_stats_multi / mft_bn_backward_act_multi (SimpleBlock's BN2 + BNshortcut as one launch pair / triple in the meta-training
+    step) against the same problems launched one by one: mean, rstd, running statistics and counter, dx, dgamma, dbeta bit for bit."""
+    from meta_fine_tuning_amd import functional_bwd as FB
+    xa, xb = rnd((rows, C), 601).to(DEV) * 1.5 + 0.3, rnd((rows, C), 602).to(DEV) * 0.7 - 0.2
+    dy, ya = rnd((rows, C), 603).to(DEV), torch.relu(rnd((rows, C), 604)).to(DEV)
+    ga, gb = (rnd((C,), 605).to(DEV) + 1.5), (rnd((C,), 606).to(DEV) + 1.5)
+
+    def running():
+        return torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+    ra, rb, ra2, rb2 = running(), running(), running(), running()
+    (ma, sa), (mb, sb) = ops.bn_stats_multi([(xa, C, rows // groups, groups) + ra, (xb, C, rows // groups, groups) + rb])
+    ma1, sa1 = ops.bn_stats(xa, C, rows // groups, groups, ra2[0], ra2[1], num_batches_tracked=ra2[2])
+    mb1, sb1 = ops.bn_stats(xb, C, rows // groups, groups, rb2[0], rb2[1], num_batches_tracked=rb2[2])
+    for got, ref in ((ma, ma1), (sa, sa1), (mb, mb1), (sb, sb1), (ra[0], ra2[0]), (ra[1], ra2[1]), (rb[0], rb2[0]), (rb[1], rb2[1])):
+        assert torch.equal(got, ref)
+    assert int(ra[2]) == int(rb[2]) == int(ra2[2]) == 1
+    (dxa, dga, dba), (dxb, dgb, dbb) = ops.bn_backward_multi([(xa, dy, ya, C, rows, groups, ma, sa, ga, ops.ACT_RELU),
+                                                              (xb, dy, ya, C, rows, groups, mb, sb, gb, ops.ACT_RELU)])
+    ra_ = FB.bn_bwd(xa, dy, C, rows, ma, sa, ga, y_act=ya, act=ops.ACT_RELU, groups=groups)
+    rb_ = FB.bn_bwd(xb, dy, C, rows, mb, sb, gb, y_act=ya, act=ops.ACT_RELU, groups=groups)
+    for got, ref in zip((dxa, dga, dba, dxb, dgb, dbb), ra_ + rb_):
+        assert torch.equal(got, ref)
