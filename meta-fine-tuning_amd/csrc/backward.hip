@@ -441,13 +441,23 @@ __global__ __launch_bounds__(256) void gather_scores_bwd_kernel(const float* __r
     const long long rows = (long long)n_ep * nq * n_way * (ns + 1);
     const long long total = rows * ldo;
     // dbias[k] (nullable) = column sums of d(out) = of dscores (every other row of d(out) is zero): the gradient of layer_last's
-    // fc.bias (gnn.py:43-56; no BatchNorm behind it), summed in row order by the first n_way threads of block 0 -- the two
-    // column-sum launches the backward otherwise spends on it
-    if (dbias && blockIdx.x == 0 && (int)threadIdx.x < n_way) {
+    // fc.bias (gnn.py:43-56; no BatchNorm behind it) by block 0 -- 16 row lanes x 16 columns, lanes combined in lane order (fixed
+    // summation order) -- instead of the two column-sum launches the backward otherwise spends on it
+    if (dbias && blockIdx.x == 0) {
+        __shared__ float red[16][17];
+        const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
         const long long nr = (long long)n_ep * n_way * nq;
         float acc = 0.f;
-        for (long long r = 0; r < nr; ++r) acc += dscores[r * n_way + threadIdx.x];
-        dbias[threadIdx.x] = acc;
+        if (c < n_way)
+            for (long long r = rl; r < nr; r += 16) acc += dscores[r * n_way + c];
+        red[rl][c] = acc;
+        __syncthreads();
+        if (rl == 0 && c < n_way) {
+            float t = red[0][c];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) t += red[j][c];
+            dbias[c] = t;
+        }
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -622,6 +632,7 @@ extern "C" int mft_build_graph_nodes_backward(const float* dnodes, int ld, float
 
 extern "C" int mft_gather_query_scores_backward(const float* dscores, float* dout, int ldo, int n_episodes, int n_way,
                                                 int n_support, int n_query, float* dbias, void* stream) {
+    if (dbias && n_way > 16) return MFT_EINVAL;
     const long long total = (long long)n_episodes * n_query * n_way * (n_support + 1) * ldo;
     hipLaunchKernelGGL(gather_scores_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dscores, dout, ldo,
                        n_episodes, n_way, n_support, n_query, dbias);
