@@ -799,6 +799,17 @@ def main():
     from meta_fine_tuning_amd import engine as eng
     from meta_fine_tuning_amd import ops, synthetic
 
+    if os.environ.get("MFT_WGRAD_TILE"):
+        from meta_fine_tuning_amd import _lib
+        _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
+    for knob in os.environ.get("MFT_CONV_KNOBS", "").split(","):          # A/B hook: mft_debug_set_conv_tile codes
+        if knob.strip():
+            from meta_fine_tuning_amd import _lib
+            _lib.lib().mft_debug_set_conv_tile(int(knob))
+    for knob in os.environ.get("MFT_X3_KNOBS", "").split(","):            # same for mft_debug_set_x3_tile
+        if knob.strip():
+            from meta_fine_tuning_amd import _lib
+            _lib.lib().mft_debug_set_x3_tile(int(knob))
     if args.workload in ("metatrain", "metafinetune"):
         return bench_metatrain(args, rank, world, dev, dist)
     if args.strong_only:
@@ -811,17 +822,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    if os.environ.get("MFT_WGRAD_TILE"):
-        from meta_fine_tuning_amd import _lib
-        _lib.lib().mft_debug_set_conv_tile(1000 + int(os.environ["MFT_WGRAD_TILE"]))
-    for knob in os.environ.get("MFT_CONV_KNOBS", "").split(","):          # A/B hook: mft_debug_set_conv_tile codes
-        if knob.strip():
-            from meta_fine_tuning_amd import _lib
-            _lib.lib().mft_debug_set_conv_tile(int(knob))
-    for knob in os.environ.get("MFT_X3_KNOBS", "").split(","):            # same for mft_debug_set_x3_tile
-        if knob.strip():
-            from meta_fine_tuning_amd import _lib
-            _lib.lib().mft_debug_set_x3_tile(int(knob))
     E = args.episodes_per_batch
     n_way, n_shot, n_query, size = 5, args.n_shot, 15, args.image_size
     if n_shot != 5 or size != 84:
