@@ -25,6 +25,10 @@ def _empty(shape, dev):
     return torch.empty(shape, device=dev, dtype=torch.float32)
 
 
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class ZeroLease:
     """Scratch buffers with ZERO padding that nobody re-fills: ``take(shape, dev)`` hands out a buffer that was zeroed when it was
     first allocated and whose users only ever write its valid columns (the padding columns feed data-gradient / weight-gradient
@@ -37,13 +41,13 @@ class ZeroLease:
 
     def __init__(self):
         self.held = []
-        self.pinned = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
+        self.pinned = _capturing()
 
     def take(self, shape, dev):
         key = (tuple(shape), dev.index if isinstance(dev, torch.device) else dev)
         lst = ZeroLease._free.get(key)
         t = lst.pop() if lst else torch.zeros(shape, device=dev, dtype=torch.float32)
-        if torch.cuda.is_current_stream_capturing():
+        if _capturing():
             self.pinned = True
         self.held.append((key, t))
         return t

@@ -22,8 +22,14 @@ def bump_versions(tensors):
     """Advance autograd's version counter of every tensor by one WITHOUT a device launch: parameters were (or are about to be)
     written through raw pointers, and the weight-pack caches of autograd_ops key on ``p._version``."""
     tensors = tuple(tensors)
-    if tensors:
-        torch._C._autograd._unsafe_set_version_counter(tensors, tuple(t._version + 1 for t in tensors))
+    if not tensors:
+        return
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        setter(tensors, tuple(t._version + 1 for t in tensors))
+    else:                                    # (a torch without the setter: one fused no-op write bumps the counters, at one launch)
+        with torch.no_grad():
+            torch._foreach_add_(list(tensors), 0)
 
 
 class GraphedLossBackward:

@@ -590,3 +590,38 @@ def test_bench_work_table_matches_the_header():
             want = 2.0 * v["n_img"] * oh * oh * v["Cout"] * v["KH"] * v["KW"] * v["Cin"]
         assert got == want, (name, params, got, want)
     assert {f for f, _ in bench.LAUNCH_WORK.values()} == {"adam", "f32", "x3"}
+
+
+def test_round6_host_pieces():
+    """Host-side pieces of round 6 that need no GPU: LockstepLoader groups k consecutive episodes (a short tail is not drawn), version
+    bumps happen without a launch, ZeroLease hands a buffer out once at a time and takes it back when the tape dies -- still zero in
+    the padding its users never write --, and WgradBatch in its disabled form refuses nothing silently."""
+    import gc
+    from meta_fine_tuning_amd import functional_bwd as FB, graph_step
+    from meta_fine_tuning_amd.methods.meta_template import LockstepLoader
+    eps = [(torch.full((5, 21, 3, 4, 4), float(i)), None) for i in range(7)]
+    ll = LockstepLoader(eps, 3)
+    got = list(ll)
+    assert len(ll) == 2 == len(got) and got[0][0].shape == (3, 5, 21, 3, 4, 4)
+    assert [float(x[j, 0, 0, 0, 0, 0]) for x, _ in got for j in range(3)] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    p = [torch.nn.Parameter(torch.zeros(3)) for _ in range(2)]
+    v0 = [q._version for q in p]
+    graph_step.bump_versions(p)
+    assert [q._version for q in p] == [v + 1 for v in v0] and all(float(q.sum()) == 0.0 for q in p)
+    graph_step.bump_versions([])
+    FB.ZeroLease._free.clear()
+    a = FB.ZeroLease()
+    b1 = a.take((4, 8), torch.device("cpu"))
+    b2 = a.take((4, 8), torch.device("cpu"))
+    assert b1.data_ptr() != b2.data_ptr() and float(b1.abs().sum()) == 0.0
+    b1[:, :5] = 1.0                                  # a user writes its valid columns only
+    ptrs = {b1.data_ptr(), b2.data_ptr()}
+    del a
+    gc.collect()
+    c = FB.ZeroLease()
+    r1, r2 = c.take((4, 8), torch.device("cpu")), c.take((4, 8), torch.device("cpu"))
+    assert {r1.data_ptr(), r2.data_ptr()} == ptrs       # the same two buffers come back: no new allocation, no fill
+    back = r1 if float(r1.abs().sum()) > 0 else r2
+    assert float(back[:, 5:].abs().sum()) == 0.0        # ... with the padding still zero
+    r3 = c.take((4, 8), torch.device("cpu"))
+    assert r3.data_ptr() not in ptrs and float(r3.abs().sum()) == 0.0
