@@ -10,5 +10,5 @@ python3 tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/${TAG}_ke
 python3 tools/rocpd_timeline.py $(find $O/kt -name "*.db" | head -1) 2 > $O/${TAG}_timeline.txt
 find $O/kt -name "*.db" -delete
 head -6 $O/${TAG}_kernel_stats_E128_pipelined.txt | cut -c1-180
-python3 bench.py > $O/${TAG}_bench_E128.json 2> $O/bench.err
+python3 bench.py --no-other-configs > $O/${TAG}_bench_E128.json 2> $O/bench.err
 tail -1 $O/${TAG}_bench_E128.json | cut -c1-200
