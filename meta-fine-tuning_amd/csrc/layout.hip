@@ -155,7 +155,11 @@ __global__ __launch_bounds__(256) void pack_oihw_multi_kernel(const PackJob* __r
         const int k = (int)(l % j.k_pad);
         const long long co = l / j.k_pad;
         float v = 0.f;
-        if (k < j.KHKW * j.Cin) {
+        if (j.KHKW < 0) {
+            // transposed job (a linear / 1x1 layer's data-gradient operand): dst [rows][k_pad] with dst[ci][co] = src[co][ci], zero
+            // beyond the real Cin rows / Cout columns -- the forward GEMM kernel then computes dx = dy @ W (csrc/conv_igemm.hip)
+            if (k < j.Cout && co < j.Cin) v = j.src[(long long)k * j.Cin + co];
+        } else if (k < j.KHKW * j.Cin) {
             const int ci = k % (int)j.Cin, khkw = k / (int)j.Cin;
             v = j.src[(co * j.Cin + ci) * j.KHKW + khkw];
         }

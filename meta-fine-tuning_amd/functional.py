@@ -940,6 +940,11 @@ class GnnHeadWeights:
             n_packed[0] += 1
             if w.data_ptr() == src.data_ptr():
                 self.plan.add(w, pk)
+                # W^T (zero-padded to [Kpad, roundup(Cout, 32)]) beside it: the meta-training backward computes dx = dy @ W with the
+                # forward GEMM kernel on this operand (round 6); refreshed with the forward packs by the one repack launch
+                pk.wT = torch.zeros((pk.shape[1], ops.round_up(w.shape[0], 32)), device=device, dtype=torch.float32)
+                self.plan.add_transposed(w, pk.wT)
+                self.has_wT = True
             return pk
 
         self.fc_w = packed(sd["fc.0.weight"])
@@ -964,9 +969,11 @@ class GnnHeadWeights:
                 g, b = dev(sd["gnn.%s.bn.weight" % name]), dev(sd["gnn.%s.bn.bias" % name])
             self.gc[name] = (packed(w), dev(sd["gnn.%s.fc.bias" % name]), g, b, w.shape[0])
         self._n_packed = n_packed[0]
+        if getattr(self, "has_wT", False):
+            self.plan.run()                                  # (fills the transposed operands once; the forward packs are rewritten with the same values)
 
     def can_repack(self):
-        return len(self.plan.jobs) == self._n_packed
+        return len(self.plan.jobs) == self._n_packed * (2 if getattr(self, "has_wT", False) else 1)
 
     def repack(self):
         """Refresh every packed weight from its (in-place updated) source parameter with one launch."""

@@ -444,7 +444,8 @@ def test_one_launch_repack_after_in_place_update():
     model.load_state_dict(synthetic.gnnnet_state_dict(seed=9))
     W0 = AG.module_weights(model.feature)
     G0 = AG.head_weights(model.gnn, model.fc, 5)
-    assert W0.can_repack() and len(W0.plan.jobs) == 12 and G0.can_repack() and len(G0.plan.jobs) == 19
+    # (the head: 19 forward packs + since round 6 their 19 transposed data-gradient operands, refreshed by the same launch)
+    assert W0.can_repack() and len(W0.plan.jobs) == 12 and G0.can_repack() and len(G0.plan.jobs) == 38
     with torch.no_grad():
         for i, p in enumerate(model.parameters()):
             p.add_(0.01 * torch.randn_like(p))                         # in place: same storage, new version
@@ -466,6 +467,13 @@ def test_one_launch_repack_after_in_place_update():
         assert torch.equal(G1.wc[name][1][0], Gf.wc[name][1][0])
     for name in G1.gc:
         assert torch.equal(G1.gc[name][0], Gf.gc[name][0])
+    # the transposed operands follow the update as well: wT[ci][co] = W[co][ci], zero beyond the real rows / columns
+    for pk, wname in ((G1.fc_w, "fc.0.weight"), (G1.wc["layer_w1"][0][0][0], "gnn.layer_w1.conv2d_1.weight"),
+                      (G1.wc["w_comp_last"][1][0], "gnn.w_comp_last.conv2d_last.weight"), (G1.gc["layer_last"][0], "gnn.layer_last.fc.weight")):
+        w = sd[wname].reshape(sd[wname].shape[0], -1)
+        ref = torch.zeros_like(pk.wT)
+        ref[:w.shape[1], :w.shape[0]] = w.t()
+        assert pk.wT.shape == (pk.shape[1], (w.shape[0] + 31) // 32 * 32) and torch.equal(pk.wT, ref), wname
     # a model moved / re-created gets a new pack
     model2 = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
     assert AG.module_weights(model2.feature) is not W0
