@@ -37,10 +37,13 @@ def main():
         configs.save_dir = tempfile.mkdtemp()
         torch.manual_seed(0)
         steps = int(os.environ.get("MFT_TEST_TRAIN_STEPS", "2"))
-        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"], n_episode=steps * W + (W - 1), size=84)          # n_episode % W != 0: every rank must still run `steps` steps
+        kk = int(os.environ.get("MFT_TEST_EPISODES_PER_RANK", "1"))          # > 1: k episodes per rank and step in lockstep (round 6)
+        extra = ["--episodes_per_rank", str(kk)] if kk > 1 else []
+        m = train.main(["--method", "gnnnet", "--model", "ResNet10", "--stop_epoch", "1", "--save_freq", "1"] + extra,
+                       n_episode=steps * kk * W + (W - 1), size=84)          # n_episode % W != 0: every rank must still run `steps` steps
         out = {k: v.detach().cpu().numpy() for k, v in m.named_parameters() if k in
                ("fc.0.weight", "gnn.layer_last.fc.weight", "feature.trunk.7.C2.weight", "feature.trunk.0.weight")}
-        st = m.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss")
+        st = m.__dict__.get("_mft_graph_steps", {}).get("set_forward_loss_lockstep" if kk > 1 else "set_forward_loss")
         out["graphed"] = np.int32(1 if (st is not None and st.graph is not None) else 0)
         np.savez(a.out + ".%d.npz" % rank, **out)
     elif a.mode == "rccl1":

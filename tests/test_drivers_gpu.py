@@ -318,6 +318,43 @@ def test_two_rank_meta_training_equals_accumulate_emulation(tmp_path):
         assert (d < 2e-5).mean() > 0.995 and d.max() <= 2.1e-3, (k, d.max(), (d < 2e-5).mean())
 
 
+def test_two_rank_lockstep_meta_training_equals_accumulate_emulation(tmp_path):
+    """train.main --episodes_per_rank 2 under torchrun with 2 ranks (round 6): every step each rank runs TWO episodes in lockstep,
+    the flat bucket sums the ranks, 1 / W is applied inside the fused Adam launch -- the step of FOUR episodes.  Both ranks end
+    identical, and equal the single-process emulation that accumulates the four episodes' gradients from common parameters."""
+    _run_ranks("train", str(tmp_path / "l2"), 2, MFT_TEST_EPISODES_PER_RANK="2")
+    p0 = dict(np.load(str(tmp_path / "l2.0.npz")))
+    p1 = dict(np.load(str(tmp_path / "l2.1.npz")))
+    p0.pop("graphed"); p1.pop("graphed")
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k
+    from meta_fine_tuning_amd import optim
+    torch.manual_seed(0)
+    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
+    model.train()
+    opt = optim.Adam(model.parameters())
+    # the ranks' streams: rank r takes episodes r, r + 2, r + 4, ...; its LockstepLoader groups two consecutive ones per step.  The
+    # emulation runs each rank's pair through the SAME lockstep launches (what the lockstep launches compute is pinned against
+    # single-episode runs by tests/test_metatrain_gpu.py::test_lockstep_*; after Adam's first steps -- lr * sign(g) -- a parameter
+    # comparison across DIFFERENT fp32 evaluations of a near-zero gradient would only measure sign flips)
+    for step in range(2):
+        grads = None
+        for r in range(2):
+            xs = torch.stack([synthetic.train_episode(r + 2 * (2 * step + j), 5, 5, 16, 84) for j in range(2)])
+            model.n_query = 16
+            opt.zero_grad()
+            model.set_forward_loss_lockstep(xs).backward()
+            g = [p.grad.clone() for p in model.parameters()]
+            grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+        for p, g in zip(model.parameters(), grads):
+            p.grad = g / 2
+        opt.step()
+    named = dict(model.named_parameters())
+    for k in p0:
+        d = np.abs(named[k].detach().cpu().numpy() - p0[k])
+        assert (d < 2e-5).mean() > 0.995 and d.max() <= 2.1e-3, (k, d.max(), (d < 2e-5).mean())
+
+
 def test_two_rank_meta_training_graphed_equals_eager(tmp_path):
     """Episode-parallel meta-training with the forward + backward replayed from a hipGraph (captured on every rank's 4th step;
     the flat-bucket all-reduce and the fused Adam step stay outside the graph) against the same 2-rank run with eager launches:
