@@ -540,8 +540,20 @@ int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, 
  *     rstd, shift = beta - mean * scale (biased variance over graphs_per_group*N*N positions; mean_out / rstd_out optional).
  *   mft_pair_mlp_score: conv2d_last (C -> 1) on BatchNorm + leaky_relu of the last raw layer -> compact symmetric scores
  *     s_ut [n_groups*graphs_per_group*P].
- *   mft_masked_softmax_ut: A[b,i,:] = softmax_j(s[b,i,j] - 1e8*[i==j]) (gnn.py:105-115) reading s through p(i,j).      */
+ *   mft_masked_softmax_ut: A[b,i,:] = softmax_j(s[b,i,j] - 1e8*[i==j]) (gnn.py:105-115) reading s through p(i,j).
+ *   mft_pair_mlp_layer_rk / mft_pair_mlp_tiles_m_rk / mft_pair_mlp_stats_finalize_rk: the same layer for SMALL problems (the
+ *     meta-training step's single episode, meta_template.py:76-92): 32-row tiles (tiles_m = mft_pair_mlp_tiles_m_rk), the whole
+ *     K (Kpad <= 256) held in registers and split over a workgroup's four waves, no LDS staging -- same arguments and outputs;
+ *     fp32 MFMA only; its finalize merges the (4x as many) tiles as a wave-wide tree, one wave per channel.  Sums in a different (fixed)
+ *     order than mft_pair_mlp_layer / _stats_finalize: equal to rounding, not bit for bit.                                   */
 int mft_pair_mlp_tiles_m(int graphs_per_group, int N);
+int mft_pair_mlp_tiles_m_rk(int graphs_per_group, int N);
+int mft_pair_mlp_layer_rk(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
+                          const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
+                          int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n, void* stream);
+int mft_pair_mlp_stats_finalize_rk(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m, int C,
+                                   const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                   float* mean_out, float* rstd_out, void* stream);
 int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
                        const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
                        int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n, int f16x2, void* stream);

@@ -316,6 +316,166 @@ __global__ __launch_bounds__(256) void pair_mlp_layer_kernel(PairArgs p) {
     }
 }
 
+// "Register-K" form of the layer for SMALL problems (ONE 5-shot episode: 7,440 pair rows -- the meta-training step,
+// meta_template.py:76-92).  At that size the 128 x 96 tile above gives 118 workgroups that each walk 3-8 K-steps of
+// (global load -> LDS -> 48 MFMAs) back to back on a quarter-filled chip: 24.5 us per layer, nearly all of it exposed latency.
+// Here a workgroup owns 32 pair rows x 96 channels over the WHOLE K (<= 256) and its four waves split K in 16-wide units (unit u
+// -> wave u mod 4).  The MFMA sums over k, so WHICH k a lane feeds is free as long as A and B agree: with v_mfma_f32_16x16x4_f32
+// lane (r, q) = (lane & 15, lane >> 4) feeds row r and k = 16 u + 4 q + e of element e of one float4 -- four neighbouring lanes
+// read 64 contiguous bytes of a row (16 cache lines per load instruction; the 32x32x2 form would touch 64).  Every load of the tile
+// is issued at once into registers (one exposed latency, no LDS staging, no barrier in the K loop).  The four partial tiles meet in
+// LDS (added in wave order: fixed summation order) and waves 0-2 each finish 32 columns: bias, raw store, weighted (mean, M2) of the
+// 32-row tile exactly as above, for the same finalize launch (tiles_m = rows / 32).  ~4x the workgroups, each ~1/16 of the work.
+template <int MODE, int NV>
+__global__ __launch_bounds__(256) void pair_mlp_layer_rk_kernel(PairArgs p) {
+    constexpr int BM = 32, BN = PM_BN, RB = BM / 16, CB = BN / 16;
+    __shared__ float s_acc[4][RB * CB][4][64];        // 48 KB
+    __shared__ float s_wrow[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+
+    int lin = blockIdx.x;                              // XCD-aware linear tile order, as above
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rmd = nwg & 7;
+        const int xcd = lin & 7, slot = lin >> 3;
+        lin = xcd * qq + (xcd < rmd ? xcd : rmd) + slot;
+    }
+    const int nt = lin % p.tiles_n;
+    const int mt = (lin / p.tiles_n) % p.tiles_m;
+    const int g = lin / (p.tiles_n * p.tiles_m);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        float wgt = 0.f;
+        if (m < p.rows_per_group) {
+            const int pk = p.ij[m % p.P];
+            wgt = ((pk >> 16) == (pk & 0xffff)) ? 1.f : 2.f;
+        }
+        s_wrow[tid] = wgt;
+    }
+
+    const int units = p.Kpad >> 4;                     // 16-wide K units; this wave takes wave, wave + 4, ...
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[RB][NV], rb[CB][NV];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const float* bp = p.w + (long long)(n0 + c * 16 + r) * p.Kpad + 4 * q;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int u = wave + 4 * v;
+            rb[c][v] = u < units ? *(const f32x4*)(bp + 16 * u) : zero4;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const int m = m0 + b * 16 + r;
+        const bool ok = m < p.rows_per_group;
+        const int mm = ok ? m : 0;
+        if (MODE == 0) {
+            const int gb = mm / p.P, pp = mm - gb * p.P;
+            const int pk = p.ij[pp];
+            const long long node0 = ((long long)g * p.graphs_per_group + gb) * p.N;
+            const float* xi = p.in + (node0 + (pk >> 16)) * p.ld_in + 4 * q;
+            const float* xj = p.in + (node0 + (pk & 0xffff)) * p.ld_in + 4 * q;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int u = wave + 4 * v;
+                f32x4 o = zero4;
+                if (ok && u < units) {
+                    const f32x4 a = *(const f32x4*)(xi + 16 * u), c = *(const f32x4*)(xj + 16 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (16 * u + 4 * q + e < p.K) ? fabsf(a[e] - c[e]) : 0.f;
+                }
+                ra[b][v] = o;
+            }
+        } else {
+            const float* xp = p.in + ((long long)g * p.rows_per_group + mm) * p.ld_in + 4 * q;
+            const float* sc = p.scale_in + (long long)g * p.K + 4 * q;
+            const float* sh = p.shift_in + (long long)g * p.K + 4 * q;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int u = wave + 4 * v;
+                f32x4 o = zero4;
+                if (ok && u < units) {
+                    const f32x4 x = *(const f32x4*)(xp + 16 * u);
+                    const f32x4 a = *(const f32x4*)(sc + 16 * u), c = *(const f32x4*)(sh + 16 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = x[e] * a[e] + c[e];
+                        o[e] = y > 0.f ? y : y * p.slope;
+                    }
+                }
+                ra[b][v] = o;
+            }
+        }
+    }
+
+    f32x4 acc[RB][CB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[b][c] = zero4;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (wave + 4 * v < units) {                    // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < RB; ++b)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c)
+                        acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[b][v][e], rb[c][v][e], acc[b][c], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_acc[wave][b * CB + c][e][lane] = acc[b][c][e];
+    __syncthreads();
+    if (wave >= BN / 32) return;
+
+    // ---- epilogue of columns [32 wave, 32 wave + 32): C/D layout of a 16 x 16 block: col = lane & 15, row = 4 * (lane >> 4) + e
+    float wr[RB][4];
+    float wl = 0.f;
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[b][e] = s_wrow[b * 16 + 4 * q + e]; wl += wr[b][e]; }
+    wl += __shfl_xor(wl, 16, 64);
+    wl += __shfl_xor(wl, 32, 64);                      // weight of the whole 32-row tile
+    const long long out_row0 = (long long)g * p.rows_per_group;
+    const long long trow = (long long)g * p.tiles_m + mt;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = wave * 2 + cc;
+        const int n = n0 + c * 16 + r;
+        const float bias = p.bias[n];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int blk = b * CB + c;
+                const float a = ((s_acc[0][blk][e][lane] + s_acc[1][blk][e][lane]) + s_acc[2][blk][e][lane]) + s_acc[3][blk][e][lane];
+                const int mrow = m0 + b * 16 + 4 * q + e;
+                if (mrow < p.rows_per_group) p.out[(out_row0 + mrow) * p.Cout + n] = a + bias;
+                s1 += wr[b][e] * a;
+                s2 += wr[b][e] * a * a;
+            }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (q == 0) {
+            p.ws_mean[trow * p.Cout + n] = bias + s1 / wl;
+            p.ws_m2[trow * p.Cout + n] = fmaxf(s2 - s1 * (s1 / wl), 0.f);
+        }
+    }
+    if (wave == 0 && nt == 0 && lane == 0) p.ws_n[trow] = wl;
+}
+
 // Chan merge of the m-tiles of one episode -> the next loader's affine: scale = gamma / sqrt(var + eps), shift = beta - mean *
 // scale (biased variance over all graphs*N*N pair positions, gnn.py:65-74 BatchNorm2d in train mode).  One workgroup per
 // (episode, 16 channels): 16 partitions each merge a contiguous range of tiles in tile order, then the 16 partials are merged
@@ -353,6 +513,45 @@ __global__ __launch_bounds__(256) void pair_stats_finalize_kernel(const float* _
                 n = nn;
             }
         }
+        const float rstd = 1.f / sqrtf(m2 / n + eps);
+        const float sc = rstd * gamma[c];
+        scale[(long long)g * C + c] = sc;
+        shift[(long long)g * C + c] = beta[c] - mean * sc;
+        if (mean_out) { mean_out[(long long)g * C + c] = mean; rstd_out[(long long)g * C + c] = rstd; }
+    }
+}
+
+// The same merge for the register-K layers' 32-row tiles (233 per 5-shot episode; the 16-partition walk above takes 10 us there:
+// 15 dependent Chan merges, two divisions each, per lane).  One WAVE per channel: lane l merges tiles l, l + 64, ... in order, then
+// six butterfly levels (lane l absorbs lane l ^ s, s = 1, 2, .. 32; lane 0 ends with the total) -- a fixed tree, 10 merges deep.
+__global__ __launch_bounds__(256) void pair_stats_finalize_tree_kernel(const float* __restrict__ ws_mean, const float* __restrict__ ws_m2,
+                                                                       const float* __restrict__ ws_n, int tiles_m, int C,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = C / 4;
+    const int g = blockIdx.x / cb, c = (blockIdx.x % cb) * 4 + wave;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = lane; t < tiles_m; t += 64) {
+        const long long row = (long long)g * tiles_m + t;
+        const float nb = ws_n[row], mb = ws_mean[row * C + c], qb = ws_m2[row * C + c];
+        const float nn = n + nb, d = mb - mean;
+        mean += d * (nb / nn);
+        m2 += qb + d * d * (n * nb / nn);
+        n = nn;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const float nb = __shfl_xor(n, s, 64), mb = __shfl_xor(mean, s, 64), qb = __shfl_xor(m2, s, 64);
+        if (nb > 0.f) {
+            const float nn = n + nb, d = mb - mean;
+            mean += d * (nb / nn);
+            m2 += qb + d * d * (n * nb / nn);
+            n = nn;
+        }
+    }
+    if (lane == 0) {
         const float rstd = 1.f / sqrtf(m2 / n + eps);
         const float sc = rstd * gamma[c];
         scale[(long long)g * C + c] = sc;
@@ -654,11 +853,61 @@ extern "C" int mft_pair_mlp_layer(const float* in, int ld_in, int mode, const in
     return mft_launch_status();
 }
 
+/* ---- register-K form for small problems (see pair_mlp_layer_rk_kernel): 32-row tiles ---- */
+extern "C" int mft_pair_mlp_tiles_m_rk(int graphs_per_group, int N) {
+    const long long P = (long long)N * (N + 1) / 2;
+    return cdiv((long long)graphs_per_group * P, 32);
+}
+
+template <int MODE>
+static int pair_rk_launch(int nv, unsigned nwg, hipStream_t st, const PairArgs& p) {
+    switch (nv) {
+#define MFT_RK_CASE(V) \
+    case V: hipLaunchKernelGGL((pair_mlp_layer_rk_kernel<MODE, V>), dim3(nwg), dim3(256), 0, st, p); break;
+        MFT_RK_CASE(1) MFT_RK_CASE(2) MFT_RK_CASE(3) MFT_RK_CASE(4)
+#undef MFT_RK_CASE
+    default: return MFT_EINVAL;
+    }
+    return mft_launch_status();
+}
+
+extern "C" int mft_pair_mlp_layer_rk(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,
+                                     const float* w, int K, int Kpad, const float* bias, float* out, int Cout, int n_groups,
+                                     int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n,
+                                     void* stream) {
+    if (Cout % PM_BN != 0 || Kpad % 32 != 0 || Kpad < 32 || Kpad > 256 || K > Kpad || ld_in % 4 != 0 || N < 1 || N > 65535 ||
+        n_groups < 1 || (mode != 0 && mode != 1) || (mode == 1 && (K != Kpad || !scale_in || !shift_in)) || (mode == 0 && ld_in < Kpad))
+        return MFT_EINVAL;
+    PairArgs p;
+    p.in = in; p.ld_in = ld_in; p.ij = ij; p.scale_in = scale_in; p.shift_in = shift_in; p.w = w; p.bias = bias; p.out = out;
+    p.K = K; p.Kpad = Kpad; p.Cout = Cout; p.N = N; p.P = N * (N + 1) / 2; p.graphs_per_group = graphs_per_group;
+    const long long rpg = (long long)graphs_per_group * p.P;
+    if (rpg > 0x7fffffffLL) return MFT_EINVAL;
+    p.rows_per_group = (int)rpg;
+    p.tiles_m = cdiv(rpg, 32);
+    p.tiles_n = Cout / PM_BN;
+    p.slope = slope; p.ws_mean = ws_mean; p.ws_m2 = ws_m2; p.ws_n = ws_n;
+    const long long nwg = (long long)p.tiles_m * p.tiles_n * n_groups;
+    if (nwg > 0x7fffffffLL) return MFT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = (Kpad / 16 + 3) / 4;            // 16-wide K units per wave
+    return mode == 0 ? pair_rk_launch<0>(nv, (unsigned)nwg, st, p) : pair_rk_launch<1>(nv, (unsigned)nwg, st, p);
+}
+
 extern "C" int mft_pair_mlp_stats_finalize(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m,
                                            int C, const float* gamma, const float* beta, float eps, float* scale, float* shift,
                                            float* mean_out, float* rstd_out, void* stream) {
     if (n_groups < 1 || tiles_m < 1 || C < 16 || C % 16 != 0) return MFT_EINVAL;
     hipLaunchKernelGGL(pair_stats_finalize_kernel, dim3(n_groups * (C / 16)), dim3(256), 0, (hipStream_t)stream, ws_mean, ws_m2, ws_n,
+                       tiles_m, C, gamma, beta, eps, scale, shift, mean_out, rstd_out);
+    return mft_launch_status();
+}
+
+extern "C" int mft_pair_mlp_stats_finalize_rk(const float* ws_mean, const float* ws_m2, const float* ws_n, int n_groups, int tiles_m,
+                                              int C, const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                              float* mean_out, float* rstd_out, void* stream) {
+    if (n_groups < 1 || tiles_m < 1 || C < 16 || C % 16 != 0) return MFT_EINVAL;
+    hipLaunchKernelGGL(pair_stats_finalize_tree_kernel, dim3(n_groups * (C / 4)), dim3(256), 0, (hipStream_t)stream, ws_mean, ws_m2, ws_n,
                        tiles_m, C, gamma, beta, eps, scale, shift, mean_out, rstd_out);
     return mft_launch_status();
 }

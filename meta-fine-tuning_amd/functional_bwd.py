@@ -14,6 +14,7 @@ from . import settings
 
 L = ops._lib
 RELU, LRELU, NONE = ops.ACT_RELU, ops.ACT_LRELU, ops.ACT_NONE
+PAIR_RK_ROWS = settings.current().pair_rk_rows    # pair rows up to which Wcompute layers take the register-K form (0: never)
 WGRAD_BATCH = settings.current().wgrad_batch      # deferred multi-problem weight gradients (ops.WgradBatch)
 
 
@@ -334,22 +335,30 @@ def wcompute_taped(G, name, x, F, n_graphs, N, groups=1):
     rows = n_graphs * P
     gpg = n_graphs // groups
     ij = Fn.pair_index_table(N, dev)
-    tiles_m = int(lib.mft_pair_mlp_tiles_m(gpg, N))
+    Kp = ops.round_up(F, 32)
+    # small problems (one or a few 5-shot episodes): 32-row tiles with the whole K in registers (csrc/pair_mlp.hip, register-K
+    # form) instead of 128-row tiles that leave three quarters of the chip idle; fp32 MFMA only
+    rk = rows <= PAIR_RK_ROWS and Kp <= 256 and not Fn.PAIR_F16X2
+    tiles_m = int(lib.mft_pair_mlp_tiles_m_rk(gpg, N) if rk else lib.mft_pair_mlp_tiles_m(gpg, N))
     ws_mean, ws_m2, ws_n = (_empty((groups * tiles_m * 192,), dev), _empty((groups * tiles_m * 192,), dev),
                             _empty((groups * tiles_m,), dev))
-    Kp = ops.round_up(F, 32)
     t = {"name": name, "F": F, "Kp": Kp, "ij": ij, "z": [], "bn": [], "groups": groups}
     h_in, ld_in, K, Kpad = x, x.shape[1], F, Kp
     sc_prev = sh_prev = None
     for li, (w, b, gam, beta, cout) in enumerate(layers):
         z = _empty((rows, cout), dev)
         sc, sh, m, s = (_empty((groups, cout), dev) for _ in range(4))
-        L.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij), ops._p(sc_prev), ops._p(sh_prev), ops._p(w), K,
-                                       Kpad, ops._p(b), ops._p(z), cout, groups, gpg, N, ops.LRELU_SLOPE, ops._p(ws_mean), ops._p(ws_m2),
-                                       ops._p(ws_n), 1 if Fn.PAIR_F16X2 else 0, ops._stream()), "mft_pair_mlp_layer")
-        L.check(lib.mft_pair_mlp_stats_finalize(ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), groups, tiles_m, cout, ops._p(gam), ops._p(beta),
-                                                ops.BN_EPS, ops._p(sc), ops._p(sh), ops._p(m), ops._p(s), ops._stream()),
-                "mft_pair_mlp_stats_finalize")
+        if rk:
+            L.check(lib.mft_pair_mlp_layer_rk(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij), ops._p(sc_prev), ops._p(sh_prev), ops._p(w),
+                                              K, Kpad, ops._p(b), ops._p(z), cout, groups, gpg, N, ops.LRELU_SLOPE, ops._p(ws_mean),
+                                              ops._p(ws_m2), ops._p(ws_n), ops._stream()), "mft_pair_mlp_layer_rk")
+        else:
+            L.check(lib.mft_pair_mlp_layer(ops._p(h_in), ld_in, 0 if li == 0 else 1, ops._p(ij), ops._p(sc_prev), ops._p(sh_prev), ops._p(w),
+                                           K, Kpad, ops._p(b), ops._p(z), cout, groups, gpg, N, ops.LRELU_SLOPE, ops._p(ws_mean),
+                                           ops._p(ws_m2), ops._p(ws_n), 1 if Fn.PAIR_F16X2 else 0, ops._stream()), "mft_pair_mlp_layer")
+        L.check((lib.mft_pair_mlp_stats_finalize_rk if rk else lib.mft_pair_mlp_stats_finalize)(
+            ops._p(ws_mean), ops._p(ws_m2), ops._p(ws_n), groups, tiles_m, cout, ops._p(gam), ops._p(beta), ops.BN_EPS, ops._p(sc),
+            ops._p(sh), ops._p(m), ops._p(s), ops._stream()), "mft_pair_mlp_stats_finalize")
         t["z"].append(z); t["bn"].append((sc, sh, m, s))
         h_in, ld_in, K, Kpad, sc_prev, sh_prev = z, cout, cout, cout, sc, sh
     s_ut = _empty((rows,), dev)

@@ -181,6 +181,47 @@ def test_fused_pair_mlp_equals_materialised_wcompute(N, F, monkeypatch):
     np.testing.assert_allclose(a_h.sum(2).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,F,B,groups", [(30, 133, 32, 2), (30, 181, 16, 1), (30, 229, 16, 1), (7, 133, 6, 2), (26, 133, 9, 3)])
+def test_register_k_pair_layers_match_tile_kernel_and_float64(N, F, B, groups, monkeypatch):
+    """The register-K form of the Wcompute layers (mft_pair_mlp_layer_rk: 32-row tiles, the whole K in registers split over four
+    waves -- what a meta-training step of one or a few episodes launches) against the 128-row tile kernel on the same inputs and
+    against the float64 statement of gnn.py:78-115: same raw layer outputs / BatchNorm tables to rounding (another fixed
+    summation order over k), A within the tile kernel's own error bound; run twice -> bit-identical."""
+    from meta_fine_tuning_amd import functional_bwd as FB
+    sd = synthetic.gnn_head_state_dict(seed=5)
+    G = Fn.GnnHeadWeights(sd, DEV, 5)
+    name = {133: "layer_w0", 181: "layer_w1", 229: "w_comp_last"}[F]
+    rs = np.random.RandomState(N + F)
+    nodes = rs.standard_normal((B, N, F)).astype(np.float32)
+    gpg = B // groups
+    nodes[gpg:] *= 1.7                                                # later episodes: different scale
+    x = torch.zeros(B * N, 256)
+    x[:, :F] = torch.from_numpy(nodes).view(B * N, F)
+    x[:, F:] = 1e30                                                   # columns beyond F must be ignored
+    xd = x.to(DEV)
+    monkeypatch.setattr(FB, "PAIR_RK_ROWS", 1 << 30)
+    a_rk, t_rk = FB.wcompute_taped(G, name, xd, F, B, N, groups)
+    a_rk2, _ = FB.wcompute_taped(G, name, xd, F, B, N, groups)
+    assert torch.equal(a_rk, a_rk2)
+    monkeypatch.setattr(FB, "PAIR_RK_ROWS", 0)
+    a_t, t_t = FB.wcompute_taped(G, name, xd, F, B, N, groups)
+    for z0, z1 in zip(t_rk["z"], t_t["z"]):
+        assert float((z0 - z1).abs().max()) <= 2e-5 * max(1.0, float(z1.abs().max()))
+    for bn0, bn1 in zip(t_rk["bn"], t_t["bn"]):
+        for u, v in zip(bn0, bn1):
+            assert float((u - v).abs().max()) <= 2e-5 * max(1.0, float(v.abs().max()))
+    ref = []
+    for e in range(groups):
+        with torch.no_grad():
+            ref.append(O.wcompute(O.clone_state(sd, torch.float64), "gnn." + name, torch.from_numpy(nodes[gpg * e:gpg * (e + 1)]).double()))
+    ref = torch.cat(ref).numpy()
+    e_rk = np.abs(a_rk.cpu().numpy() - ref).max()
+    e_t = np.abs(a_t.cpu().numpy() - ref).max()
+    assert e_rk < 2e-5 and e_rk <= 3.0 * e_t + 2e-6, (e_rk, e_t)
+    np.testing.assert_allclose(a_rk.sum(2).cpu().numpy(), 1.0, atol=1e-5)
+    assert float(a_rk.diagonal(dim1=1, dim2=2).abs().max()) == 0.0
+
+
 def test_gnnnet_scores_50shot_fold(golden_dir):
     g = _g(golden_dir, "g7_gnnnet50.npz")
     sd = synthetic.gnn_head_state_dict(seed=19)
