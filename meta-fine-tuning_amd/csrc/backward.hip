@@ -37,7 +37,8 @@ __device__ __forceinline__ void bn_bwd_partial_body(const BnBwdArgs& p, const in
         const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
         const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
         const int rbeg = chunk * p.rows_per_chunk, rend = min(rbeg + p.rows_per_chunk, p.rows_per_group);
-        for (int rr = rbeg + rl; rr < rend; rr += 16) {
+#pragma unroll 4
+        for (int rr = rbeg + rl; rr < rend; rr += 16) {               // (the loads of four rows in flight; same order of additions)
             f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
             if (p.y_act) {
                 const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + rr) * p.ldya + c);
@@ -78,6 +79,7 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdArgs& p, float* 
     for (int g = g0; g < g1; ++g) {
         float s1 = 0.f, s2 = 0.f;
         if (c < p.C)
+#pragma unroll 4
             for (int k = kl; k < p.chunks; k += LPC) {
                 const float* o = p.ws + (((long long)g * p.chunks + k) * p.C + c) * 2;
                 s1 += o[0];
@@ -395,12 +397,14 @@ __global__ __launch_bounds__(256) void graph_aggregate_bwd_kernel(const float* _
     const int i = (int)(row % N);
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         float s = dy[row * lddy + f];
-        for (int j = 0; j < N; ++j) s += A[(b * N + j) * N + i] * dy[(b * N + j) * lddy + F + f];
+#pragma unroll 10
+        for (int j = 0; j < N; ++j) s += A[(b * N + j) * N + i] * dy[(b * N + j) * lddy + F + f];      // (ten loads in flight; same order)
         dx[row * lddx + f] = accumulate ? dx[row * lddx + f] + s : s;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int j = wv; j < N; j += 4) {
         float s = 0.f;
+#pragma unroll 4
         for (int f = lane; f < F; f += 64) s += dy[row * lddy + F + f] * x[(b * N + j) * ldx + f];
         s = wave_sum(s);
         if (lane == 0) dA[row * N + j] = s;

@@ -33,7 +33,8 @@ __device__ __forceinline__ void bn_stats_partial_body(const float* __restrict__ 
         const f32x4 sh = *(const f32x4*)(x + row0 * ldx + c);
         const int rbeg = chunk * rows_per_chunk;
         const int rend = min(rbeg + rows_per_chunk, rows_per_group);
-        for (int rr = rbeg + rl; rr < rend; rr += ST_ROWS) {
+#pragma unroll 4
+        for (int rr = rbeg + rl; rr < rend; rr += ST_ROWS) {         // (four loads in flight; same order of additions)
             f32x4 v = *(const f32x4*)(x + (row0 + rr) * ldx + c);
             v -= sh;
             s1 += v;
@@ -78,6 +79,7 @@ __device__ __forceinline__ void bn_stats_finalize_body(const float* __restrict__
     const int g = by;
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
+#pragma unroll 4
         for (int k = kl; k < chunks; k += LPC) {
             const float* o = ws + (((long long)g * chunks + k) * C + c) * 2;
             s1 += o[0];

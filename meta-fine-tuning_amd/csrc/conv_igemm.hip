@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void reduce_ksplit_kernel(const float* __restr
         const long long m = i / cq;
         const int c = (int)(i - m * cq) * 4;
         f32x4 s = *(const f32x4*)(ws + m * C + c);
+#pragma unroll 4
         for (int z = 1; z < splits; ++z) s += *(const f32x4*)(ws + z * slice + m * C + c);
         if (bias) s += *(const f32x4*)(bias + c);
         *(f32x4*)(out + m * ldo + c) = s;
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
         const long long i = i0 + q;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (i < nq)
+#pragma unroll 4
             for (int c = l; c < chunks; c += 8) s += *(const f32x4*)(ws + ((long long)g * chunks + c) * dwgs + i * 4);
         red[l][q] = s;
         __syncthreads();
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceMultiArg
         const long long i = i0 + q;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (i < nq)
+#pragma unroll 4
             for (int c = l; c < chunks; c += 8) s += *(const f32x4*)(ws + (long long)c * dwgs + i * 4);
         red[l][q] = s;
         __syncthreads();

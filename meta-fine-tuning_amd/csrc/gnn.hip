@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void graph_aggregate_kernel(const float* __res
         else if (c < 2 * F) {
             const int f = c - F;
             float acc = 0.f;
-            for (int j = 0; j < N; ++j) acc += Ar[j] * xb[(long long)j * ldx + f];
+#pragma unroll 10
+            for (int j = 0; j < N; ++j) acc += Ar[j] * xb[(long long)j * ldx + f];      // (unrolled: ten loads in flight, same order of additions)
             o = acc;
         }
         yr[c] = o;

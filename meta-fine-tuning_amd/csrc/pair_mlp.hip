@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256) void softmax_ut_backward_kernel(const float* _
             rdi = 0.f; rdj = 0.f;
             const float* Ai = A + base + (long long)i * N; const float* dAi = dA + base + (long long)i * N;
             const float* Aj = A + base + (long long)j * N; const float* dAj = dA + base + (long long)j * N;
+#pragma unroll 10
             for (int k = 0; k < N; ++k) { rdi += Ai[k] * dAi[k]; rdj += Aj[k] * dAj[k]; }
         } else {
             rdi = rd[rb + i]; rdj = rd[rb + j];
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __rest
         const f32x4 mu = *(const f32x4*)(mean + go + c4), rs = *(const f32x4*)(rstd + go + c4);
         const long long r0 = (long long)blockIdx.x * rows_per_block;
         const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+#pragma unroll 4
         for (long long r = r0 + rl; r < r1; r += rp) {
             const f32x4 gv = *(const f32x4*)(g + (gro + r) * ldg + c4), zv = *(const f32x4*)(z + (gro + r) * C + c4);
 #pragma unroll
@@ -799,14 +801,15 @@ __global__ __launch_bounds__(256) void pair_dx_gather_kernel(const float* __rest
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         const float xi = x[node * ldx + f];
         float acc = 0.f;
-        for (int j = 0; j < N; ++j) {
-            if (j == i) continue;
+#pragma unroll 6
+        for (int j = 0; j < N; ++j) {                  // branch-free body: the loads of six j are in flight together
             const int a = i < j ? i : j, c = i < j ? j : i;
             const long long r = (long long)b * P + (a * N - (a * (a - 1)) / 2 + (c - a)) - row0;
-            if (r < 0 || r >= nrows) continue;
+            const bool ok = j != i && r >= 0 && r < nrows;
             const float df = xi - x[((long long)b * N + j) * ldx + f];
             const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            acc += sg * dd[r * lddd + f];
+            const float d = dd[(ok ? r : 0) * lddd + f];
+            if (ok) acc += sg * d;
         }
         dX[node * lddx + f] += acc;
     }
