@@ -907,6 +907,57 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceMultiArg
     const int lb = blockIdx.x - a.start[j], nb = a.start[j + 1] - a.start[j];
     const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
     const long long nq = n >> 2;
+    if (chunks <= 8 && taps == 9 && cin_out == Cin && (Cin & 3) == 0 && Kpad == 9 * Cin) {
+        // Few chunks, 3x3 layer (the deep trunk layers: 2-6 chunks, 88 % of the trunk's weights).  One thread per (output channel,
+        // four input channels): the nine taps of its four channels are 36 CONSECUTIVE floats of torch's [Cout][Cin][3][3] -- nine
+        // 16-byte stores per thread, whole cache lines per wave (the element-wise form below writes every float on its own, 36
+        // bytes from its neighbour's).  Chunks added in order: the sum the lane form gives for <= 8 chunks.
+        const int cq = Cin >> 2;
+        const long long groups4 = (long long)cout_out * cq;
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < groups4; i += (long long)nb * 256) {
+            const int co = (int)(i / cq), c4 = (int)(i - (long long)co * cq) * 4;
+            const float* src = ws + (long long)co * Kpad + c4;
+            f32x4 t[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) t[tap] = *(const f32x4*)(src + tap * Cin);
+            for (int c = 1; c < chunks; ++c) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) t[tap] += *(const f32x4*)(src + (long long)c * dwgs + tap * Cin);
+            }
+            float o[36];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) o[e * 9 + tap] = t[tap][e];
+            float* dst = dw + ((long long)co * Cin + c4) * 9;
+#pragma unroll
+            for (int v = 0; v < 9; ++v) {
+                const f32x4 w4 = {o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
+                *(f32x4*)(dst + 4 * v) = w4;
+            }
+        }
+        return;
+    }
+    if (chunks <= 8) {
+        // Few chunks, any other shape: with eight lanes per element group most lanes would hold no chunk at all.  One thread per
+        // group of four elements, chunks added in order -- the same sum as the lane form produces for <= 8 chunks (lane l holds
+        // chunk l alone; the lanes are combined in lane order).
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < nq; i += (long long)nb * 256) {
+            f32x4 t = *(const f32x4*)(ws + i * 4);
+            for (int c = 1; c < chunks; ++c) t += *(const f32x4*)(ws + (long long)c * dwgs + i * 4);
+            const long long e0 = i * 4;
+            const int co = (int)(e0 / Kpad), k0 = (int)(e0 - (long long)co * Kpad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                if (k < taps * Cin && co < cout_out) {
+                    const int tap = k / Cin, ci = k - tap * Cin;
+                    if (ci < cin_out) dw[((long long)co * cin_out + ci) * taps + tap] = t[e];
+                }
+            }
+        }
+        return;
+    }
     for (long long i0 = (long long)lb * 32; i0 < nq; i0 += (long long)nb * 32) {
         const long long i = i0 + q;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};

@@ -777,6 +777,8 @@ def test_adam_slab_placement_changes_no_result(monkeypatch):
             assert rep is None
         else:
             assert rep["candidates"] >= 5 and len(set(rep["chosen"])) == 4
-            assert rep["chosen_gbs"] >= 0.98 * rep["first_three_allocations_gbs"] and rep["worst_gbs"] <= rep["chosen_gbs"] <= rep["best_gbs"]
+            # (a triple confirmed from an earlier process's hint is re-measured: its fresh rate may sit a little above the recorded best)
+            assert rep["chosen_gbs"] >= 0.98 * rep["first_three_allocations_gbs"]
+            assert 0.97 * rep["worst_gbs"] <= rep["chosen_gbs"] <= 1.03 * rep["best_gbs"], rep
         e.close()
     assert torch.equal(outs["12"], outs["0"])
