@@ -143,27 +143,90 @@ extern "C" int mft_pack_oihw(const float* w_oihw, float* w_pk, int Cout, int Cin
 // element is <= e.
 struct PackJob { const float* src; float* dst; long long Cout, Cin, KHKW, k_pad, start; };
 
+__device__ __forceinline__ bool pack_job_is_3x3_quads(const PackJob& j) {
+    return j.KHKW == 9 && (j.Cin & 3) == 0 && j.k_pad == 9 * j.Cin && ((unsigned long long)j.src & 15) == 0 && ((unsigned long long)j.dst & 15) == 0;
+}
+
+__device__ __forceinline__ void pack_oihw_element(const PackJob& j, const long long l) {
+    const int k = (int)(l % j.k_pad);
+    const long long co = l / j.k_pad;
+    float v = 0.f;
+    if (j.KHKW < 0) {
+        // transposed job (a linear / 1x1 layer's data-gradient operand): dst [rows][k_pad] with dst[ci][co] = src[co][ci], zero
+        // beyond the real Cin rows / Cout columns -- the forward GEMM kernel then computes dx = dy @ W (csrc/conv_igemm.hip)
+        if (k < j.Cout && co < j.Cin) v = j.src[(long long)k * j.Cin + co];
+    } else if (k < j.KHKW * j.Cin) {
+        const int ci = k % (int)j.Cin, khkw = k / (int)j.Cin;
+        v = j.src[(co * j.Cin + ci) * j.KHKW + khkw];
+    }
+    j.dst[l] = v;
+}
+
+// Work is dealt in UNITS: one element of a job's packed output -- or, for a 3x3 layer whose Cin is a multiple of 4 (no padding
+// columns: 98 % of ResNet10's weights), one (output channel, four input channels) group = 36 consecutive source floats read as
+// nine 16-byte loads and written as nine 16-byte stores, one per tap (the element form gathers every float on its own, 36 bytes
+// from its neighbour's).  The unit prefix of the jobs is formed by every workgroup in LDS (<= 64 jobs; more: elements only).
 __global__ __launch_bounds__(256) void pack_oihw_multi_kernel(const PackJob* __restrict__ jobs, int n_jobs, long long total) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    __shared__ long long ustart[65];
+    if (n_jobs > 64) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            int lo = 0, hi = n_jobs - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+            }
+            const PackJob j = jobs[lo];
+            pack_oihw_element(j, i - j.start);
+        }
+        return;
+    }
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        long long u = 0;
+        if (t < n_jobs) {
+            const PackJob j = jobs[t];
+            const long long elems = (t + 1 < n_jobs ? jobs[t + 1].start : total) - j.start;
+            const bool fast = pack_job_is_3x3_quads(j);
+            u = fast ? j.Cout * (j.Cin >> 2) : elems;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {          // inclusive scan over the wave
+            const long long o = __shfl_up(u, off, 64);
+            if (t >= off) u += o;
+        }
+        ustart[t + 1] = u;
+        if (t == 0) ustart[0] = 0;
+    }
+    __syncthreads();
+    const long long units = ustart[n_jobs];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
         int lo = 0, hi = n_jobs - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+            if (ustart[mid] <= i) lo = mid; else hi = mid - 1;
         }
         const PackJob j = jobs[lo];
-        const long long l = i - j.start;
-        const int k = (int)(l % j.k_pad);
-        const long long co = l / j.k_pad;
-        float v = 0.f;
-        if (j.KHKW < 0) {
-            // transposed job (a linear / 1x1 layer's data-gradient operand): dst [rows][k_pad] with dst[ci][co] = src[co][ci], zero
-            // beyond the real Cin rows / Cout columns -- the forward GEMM kernel then computes dx = dy @ W (csrc/conv_igemm.hip)
-            if (k < j.Cout && co < j.Cin) v = j.src[(long long)k * j.Cin + co];
-        } else if (k < j.KHKW * j.Cin) {
-            const int ci = k % (int)j.Cin, khkw = k / (int)j.Cin;
-            v = j.src[(co * j.Cin + ci) * j.KHKW + khkw];
+        const long long l = i - ustart[lo];
+        if (pack_job_is_3x3_quads(j)) {
+            const int cq = (int)(j.Cin >> 2);
+            const long long co = l / cq;
+            const int c4 = (int)(l - co * cq) * 4;
+            const float* src = j.src + (co * j.Cin + c4) * 9;
+            float v[36];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const f32x4 x = *(const f32x4*)(src + 4 * q);
+                v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+            }
+            float* dst = j.dst + co * j.k_pad + c4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const f32x4 o = {v[tap], v[9 + tap], v[18 + tap], v[27 + tap]};
+                *(f32x4*)(dst + tap * j.Cin) = o;
+            }
+        } else {
+            pack_oihw_element(j, l);
         }
-        j.dst[l] = v;
     }
 }
 
