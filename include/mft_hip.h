@@ -546,6 +546,12 @@ int mft_masked_softmax(const float* s, int lds_, float* A, int n_graphs, int N, 
  *     K (Kpad <= 256) held in registers and split over a workgroup's four waves, no LDS staging -- same arguments and outputs;
  *     fp32 MFMA only; its finalize merges the (4x as many) tiles as a wave-wide tree, one wave per channel.  Sums in a different (fixed)
  *     order than mft_pair_mlp_layer / _stats_finalize: equal to rounding, not bit for bit.                                   */
+/* Skinny GEMM of the head's linear layers in a meta-training step (gnnnet.py:44 fc; gnn.py:134-166 Gconv.fc; meta_template.py:76-92):
+ * out[m][n] = sum_k a[m][k] * w[n][k] + bias[n] for m < M, n < N.  Register-K form: 16-row tiles, the whole K (<= 512, K % 16 == 0)
+ * in registers over four waves, no LDS staging (csrc/gnn.hip).  w: packed [w_rows >= N][K]; lda % 4 == 0, lda >= K; columns
+ * N..ldo-1 of out are left alone; bias nullable.  Same result as mft_conv2d_nhwc's 1x1 form to rounding (another fixed order over k). */
+int mft_gemm_rk(const float* a, int lda, const float* w, int w_rows, int K, const float* bias, float* out, int ldo, int M, int N,
+                void* stream);
 int mft_pair_mlp_tiles_m(int graphs_per_group, int N);
 int mft_pair_mlp_tiles_m_rk(int graphs_per_group, int N);
 int mft_pair_mlp_layer_rk(const float* in, int ld_in, int mode, const int* ij, const float* scale_in, const float* shift_in,

@@ -192,6 +192,86 @@ inline int ggrid(long long total) {
     return (int)b;
 }
 
+// Skinny GEMM of the GNN head's linear layers in a meta-training step (gnnnet.py:44 fc 512 -> 128 on 105 feature rows; gnn.py:134-166
+// Gconv 2F -> 48 / n_way on 480 node rows): out[m][n] = sum_k a[m][k] w[n][k] + bias[n].  The tile kernel of csrc/conv_igemm.hip
+// runs these on 4-8 workgroups that walk 9-16 K-steps back to back: 16-21 us of exposed latency each.  Register-K form (as
+// pair_mlp_layer_rk_kernel, csrc/pair_mlp.hip): a workgroup owns 16 rows x 16 CB columns over the whole K (<= 512); its four waves
+// take the 16-wide K units u = wave, wave + 4, ...; lane (r, q) feeds row r and k = 16 u + 4 q + e of v_mfma_f32_16x16x4_f32 -- every
+// load of the tile is issued at once, no LDS staging; the four partial tiles are added in wave order in LDS and wave c finishes
+// column block c.
+template <int NV, int CB>
+__global__ __launch_bounds__(256) void gemm_rk_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w, int w_rows,
+                                                      int K, const float* __restrict__ bias, float* __restrict__ out, int ldo, int M,
+                                                      int N, int tiles_n) {
+    __shared__ float s_acc[4][CB][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nt = blockIdx.x % tiles_n, mt = blockIdx.x / tiles_n;
+    const int m0 = mt * 16, n0 = nt * 16 * CB;
+    const int units = K >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[NV], rb[CB][NV];
+    {
+        const int m = m0 + r;
+        const float* ap = a + (long long)(m < M ? m : 0) * lda + 4 * q;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int u = wave + 4 * v;
+            ra[v] = (m < M && u < units) ? *(const f32x4*)(ap + 16 * u) : zero4;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int n = n0 + c * 16 + r;
+        const float* bp = w + (long long)(n < w_rows ? n : 0) * K + 4 * q;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int u = wave + 4 * v;
+            rb[c][v] = (n < w_rows && u < units) ? *(const f32x4*)(bp + 16 * u) : zero4;
+        }
+    }
+    f32x4 acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = zero4;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (wave + 4 * v < units) {                    // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[v][e], rb[c][v][e], acc[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_acc[wave][c][e][lane] = acc[c][e];
+    __syncthreads();
+    if (wave >= CB) return;
+    // column block `wave`: C/D layout of a 16 x 16 block: col = lane & 15, row = 4 * (lane >> 4) + e
+    const int n = n0 + wave * 16 + r;
+    const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = ((s_acc[0][wave][e][lane] + s_acc[1][wave][e][lane]) + s_acc[2][wave][e][lane]) + s_acc[3][wave][e][lane];
+        const int m = m0 + 4 * q + e;
+        if (m < M && n < N) out[(long long)m * ldo + n] = t + bv;
+    }
+}
+
+template <int CB>
+int gemm_rk_launch(int nv, unsigned nwg, hipStream_t st, const float* a, int lda, const float* w, int w_rows, int K, const float* bias,
+                   float* out, int ldo, int M, int N, int tiles_n) {
+    switch (nv) {
+#define MFT_GRK_CASE(V) \
+    case V: hipLaunchKernelGGL((gemm_rk_kernel<V, CB>), dim3(nwg), dim3(256), 0, st, a, lda, w, w_rows, K, bias, out, ldo, M, N, tiles_n); break;
+        MFT_GRK_CASE(1) MFT_GRK_CASE(2) MFT_GRK_CASE(3) MFT_GRK_CASE(4) MFT_GRK_CASE(5) MFT_GRK_CASE(6) MFT_GRK_CASE(7) MFT_GRK_CASE(8)
+#undef MFT_GRK_CASE
+    default: return MFT_EINVAL;
+    }
+    return mft_launch_status();
+}
+
 }  // namespace
 
 extern "C" int mft_pair_absdiff(const float* x, int ldx, float* d, int ldd, int n_graphs, int N, int F, void* stream) {
@@ -207,6 +287,27 @@ extern "C" int mft_masked_softmax(const float* s, int lds_, float* A, int n_grap
     hipLaunchKernelGGL(masked_softmax_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lds_,
                        A, n_graphs, N);
     return mft_launch_status();
+}
+
+/* out[m][n] = sum_k a[m][k] * w[n][k] + bias[n]  (m < M, n < N) -- the skinny register-K form for the head's linear layers in a
+ * meta-training step (see gemm_rk_kernel).  w: packed [w_rows >= N][K] (rows beyond N are read as zero padding when present), K % 16
+ * == 0, K <= 512, lda % 4 == 0, lda >= K.  Columns N..ldo-1 of `out` are not written. */
+extern "C" int mft_gemm_rk(const float* a, int lda, const float* w, int w_rows, int K, const float* bias, float* out, int ldo, int M,
+                           int N, void* stream) {
+    if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || K > 512 || lda % 4 != 0 || lda < K || w_rows < N || ldo < N) return MFT_EINVAL;
+    const int cbs = (N + 15) / 16;
+    const int CB = cbs >= 4 ? 4 : cbs;
+    const int tiles_n = (N + 16 * CB - 1) / (16 * CB);
+    const long long nwg = (long long)((M + 15) / 16) * tiles_n;
+    if (nwg > 0x7fffffffLL) return MFT_EINVAL;
+    const int nv = (K / 16 + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+    switch (CB) {
+    case 1: return gemm_rk_launch<1>(nv, (unsigned)nwg, st, a, lda, w, w_rows, K, bias, out, ldo, M, N, tiles_n);
+    case 2: return gemm_rk_launch<2>(nv, (unsigned)nwg, st, a, lda, w, w_rows, K, bias, out, ldo, M, N, tiles_n);
+    case 3: return gemm_rk_launch<3>(nv, (unsigned)nwg, st, a, lda, w, w_rows, K, bias, out, ldo, M, N, tiles_n);
+    default: return gemm_rk_launch<4>(nv, (unsigned)nwg, st, a, lda, w, w_rows, K, bias, out, ldo, M, N, tiles_n);
+    }
 }
 
 extern "C" int mft_graph_aggregate(const float* A, const float* x, int ldx, float* y, int ldy, int n_graphs, int N,

@@ -15,6 +15,7 @@ from . import settings
 L = ops._lib
 RELU, LRELU, NONE = ops.ACT_RELU, ops.ACT_LRELU, ops.ACT_NONE
 PAIR_RK_ROWS = settings.current().pair_rk_rows    # pair rows up to which Wcompute layers take the register-K form (0: never)
+GEMM_RK_ROWS = settings.current().gemm_rk_rows    # linear layers of at most this many rows take the skinny register-K GEMM (0: never)
 WGRAD_BATCH = settings.current().wgrad_batch      # deferred multi-problem weight gradients (ops.WgradBatch)
 
 
@@ -282,8 +283,16 @@ def _linear_fwd(h, K, w, b, cout, lease=None):
         o = _empty((rows, ld), h.device)
     else:
         o = lease.take((rows, ld), h.device) if lease is not None else _zeros((rows, ld), h.device)
-    ops.gemm(h, K, w, cout, bias=b, out=o)
+    _gemm_fwd(h, K, w, cout, b, o)
     return o
+
+
+def _gemm_fwd(h, K, w, cout, b, out=None):
+    """Forward GEMM of a head linear layer: the skinny register-K kernel for the few hundred rows of a meta-training step (one or a
+    few episodes), the tile kernel otherwise."""
+    if 0 < h.shape[0] <= GEMM_RK_ROWS and w.dim() == 2 and K <= 512 and w.shape[1] == K:
+        return ops.gemm_rk(h, K, w, cout, bias=b, out=out)
+    return ops.gemm(h, K, w, cout, bias=b, out=out)
 
 
 def _linear_bwd(h, K, w, d_o, cout, need_dx=True, k_valid=0, db=None, wb=None):
@@ -512,7 +521,7 @@ def head_forward_taped(G, feats, n_way, n_support, n_query, fold=False, episodes
     assert rows % k == 0
     lease = ZeroLease()
     t = {"feats": feats, "n_way": n_way, "ns": n_support, "nq": n_query, "fold": fold, "lease": lease, "episodes": k}
-    z_raw = ops.gemm(feats, 512, G.fc_w, 128, bias=G.fc_b)
+    z_raw = _gemm_fwd(feats, 512, G.fc_w, 128, G.fc_b)
     mz, sz = ops.bn_stats(z_raw, 128, rows // k, k)
     z = ops.bn_apply(z_raw, 128, rows // k, k, mz, sz, G.fc_g, G.fc_beta, act=NONE, out=_empty(z_raw.shape, dev))
     t.update(z_raw=z_raw, mz=mz, sz=sz)

@@ -361,6 +361,22 @@ def gemm(a, K, w_pk, N, bias=None, out=None, ldo=None, rows_per_group=0):
     return out
 
 
+def gemm_rk(a, K, w_pk, N, bias=None, out=None, ldo=None):
+    """``gemm`` for the skinny linear layers of a meta-training step (a few hundred rows, K <= 512): the register-K kernel
+    (mft_gemm_rk, csrc/gnn.hip) -- 16-row tiles, no LDS staging.  Same contract as ``gemm`` for a 2-D pack; columns N.. of ``out``
+    are left alone."""
+    _f32c(a)
+    M, lda = a.shape
+    assert w_pk.dim() == 2 and w_pk.shape[1] == K and w_pk.shape[0] >= N and K % 16 == 0 and K <= 512, (tuple(w_pk.shape), K, N)
+    if out is None:
+        ldo = N if ldo is None else ldo
+        out = torch.empty((M, ldo), device=a.device, dtype=torch.float32)
+    else:
+        ldo = out.shape[1]
+    _lib.check(_lib.lib().mft_gemm_rk(_p(a), lda, _p(w_pk), w_pk.shape[0], K, _p(bias), _p(out), ldo, M, N, _stream()), "mft_gemm_rk")
+    return out
+
+
 def conv2d_dgrad(dy, w_pk, Cin, KH, KW, pad, imgs_per_group=0, out=None, stride=1, in_hw=None):
     """dy [n,OH,OW,Cout], forward weight pack [Cout,KH*KW*Cin] or [groups,...] -> dx [n,H,W,Cin].
     ``in_hw`` = (H, W) of the forward input (needed when stride > 1; defaults to dy's size for stride 1)."""

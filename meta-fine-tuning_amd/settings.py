@@ -67,6 +67,7 @@ KNOBS = (
     ("train_x3", "MFT_TRAIN_X3", _flag, True, "meta-training: 3x3 layers with >= 8192 output rows on the bf16x3 kernels, forward and stride-1 data gradient (0: fp32 MFMA everywhere)"),
     ("wgrad_batch", "MFT_WGRAD_BATCH", _flag, True, "meta-training backward: every layer's weight gradient deferred to the end of the pass and run in one multi-problem launch pair per 16 layers (0: one launch pair per layer, as round 5; bit-identical)"),
     ("pair_f16x2", "MFT_PAIR_F16X2", _flag, False, "GNN pair-MLP layers (Wcompute) as f16x2 products on the fp16 matrix cores (fp32-accurate; 0: fp32 MFMA)"),
+    ("gemm_rk_rows", "MFT_GEMM_RK_ROWS", int, 4096, "meta-training: head linear layers (fc, Gconv.fc) of at most this many rows take the skinny register-K GEMM (0: the tile kernel always)"),
     ("pair_rk_rows", "MFT_PAIR_RK_ROWS", int, 16384, "meta-training: Wcompute layers over at most this many pair rows (all episodes of the step) take the register-K small-problem kernel, 32-row tiles, no LDS staging (0: the 128-row tile kernel always)"),
     ("train_source", "MFT_TRAIN_SOURCE", str, "pool", "train.main --dataset miniImageNet: 'pool' = resident uint8 class pool, 'synthetic' = host fp32 episodes"),
     # ---- drivers (finetune.main / train.main)
@@ -116,6 +117,7 @@ class Settings:
     train_x3: bool = True
     wgrad_batch: bool = True
     pair_f16x2: bool = False
+    gemm_rk_rows: int = 4096
     pair_rk_rows: int = 16384
     train_source: str = "pool"
     standin_weights: bool = False
@@ -168,7 +170,7 @@ def current():
 # in that process); every other knob is read live through ``current()`` at the point of use.
 IMPORT_TIME = frozenset((
     "debug_skip_trunk", "adapt_graph", "adapt_batched_trunk", "fused_dgrad", "fused_last_block", "x3_planes", "x3_fused_stats",
-    "x3_fold_bn", "trunk_f16x2", "train_x3", "fuse_next_c2_only", "fused_pair_mlp", "pair_f16x2", "pair_rk_rows", "pair_mlp_gb", "wgrad_batch",
+    "x3_fold_bn", "trunk_f16x2", "train_x3", "fuse_next_c2_only", "fused_pair_mlp", "pair_f16x2", "pair_rk_rows", "gemm_rk_rows", "pair_mlp_gb", "wgrad_batch",
     "train_graph", "small_groups", "wf_xcd",
 ))
 assert IMPORT_TIME <= set(k[0] for k in KNOBS), IMPORT_TIME - set(k[0] for k in KNOBS)

@@ -86,6 +86,33 @@ def test_gemm_padded(M, K, N):
     assert float((y.cpu().double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("M,K,N", [(105, 512, 128), (480, 266, 48), (480, 362, 48), (480, 458, 5), (1920, 458, 48), (7, 32, 33), (1, 16, 1), (33, 500, 70)])
+def test_gemm_register_k_skinny(M, K, N):
+    """mft_gemm_rk (the head's linear layers in a meta-training step: 16-row tiles, the whole K in registers over four waves) against
+    float64 and against the tile kernel; junk beyond K in the operand rows is masked by the pack's zero columns; columns N.. of a
+    caller-provided output are left alone; two runs are bit-identical."""
+    Kp = ops.round_up(K, 32)
+    a = torch.zeros(M, Kp + 32)
+    a[:, :K] = rnd((M, K), 5)
+    a[:, K:] = 7.0
+    w = rnd((N, K), 6, scale=K ** -0.5)
+    b = rnd((N,), 7)
+    ref = a[:, :K].double() @ w.double().t() + b.double()
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    ad, bd = a.to(DEV), b.to(DEV)
+    y = ops.gemm_rk(ad, Kp, wpk, N, bias=bd)
+    y2 = ops.gemm_rk(ad, Kp, wpk, N, bias=bd)
+    yt = ops.gemm(ad, Kp, wpk, N, bias=bd)
+    assert torch.equal(y, y2)
+    tol = 2e-5 * max(float(ref.abs().max()), 1.0)
+    assert float((y.cpu().double() - ref).abs().max()) <= tol
+    assert float((y - yt).abs().max()) <= tol
+    ld = ops.round_up(N, 32) + 32
+    out = torch.full((M, ld), -3.0, device=DEV)
+    ops.gemm_rk(ad, Kp, wpk, N, bias=None, out=out)
+    assert float((out[:, :N].cpu().double() + b.double() - ref).abs().max()) <= tol and bool((out[:, N:] == -3.0).all())
+
+
 def test_pack_roundtrip_and_dgrad():
     Cout, Cin, k, H, n = 512, 512, 3, 3, 5
     w = rnd((Cout, Cin, k, k), 8, scale=0.02)

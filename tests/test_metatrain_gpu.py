@@ -63,9 +63,16 @@ def test_set_forward_loss_backward_all_parameters(golden_dir):
     gn = {k: float(p.grad.norm()) for k, p in named.items()}
     for name, refn in zip(g["gradnames"], g["gradnorms"]):
         assert abs(gn[str(name)] - refn) <= 5e-3 * refn + 1e-6, name
-    np.testing.assert_allclose(named["fc.0.weight"].grad[:4, :8].cpu().numpy(), g["grad_fc0w_slice"], atol=2e-5)
-    np.testing.assert_allclose(named["feature.trunk.7.C2.weight"].grad[:2, :4, 1, 1].cpu().numpy(), g["grad_c7c2_slice"], atol=2e-5)
-    np.testing.assert_allclose(named["feature.trunk.0.weight"].grad[:2, :, 3, 3].cpu().numpy(), g["grad_stem_slice"], atol=1e-3)
+    # element slices against the reference's own fp32 run (layout / indexing: a transposed or mis-sliced gradient is off by O(1)
+    # of the slice's scale).  Two fp32 runs of this step differ by the chaos above: over four (weights, episode) draws the per-tensor
+    # relative L2 error against float64 is 1.3e-4 .. 2.3e-3 in the median, 7e-3 at most, and moves by that much when one GEMM of the
+    # head sums in another order (tools/g3_grad_error_draws.py, profiles/r06_n_g3_grad_error_draws.txt) -- so the bar is 3e-3 of the
+    # slice's largest element (fc: 1.2e-4; the absolute 2e-5 that stood here held for one summation order of this draw only)
+    def near(got, want, floor):
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=max(floor, 3e-3 * float(np.abs(want).max())))
+    near(named["fc.0.weight"].grad[:4, :8], g["grad_fc0w_slice"], 2e-5)
+    near(named["feature.trunk.7.C2.weight"].grad[:2, :4, 1, 1], g["grad_c7c2_slice"], 2e-5)
+    near(named["feature.trunk.0.weight"].grad[:2, :, 3, 3], g["grad_stem_slice"], 1e-3)
 
 
 def test_split_precision_training_layers_match_the_fp32_launches(monkeypatch):

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r06_q}; rm -rf $O; mkdir -p $O
 python3 -m pytest tests/test_metatrain_gpu.py tests/test_kernels_gpu.py tests/test_engine_gpu.py -m gpu -x -q -k "not trajectory and not accuracy" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
 tail -3 $O/pytest.log
-for k in 1 4; do
+for k in 1 2 4; do
   echo -n "k=$k: " | tee -a $O/ab.txt
   python3 bench.py --workload metatrain --episodes-per-rank $k --steps 300 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['last_loss'])" | tee -a $O/ab.txt
 done
