@@ -3,13 +3,15 @@
 // column sums (bias gradients), and the GNN head's backward glue (masked-softmax, |x_i-x_j|, graph aggregation, node
 // assembly, score gather).  All HBM-bound; reductions are fixed-order (bit-reproducible).
 #include "mft_common.h"
+#include <type_traits>
 
 namespace {
 
+// (branch-free: `act` is uniform, so the two selects are scalar; with branches per element the loops that call this waited for every
+// load before issuing the next one)
 __device__ __forceinline__ float act_grad(float y, int act, float slope) {
-    if (act == MFT_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-    if (act == MFT_ACT_LRELU) return y > 0.f ? 1.f : slope;
-    return 1.f;
+    const float neg = act == MFT_ACT_RELU ? 0.f : (act == MFT_ACT_LRELU ? slope : 1.f);
+    return y > 0.f ? 1.f : neg;
 }
 
 // ---------------------------------------------------------------------------------- BN backward, two phase
@@ -37,18 +39,22 @@ __device__ __forceinline__ void bn_bwd_partial_body(const BnBwdArgs& p, const in
         const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c);
         const f32x4 rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
         const int rbeg = chunk * p.rows_per_chunk, rend = min(rbeg + p.rows_per_chunk, p.rows_per_group);
+        // (the y_act test is hoisted out of the row walk: with it inside, every unrolled row waited for its own loads)
+        auto walk = [&](auto with_act) {
 #pragma unroll 4
-        for (int rr = rbeg + rl; rr < rend; rr += 16) {               // (the loads of four rows in flight; same order of additions)
-            f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
-            if (p.y_act) {
-                const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + rr) * p.ldya + c);
+            for (int rr = rbeg + rl; rr < rend; rr += 16) {           // (the loads of four rows in flight; same order of additions)
+                f32x4 d = *(const f32x4*)(p.dy + (row0 + rr) * p.lddy + c);
+                if constexpr (decltype(with_act)::value) {
+                    const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + rr) * p.ldya + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+                    for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+                }
+                const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
+                s1 += d;
+                s2 += d * xh;
             }
-            const f32x4 xh = (*(const f32x4*)(p.x + (row0 + rr) * p.ldx + c) - mu) * rs;
-            s1 += d;
-            s2 += d * xh;
-        }
+        };
+        if (p.y_act) walk(std::true_type{}); else walk(std::false_type{});
     }
     red1[rl][cq] = s1;
     red2[rl][cq] = s2;

@@ -801,15 +801,24 @@ __global__ __launch_bounds__(256) void pair_dx_gather_kernel(const float* __rest
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         const float xi = x[node * ldx + f];
         float acc = 0.f;
-#pragma unroll 6
-        for (int j = 0; j < N; ++j) {                  // branch-free body: the loads of six j are in flight together
-            const int a = i < j ? i : j, c = i < j ? j : i;
-            const long long r = (long long)b * P + (a * N - (a * (a - 1)) / 2 + (c - a)) - row0;
-            const bool ok = j != i && r >= 0 && r < nrows;
-            const float df = xi - x[((long long)b * N + j) * ldx + f];
-            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            const float d = dd[(ok ? r : 0) * lddd + f];
-            if (ok) acc += sg * d;
+        for (int j0 = 0; j0 < N; j0 += 6) {            // six j at a time: twelve unconditional loads in flight, then the adds in j order
+            float xv[6], dv[6];
+            bool okv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int j = j0 + u < N ? j0 + u : N - 1;
+                const int a = i < j ? i : j, c = i < j ? j : i;
+                const long long r = (long long)b * P + (a * N - (a * (a - 1)) / 2 + (c - a)) - row0;
+                okv[u] = j0 + u < N && j != i && r >= 0 && r < nrows;
+                xv[u] = x[((long long)b * N + j) * ldx + f];
+                dv[u] = dd[(okv[u] ? r : 0) * lddd + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const float df = xi - xv[u];
+                const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                acc += okv[u] ? sg * dv[u] : 0.f;
+            }
         }
         dX[node * lddx + f] += acc;
     }
