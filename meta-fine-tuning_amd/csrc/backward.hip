@@ -290,6 +290,52 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_arg_kernel(const float* _
     }
 }
 
+// The same for C % 4 == 0, four channels per thread: the nine taps are loaded unconditionally (coordinates clamped, a tap outside the
+// image masked to -inf afterwards), so all nine 16-byte loads are in flight together -- the scalar form above walks its taps through
+// branches, one exposed load latency each (31 us for the 105-image stem output; this form: HBM-bound).  Same arithmetic per element,
+// same tie rule (first maximum in (dh, dw) order).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_arg4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   unsigned char* __restrict__ arg, int n_img, int H, int W,
+                                                                   int C, int OH, int OW, int imgs_per_group,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta) {
+    const int cq = C >> 2;
+    const long long total = (long long)n_img * OH * OW * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const int g = n / imgs_per_group;
+        const f32x4 mu = *(const f32x4*)(mean + (long long)g * C + c), rs = *(const f32x4*)(rstd + (long long)g * C + c);
+        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        f32x4 xv[9];
+        bool ok[9];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int ih = oh * 2 - 1 + dh, iw = ow * 2 - 1 + dw;
+                ok[dh * 3 + dw] = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+                xv[dh * 3 + dw] = *(const f32x4*)(x + (((long long)n * H + ihc) * W + iwc) * C + c);
+            }
+        f32x4 best = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+        unsigned barg = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf((xv[k][e] - mu[e]) * rs[e] * ga[e] + be[e], 0.f);
+                if (ok[k] && v > best[e]) { best[e] = v; barg = (barg & ~(0xffu << (8 * e))) | ((unsigned)k << (8 * e)); }
+            }
+        }
+        *(f32x4*)(y + i * 4) = best;
+        *(unsigned*)(arg + i * 4) = barg;
+    }
+}
+
 // gradient w.r.t. the BN output (pre-ReLU): each input pixel gathers from the <= 4 windows that contain it
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __restrict__ dy,
                                                                const unsigned char* __restrict__ arg,
@@ -320,36 +366,54 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* __re
     }
 }
 
-// the same gather, four channels per thread (float4 of dy / y, uchar4 of the argmax), 32-bit index arithmetic: the scalar form
-// spent its time on per-element 64-bit divisions and byte loads (96 us for the 105 x 42 x 42 x 64 stem activation; this one ~25)
-__global__ __launch_bounds__(256) void maxpool_relu_bwd4_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                                                const float* __restrict__ y, float* __restrict__ dx, int n_img,
-                                                                int H, int W, int C, int OH, int OW) {
-    const int cq = C >> 2;
-    const int total = n_img * H * W * cq;
+// C % 4 == 0: one thread per 2 x 2 block of input pixels (ih = 2a, 2a+1; iw = 2b, 2b+1) and four channels: the block lies in the windows
+// (oh, ow) in {a, a+1} x {b, b+1} only, so four window loads (argmax, y, dy) serve four input pixels -- a per-pixel form loads
+// up to four windows for every pixel (427 MB of cache traffic for the 105-image stem output: 27 us against 19).  Per pixel the contributions are added
+// in the same (oh, ow)-ascending order: identical results.
+__global__ __launch_bounds__(256) void maxpool_relu_bwd4_2x2_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                    const float* __restrict__ y, float* __restrict__ dx, int n_img,
+                                                                    int H, int W, int C, int OH, int OW) {
+    const int cq = C >> 2, HB = (H + 1) >> 1, WB = (W + 1) >> 1;
+    const int total = n_img * HB * WB * cq;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int c = (i % cq) * 4;
         int t = i / cq;
-        const int iw = t % W; t /= W;
-        const int ih = t % H;
-        const int n = t / H;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
-            if (oh >= OH) continue;
-            const int dh = ih - (oh * 2 - 1);
-            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow >= OW) continue;
-                const int dw = iw - (ow * 2 - 1);
-                const long long o = (((long long)n * OH + oh) * OW + ow) * C + c;
-                const unsigned a4 = *(const unsigned*)(arg + o);
-                const f32x4 yv = *(const f32x4*)(y + o), dv = *(const f32x4*)(dy + o);
-                const unsigned want = (unsigned)(dh * 3 + dw);
+        const int wb = t % WB; t /= WB;
+        const int hb = t % HB;
+        const int n = t / HB;
+        unsigned a4[4];
+        f32x4 yv[4], dv[4];
+        bool wok[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (((a4 >> (8 * e)) & 0xffu) == want && yv[e] > 0.f) s[e] += dv[e];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oh = hb + a, ow = wb + b, k = a * 2 + b;
+                wok[k] = oh < OH && ow < OW;
+                const long long o = (((long long)n * OH + (oh < OH ? oh : OH - 1)) * OW + (ow < OW ? ow : OW - 1)) * C + c;
+                a4[k] = *(const unsigned*)(arg + o);
+                yv[k] = *(const f32x4*)(y + o);
+                dv[k] = *(const f32x4*)(dy + o);
             }
-        }
-        *(f32x4*)(dx + (long long)i * 4) = s;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int ih = 2 * hb + pa, iw = 2 * wb + pb;
+                if (ih >= H || iw >= W) continue;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a <= pa; ++a)                       // pixel row 2a: window a only; row 2a+1: windows a and a+1
+#pragma unroll
+                    for (int b = 0; b <= pb; ++b) {
+                        const int k = a * 2 + b;
+                        const unsigned want = (unsigned)((ih - ((hb + a) * 2 - 1)) * 3 + (iw - ((wb + b) * 2 - 1)));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (wok[k] && ((a4[k] >> (8 * e)) & 0xffu) == want && yv[k][e] > 0.f) s[e] += dv[k][e];
+                    }
+                *(f32x4*)(dx + ((((long long)n * H + ih) * W + iw) * C + c)) = s;
+            }
     }
 }
 
@@ -408,6 +472,32 @@ __global__ __launch_bounds__(256) void graph_aggregate_bwd_kernel(const float* _
         dx[row * lddx + f] = accumulate ? dx[row * lddx + f] + s : s;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (F <= 256) {
+        // dy's row is the same for every j: kept in registers; four j per wave and round -- sixteen loads of x in flight, then four
+        // wave sums (per lane the same f-ascending products as the loop below: identical results)
+        float dyv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dyv[t] = lane + 64 * t < F ? dy[row * lddy + F + lane + 64 * t] : 0.f;
+        for (int j0 = wv; j0 < N; j0 += 16) {
+            float xv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u < N ? j0 + 4 * u : N - 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[u][t] = lane + 64 * t < F ? x[(b * N + j) * ldx + lane + 64 * t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float sj = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (lane + 64 * t < F) sj += dyv[t] * xv[u][t];
+                sj = wave_sum(sj);
+                if (lane == 0 && j0 + 4 * u < N) dA[row * N + j0 + 4 * u] = sj;
+            }
+        }
+        return;
+    }
     for (int j = wv; j < N; j += 4) {
         float s = 0.f;
 #pragma unroll 4
@@ -592,8 +682,12 @@ extern "C" int mft_bn_relu_maxpool_arg(const float* x, float* y, unsigned char* 
     if (imgs_per_group <= 0) imgs_per_group = n_img;
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)n_img * OH * OW * C;
-    hipLaunchKernelGGL(bn_relu_maxpool_arg_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
-                       n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(bn_relu_maxpool_arg4_kernel, dim3(bgrid(total / 4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
+                           n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_arg_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
+                           n_img, H, W, C, OH, OW, imgs_per_group, mean, rstd, gamma, beta);
     return mft_launch_status();
 }
 
@@ -602,8 +696,8 @@ extern "C" int mft_maxpool_relu_backward(const float* dy, const unsigned char* a
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)n_img * H * W * C;
     if (C % 4 == 0 && total < 0x7fffffffLL)
-        hipLaunchKernelGGL(maxpool_relu_bwd4_kernel, dim3(bgrid(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, y, dx,
-                           n_img, H, W, C, OH, OW);
+        hipLaunchKernelGGL(maxpool_relu_bwd4_2x2_kernel, dim3(bgrid((long long)n_img * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4))), dim3(256), 0,
+                           (hipStream_t)stream, dy, argmax, y, dx, n_img, H, W, C, OH, OW);
     else
         hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(bgrid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, y, dx,
                            n_img, H, W, C, OH, OW);
