@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceMultiArg
     const int lb = blockIdx.x - a.start[j], nb = a.start[j + 1] - a.start[j];
     const int q = threadIdx.x & 31, l = threadIdx.x >> 5;
     const long long nq = n >> 2;
-    if (chunks <= 8 && taps == 9 && cin_out == Cin && (Cin & 3) == 0 && Kpad == 9 * Cin) {
+    if (chunks <= 8 && taps == 9 && cin_out == Cin && (Cin & 3) == 0 && Kpad == 9 * Cin && ((unsigned long long)dw & 15) == 0) {
         // Few chunks, 3x3 layer (the deep trunk layers: 2-6 chunks, 88 % of the trunk's weights).  One thread per (output channel,
         // four input channels): the nine taps of its four channels are 36 CONSECUTIVE floats of torch's [Cout][Cin][3][3] -- nine
         // 16-byte stores per thread, whole cache lines per wave (the element-wise form below writes every float on its own, 36

@@ -294,7 +294,9 @@ extern "C" int mft_masked_softmax(const float* s, int lds_, float* A, int n_grap
  * == 0, K <= 512, lda % 4 == 0, lda >= K.  Columns N..ldo-1 of `out` are not written. */
 extern "C" int mft_gemm_rk(const float* a, int lda, const float* w, int w_rows, int K, const float* bias, float* out, int ldo, int M,
                            int N, void* stream) {
-    if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || K > 512 || lda % 4 != 0 || lda < K || w_rows < N || ldo < N) return MFT_EINVAL;
+    if (M < 1 || N < 1 || K < 16 || K % 16 != 0 || K > 512 || lda % 4 != 0 || lda < K || w_rows < N || ldo < N ||
+        ((unsigned long long)a & 15) != 0 || ((unsigned long long)w & 15) != 0)        // 16-byte operand loads
+        return MFT_EINVAL;
     const int cbs = (N + 15) / 16;
     const int CB = cbs >= 4 ? 4 : cbs;
     const int tiles_n = (N + 16 * CB - 1) / (16 * CB);

@@ -888,7 +888,8 @@ extern "C" int mft_pair_mlp_layer_rk(const float* in, int ld_in, int mode, const
                                      int graphs_per_group, int N, float slope, float* ws_mean, float* ws_m2, float* ws_n,
                                      void* stream) {
     if (Cout % PM_BN != 0 || Kpad % 32 != 0 || Kpad < 32 || Kpad > 256 || K > Kpad || ld_in % 4 != 0 || N < 1 || N > 65535 ||
-        n_groups < 1 || (mode != 0 && mode != 1) || (mode == 1 && (K != Kpad || !scale_in || !shift_in)) || (mode == 0 && ld_in < Kpad))
+        n_groups < 1 || (mode != 0 && mode != 1) || (mode == 1 && (K != Kpad || !scale_in || !shift_in)) || (mode == 0 && ld_in < Kpad) ||
+        ((unsigned long long)in & 15) != 0 || ((unsigned long long)w & 15) != 0)        // 16-byte operand loads
         return MFT_EINVAL;
     PairArgs p;
     p.in = in; p.ld_in = ld_in; p.ij = ij; p.scale_in = scale_in; p.shift_in = shift_in; p.w = w; p.bias = bias; p.out = out;
