@@ -735,32 +735,23 @@ def test_meta_training_step_issues_no_torch_device_ops():
     """One eager meta-training step (zero_grad, set_forward_loss, backward with an explicit upstream gradient, optimizer.step) is
     C-ABI launches only: the torch profiler sees no aten fill / copy / arithmetic kernel on the device (round-5 verdict, row a7:
     25 ATen kernels per step).  The only device-side torch work left is what autograd itself adds around the functions (none for
-    this graph) -- asserted by name."""
-    from torch.profiler import ProfilerActivity, profile
-    from meta_fine_tuning_amd import optim
-    model = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5).cuda()
-    model.load_state_dict(synthetic.gnnnet_state_dict(seed=0))
-    model.train()
-    model.n_query = 16
-    opt = optim.Adam(model.parameters())
-    x = synthetic.train_episode(5, 5, 5, 16, 84).cuda()
-    one = torch.ones((), device="cuda")
-    for _ in range(2):
-        opt.zero_grad()
-        model.set_forward_loss(x).backward(one)
-        opt.step()
-    torch.cuda.synchronize()
-    nbt0 = int(model.feature.trunk[1].num_batches_tracked)
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        opt.zero_grad()
-        model.set_forward_loss(x).backward(one)
-        opt.step()
-        torch.cuda.synchronize()
-    dev_kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-    aten = sorted({n for n in dev_kernels if "at::native" in n or n.startswith("void at::")})
-    assert dev_kernels, "the profiler recorded no device kernels"
-    assert not aten, aten
-    assert int(model.feature.trunk[1].num_batches_tracked) == nbt0 + 1 == int(model.feature.trunk[7].BN2.num_batches_tracked)
+    this graph) -- asserted by name.  The profiled step runs in a child process (tests/profile_step_worker.py): the profiler's
+    tracing thread has been seen to abort its process after the fact; the child prints its result line before that can happen."""
+    import json
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profile_step_worker.py")
+    res = None
+    for attempt in range(2):                                # (a child lost before its result line is retried once)
+        r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        if lines:
+            res = json.loads(lines[-1][len("RESULT "):])
+            break
+    assert res is not None, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert res["n_dev"] > 0, "the profiler recorded no device kernels"
+    assert not res["aten"], res["aten"]
+    assert res["nbt_ok"]
 
 
 # ------------------------------------------------------------------------------------------------ round 6: k episodes in lockstep
