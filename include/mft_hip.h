@@ -349,6 +349,22 @@ typedef struct MftBnStatsJob {
     int ldx, C, rows_per_group, n_groups; float eps, momentum;
 } MftBnStatsJob;
 int mft_bn_stats_multi(const MftBnStatsJob* jobs, int n_jobs, void* stream);
+/* Train-mode BatchNorm of a SMALL tensor in ONE launch: batch statistics (+ running-statistics update from group 0 + counter, as
+ * mft_bn_stats), then y = act( bn(x) [+ res | + bn_r(res)] ) as mft_bn_apply -- for the head's BatchNorm1d layers of a meta-training step
+ * (gnnnet.py:44, gnn.py:134-166: 105 / 480 rows per episode), where statistics -> finalize -> apply are three dependent launches of a
+ * few microseconds of work.  One workgroup per (group, 4 channels) walks all rows twice; the caller chooses it up to
+ * mft_bn_forward_small_max_rows() rows per group (512: at the trunk's 945 / 3,780-row layers the three launches are faster).  res_gamma != NULL: the residual
+ * goes through its own BatchNorm (statistics taken here, saved to res_mean / res_rstd, res_running_* updated).  Same formulas as
+ * mft_bn_stats + mft_bn_apply; the sums are taken in another fixed order (equal to rounding). */
+typedef struct MftBnFwdJob {
+    const float* x; float* y; const float* gamma; const float* beta; float* mean; float* rstd;
+    float* running_mean; float* running_var; long long* num_batches_tracked;
+    const float* res; const float* res_gamma; const float* res_beta; float* res_mean; float* res_rstd;
+    float* res_running_mean; float* res_running_var; long long* res_num_batches_tracked;
+    int ldx, ldy, ldr, C, rows_per_group, n_groups, act; float eps, momentum, slope;
+} MftBnFwdJob;
+int mft_bn_forward_small(const MftBnFwdJob* job, void* stream);
+int mft_bn_forward_small_max_rows(void);
 /* Several independent BatchNorm-apply problems (no residual) in ONE launch: the meta-training backward re-creates the twelve pair-MLP
  * activations h_l = leaky_relu(BatchNorm(z_l)) (gnn.py:87-102; the forward keeps only the raw z_l) in front of its weight-gradient
  * launches -- all twelve depend on the forward's tape only.  jobs: HOST array, up to 16 per launch; each job = mft_bn_apply's

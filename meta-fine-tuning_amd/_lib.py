@@ -121,6 +121,8 @@ SIGNATURES = {
     "mft_masked_softmax": [_P, _I, _P, _I, _I, _P],
     "mft_pair_mlp_tiles_m": [_I, _I],
     "mft_pair_mlp_layer": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P],
+    "mft_bn_forward_small": [_P, _P],
+    "mft_bn_forward_small_max_rows": [],
     "mft_gemm_rk": [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "mft_pair_mlp_tiles_m_rk": [_I, _I],
     "mft_pair_mlp_layer_rk": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],

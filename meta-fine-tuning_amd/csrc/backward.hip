@@ -255,6 +255,119 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (c < C && kl == 0) out[c] = s;
 }
 
+// ---------------------------------------------------------------------------------- BN backward, SMALL problems: one launch
+// The three-phase form above needs two grid-wide hand-offs (partial sums -> sums -> dx): three dependent launches, >= 4.7 us each in a
+// replayed meta-training step whatever they do -- and the deep layers of a single 105-image episode (trunk.6: 3,780 rows, trunk.7:
+// 945 rows) and the head's BatchNorm1d layers (105 / 480 rows) are a few hundred KB.  Here one workgroup owns FOUR CHANNELS over
+// ALL rows of all groups: 256 row lanes, two passes over its 16-byte column (the second out of cache), the sums reduced inside the
+// workgroup (wave xor tree, then the four waves in order: fixed) -- no hand-off between workgroups, one launch.  Groups are walked in
+// order by the same workgroup (the sums over the groups are formed in group order, as the finalize launch above does).  Several jobs
+// per launch (grid.y = job).  Same formulas as the three-phase form; the sums are taken in another (fixed) order.
+constexpr int BNS_JOBS = 8;
+struct BnBwdSmallArgs {
+    BnBwdArgs job[BNS_JOBS];
+    int n;
+};
+static_assert(sizeof(BnBwdSmallArgs) <= 4000, "kernarg segment");
+
+__device__ __forceinline__ void block_sum2_f4(f32x4& a, f32x4& b, float (*red)[4][8]) {       // red[2 buffers][4 waves][8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] += __shfl_xor(a[e], off, 64);
+            b[e] += __shfl_xor(b[e], off, 64);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { (*red)[wave][e] = a[e]; (*red)[wave][4 + e] = b[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (((*red)[0][e] + (*red)[1][e]) + (*red)[2][e]) + (*red)[3][e];
+        b[e] = (((*red)[0][4 + e] + (*red)[1][4 + e]) + (*red)[2][4 + e]) + (*red)[3][4 + e];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdSmallArgs a) {
+    __shared__ float red[2][4][8];
+    const BnBwdArgs p = a.job[blockIdx.y];
+    const int c = blockIdx.x * 4;
+    if (c >= p.C) return;
+    const int t = threadIdx.x;
+    const f32x4 ga = *(const f32x4*)(p.gamma + c);
+    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+    for (int g = 0; g < p.n_groups; ++g) {
+        const long long row0 = (long long)g * p.rows_per_group;
+        const f32x4 mu = *(const f32x4*)(p.mean + (long long)g * p.C + c), rs = *(const f32x4*)(p.rstd + (long long)g * p.C + c);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        auto walk = [&](auto with_act) {
+#pragma unroll 4
+            for (int r = t; r < p.rows_per_group; r += 256) {
+                f32x4 d = *(const f32x4*)(p.dy + (row0 + r) * p.lddy + c);
+                if constexpr (decltype(with_act)::value) {
+                    const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + r) * p.ldya + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+                }
+                const f32x4 xh = (*(const f32x4*)(p.x + (row0 + r) * p.ldx + c) - mu) * rs;
+                s1 += d;
+                s2 += d * xh;
+            }
+        };
+        if (p.y_act) walk(std::true_type{}); else walk(std::false_type{});
+        block_sum2_f4(s1, s2, &red[g & 1]);            // (two buffers: the next group's writes cannot overtake this group's reads)
+        if (t == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.dbeta) p.dbeta[(long long)g * p.C + c + e] = s1[e];
+                if (p.dgamma) p.dgamma[(long long)g * p.C + c + e] = s2[e];
+            }
+        }
+        t1 += s1;
+        t2 += s2;
+        if (p.dx) {
+            const float inv = 1.f / (float)p.rows_per_group;      // (the three-phase form divides: s / rows; kept as a division below)
+            (void)inv;
+            f32x4 m1, m2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { m1[e] = s1[e] / (float)p.rows_per_group; m2[e] = s2[e] / (float)p.rows_per_group; }
+            auto apply = [&](auto with_act) {
+#pragma unroll 4
+                for (int r = t; r < p.rows_per_group; r += 256) {
+                    f32x4 d = *(const f32x4*)(p.dy + (row0 + r) * p.lddy + c);
+                    if constexpr (decltype(with_act)::value) {
+                        const f32x4 ya = *(const f32x4*)(p.y_act + (row0 + r) * p.ldya + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] *= act_grad(ya[e], p.act, p.slope);
+                    }
+                    const f32x4 xh = (*(const f32x4*)(p.x + (row0 + r) * p.ldx + c) - mu) * rs;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ga[e] * rs[e] * (d[e] - m1[e] - xh[e] * m2[e]);
+                    *(f32x4*)(p.dx + (row0 + r) * p.lddx + c) = o;
+                }
+            };
+            if (p.y_act) apply(std::true_type{}); else apply(std::false_type{});
+        }
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p.dbeta_sum) p.dbeta_sum[c + e] = t1[e];
+            if (p.dgamma_sum) p.dgamma_sum[c + e] = t2[e];
+            if (p.dbias_zero) p.dbias_zero[c + e] = 0.f;
+        }
+    }
+}
+
+// rows per group up to which BatchNorm backward runs as the one-launch form (0: never).  512 = the head's BatchNorm1d layers (105 / 480
+// rows: 5-8 us against three launches of ~5 us).  Measured at the trunk's deep layers the form LOSES: a workgroup's 16-byte column is an
+// eighth of every cache line it touches and 64-128 workgroups walk 945-3,780 rows each -- trunk.7 22-25 us, trunk.6 63 us against ~17.
+int g_bn_small_rows = 512;
+
 // ---------------------------------------------------------------------------------- max pool with argmax
 __global__ __launch_bounds__(256) void bn_relu_maxpool_arg_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   unsigned char* __restrict__ arg, int n_img, int H, int W,
@@ -591,6 +704,16 @@ inline int bwd_chunks(int rows_per_group, int n_groups, int C) {
 
 }  // namespace
 
+// (C++ linkage: not part of the C ABI; reached through mft_debug_set_conv_tile(11000 + rows), include/mft_hip_testing.h)
+void mft_bn_small_set_rows(int rows) { g_bn_small_rows = rows; }
+
+// (the one workgroup of a channel group walks the lockstep groups one after the other: beyond two groups' worth of rows the three
+// launches, which spread the groups over workgroups, are faster again -- k = 4: 6.66 against 6.58 ms per step)
+static bool bn_bwd_small_ok(int C, int rows_per_group, int n_groups, long long gbs) {
+    return g_bn_small_rows > 0 && rows_per_group <= g_bn_small_rows && (long long)rows_per_group * n_groups <= 2LL * g_bn_small_rows &&
+           C % 4 == 0 && gbs == 0;
+}
+
 extern "C" long long mft_bn_backward_ws_floats(int C, int rows_per_group, int n_groups) {
     return 2LL * n_groups * bwd_chunks(rows_per_group, n_groups, C) * C + 2LL * n_groups * C;
 }
@@ -610,6 +733,12 @@ extern "C" int mft_bn_backward_act(const float* x, int ldx, const float* dy, int
     p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.gbs = gb_group_stride;
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws; p.act = act; p.slope = slope;
     p.dgamma_sum = dgamma_sum; p.dbeta_sum = dbeta_sum; p.dbias_zero = dbias_zero; p.n_groups = n_groups;
+    if (bn_bwd_small_ok(C, rows_per_group, n_groups, gb_group_stride)) {          // a few hundred KB: one launch, no hand-off between workgroups
+        BnBwdSmallArgs a = {};
+        a.job[0] = p; a.n = 1;
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(C / 4, 1), dim3(256), 0, s, a);
+        return mft_launch_status();
+    }
     const bool walk = dgamma_sum != nullptr || dbeta_sum != nullptr;
     float* sums = ws + 2LL * n_groups * p.chunks * C;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.chunks, (C + 63) / 64, n_groups), dim3(256), 0, s, p);
@@ -651,6 +780,21 @@ extern "C" int mft_bn_backward_act_multi(const MftBnBwdJob* jobs, int n_jobs, vo
     }
     a.start_p[n_jobs] = bp; a.start_f[n_jobs] = bf; a.start_a[n_jobs] = ba; a.n = n_jobs;
     hipStream_t s = (hipStream_t)stream;
+    {
+        bool small = true;
+        int cmax = 0;
+        for (int j = 0; j < n_jobs; ++j) {
+            small = small && bn_bwd_small_ok(jobs[j].C, jobs[j].rows_per_group, jobs[j].n_groups, 0);
+            cmax = jobs[j].C > cmax ? jobs[j].C : cmax;
+        }
+        if (small) {                               // every job is small: one launch for all of them (grid.y = job)
+            BnBwdSmallArgs sa = {};
+            for (int j = 0; j < n_jobs; ++j) sa.job[j] = a.job[j];
+            sa.n = n_jobs;
+            hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(cmax / 4, n_jobs), dim3(256), 0, s, sa);
+            return mft_launch_status();
+        }
+    }
     hipLaunchKernelGGL(bn_bwd_partial_multi_kernel, dim3(bp), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3(bf), dim3(256), 0, s, a);
     hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3(ba), dim3(256), 0, s, a);

@@ -572,10 +572,154 @@ inline int stats_chunks(int rows_per_group, int n_groups, int C) {
     return (int)want;
 }
 
+// ------------------------------------------------------------------------------------------- train-mode BatchNorm, SMALL problems
+// statistics -> finalize -> apply are three dependent launches (>= 4.7 us each in a replayed meta-training step); the deep layers of
+// a single 105-image episode (trunk.6 / trunk.7: 3,780 / 945 rows) and the head's BatchNorm1d layers (105 / 480 rows) are a few hundred
+// KB.  One workgroup per (group, four channels): 256 row lanes, pass 1 sums (x - pivot) and its square over the group's rows (the
+// pivot-shifted one-pass form of the launches above), the 256 lanes are reduced inside the workgroup (wave xor tree, then the four
+// waves in order: fixed), pass 2 re-reads the 16-byte column out of cache and applies.  A residual may go through its OWN BatchNorm
+// (SimpleBlock's shortcut, backbone.py:256-260): its statistics are taken in the same pass.  No hand-off between workgroups, one launch.
+struct BnFwdSmallArgs {
+    const float* x; float* y; const float* gamma; const float* beta; float* mean; float* rstd;
+    float* running_mean; float* running_var; long long* nbt;
+    const float* res; const float* rgamma; const float* rbeta; float* rmean; float* rrstd;
+    float* rrunning_mean; float* rrunning_var; long long* rnbt;
+    int ldx, ldy, ldr, C, rows_per_group, n_groups, act;
+    float eps, momentum, slope;
+};
+
+__device__ __forceinline__ void bn_small_block_sum(f32x4& a, f32x4& b, float (*red)[8]) {     // red[4 waves][8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] += __shfl_xor(a[e], off, 64);
+            b[e] += __shfl_xor(b[e], off, 64);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[wave][e] = a[e]; red[wave][4 + e] = b[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        b[e] = ((red[0][4 + e] + red[1][4 + e]) + red[2][4 + e]) + red[3][4 + e];
+    }
+}
+
+__device__ __forceinline__ void bn_small_finish(const f32x4 s1, const f32x4 s2, const f32x4 pivot, int rows, float eps, f32x4& mu,
+                                                f32x4& rs, f32x4& var) {
+    const float inv = 1.f / (float)rows;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = s1[e] * inv;
+        mu[e] = pivot[e] + d;
+        var[e] = fmaxf(s2[e] * inv - d * d, 0.f);
+        rs[e] = 1.0f / sqrtf(var[e] + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_forward_small_kernel(BnFwdSmallArgs p) {
+    __shared__ float red[2][4][8];
+    const int c = blockIdx.x * 4, g = blockIdx.y, t = threadIdx.x;
+    const long long row0 = (long long)g * p.rows_per_group;
+    const bool rbn = p.res != nullptr && p.rgamma != nullptr;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 pv = *(const f32x4*)(p.x + row0 * p.ldx + c);
+    const f32x4 pr = rbn ? *(const f32x4*)(p.res + row0 * p.ldr + c) : zero4;
+    f32x4 s1 = zero4, s2 = zero4, q1 = zero4, q2 = zero4;
+    if (rbn) {
+#pragma unroll 4
+        for (int r = t; r < p.rows_per_group; r += 256) {
+            const f32x4 v = *(const f32x4*)(p.x + (row0 + r) * p.ldx + c) - pv;
+            const f32x4 w = *(const f32x4*)(p.res + (row0 + r) * p.ldr + c) - pr;
+            s1 += v; s2 += v * v;
+            q1 += w; q2 += w * w;
+        }
+    } else {
+#pragma unroll 4
+        for (int r = t; r < p.rows_per_group; r += 256) {
+            const f32x4 v = *(const f32x4*)(p.x + (row0 + r) * p.ldx + c) - pv;
+            s1 += v; s2 += v * v;
+        }
+    }
+    bn_small_block_sum(s1, s2, red[0]);
+    f32x4 mu, rs, var, rmu = zero4, rrs = zero4, rvar = zero4;
+    bn_small_finish(s1, s2, pv, p.rows_per_group, p.eps, mu, rs, var);
+    if (rbn) {
+        bn_small_block_sum(q1, q2, red[1]);
+        bn_small_finish(q1, q2, pr, p.rows_per_group, p.eps, rmu, rrs, rvar);
+    }
+    if (t == 0) {
+        const float unbias = (float)p.rows_per_group / (float)max(p.rows_per_group - 1, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            p.mean[(long long)g * p.C + c + e] = mu[e];
+            p.rstd[(long long)g * p.C + c + e] = rs[e];
+            if (p.running_mean && g == 0) {      // group 0 advances the buffers (rank 0's episode), as mft_bn_stats
+                p.running_mean[c + e] = (1.f - p.momentum) * p.running_mean[c + e] + p.momentum * mu[e];
+                p.running_var[c + e] = (1.f - p.momentum) * p.running_var[c + e] + p.momentum * (var[e] * unbias);
+            }
+            if (rbn) {
+                p.rmean[(long long)g * p.C + c + e] = rmu[e];
+                p.rrstd[(long long)g * p.C + c + e] = rrs[e];
+                if (p.rrunning_mean && g == 0) {
+                    p.rrunning_mean[c + e] = (1.f - p.momentum) * p.rrunning_mean[c + e] + p.momentum * rmu[e];
+                    p.rrunning_var[c + e] = (1.f - p.momentum) * p.rrunning_var[c + e] + p.momentum * (rvar[e] * unbias);
+                }
+            }
+        }
+        if (c == 0 && g == 0) {
+            if (p.nbt) *p.nbt += 1;
+            if (rbn && p.rnbt) *p.rnbt += 1;
+        }
+    }
+    const f32x4 ga = *(const f32x4*)(p.gamma + c), be = *(const f32x4*)(p.beta + c);
+    const f32x4 rga = rbn ? *(const f32x4*)(p.rgamma + c) : zero4, rbe = rbn ? *(const f32x4*)(p.rbeta + c) : zero4;
+#pragma unroll 4
+    for (int r = t; r < p.rows_per_group; r += 256) {
+        const f32x4 v = *(const f32x4*)(p.x + (row0 + r) * p.ldx + c);
+        f32x4 o = (v - mu) * rs * ga + be;
+        if (p.res) {
+            f32x4 rv = *(const f32x4*)(p.res + (row0 + r) * p.ldr + c);
+            if (rbn) rv = (rv - rmu) * rrs * rga + rbe;
+            o += rv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
+        *(f32x4*)(p.y + (row0 + r) * p.ldy + c) = o;
+    }
+}
+
+int g_bn_fwd_small_rows = 512;     // (the head's 105 / 480-row layers: 5-6 us against ~15; trunk.7 / trunk.6 measured 10-18 / 29-47 us against ~15: not taken)
+
 }  // namespace
 
 extern "C" long long mft_bn_stats_ws_floats(int C, int rows_per_group, int n_groups) {
     return 2LL * n_groups * stats_chunks(rows_per_group, n_groups, C) * C;
+}
+
+void mft_bn_fwd_small_set_rows(int rows) { g_bn_fwd_small_rows = rows; }      // (C++ linkage; mft_debug_set_conv_tile(11000 + rows))
+
+extern "C" int mft_bn_forward_small_max_rows(void) { return g_bn_fwd_small_rows; }
+
+extern "C" int mft_bn_forward_small(const MftBnFwdJob* jb, void* stream) {
+    if (jb == nullptr || jb->C % 4 != 0 || jb->ldx % 4 != 0 || jb->ldy % 4 != 0 || jb->rows_per_group < 1 || jb->n_groups < 1 ||
+        jb->x == nullptr || jb->y == nullptr || jb->mean == nullptr || jb->rstd == nullptr || (jb->res && jb->ldr % 4 != 0) ||
+        (jb->num_batches_tracked && !jb->running_mean) || (jb->res_gamma && (!jb->res || !jb->res_beta || !jb->res_mean || !jb->res_rstd)) ||
+        jb->rows_per_group > 65536)
+        return MFT_EINVAL;
+    BnFwdSmallArgs p;
+    p.x = jb->x; p.y = jb->y; p.gamma = jb->gamma; p.beta = jb->beta; p.mean = jb->mean; p.rstd = jb->rstd;
+    p.running_mean = jb->running_mean; p.running_var = jb->running_var; p.nbt = jb->num_batches_tracked;
+    p.res = jb->res; p.rgamma = jb->res_gamma; p.rbeta = jb->res_beta; p.rmean = jb->res_mean; p.rrstd = jb->res_rstd;
+    p.rrunning_mean = jb->res_running_mean; p.rrunning_var = jb->res_running_var; p.rnbt = jb->res_num_batches_tracked;
+    p.ldx = jb->ldx; p.ldy = jb->ldy; p.ldr = jb->ldr; p.C = jb->C; p.rows_per_group = jb->rows_per_group; p.n_groups = jb->n_groups;
+    p.act = jb->act; p.eps = jb->eps; p.momentum = jb->momentum; p.slope = jb->slope;
+    hipLaunchKernelGGL(bn_forward_small_kernel, dim3(jb->C / 4, jb->n_groups), dim3(256), 0, (hipStream_t)stream, p);
+    return mft_launch_status();
 }
 
 extern "C" int mft_bn_stats(const float* x, int ldx, int C, int rows_per_group, int n_groups, float eps,

@@ -25,6 +25,8 @@ void mft_skinny_set_dgrad_slices(int n);
 void mft_skinny_set_tap(int v);
 void mft_skinny_set_x3(int v);
 void mft_skinny_set_nw(int v);
+void mft_bn_small_set_rows(int rows);      // csrc/backward.hip / csrc/bn.hip: one-launch BatchNorm forms for small problems
+void mft_bn_fwd_small_set_rows(int rows);
 void mft_skinny_set_lines(int v);
 int mft_skinny_dgrad_dispatch(const float* dy, int ldy, const float* w, float* dx, int ldx, int n_img, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int imgs_per_group,
@@ -1190,7 +1192,8 @@ extern "C" int mft_debug_set_conv_tile(int tile) {
     if (tile >= 9000 && tile < 9100 && tile != 9003 && tile != 9007) return MFT_EINVAL;        // cache-policy / ablation variants
     if (tile > 4000 && tile < 5000) return MFT_EINVAL;                                         // occupancy throttle
 #endif
-    if (tile >= 9800) g_dgrad_parity = tile - 9800;          // 9800 / 9801: stride-2 data gradient over all taps / by pixel parity class
+    if (tile >= 11000) { mft_bn_small_set_rows(tile - 11000); mft_bn_fwd_small_set_rows(tile - 11000); }   // 11000: the multi-launch BatchNorm forms always; 11000 + r: one launch up to r rows per group
+    else if (tile >= 9800) g_dgrad_parity = tile - 9800;          // 9800 / 9801: stride-2 data gradient over all taps / by pixel parity class
     else if (tile >= 9700) mft_skinny_set_lines(tile - 9700);
     else if (tile >= 9600) g_wgrad_trim = tile - 9600;
     else if (tile >= 9500) g_wgrad_rows = tile - 9500;
@@ -1219,6 +1222,7 @@ extern "C" int mft_debug_reset(void) {
     g_dgrad_parity = 1; g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
     mft_skinny_set_lines(1); mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(31); mft_debug_set_x3_tile(41);
+    mft_bn_small_set_rows(512); mft_bn_fwd_small_set_rows(512);
     mft_debug_set_x3_tile(60); mft_debug_set_x3_tile(70); mft_debug_set_x3_tile(80); mft_debug_set_x3_tile(91); mft_debug_set_x3_tile(100); mft_debug_set_x3_tile(200);
     return 0;
 }

@@ -152,11 +152,29 @@ def resnet10_forward_taped(W, x, running=None, groups=1):
         rows = n * OH * OH
         b = {"p": p, "x": a, "cin": cin, "cout": cout, "stride": stride, "rows": rows}
         c1 = conv3x3(p + ".C1", a, cin, cout, stride, rows)
-        m1, s1 = bn_stats(c1.view(-1, cout), cout, rows, run(p + ".BN1"), groups)
         g1, be1 = W.bn[p + ".BN1"]
-        r1 = ops.bn_apply(c1.view(-1, cout), cout, rows // groups, groups, m1, s1, g1, be1, act=RELU).view(n, OH, OH, cout)
+        small = ops.bn_forward_small_ok(cout, rows // groups)       # (<= 512 rows per group: not at 84 x 84; smaller inputs only)
+        if small:
+            r1, m1, s1 = ops.bn_forward_small(c1.view(-1, cout), cout, rows // groups, groups, g1, be1, act=RELU, running=run(p + ".BN1"))
+            r1 = r1.view(n, OH, OH, cout)
+        else:
+            m1, s1 = bn_stats(c1.view(-1, cout), cout, rows, run(p + ".BN1"), groups)
+            r1 = ops.bn_apply(c1.view(-1, cout), cout, rows // groups, groups, m1, s1, g1, be1, act=RELU).view(n, OH, OH, cout)
         c2 = conv3x3(p + ".C2", r1, cout, cout, 1, rows)
         g2, be2 = W.bn[p + ".BN2"]
+        if cin != cout and small:
+            # BN2 + BNshortcut + add + ReLU of a small block exit: ONE launch (both statistics taken in its first pass)
+            sc = ops.conv2d(a, W.conv[p + ".shortcut"], cout, 1, 1, stride, 0)
+            gs, bs = W.bn[p + ".BNshortcut"]
+            out, m2, s2, ms, ss = ops.bn_forward_small(c2.view(-1, cout), cout, rows // groups, groups, g2, be2, act=RELU,
+                                                       running=run(p + ".BN2"), res=sc.view(-1, cout),
+                                                       res_bn=(gs, bs, run(p + ".BNshortcut")))
+            out = out.view(n, OH, OH, cout)
+            b.update(sc=sc, ms=ms, ss=ss)
+            b.update(c1=c1, m1=m1, s1=s1, r1=r1, c2=c2, m2=m2, s2=s2, out=out)
+            blocks.append(b)
+            a = out
+            continue
         if cin != cout and WGRAD_BATCH:
             # BN2 and BNshortcut normalise two tensors that exist together: ONE statistics launch pair for both (mft_bn_stats_multi)
             sc = ops.conv2d(a, W.conv[p + ".shortcut"], cout, 1, 1, stride, 0)
@@ -482,8 +500,11 @@ def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1):
     o = _linear_fwd(y, ldy, w, b, cout, lease)
     t = {"name": name, "F": F, "y": y, "raw": o, "A": A, "lease": lease, "groups": groups}
     if g is not None:
-        m, s = ops.bn_stats(o, cout, rows // groups, groups)
-        ob = ops.bn_apply(o, cout, rows // groups, groups, m, s, g, beta, act=NONE, out=_empty(o.shape, o.device))
+        if ops.bn_forward_small_ok(cout, rows // groups):      # 480 node rows per episode: statistics + apply in one launch
+            ob, m, s = ops.bn_forward_small(o, cout, rows // groups, groups, g, beta, act=NONE, out=_empty(o.shape, o.device))
+        else:
+            m, s = ops.bn_stats(o, cout, rows // groups, groups)
+            ob = ops.bn_apply(o, cout, rows // groups, groups, m, s, g, beta, act=NONE, out=_empty(o.shape, o.device))
         t["stats"] = (m, s)
         return ob, t
     return o, t
@@ -522,8 +543,11 @@ def head_forward_taped(G, feats, n_way, n_support, n_query, fold=False, episodes
     lease = ZeroLease()
     t = {"feats": feats, "n_way": n_way, "ns": n_support, "nq": n_query, "fold": fold, "lease": lease, "episodes": k}
     z_raw = _gemm_fwd(feats, 512, G.fc_w, 128, G.fc_b)
-    mz, sz = ops.bn_stats(z_raw, 128, rows // k, k)
-    z = ops.bn_apply(z_raw, 128, rows // k, k, mz, sz, G.fc_g, G.fc_beta, act=NONE, out=_empty(z_raw.shape, dev))
+    if ops.bn_forward_small_ok(128, rows // k):
+        z, mz, sz = ops.bn_forward_small(z_raw, 128, rows // k, k, G.fc_g, G.fc_beta, act=NONE, out=_empty(z_raw.shape, dev))
+    else:
+        mz, sz = ops.bn_stats(z_raw, 128, rows // k, k)
+        z = ops.bn_apply(z_raw, 128, rows // k, k, mz, sz, G.fc_g, G.fc_beta, act=NONE, out=_empty(z_raw.shape, dev))
     t.update(z_raw=z_raw, mz=mz, sz=sz)
     N = n_way * (n_support + 1)
     n_graphs = k * n_query

@@ -630,6 +630,55 @@ def bn_stats_multi(jobs, momentum=0.1, eps=BN_EPS):
     return out
 
 
+class _BnFwdJob(ctypes.Structure):
+    """MftBnFwdJob (include/mft_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "y", "gamma", "beta", "mean", "rstd", "running_mean", "running_var", "nbt", "res",
+                                                "res_gamma", "res_beta", "res_mean", "res_rstd", "res_running_mean", "res_running_var",
+                                                "res_nbt")] + \
+               [(n, ctypes.c_int) for n in ("ldx", "ldy", "ldr", "C", "rows_per_group", "n_groups", "act")] + \
+               [(n, ctypes.c_float) for n in ("eps", "momentum", "slope")]
+
+
+def bn_forward_small_ok(C, rows_per_group):
+    """The one-launch train-mode BatchNorm (mft_bn_forward_small) takes this problem: four-channel column groups, at most
+    mft_bn_forward_small_max_rows() rows per group (512: the head's BatchNorm1d layers; a test hook can move it)."""
+    return C % 4 == 0 and 0 < rows_per_group <= int(_lib.lib().mft_bn_forward_small_max_rows())
+
+
+def bn_forward_small(x2d, C, rows_per_group, n_groups, gamma, beta, act=ACT_NONE, running=None, res=None, res_bn=None, out=None,
+                     momentum=0.1, eps=BN_EPS, slope=LRELU_SLOPE):
+    """bn_stats + bn_apply of a small tensor in ONE launch: -> (y, mean, rstd) -- or (y, mean, rstd, res_mean, res_rstd) when the
+    residual goes through its own BatchNorm: ``res_bn`` = (gamma, beta, running | None).  ``running`` = (running_mean, running_var,
+    num_batches_tracked) or None; group 0 advances them, as bn_stats does."""
+    _f32c(x2d)
+    dev = x2d.device
+    if out is None:
+        out = torch.empty_like(x2d)
+    mean = torch.empty((n_groups, C), device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    j = _BnFwdJob()
+    j.x, j.y, j.gamma, j.beta, j.mean, j.rstd = (t.data_ptr() for t in (x2d, out, gamma, beta, mean, rstd))
+    rm, rv, nbt = running if running is not None else (None, None, None)
+    j.running_mean, j.running_var, j.nbt = (None if t is None else t.data_ptr() for t in (rm, rv, nbt))
+    rmean = rrstd = None
+    if res is not None:
+        _f32c(res)
+        j.res, j.ldr = res.data_ptr(), res.shape[-1]
+        if res_bn is not None:
+            rg, rb, rrun = res_bn
+            rmean = torch.empty((n_groups, C), device=dev, dtype=torch.float32)
+            rrstd = torch.empty_like(rmean)
+            j.res_gamma, j.res_beta, j.res_mean, j.res_rstd = rg.data_ptr(), rb.data_ptr(), rmean.data_ptr(), rrstd.data_ptr()
+            rrm, rrv, rnbt = rrun if rrun is not None else (None, None, None)
+            j.res_running_mean, j.res_running_var, j.res_nbt = (None if t is None else t.data_ptr() for t in (rrm, rrv, rnbt))
+    j.ldx, j.ldy, j.C, j.rows_per_group, j.n_groups, j.act = x2d.shape[-1], out.shape[-1], C, rows_per_group, n_groups, act
+    j.eps, j.momentum, j.slope = eps, momentum, slope
+    _lib.check(_lib.lib().mft_bn_forward_small(ctypes.byref(j), _stream(dev)), "mft_bn_forward_small")
+    if rmean is not None:
+        return out, mean, rstd, rmean, rrstd
+    return out, mean, rstd
+
+
 class _BnBwdJob(ctypes.Structure):
     """MftBnBwdJob (include/mft_hip.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "y_act", "dx", "mean", "rstd", "gamma", "dgamma", "dbeta", "ws", "dgamma_sum",

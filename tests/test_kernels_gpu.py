@@ -243,6 +243,77 @@ def test_bn_stats_apply_backward(rows, C, G):
             assert float((db[g].cpu().double() - gb).abs().max()) < 1e-4 * max(1.0, float(gb.abs().max()))
 
 
+@pytest.mark.parametrize("rows,C,G", [(945, 512, 1), (3780, 256, 1), (945, 512, 4), (105, 128, 1), (480, 48, 2), (1, 64, 2), (4096, 64, 1)])
+def test_bn_forward_small_one_launch(rows, C, G):
+    """mft_bn_forward_small (statistics + running update + apply of a small train-mode BatchNorm in ONE launch; SimpleBlock's tail with
+    the shortcut's own BatchNorm in the same launch) against float64 and against the launches it replaces (mft_bn_stats /
+    mft_bn_stats_multi + mft_bn_apply): mean, rstd, running statistics (group 0 advances them), counter, output."""
+    assert ops.bn_forward_small_ok(48, 480) and not ops.bn_forward_small_ok(48, 100000) and not ops.bn_forward_small_ok(6, 480)
+    ld = ops.round_up(C, 32)
+    x = torch.zeros(G * rows, ld)
+    x[:, :C] = rnd((G * rows, C), 31) * 2.0 + 3.0
+    r = rnd((G * rows, C), 32) * 0.7 - 1.0
+    gamma, beta, rgam, rbet = rnd((C,), 33).abs() + 0.5, rnd((C,), 34), rnd((C,), 35).abs() + 0.5, rnd((C,), 36)
+    xg, rg_ = x.to(DEV), r.to(DEV)
+
+    def running():
+        return torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+    ra, rb = running(), running()
+    y, m, s, mr, sr = ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_RELU, running=ra, res=rg_,
+                                           res_bn=(rgam.to(DEV), rbet.to(DEV), rb))
+    xd, rd = x[:, :C].double().view(G, rows, C), r.double().view(G, rows, C)
+
+    def stats(t):
+        return t.mean(1), t.var(1, unbiased=False)
+    (mx, vx), (mrr, vr) = stats(xd), stats(rd)
+    assert float((m.cpu().double() - mx).abs().max()) < 1e-5 and float((mr.cpu().double() - mrr).abs().max()) < 1e-5
+    np.testing.assert_allclose(s.cpu().double().numpy(), (1.0 / torch.sqrt(vx + 1e-5)).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(sr.cpu().double().numpy(), (1.0 / torch.sqrt(vr + 1e-5)).numpy(), rtol=2e-5)
+    ref = torch.relu((xd - mx[:, None]) / torch.sqrt(vx[:, None] + 1e-5) * gamma.double() + beta.double() +
+                     (rd - mrr[:, None]) / torch.sqrt(vr[:, None] + 1e-5) * rgam.double() + rbet.double())
+    assert float((y[:, :C].cpu().double().view(G, rows, C) - ref).abs().max()) < 3e-5
+    assert int(ra[2]) == int(rb[2]) == 1
+    if rows > 1:
+        np.testing.assert_allclose(ra[0].cpu().numpy(), (0.1 * mx[0]).float().numpy(), atol=1e-6)
+        np.testing.assert_allclose(ra[1].cpu().numpy(), (0.9 + 0.1 * xd.var(1, unbiased=True)[0]).float().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(rb[1].cpu().numpy(), (0.9 + 0.1 * rd.var(1, unbiased=True)[0]).float().numpy(), rtol=2e-5)
+    # against the launches it replaces
+    m0, s0 = ops.bn_stats(xg, C, rows, G)
+    m1, s1 = ops.bn_stats(rg_, C, rows, G)
+    y0 = ops.bn_apply(xg, C, rows, G, m0, s0, gamma.to(DEV), beta.to(DEV), act=ops.ACT_RELU, res=rg_, res_bn=(m1, s1, rgam.to(DEV), rbet.to(DEV)))
+    assert float((m - m0).abs().max()) < 1e-5 and float((s / s0 - 1).abs().max()) < 2e-5
+    assert float((y[:, :C] - y0[:, :C]).abs().max()) < 3e-5
+    # plain residual, no activation, no running statistics; leaky_relu without residual; run twice -> bit-identical
+    y2, m2, s2 = ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_NONE, res=rg_)
+    ref2 = (xd - mx[:, None]) / torch.sqrt(vx[:, None] + 1e-5) * gamma.double() + beta.double() + rd
+    assert float((y2[:, :C].cpu().double().view(G, rows, C) - ref2).abs().max()) < 3e-5
+    y3, _, _ = ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_LRELU)
+    y4, _, _ = ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_LRELU)
+    ref3 = F.leaky_relu((xd - mx[:, None]) / torch.sqrt(vx[:, None] + 1e-5) * gamma.double() + beta.double(), 0.01)
+    assert float((y3[:, :C].cpu().double().view(G, rows, C) - ref3).abs().max()) < 3e-5 and torch.equal(y3[:, :C], y4[:, :C])
+
+
+@pytest.mark.parametrize("rows,C,G", [(945, 512, 1), (3780, 256, 1), (945, 512, 2), (480, 48, 2)])
+def test_bn_backward_small_matches_three_phase_form(rows, C, G):
+    """The one-launch BatchNorm backward that mft_bn_backward_act(_multi) takes for small problems against the three-launch form on the
+    same inputs (test hook 11000 + r: small up to r rows per group, 11000: never): dx, dgamma, dbeta to rounding (the sums are taken in another fixed order)."""
+    from meta_fine_tuning_amd import _lib
+    from meta_fine_tuning_amd import functional_bwd as FB
+    x = rnd((G * rows, C), 41).to(DEV) * 1.5 + 0.3
+    dy, ya = rnd((G * rows, C), 42).to(DEV), torch.relu(rnd((G * rows, C), 43)).to(DEV)
+    ga = rnd((C,), 44).to(DEV) + 1.5
+    m, s = ops.bn_stats(x, C, rows, G)
+    assert _lib.lib().mft_debug_set_conv_tile(11000 + 4096) == 0          # (default: up to 512 rows per group)
+    small = FB.bn_bwd(x, dy, C, G * rows, m, s, ga, y_act=ya, act=ops.ACT_RELU, groups=G)
+    small2 = FB.bn_bwd(x, dy, C, G * rows, m, s, ga, y_act=ya, act=ops.ACT_RELU, groups=G)
+    assert _lib.lib().mft_debug_set_conv_tile(11000) == 0
+    big = FB.bn_bwd(x, dy, C, G * rows, m, s, ga, y_act=ya, act=ops.ACT_RELU, groups=G)
+    _lib.lib().mft_debug_reset()
+    for a, b, c in zip(small, big, small2):
+        assert torch.equal(a, c)
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+
+
 def test_bn_apply_residual_bn():
     rows, C, G = 45, 512, 3
     x, r = rnd((G * rows, C), 17), rnd((G * rows, C), 18)
