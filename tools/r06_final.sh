@@ -24,3 +24,4 @@ for K in 1 4; do
   head -3 $O/metatrain_graph_timeline_k$K.txt | cut -c1-200
 done
 find $O -name "*.csv" -size +1M -delete
+python3 tools/accuracy_g19.py > $O/accuracy_g19.txt 2>&1; cat $O/accuracy_g19.txt | tail -12
