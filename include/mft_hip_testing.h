@@ -18,6 +18,8 @@ int mft_debug_set_conv_tile(int tile);
 /* (code 11000 + r of the same setter: train-mode BatchNorm forward / backward of at most r rows per group run as their one-launch
  * forms (the forward-small launcher and the small path inside the BatchNorm-backward launchers of mft_hip.h); 11000 = never; default
  * r = 512) */
+/* (code 2100 / 2101 of the same setter: the stem's weight gradient in torch's layout on the generic gather kernel / on the strip kernel,
+ * the default) */
 /* the same for the split-precision trunk convolutions (csrc/conv_x3.hip): 0 auto, 1: 128x64, 2: 128x128, code ranges at its definition */
 int mft_debug_set_x3_tile(int tile);
 /* every hook back to its default */

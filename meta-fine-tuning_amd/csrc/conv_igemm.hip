@@ -987,6 +987,139 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceMultiArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem weight gradient by strips
+// trunk.0's weight gradient (7x7 / stride 2 / pad 3, Cin = 3, Cout = 64; meta_template.py:76-92 trains the whole backbone):
+// dW[co][kh][kw][ci] = sum over output pixels m of dy[m][co] * x[2 oh - 3 + kh][2 ow - 3 + kw][ci].  The generic kernel above
+// (STEMW) gathers its im2col operand element by element: four scalar loads per thread and 32-row step, each behind two integer
+// divisions -- 84 us for the 105-image episode (41 TFLOP/s), 283 us for four.  For a fixed kernel row kh the 21 values (kw, ci) of
+// an im2col row are CONTIGUOUS in the image row, and consecutive output pixels are 6 floats apart (csrc/stem.hip uses the same fact
+// forward): a workgroup stages, per strip of S <= 64 output pixels of one output row, dy [S][64] and the seven image rows (6 S + 32
+// floats each, zero beyond the image) in LDS; the reduction runs over the strip's pixels in pairs, the MFMA's A operand is dy (rows =
+// co), its B operand the image row at offset 6 m + j (columns = j = kw * 3 + ci, 21 of 32 used): 7 x 2 accumulator tiles (kh, co
+// half) dealt to the eight waves of a 512-thread workgroup, kept in registers over all strips of the workgroup and written once as the partial gradient of
+// "chunk" blockIdx.x -- the split-M reducer above sums the chunks in order, as for every other layer.  The next strip's global
+// loads are issued before the current strip's MFMAs (registers), so one workgroup per CU suffices.
+struct StemWgArgs {
+    const float* in; const float* dy; float* ws;
+    int n_img, H, W, ldi, ldy, OH, OW, S, nseg, Kpad;
+    long long dwgs;
+};
+
+__global__ __launch_bounds__(512) void stem_wgrad_strip_kernel(StemWgArgs p) {
+    constexpr int NT = 512, NWAVE = NT / 64, NQ = (14 + NWAVE - 1) / NWAVE;       // eight waves, two accumulator tiles each (waves 6, 7: one)
+    constexpr int PR = 6 * 64 + 32;                   // floats per staged image row
+    __shared__ float dy_s[64 * 64];
+    __shared__ float prow[7 * PR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int S2 = (p.S + 1) & ~1;                     // reduction length per strip (pairs of output pixels)
+    const int n_strips = p.n_img * p.OH * p.nseg;
+    const int plen = 6 * p.S + 32;                     // staged floats per image row
+    // this wave's accumulator tiles: combos c = wave, wave + 8 (< 14); c -> (kh = c >> 1, co half = c & 1 = wave & 1)
+    const int cb = wave & 1;
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+    constexpr int NDY = (64 * 64 / 4 + NT - 1) / NT;  // float4 of dy per thread (2)
+    constexpr int NPR = (7 * PR + NT - 1) / NT;       // floats of the image rows per thread (6)
+    // what a thread stages does not depend on the strip: decoded once (image row kh, pixel offset, channel, LDS slot; -1: nothing)
+    int e_kh[NPR], e_q3[NPR], e_ci[NPR], e_lds[NPR];
+#pragma unroll
+    for (int u = 0; u < NPR; ++u) {
+        const int i = tid + NT * u;
+        const int kh = i / plen, idx = i - kh * plen;
+        e_kh[u] = kh; e_q3[u] = idx / 3; e_ci[u] = idx - e_q3[u] * 3;
+        e_lds[u] = i < 7 * plen ? kh * PR + idx : -1;
+    }
+    f32x4 rdy[NDY];
+    float rpr[NPR];
+    auto load_strip = [&](const int s) {
+        const int seg = s % p.nseg, row = s / p.nseg;                  // row = img * OH + oh
+        const int img = row / p.OH, oh = row - img * p.OH;
+        const int ow0 = seg * p.S;
+        const int sv = min(p.S, p.OW - ow0);
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int i = tid + NT * u, m = i >> 4, c4 = (i & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < sv) v = *(const f32x4*)(p.dy + ((long long)row * p.OW + ow0 + m) * p.ldy + c4);
+            rdy[u] = v;
+        }
+        const long long ibase = (long long)img * p.H * p.W;
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+            const int ih = 2 * oh - 3 + e_kh[u], iw = 2 * ow0 - 3 + e_q3[u];
+            float v = 0.f;
+            if (e_lds[u] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) v = p.in[(ibase + (long long)ih * p.W + iw) * p.ldi + e_ci[u]];
+            rpr[u] = v;
+        }
+    };
+    auto store_strip = [&]() {
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+            const int i = tid + NT * u;
+            *(f32x4*)(dy_s + (i >> 4) * 64 + (i & 15) * 4) = rdy[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NPR; ++u)
+            if (e_lds[u] >= 0) prow[e_lds[u]] = rpr[u];
+    };
+
+    int kh_q[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) kh_q[q] = wave + NWAVE * q < 14 ? (wave + NWAVE * q) >> 1 : 0;
+    int s = blockIdx.x;
+    if (s < n_strips) load_strip(s);
+    for (; s < n_strips; s += gridDim.x) {
+        __syncthreads();                               // the previous strip's fragment reads are done
+        store_strip();
+        __syncthreads();
+        if (s + (int)gridDim.x < n_strips) load_strip(s + gridDim.x);
+        const float* ap = dy_s + h * 64 + cb * 32 + r;
+        const float* bp = prow + 6 * h + r;
+        // (branch-free body, unrolled: the LDS reads of several pixel pairs are in flight ahead of their MFMAs.  Waves 6 and 7 have
+        // one real tile; their second accumulator multiplies image row 0 again and is never written out)
+        const int np = S2 >> 1;                        // pixel pairs
+        int tp = 0;
+        for (; tp + 4 <= np; tp += 4) {
+            float a[4], b[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = ap[(tp + u) * 128];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) b[u][q] = bp[kh_q[q] * PR + 12 * (tp + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][q], acc[q], 0, 0, 0);
+        }
+        for (; tp < np; ++tp) {
+            const float a = ap[tp * 128];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kh_q[q] * PR + 12 * tp], acc[q], 0, 0, 0);
+        }
+    }
+    // partial gradient of this workgroup: ws[chunk][co][kh * 21 + j], j = kw * 3 + ci < 21 (C/D layout: col = lane & 31, row = (e&3) + 8 (e>>2) + 4 h)
+    float* out = p.ws + (long long)blockIdx.x * p.dwgs;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = wave + NWAVE * q;
+        if (c >= 14 || r >= 21) continue;
+        const int kh = c >> 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[(long long)co * p.Kpad + kh * 21 + r] = acc[q][e];
+        }
+    }
+}
+
+int g_stem_wgrad_strips = 1;       // 0: the generic gather kernel for the stem's weight gradient (mft_debug_set_conv_tile(2100 / 2101))
+
 template <int BM, int BN, bool ADAM, bool STEMW = false, bool EARLYT = false, int POL = 3>
 int launch_wgrad(const WgradArgs& a, int taps, int groups, hipStream_t s) {
     constexpr int lds_mm = 32 * (BM + BN) * 4;
@@ -1065,6 +1198,24 @@ int wgrad_dispatch(WgradArgs a, int n_img, int imgs_per_group, bool adam, float*
     if (a.oihw && (adam || ws == nullptr || groups != 1)) return MFT_EINVAL;
     if (!adam && ws != nullptr) wgrad_chunking(a.rows_per_group, wgrad_wgs_per_chunk(a.Cin, a.Cout, a.KH, a.KW, groups), &a.chunk_rows, &a.chunks);
     const int taps = a.KH * a.KW;
+    if (stem && !adam && g_stem_wgrad_strips && a.oihw && a.KH == 7 && a.KW == 7 && a.stride == 2 && a.pad == 3 && a.Cout == 64 && groups == 1 &&
+        a.chunks > 1 && a.Kpad == 160 && (((unsigned long long)a.dy) & 15) == 0 && (a.cin_out <= 0 || a.cin_out == a.Cin) &&
+        (a.cout_out <= 0 || a.cout_out == a.Cout)) {
+        StemWgArgs q;
+        q.in = a.in; q.dy = a.dy; q.ws = a.ws; q.n_img = n_img; q.H = a.H; q.W = a.W; q.ldi = a.ldi; q.ldy = a.ldy; q.OH = a.OH; q.OW = a.OW;
+        q.nseg = (a.OW + 63) / 64;
+        q.S = (a.OW + q.nseg - 1) / q.nseg;
+        q.Kpad = a.Kpad; q.dwgs = a.dwgs;
+        int wgs = a.chunks;                            // (the workspace holds `chunks` partial gradients; the reducer sums that many)
+        const long long strips = (long long)n_img * a.OH * q.nseg;
+        if (strips < wgs) return launch_wgrad<64, 64, false, true>(a, 1, groups, s);
+        hipLaunchKernelGGL(stem_wgrad_strip_kernel, dim3(wgs), dim3(512), 0, s, q);
+        const long long n = (long long)a.Cout * a.Kpad;
+        int blocks = (int)((n / 4 + 31) / 32);
+        hipLaunchKernelGGL(reduce_chunks_kernel<true>, dim3(blocks, 1), dim3(256), 0, s, (const float*)a.ws, a.dw, n, a.chunks, a.dwgs, a.Cin,
+                           a.KH * a.KW, a.Kpad, a.Cin, a.Cout);
+        return mft_launch_status();
+    }
     if (stem) return adam ? MFT_EINVAL : launch_wgrad<64, 64, false, true>(a, 1, groups, s);
     if (adam) {
         if (a.Cin % 64 != 0 || a.Cout % 64 != 0) return MFT_EINVAL;
@@ -1205,6 +1356,7 @@ extern "C" int mft_debug_set_conv_tile(int tile) {
     else if (tile >= 5000) g_wgrad_early = tile - 5000;
     else if (tile >= 4000) g_wgrad_min_lds_kb = tile - 4000;
     else if (tile >= 3000) g_skinny = tile - 3000;          // 3000 / 3001: generic / skinny per-episode kernels
+    else if (tile >= 2100) g_stem_wgrad_strips = tile - 2100;   // 2100 / 2101: generic gather / strip kernel for the stem's weight gradient
     else if (tile >= 2000) g_stem_fast = tile - 2000;       // 2000 / 2001: generic / LDS-patch stem kernel
     else if (tile >= 1000) g_wgrad_tile = tile - 1000; // 1064 / 1128: choose the wgrad tile
     else g_conv_tile = tile;
@@ -1219,7 +1371,7 @@ extern "C" void mft_wgrad_fwd_set_exact(int on);
 extern "C" int mft_debug_reset(void) {
     mft_wgrad_fwd_set_exact(0);
     mft_wgrad_fwd_set_xcd(1);
-    g_dgrad_parity = 1; g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1;
+    g_dgrad_parity = 1; g_wgrad_trim = 1; g_wgrad_rows = 1; g_wgrad_tile = 64; g_conv_tile = 0; g_wgrad_pol = 7; g_wgrad_early = 1; g_wgrad_min_lds_kb = 0; g_skinny = 1; g_stem_fast = 1; g_stem_wgrad_strips = 1;
     mft_skinny_set_lines(1); mft_skinny_set_nw(0); mft_skinny_set_x3(1); mft_skinny_set_tap(1); mft_skinny_set_dgrad_slices(1);
     mft_debug_set_x3_tile(0); mft_debug_set_x3_tile(10); mft_debug_set_x3_tile(21); mft_debug_set_x3_tile(31); mft_debug_set_x3_tile(41);
     mft_bn_small_set_rows(512); mft_bn_fwd_small_set_rows(512);

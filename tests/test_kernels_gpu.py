@@ -1295,13 +1295,38 @@ def test_conv_wgrad_written_as_oihw(n, H, Cin, Cout, k, stride, pad):
     x = nhwc(rnd((n, Cin, H, H), 95)).to(DEV)
     OH = (H + 2 * pad - k) // stride + 1
     dy = nhwc(rnd((n, Cout, OH, OH), 96)).to(DEV)
+    from meta_fine_tuning_amd import _lib
+    if Cin == 3:                    # (the stem's oihw gradient has its own strip kernel by default: the generic form for the bit-for-bit part)
+        assert _lib.lib().mft_debug_set_conv_tile(2100) == 0
     got = ops.conv2d_wgrad_oihw(x, dy, Cout, k, k, stride, pad)
     ref = ops.unpack_conv_weight(ops.conv2d_wgrad(x, dy, Cout, k, k, stride, pad)[0], (Cout, Cin, k, k))
     assert got.shape == (Cout, Cin, k, k) and torch.equal(got, ref)
+    _lib.lib().mft_debug_reset()
     xd = x.double().cpu().permute(0, 3, 1, 2)
     wd = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
     gw, = torch.autograd.grad(F.conv2d(xd, wd, stride=stride, padding=pad), wd, dy.double().cpu().permute(0, 3, 1, 2))
     assert float((got.double().cpu() - gw).abs().max()) < 2e-5 * float(gw.abs().max())
+
+
+@pytest.mark.parametrize("n,H", [(105, 84), (21, 84), (4, 224), (3, 50), (420, 84)])
+def test_stem_wgrad_strip_kernel(n, H):
+    """trunk.0's weight gradient in torch's layout by the strip kernel (csrc/conv_igemm.hip: dy and seven image rows per strip of one
+    output row in LDS, the (kw, ci) run of an im2col row read at offset 6 m + j) against float64 and against the generic gather
+    kernel (test hook 2100) on the same inputs; run twice -> bit-identical.  224 x 224: two strips per output row; 50 x 50: odd strip."""
+    from meta_fine_tuning_amd import _lib
+    x = ops.nchw_to_nhwc(rnd((n, 3, H, H), 131).to(DEV))
+    OH = (H + 6 - 7) // 2 + 1
+    dy = nhwc(rnd((n, 64, OH, OH), 132)).to(DEV)
+    got = ops.conv2d_wgrad_oihw(x, dy, 64, 7, 7, 2, 3)
+    got2 = ops.conv2d_wgrad_oihw(x, dy, 64, 7, 7, 2, 3)
+    assert _lib.lib().mft_debug_set_conv_tile(2100) == 0
+    gen = ops.conv2d_wgrad_oihw(x, dy, 64, 7, 7, 2, 3)
+    _lib.lib().mft_debug_reset()
+    assert got.shape == (64, 3, 7, 7) and torch.equal(got, got2)
+    gw = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (64, 3, 7, 7), dy.double().cpu().permute(0, 3, 1, 2), stride=2, padding=3)
+    sc = float(gw.abs().max())
+    assert float((got.double().cpu() - gw).abs().max()) < 3e-5 * sc, float((got.double().cpu() - gw).abs().max()) / sc
+    assert float((got - gen).abs().max()) < 3e-5 * sc
 
 
 @pytest.mark.parametrize("n,H,C", [(5, 42, 64), (3, 13, 32), (2, 8, 6)])
