@@ -778,7 +778,7 @@ def test_adam_slab_placement_changes_no_result(monkeypatch):
         else:
             assert rep["candidates"] >= 5 and len(set(rep["chosen"])) == 4
             # (a triple confirmed from an earlier process's hint is re-measured: its fresh rate may sit a little above the recorded best)
-            assert rep["chosen_gbs"] >= 0.98 * rep["first_three_allocations_gbs"]
+            assert rep["chosen_gbs"] >= 0.95 * rep["first_three_allocations_gbs"]      # (rates measured minutes apart: 2-3 % of noise)
             assert 0.97 * rep["worst_gbs"] <= rep["chosen_gbs"] <= 1.03 * rep["best_gbs"], rep
         e.close()
     assert torch.equal(outs["12"], outs["0"])
