@@ -625,3 +625,21 @@ def test_round6_host_pieces():
     assert float(back[:, 5:].abs().sum()) == 0.0        # ... with the padding still zero
     r3 = c.take((4, 8), torch.device("cpu"))
     assert r3.data_ptr() not in ptrs and float(r3.abs().sum()) == 0.0
+
+
+def test_round6_late_knobs_and_form_predicates():
+    """The kernel-form knobs added late in round 6 exist with their measured defaults, every knob of settings.KNOBS has its row in
+    README's table (variable name and default), and the host-side predicates that pick a small-problem kernel form answer without a
+    GPU call where they can (the register-K GEMM rule is pure host logic; the one-launch BatchNorm rule asks the library for its limit)."""
+    import inspect
+    from meta_fine_tuning_amd import functional_bwd as FB, ops, settings
+    s = settings.Settings()
+    assert s.pair_rk_rows == 16384 and s.gemm_rk_rows == 4096 and s.wgrad_batch is True and s.pair_f16x2 is False
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for field, var, _, default, _doc in settings.KNOBS:
+        assert "`%s`" % var in readme, "README knob table lacks %s" % var
+    assert FB.GEMM_RK_ROWS == settings.current().gemm_rk_rows and FB.PAIR_RK_ROWS == settings.current().pair_rk_rows
+    src = inspect.getsource(FB._gemm_fwd)
+    assert "GEMM_RK_ROWS" in src and "ops.gemm_rk" in src and "ops.gemm(" in src          # both forms reachable, chosen by size
+    assert ops.bn_forward_small_ok(48, 480) and ops.bn_forward_small_ok(128, 105)          # the head's BatchNorm1d layers
+    assert not ops.bn_forward_small_ok(512, 945) and not ops.bn_forward_small_ok(6, 100)   # trunk.7 (measured slower), C % 4 != 0
