@@ -37,7 +37,7 @@ X3_FOLD_BN = settings.current().x3_fold_bn
 # passes ``f16x2_safe`` (every operand provably inside fp16's range); MFT_TRUNK_F16X2=0 keeps the bf16x3 kernels.
 TRUNK_F16X2 = settings.current().trunk_f16x2
 TRAIN_X3 = settings.current().train_x3            # meta-training: large 3x3 layers on the bf16x3 kernels (ResNet10Weights.train_planes)
-TRAIN_X3_MIN_ROWS = 8192
+TRAIN_X3_MIN_ROWS = settings.current().train_x3_min_rows
 # fused next-step forward (engine.fuse_next), opt-in variant: only trunk.7.C2's launch is the fused walking kernel, C1 / shortcut keep
 # the plain gradient + Adam launches + one entry launch (last_block_backward).  Alone that chain is 100 us shorter, in situ it is
 # slower: 87.2 vs 88.8-89.0 episodes/s (profiles/r04_d_fuse_c2_only_ab.txt) -- default 0 = all three layers fused

@@ -65,6 +65,7 @@ KNOBS = (
     # ---- training path
     ("train_graph", "MFT_TRAIN_GRAPH", _flag, True, "MetaTemplate episode loop: loss + backward replayed from one hipGraph"),
     ("train_x3", "MFT_TRAIN_X3", _flag, True, "meta-training: 3x3 layers with >= 8192 output rows on the bf16x3 kernels, forward and stride-1 data gradient (0: fp32 MFMA everywhere)"),
+    ("train_x3_min_rows", "MFT_TRAIN_X3_MIN_ROWS", int, 6000, "meta-training: output rows from which a 3x3 layer takes the bf16x3 kernels (below: fp32 MFMA with K slices; measured at 3,780 / 945 rows in profiles/r06_q_train_x3_min_rows.txt)"),
     ("wgrad_batch", "MFT_WGRAD_BATCH", _flag, True, "meta-training backward: every layer's weight gradient deferred to the end of the pass and run in one multi-problem launch pair per 16 layers (0: one launch pair per layer, as round 5; bit-identical)"),
     ("pair_f16x2", "MFT_PAIR_F16X2", _flag, False, "GNN pair-MLP layers (Wcompute) as f16x2 products on the fp16 matrix cores (fp32-accurate; 0: fp32 MFMA)"),
     ("gemm_rk_rows", "MFT_GEMM_RK_ROWS", int, 4096, "meta-training: head linear layers (fc, Gconv.fc) of at most this many rows take the skinny register-K GEMM (0: the tile kernel always)"),
@@ -115,6 +116,7 @@ class Settings:
     pair_mlp_gb: float = 6.0
     train_graph: bool = True
     train_x3: bool = True
+    train_x3_min_rows: int = 6000
     wgrad_batch: bool = True
     pair_f16x2: bool = False
     gemm_rk_rows: int = 4096
@@ -170,7 +172,7 @@ def current():
 # in that process); every other knob is read live through ``current()`` at the point of use.
 IMPORT_TIME = frozenset((
     "debug_skip_trunk", "adapt_graph", "adapt_batched_trunk", "fused_dgrad", "fused_last_block", "x3_planes", "x3_fused_stats",
-    "x3_fold_bn", "trunk_f16x2", "train_x3", "fuse_next_c2_only", "fused_pair_mlp", "pair_f16x2", "pair_rk_rows", "gemm_rk_rows", "pair_mlp_gb", "wgrad_batch",
+    "x3_fold_bn", "trunk_f16x2", "train_x3", "train_x3_min_rows", "fuse_next_c2_only", "fused_pair_mlp", "pair_f16x2", "pair_rk_rows", "gemm_rk_rows", "pair_mlp_gb", "wgrad_batch",
     "train_graph", "small_groups", "wf_xcd",
 ))
 assert IMPORT_TIME <= set(k[0] for k in KNOBS), IMPORT_TIME - set(k[0] for k in KNOBS)
