@@ -329,9 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(BnBwdSmallArgs a) {
         t1 += s1;
         t2 += s2;
         if (p.dx) {
-            const float inv = 1.f / (float)p.rows_per_group;      // (the three-phase form divides: s / rows; kept as a division below)
-            (void)inv;
-            f32x4 m1, m2;
+            f32x4 m1, m2;                                           // (divisions, as the three-phase form's finalize: s / rows)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { m1[e] = s1[e] / (float)p.rows_per_group; m2[e] = s2[e] / (float)p.rows_per_group; }
             auto apply = [&](auto with_act) {

@@ -851,3 +851,41 @@ def test_lockstep_loop_graphed_matches_eager(capsys, monkeypatch):
     assert pa == pb and "Batch 0/6" in pa
     for k_ in a:
         assert torch.equal(a[k_], b[k_]), k_
+
+
+def test_small_image_step_takes_the_one_launch_batchnorms():
+    """At 32 x 32 the deep blocks of a 105-image episode have 420 / 105 rows: trunk.6 / trunk.7 then run their BatchNorms as the
+    one-launch forms too (BN1 alone; BN2 + BNshortcut + add + ReLU of the block exit in one launch; the backward's small path), which at
+    84 x 84 only the head does.  Same loss and gradients as with the multi-launch forms (test hook 11000) to rounding, running statistics
+    and counters included; against float64 within the bounds of the 84 x 84 test."""
+    from meta_fine_tuning_amd import _lib
+    sd = synthetic.gnnnet_state_dict(seed=17)
+    x = synthetic.train_episode(91, 5, 5, 16, 32)
+
+    def run(code):
+        if code is not None:
+            assert _lib.lib().mft_debug_set_conv_tile(code) == 0
+        m = GnnNet(model_dict['ResNet10'], n_way=5, n_support=5)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        m.train()
+        m.n_query = 16
+        loss = m.set_forward_loss(x)
+        loss.backward()
+        torch.cuda.synchronize()
+        _lib.lib().mft_debug_reset()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters()}, {n: b.clone() for n, b in m.named_buffers()}
+    l1, g1, b1 = run(None)
+    l0, g0, b0 = run(11000)
+    assert abs(l1 - l0) < 1e-5
+    for n in g0:
+        d, sc = float((g1[n] - g0[n]).norm()), float(g0[n].norm())
+        assert d <= 1e-3 * sc + 1e-6, (n, d, sc)
+    for n in b0:
+        assert float((b1[n].double() - b0[n].double()).abs().max()) <= 1e-5 * max(1.0, float(b0[n].double().abs().max())), n
+    ref_loss, _, ref = _oracle_grads(sd, x)
+    assert abs(l1 - ref_loss) < 2e-4
+    for k, gr in ref.items():
+        nrm = float(gr.norm())
+        if nrm >= 1e-9:
+            assert float((g1[k].cpu().double() - gr).norm()) / nrm < 3e-2, k
