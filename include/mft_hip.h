@@ -355,7 +355,8 @@ int mft_bn_stats_multi(const MftBnStatsJob* jobs, int n_jobs, void* stream);
  * few microseconds of work.  One workgroup per (group, 4 channels) walks all rows twice; the caller chooses it up to
  * mft_bn_forward_small_max_rows() rows per group (512: at the trunk's 945 / 3,780-row layers the three launches are faster).  res_gamma != NULL: the residual
  * goes through its own BatchNorm (statistics taken here, saved to res_mean / res_rstd, res_running_* updated).  Same formulas as
- * mft_bn_stats + mft_bn_apply; the sums are taken in another fixed order (equal to rounding). */
+ * mft_bn_stats + mft_bn_apply; the sums are taken in another fixed order (equal to rounding).  y may be a column window of a wider
+ * matrix (ldy = its row length; any 4-byte alignment): Gconv's output lands in the node-feature matrix directly (gnn.py:160-165). */
 typedef struct MftBnFwdJob {
     const float* x; float* y; const float* gamma; const float* beta; float* mean; float* rstd;
     float* running_mean; float* running_var; long long* num_batches_tracked;

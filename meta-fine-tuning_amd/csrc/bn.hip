@@ -586,6 +586,7 @@ struct BnFwdSmallArgs {
     float* rrunning_mean; float* rrunning_var; long long* rnbt;
     int ldx, ldy, ldr, C, rows_per_group, n_groups, act;
     float eps, momentum, slope;
+    int y_scalar;        // y is not 16-byte aligned (a column window of a wider matrix): four 4-byte stores per thread
 };
 
 __device__ __forceinline__ void bn_small_block_sum(f32x4& a, f32x4& b, float (*red)[8]) {     // red[4 waves][8]
@@ -689,7 +690,9 @@ __global__ __launch_bounds__(256) void bn_forward_small_kernel(BnFwdSmallArgs p)
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_f(o[e], p.act, p.slope);
-        *(f32x4*)(p.y + (row0 + r) * p.ldy + c) = o;
+        float* yp = p.y + (row0 + r) * p.ldy + c;
+        if (p.y_scalar) { yp[0] = o[0]; yp[1] = o[1]; yp[2] = o[2]; yp[3] = o[3]; }
+        else *(f32x4*)yp = o;
     }
 }
 
@@ -718,6 +721,7 @@ extern "C" int mft_bn_forward_small(const MftBnFwdJob* jb, void* stream) {
     p.rrunning_mean = jb->res_running_mean; p.rrunning_var = jb->res_running_var; p.rnbt = jb->res_num_batches_tracked;
     p.ldx = jb->ldx; p.ldy = jb->ldy; p.ldr = jb->ldr; p.C = jb->C; p.rows_per_group = jb->rows_per_group; p.n_groups = jb->n_groups;
     p.act = jb->act; p.eps = jb->eps; p.momentum = jb->momentum; p.slope = jb->slope;
+    p.y_scalar = (((unsigned long long)jb->y) & 15) != 0 ? 1 : 0;
     hipLaunchKernelGGL(bn_forward_small_kernel, dim3(jb->C / 4, jb->n_groups), dim3(256), 0, (hipStream_t)stream, p);
     return mft_launch_status();
 }

@@ -492,7 +492,10 @@ def wcompute_backward(G, t, dA, x, dX, n_graphs, N, grads, prefix, wb=None):
             grads[prefix + ".conv2d_1.weight"] = dW.view(cout, F, 1, 1)
 
 
-def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1):
+def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1, into_x=False):
+    """gnn.Gconv.forward (gnn.py:134-166).  ``into_x``: the caller appends leaky_relu(output) to the node features (GNN_nl's loop,
+    gnn.py:160-165): where the one-launch BatchNorm runs, it writes x[:, F : F + cout] itself and None is returned in place of the
+    output (no copy launch)."""
     w, b, g, beta, cout = G.gc[name]
     rows = n_graphs * N
     ldy = ops.round_up(2 * F, 32)
@@ -501,6 +504,10 @@ def gconv_taped(G, name, A, x, F, n_graphs, N, lease=None, groups=1):
     t = {"name": name, "F": F, "y": y, "raw": o, "A": A, "lease": lease, "groups": groups}
     if g is not None:
         if ops.bn_forward_small_ok(cout, rows // groups):      # 480 node rows per episode: statistics + apply in one launch
+            if into_x:
+                _, m, s = ops.bn_forward_small(o, cout, rows // groups, groups, g, beta, act=LRELU, out=x, out_col=F)
+                t["stats"] = (m, s)
+                return None, t
             ob, m, s = ops.bn_forward_small(o, cout, rows // groups, groups, g, beta, act=NONE, out=_empty(o.shape, o.device))
         else:
             m, s = ops.bn_stats(o, cout, rows // groups, groups)
@@ -557,8 +564,9 @@ def head_forward_taped(G, feats, n_way, n_support, n_query, fold=False, episodes
     for i in range(2):
         A, tw = wcompute_taped(G, "layer_w%d" % i, x, F, n_graphs, N, k)
         tw["lease"] = lease
-        ob, tg = gconv_taped(G, "layer_l%d" % i, A, x, F, n_graphs, N, lease, k)
-        ops.copy_cols(ob, x, F, 48, act=LRELU)
+        ob, tg = gconv_taped(G, "layer_l%d" % i, A, x, F, n_graphs, N, lease, k, into_x=True)
+        if ob is not None:
+            ops.copy_cols(ob, x, F, 48, act=LRELU)
         t["wc"].append(tw); t["gc"].append(tg); t["Fs"].append(F)
         F += 48
     A, tw = wcompute_taped(G, "w_comp_last", x, F, n_graphs, N, k)

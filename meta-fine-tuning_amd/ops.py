@@ -646,18 +646,21 @@ def bn_forward_small_ok(C, rows_per_group):
 
 
 def bn_forward_small(x2d, C, rows_per_group, n_groups, gamma, beta, act=ACT_NONE, running=None, res=None, res_bn=None, out=None,
-                     momentum=0.1, eps=BN_EPS, slope=LRELU_SLOPE):
+                     momentum=0.1, eps=BN_EPS, slope=LRELU_SLOPE, out_col=0):
     """bn_stats + bn_apply of a small tensor in ONE launch: -> (y, mean, rstd) -- or (y, mean, rstd, res_mean, res_rstd) when the
     residual goes through its own BatchNorm: ``res_bn`` = (gamma, beta, running | None).  ``running`` = (running_mean, running_var,
-    num_batches_tracked) or None; group 0 advances them, as bn_stats does."""
+    num_batches_tracked) or None; group 0 advances them, as bn_stats does.  ``out_col``: write into columns out_col .. out_col + C of
+    the (wider) matrix ``out``."""
     _f32c(x2d)
     dev = x2d.device
     if out is None:
         out = torch.empty_like(x2d)
+    assert out_col >= 0 and out_col + C <= out.shape[-1]
     mean = torch.empty((n_groups, C), device=dev, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     j = _BnFwdJob()
     j.x, j.y, j.gamma, j.beta, j.mean, j.rstd = (t.data_ptr() for t in (x2d, out, gamma, beta, mean, rstd))
+    j.y = out.data_ptr() + 4 * out_col
     rm, rv, nbt = running if running is not None else (None, None, None)
     j.running_mean, j.running_var, j.nbt = (None if t is None else t.data_ptr() for t in (rm, rv, nbt))
     rmean = rrstd = None

@@ -291,6 +291,11 @@ def test_bn_forward_small_one_launch(rows, C, G):
     y4, _, _ = ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_LRELU)
     ref3 = F.leaky_relu((xd - mx[:, None]) / torch.sqrt(vx[:, None] + 1e-5) * gamma.double() + beta.double(), 0.01)
     assert float((y3[:, :C].cpu().double().view(G, rows, C) - ref3).abs().max()) < 3e-5 and torch.equal(y3[:, :C], y4[:, :C])
+    # into a column window of a wider matrix at an odd offset (Gconv's output appended to the node features): 4-byte stores, same values
+    if C <= 128:
+        wide, off = torch.full((G * rows, 320), -7.0, device=DEV), 133
+        ops.bn_forward_small(xg, C, rows, G, gamma.to(DEV), beta.to(DEV), act=ops.ACT_LRELU, out=wide, out_col=off)
+        assert torch.equal(wide[:, off:off + C], y3[:, :C]) and bool((wide[:, :off] == -7.0).all()) and bool((wide[:, off + C:] == -7.0).all())
 
 
 @pytest.mark.parametrize("rows,C,G", [(945, 512, 1), (3780, 256, 1), (945, 512, 2), (480, 48, 2)])
