@@ -709,36 +709,28 @@ __global__ __launch_bounds__(256) void pair_bwd_stats_kernel(const float* __rest
 
 // 16 (sum kind, channel) entries per block, 16 lanes per entry over the block partials (lane l takes partials l, l+16, ...),
 // combined in lane order: fixed summation order, and chains of ~8 dependent loads instead of one of ~120 (the serial form took
-// 28 us per call -- 12 calls per meta-training step -- for 178 KB of partials).  The groups are walked in order: sums[g][2C] per
-// group (what phase 2 subtracts), dparams[2C] = their sum over the groups = (d beta | d gamma) of the shared affine parameters;
-// dbias_zero [C] (nullable): the gradient of the 1x1 convolution's bias in front of this BatchNorm -- identically zero.
+// 28 us per call -- 12 calls per meta-training step -- for 178 KB of partials).  One block row per group: sums[g][2C] (what phase 2
+// subtracts).  Their sum over the groups in group order, dparams[2C] = (d beta | d gamma) of the shared affine parameters, and the
+// identically-zero bias gradient dbias_zero [C] are written by workgroup 0 of the phase-2 launch.
 __global__ __launch_bounds__(256) void pair_bwd_stats_final_kernel(const float* __restrict__ ws, int nblk, int C, int n_groups,
-                                                                   float* __restrict__ sums, float* __restrict__ dparams,
-                                                                   float* __restrict__ dbias_zero) {
+                                                                   float* __restrict__ sums) {
     __shared__ float red[16][17];
     const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + e;                 // over 2 * C
-    float tot = 0.f;
-    for (int grp = 0; grp < n_groups; ++grp) {
-        float s = 0.f;
-        if (i < 2 * C) {
-            const int k = i / C, c = i - k * C;
-            for (int b = l; b < nblk; b += 16) s += ws[(((long long)grp * nblk + b) * 2 + k) * C + c];
-        }
-        red[l][e] = s;
-        __syncthreads();
-        if (l == 0 && i < 2 * C) {
-            float t = red[0][e];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) t += red[j][e];
-            sums[(long long)grp * 2 * C + i] = t;
-            tot += t;
-        }
-        __syncthreads();
+    const int grp = blockIdx.y;                        // one block row per group: k episodes in lockstep are reduced side by side
+    float s = 0.f;
+    if (i < 2 * C) {
+        const int k = i / C, c = i - k * C;
+#pragma unroll 8
+        for (int b = l; b < nblk; b += 16) s += ws[(((long long)grp * nblk + b) * 2 + k) * C + c];
     }
+    red[l][e] = s;
+    __syncthreads();
     if (l == 0 && i < 2 * C) {
-        if (dparams) dparams[i] = tot;
-        if (dbias_zero && i < C) dbias_zero[i] = 0.f;
+        float t = red[0][e];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][e];
+        sums[(long long)grp * 2 * C + i] = t;
     }
 }
 
@@ -749,7 +741,16 @@ __global__ __launch_bounds__(256) void pair_bwd_dz_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
                                                           const int* __restrict__ ij, int P, float inv_n_tot, float slope,
-                                                          long long rows, long long rows_per_group, float* __restrict__ dz) {
+                                                          long long rows, long long rows_per_group, float* __restrict__ dz,
+                                                          int n_groups, float* __restrict__ dparams, float* __restrict__ dbias_zero) {
+    if (blockIdx.x == 0) {                             // (d beta | d gamma) = the groups' sums added in group order; the zero bias gradient
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float tot = 0.f;
+            for (int g = 0; g < n_groups; ++g) tot += sums[(long long)g * 2 * C + i];
+            if (dparams) dparams[i] = tot;
+            if (dbias_zero && i < C) dbias_zero[i] = 0.f;
+        }
+    }
     const int q = C / 4;
     const long long total = rows * q;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -985,12 +986,12 @@ extern "C" int mft_pair_bn_act_backward(const float* g, int ldg, const float* z,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pair_bwd_stats_kernel, dim3((unsigned)nblk, (unsigned)n_groups), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean,
                        rstd, slope, rows_per_group, rpb, ws);
-    hipLaunchKernelGGL(pair_bwd_stats_final_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)ws, (int)nblk, C, n_groups, sums,
-                       dparams, dbias_zero);
+    hipLaunchKernelGGL(pair_bwd_stats_final_kernel, dim3((2 * C + 15) / 16, (unsigned)n_groups), dim3(256), 0, st, (const float*)ws, (int)nblk, C,
+                       n_groups, sums);
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(pair_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, ldg, z, C, scale, shift, mean, rstd, gamma,
-                       (const float*)sums, ij, (int)P, 1.0f / (float)n_tot, slope, rows, rows_per_group, dz);
+                       (const float*)sums, ij, (int)P, 1.0f / (float)n_tot, slope, rows, rows_per_group, dz, n_groups, dparams, dbias_zero);
     return mft_launch_status();
 }
 
